@@ -1,0 +1,118 @@
+"""The CPU oracle (oracle/uformer_oracle.py) against golden vectors captured from the reference itself
+(tests/golden/gen_golden.py).  This is what pins the oracle; the -m gpu tests then compare HIP to it."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import uformer_oracle as O
+
+T = torch.from_numpy
+
+
+def sd_from(g, prefix="sd/"):
+    return {k[len(prefix):]: T(g[k]) for k in g.files if k.startswith(prefix)}
+
+
+def test_rng_stream(golden):
+    g = golden("rng_stream")
+    torch.manual_seed(0)
+    batched = torch.randint(64, (3, 64, 25))
+    assert np.array_equal(batched.numpy(), g["idx"].astype(np.int64))
+
+
+@pytest.mark.parametrize("case", ["h1_nomask_bias", "h2_mask_bias", "h16_nomask_nobias", "h2_mask_nobias",
+                                  "h2_mask_bias_d64"])
+def test_prob_attention(golden, case):
+    g = golden("probattn_" + case)
+    q, k, v = (T(g[n]).transpose(1, 2).contiguous().requires_grad_() for n in "qkv")   # -> B_,H,N,d
+    bias = T(g["bias"]).requires_grad_()
+    use_bias = bool(g["use_bias"])
+    mask = T(g["mask"]) if g["mask"].size else None
+    idx = T(g["idx"].astype(np.int64))
+    ctx, top, Mq, scores, a = O.prob_attention(q, k, v, idx, bias if use_bias else None, mask, return_aux=True)
+    # selection: same SET of queries per (window, head)
+    ref_top = np.sort(g["top"].astype(np.int64), -1)
+    assert np.array_equal(np.sort(top.numpy(), -1), ref_top)
+    ref_ctx = T(g["ctx"]).transpose(1, 2)
+    assert torch.allclose(ctx, ref_ctx, atol=2e-6, rtol=1e-5)
+    (ctx * T(g["gout"]).transpose(1, 2)).sum().backward()
+    for name, t in (("dq", q), ("dk", k), ("dv", v)):
+        assert torch.allclose(t.grad, T(g[name]).transpose(1, 2), atol=5e-6, rtol=1e-4), name
+    if use_bias:
+        assert torch.allclose(bias.grad, T(g["dbias"]), atol=5e-6, rtol=1e-4)
+
+
+def test_shift_mask(golden):
+    g = golden("shift_mask")
+    m16 = O.shift_attn_mask(16, 16, 8, 4)
+    assert np.array_equal((m16 != 0).numpy().astype(np.uint8), g["m16"])
+    m128 = O.shift_attn_mask(128, 128, 8, 4)
+    assert tuple(g["m128_shape"]) == tuple(m128.shape)
+    assert np.array_equal(np.packbits((m128 != 0).numpy()), g["m128_packed"])
+    assert set(np.unique(m128.numpy())) <= {0.0, -100.0} and set(g["vals"]) == {0.0, -100.0}
+
+
+@pytest.mark.parametrize("name,variant,heads,shift", [
+    ("block_m1_c32_shift0", "probsparse", 1, 0), ("block_m1_c32_shift4", "probsparse", 1, 4),
+    ("block_m1_c64_shift4", "probsparse", 2, 4), ("block_m0_c32_shift0", "dense", 1, 0),
+    ("block_m0_c32_shift4", "dense", 1, 4), ("block_m0_c64_shift4", "dense", 2, 4)])
+def test_block(golden, name, variant, heads, shift):
+    g = golden(name)
+    P = {k: v.requires_grad_() if v.dtype.is_floating_point else v for k, v in sd_from(g).items()}
+    x = T(g["x"]).requires_grad_()
+    idx = T(g["idx"].astype(np.int64))
+    y = O.lewin_block(x, P, "", heads, 8, shift, variant, idx)
+    assert torch.allclose(y, T(g["y"]), atol=1e-5, rtol=1e-5)
+    (y * T(g["gout"])).sum().backward()
+    assert torch.allclose(x.grad, T(g["dx"]), atol=2e-5, rtol=1e-4)
+    for k in g.files:
+        if k.startswith("g/"):
+            ref = g[k]
+            p = P[k[2:]]
+            if ref.size == 0:
+                assert p.grad is None, k
+            else:
+                assert torch.allclose(p.grad, T(ref), atol=5e-5, rtol=2e-4), k
+
+
+@pytest.mark.parametrize("tag", ["leff", "down", "up", "inproj", "outproj"])
+def test_small_modules(golden, tag):
+    g = golden("small_modules")
+    P = {k[len(tag) + 4:]: T(g[k]).requires_grad_() for k in g.files if k.startswith(tag + "/sd/")}
+    x = T(g[tag + "/x"]).requires_grad_()
+    if tag == "leff":
+        y = O.leff(x, P, "")
+    elif tag == "down":
+        y = O.downsample(x, {"d." + k: v for k, v in P.items()}, "d")
+    elif tag == "up":
+        y = O.upsample(x, {"u." + k: v for k, v in P.items()}, "u")
+    elif tag == "inproj":
+        y = O.input_proj(x, {"input_proj." + k: v for k, v in P.items()})
+    else:
+        y = O.output_proj(x, {"output_proj." + k: v for k, v in P.items()})
+    assert torch.allclose(y, T(g[tag + "/y"]), atol=1e-5, rtol=1e-5)
+    (y * T(g[tag + "/gout"])).sum().backward()
+    assert torch.allclose(x.grad, T(g[tag + "/dx"]), atol=1e-5, rtol=1e-4)
+    for k, p in P.items():
+        assert torch.allclose(p.grad, T(g[f"{tag}/g/{k}"]), atol=1e-4, rtol=1e-4), k
+
+
+def test_losses(golden):
+    g = golden("losses")
+    x = T(g["char_x"]).requires_grad_()
+    l = O.charbonnier(x, T(g["char_y"]))
+    assert abs(l.item() - float(g["char_loss"])) < 1e-7
+    l.backward()
+    assert torch.allclose(x.grad, T(g["char_dx"]), atol=1e-8, rtol=1e-5)
+    W = O.seeded_vgg_weights()
+    assert torch.equal(W[0][0], T(g["cr/vgg_w0"]))
+    for tag, ab in (("cr", False), ("cr_ab", True)):
+        a = T(g[tag + "/a"]).requires_grad_()
+        loss, ap, an = O.contrast_loss(a, T(g[tag + "/p"]), T(g[tag + "/n"]), W, ablation=ab)
+        assert abs(loss.item() - float(g[tag + "/loss"])) < 2e-6 * max(1, abs(float(g[tag + "/loss"])))
+        assert abs(float(ap) - float(g[tag + "/all_ap"])) < 1e-5
+        assert abs(float(an) - float(g[tag + "/all_an"])) < 1e-5
+        loss.backward()
+        assert torch.allclose(a.grad, T(g[tag + "/da"]), atol=1e-7, rtol=1e-3)
+    feats = O.vgg19_features(T(g["cr/a"]), W)
+    assert [list(f.shape) for f in feats] == g["cr/feat_shapes"].tolist()
