@@ -1,0 +1,142 @@
+/*
+ * dehaze_hip.h - C-ABI of the MI355X (gfx950) kernels behind the Uformer_ProbSparse training path.
+ *
+ * The reference (xin-fight/...Image-Dehazing...Vision-Transformer) is pure Python/PyTorch: it has no
+ * FFI layer of its own, so every entry point below replaces a *sequence of ATen ops* in the reference;
+ * the file:line each one replaces is cited (M1 = Uformer_ProbSparse/My_model_1.py, M0 = My_model.py,
+ * ATT = Uformer_ProbSparse/ProbSparse/attn.py, TR = My_train.py).  The reference-side binding a
+ * maintainer would add is a ctypes stub - see INTEGRATION.md.
+ *
+ * Conventions
+ *   - plain C: raw DEVICE pointers, sizes, an explicit hipStream_t passed as void*; no torch types.
+ *   - the caller owns every buffer (allocate through the framework's caching allocator); no entry
+ *     point allocates, frees or synchronises; all work is enqueued on `stream`.
+ *   - return 0 on success, a negative DHZ_E* code otherwise; dhz_last_error() gives the message of
+ *     the last failure on the calling thread.
+ *   - all floating-point tensors are fp32, contiguous unless a leading dimension `ld*` is given.
+ *   - re-entrant across streams/devices; no hidden global state.
+ */
+#ifndef DEHAZE_HIP_H
+#define DEHAZE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DHZ_OK 0
+#define DHZ_EINVAL (-22)  /* bad argument (shape / null pointer / unsupported head_dim) */
+#define DHZ_ELAUNCH (-5)  /* hipLaunchKernel reported an error */
+
+#define DHZ_NTOK 64 /* tokens per 8x8 window */
+#define DHZ_NTOP 25 /* u = U_part = 5*ceil(ln 64)  (ATT:310-315) */
+
+int dhz_abi_version(void);
+const char* dhz_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * K3  ProbSparse window attention core.   Replaces ProbAttention.forward  ATT:287-342
+ *     (_prob_QK ATT:71-152, _get_initial_context ATT:154-176, _update_context ATT:178-281).
+ *
+ * q,k,v : [B_, 64, H, d] fp32 with token stride `ld` floats (element (b,n,h,e) at
+ *         ((b*64+n)*ld + h*d + e)); ld = H*d for separate projections, 3*H*d for a packed QKV.
+ * idx   : [64, 25] uint8 sampled key ids, shared by all windows/heads (ATT:91).
+ * bias  : [H, 64, 64] relative-position bias (M1:408-410) or NULL (options.is_relative_position_bias
+ *         False, ATT:227-232).   mask: [nW, 64, 64] (0 / -100) or NULL; window id = b mod nW.
+ * out   : [B_, 64, H, d], token stride ldo.
+ * rank  : [B_, H, 64] uint8 - for each query its position (0..24, by descending sparsity measure M)
+ *         in the top-u set, 255 if not selected.  Saved for backward.
+ * d must be 32 or 64.
+ */
+int dhz_ps_attn_fwd(const float* q, const float* k, const float* v, int ld, const uint8_t* idx,
+                    const float* bias, const float* mask, float* out, int ldo, uint8_t* rank,
+                    int B_, int H, int nW, int d, void* stream);
+
+/* Backward of the above (autograd of ATT:287-342; gradient flows through steps 6-12 only).
+ * dout: [B_,64,H,d] stride ldo.  dq,dk,dv: [B_,64,H,d] stride ldg (every element written).
+ * dbias_part: workspace [dhz_ps_attn_bwd_parts(B_,H), 64, 64] fp32 (written, not accumulated) or
+ *             NULL when bias == NULL.  Row p holds the partial bias gradient of head (p % H);
+ *             reduce with dhz_bias_table_grad.
+ */
+int dhz_ps_attn_bwd_parts(int B_, int H);
+int dhz_ps_attn_bwd(const float* q, const float* k, const float* v, int ld, const float* bias,
+                    const float* mask, const uint8_t* rank, const float* dout, int ldo, float* dq,
+                    float* dk, float* dv, int ldg, float* dbias_part, int B_, int H, int nW, int d,
+                    void* stream);
+
+/* K7  relative-position bias:  bias[h,i,j] = table[rel_index(i,j), h]   (M1:408-410, win = 8).
+ * table: [225, H].  bias: [H,64,64]. */
+int dhz_bias_gather(const float* table, float* bias, int H, void* stream);
+/* dtable[t,h] (+)= sum_p sum_{(i,j): rel_index(i,j)=t} dbias_part[p,i,j] over parts p with p%H==h.
+ * dtable: [225,H], overwritten when accumulate == 0. */
+int dhz_bias_table_grad(const float* dbias_part, int parts, float* dtable, int H, int accumulate,
+                        void* stream);
+
+/* K6  shift mask builder: mask[nW,64,64] in {0,-100}  (M1:803-836), Hres x Wres map, win 8. */
+int dhz_shift_mask(float* mask, int Hres, int Wres, int shift, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K1  LayerNorm + cyclic shift + window partition.  Replaces norm1 M1:839, roll M1:846,
+ *     window_partition M1:550-574.   x: [B, Hres*Wres, C] -> xw: [B*nW, 64, C].
+ *     stats: [B*Hres*Wres, 2] (mean, rstd) saved for backward.  eps = 1e-5.  C % 4 == 0, C <= 1024.
+ *     partition == 0: plain LayerNorm, tokens stay in place (norm2, M1:873).
+ */
+int dhz_ln_partition_fwd(const float* x, const float* gamma, const float* beta, float* xw,
+                         float* stats, int B, int Hres, int Wres, int C, int shift, int partition,
+                         void* stream);
+/* dxw: [B*nW,64,C] -> dx: [B,HW,C] (overwritten, or accumulated into when accumulate != 0);
+ * dgamma,dbeta [C] are ACCUMULATED (caller zeroes). */
+int dhz_ln_partition_bwd(const float* dxw, const float* x, const float* gamma, const float* stats,
+                         float* dx, float* dgamma, float* dbeta, int B, int Hres, int Wres, int C,
+                         int shift, int partition, int accumulate, void* stream);
+
+/* K4 (tail)  window reverse + un-shift + residual with per-sample DropPath scale.
+ *     Replaces window_reverse M1:577-601, roll M1:866, shortcut + drop_path(x) M1:872.
+ *     out[b,p,:] = shortcut[b,p,:] + scale[b] * yw[window-position(b,p),:]   (scale == NULL -> 1).
+ *     partition == 0: yw is already in token order (the LeFF residual x + drop_path(mlp(..)), M1:873).
+ */
+int dhz_reverse_residual_fwd(const float* yw, const float* shortcut, const float* scale, float* out,
+                             int B, int Hres, int Wres, int C, int shift, int partition, void* stream);
+/* dyw[window-position] = scale[b] * dout[b,p,:]  (the shortcut gradient is dout itself). */
+int dhz_reverse_residual_bwd(const float* dout, const float* scale, float* dyw, int B, int Hres,
+                             int Wres, int C, int shift, int partition, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K5 (middle)  LeFF depthwise stage in token (NHWC) layout.  Replaces the NHWC<->NCHW rearranges,
+ *     the GELU after linear1, the depthwise 3x3 conv and its GELU  (M1:488,514-520).
+ *     u: [B, Hres*Wres, Ch] = linear1 output BEFORE GELU.  w: [Ch,1,3,3] (PyTorch layout), b: [Ch].
+ *     t = dwconv3x3(gelu(u)) + b   (pre-activation, saved when t != NULL)      z = gelu(t).
+ */
+int dhz_leff_dwconv_fwd(const float* u, const float* w, const float* b, float* t, float* z, int B,
+                        int Hres, int Wres, int Ch, void* stream);
+/* du (overwritten); dw [Ch*9], db [Ch] ACCUMULATED (caller zeroes). */
+int dhz_leff_dwconv_bwd(const float* dz, const float* u, const float* t, const float* w, float* du,
+                        float* dw, float* db, int B, int Hres, int Wres, int Ch, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K10  Charbonnier loss on clamp(x,0,1)  (TR:230 + losses.py:48-52).
+ *      loss_sum (1 float, ACCUMULATED; caller zeroes) = sum sqrt((clamp(x)-y)^2 + eps^2).
+ *      The mean is loss_sum / n.  Backward: dx = gscale * d/sqrt(d^2+eps^2) inside (0,1), 0 outside
+ *      (clamp has zero gradient outside [0,1]; boundary convention of torch.clamp: pass-through at
+ *      exactly 0 or 1).  `clampd` (optional, may be NULL) receives clamp(x,0,1).
+ *      clamp01 == 0: plain CharbonnierLoss.forward(x, y) without the clamp.
+ */
+int dhz_charbonnier_fwd(const float* x, const float* y, float* clampd, float* loss_sum, int64_t n,
+                        float eps, int clamp01, void* stream);
+/* gclamp (optional): gradient arriving at clamp(x,0,1) from other consumers (the contrastive loss);
+ * dx = inside(x) * (gscale[0]*inv_n * d/sqrt(d^2+eps^2) + gclamp). */
+int dhz_charbonnier_bwd(const float* x, const float* y, const float* gscale, const float* gclamp,
+                        float* dx, int64_t n, float eps, float inv_n, int clamp01, void* stream);
+
+/* K12  AdamW step over one flat fp32 buffer (torch.optim.AdamW semantics, TR:90-92):
+ *      p *= 1 - lr*wd;  m = b1*m + (1-b1)*g;  v = b2*v + (1-b2)*g*g;
+ *      p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps).   `step` is t (>= 1).
+ *      grad_scale multiplies g first (1/world_size after a sum all-reduce). */
+int dhz_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
+                   float beta2, float eps, float wd, int step, float grad_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DEHAZE_HIP_H */

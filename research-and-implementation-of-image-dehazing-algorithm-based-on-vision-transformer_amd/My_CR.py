@@ -1,0 +1,117 @@
+"""Drop-in for Uformer_ProbSparse/My_CR.py: Vgg19 feature slicer (My_CR.py:56-86) and ContrastLoss
+(My_CR.py:89-123), device-agnostic (the reference hard-codes `.cuda()`, My_CR.py:94).
+
+VGG19 weights: the reference pulls torchvision's ImageNet checkpoint at run time (My_CR.py:59).  That
+file is a third-party artefact and there is no network here, so `Vgg19` loads a user-supplied
+state_dict when given (`weights=` or $DEHAZE_VGG19_WEIGHTS, torchvision `features.N.*` or
+`sliceK.N.*` keys) and otherwise falls back to SEEDED RANDOM weights (same FLOPs; flagged with a
+warning).  No ImageNet mean/std normalisation is applied - the reference applies none either.
+"""
+import os
+import warnings
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+# torchvision cfg 'E' up to features[29]; slice boundaries of My_CR.py:65-74
+_CFG = (64, 64, 'M', 128, 128, 'M', 256, 256, 256, 256, 'M', 512, 512, 512, 512, 'M', 512)
+_SLICES = ((0, 2), (2, 7), (7, 12), (12, 21), (21, 30))
+
+
+def _feature_layers():
+    layers, cin = [], 3
+    for v in _CFG:
+        if v == 'M':
+            layers.append(nn.MaxPool2d(kernel_size=2, stride=2))
+        else:
+            layers += [nn.Conv2d(cin, v, kernel_size=3, padding=1), nn.ReLU(inplace=True)]
+            cin = v
+    return layers          # 30 entries = torchvision vgg19().features[0:30]
+
+
+def seeded_vgg_init_(layers, seed=1905):
+    g = torch.Generator().manual_seed(seed)
+    full = (64, 64, 'M', 128, 128, 'M', 256, 256, 256, 256, 'M', 512, 512, 512, 512, 'M', 512, 512, 512, 512, 'M')
+    convs = [m for m in layers if isinstance(m, nn.Conv2d)]
+    ci, cin = 0, 3
+    for v in full:                      # draw for all 16 convs so the stream matches a full vgg19 init
+        if v == 'M':
+            continue
+        w = torch.randn(v, cin, 3, 3, generator=g) * (2.0 / (cin * 9)) ** 0.5
+        b = torch.randn(v, generator=g) * 0.05
+        if ci < len(convs):
+            convs[ci].weight.data.copy_(w)
+            convs[ci].bias.data.copy_(b)
+        ci += 1
+        cin = v
+
+
+class Vgg19(nn.Module):
+    def __init__(self, requires_grad=False, weights=None):
+        super().__init__()
+        feats = _feature_layers()
+        for k, (lo, hi) in enumerate(_SLICES, 1):
+            seq = nn.Sequential()
+            for x in range(lo, hi):
+                seq.add_module(str(x), feats[x])
+            setattr(self, f"slice{k}", seq)
+        weights = weights or os.environ.get("DEHAZE_VGG19_WEIGHTS")
+        if weights:
+            sd = torch.load(weights, map_location="cpu")
+            sd = sd.get("state_dict", sd)
+            mine = self.state_dict()
+            for k in mine:
+                n = k.split(".", 1)[1]                      # 'slice3.7.weight' -> '7.weight'
+                src = sd.get(k, sd.get("features." + n))
+                if src is None:
+                    raise KeyError(f"VGG19 weight file lacks {k} / features.{n}")
+                mine[k].copy_(src)
+            self.pretrained = True
+        else:
+            warnings.warn("Vgg19: no ImageNet checkpoint available offline - using SEEDED RANDOM weights "
+                          "(set DEHAZE_VGG19_WEIGHTS=/path/to/vgg19-dcbb9e9d.pth for the reference behaviour)")
+            seeded_vgg_init_(feats)
+            self.pretrained = False
+        if not requires_grad:
+            for p in self.parameters():
+                p.requires_grad = False
+
+    def forward(self, X):
+        h1 = self.slice1(X)
+        h2 = self.slice2(h1)
+        h3 = self.slice3(h2)
+        h4 = self.slice4(h3)
+        h5 = self.slice5(h4)
+        return [h1, h2, h3, h4, h5]
+
+
+class ContrastLoss(nn.Module):
+    """sum_i w_i * L1(a_i,p_i) / (L1(a_i,n_i) + 1e-7), w = [1/32,1/16,1/8,1/4,1]; ablation -> numerator
+    only.  Returns (loss, all_ap, all_an) like the reference."""
+
+    def __init__(self, ablation=False, weights=None):
+        super().__init__()
+        self.vgg = Vgg19(weights=weights)
+        self.l1 = nn.L1Loss()
+        self.weights = [1.0 / 32, 1.0 / 16, 1.0 / 8, 1.0 / 4, 1.0]
+        self.ab = ablation
+
+    def forward(self, a, p, n):
+        # p and n never need gradients: one batched VGG pass for both, one (with grad) for a
+        with torch.no_grad():
+            pn = self.vgg(torch.cat([p, n], 0)) if not self.ab else self.vgg(p)
+        a_vgg = self.vgg(a)
+        B = a.shape[0]
+        loss, all_ap, all_an = 0, 0, 0
+        for i in range(len(a_vgg)):
+            d_ap = self.l1(a_vgg[i], pn[i][:B])
+            all_ap = all_ap + d_ap
+            if not self.ab:
+                d_an = self.l1(a_vgg[i], pn[i][B:])
+                all_an = all_an + d_an
+                contrastive = d_ap / (d_an + 1e-7)
+            else:
+                contrastive = d_ap
+            loss = loss + self.weights[i] * contrastive
+        return loss, all_ap, all_an

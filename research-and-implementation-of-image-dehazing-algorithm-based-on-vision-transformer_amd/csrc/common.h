@@ -1,0 +1,64 @@
+// Shared helpers for the gfx950 kernels (wave64, fp32-input MFMA).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "dehaze_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+void dhz_set_error(const char* fmt, ...);
+
+#define DHZ_REQUIRE(cond, ...)            \
+    do {                                  \
+        if (!(cond)) {                    \
+            dhz_set_error(__VA_ARGS__);   \
+            return DHZ_EINVAL;            \
+        }                                 \
+    } while (0)
+
+#define DHZ_CHECK_LAUNCH(name)                                                   \
+    do {                                                                         \
+        hipError_t e_ = hipGetLastError();                                       \
+        if (e_ != hipSuccess) {                                                  \
+            dhz_set_error("%s: launch failed: %s", name, hipGetErrorString(e_)); \
+            return DHZ_ELAUNCH;                                                  \
+        }                                                                        \
+    } while (0)
+
+// v_mfma_f32_16x16x4_f32: D[16x16] += A[16x4] * B[4x16].  lane l: a = A[l&15][l>>4], b = B[l>>4][l&15];
+// acc[j] = D[4*(l>>4)+j][l&15].
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 acc) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+}
+
+// One 16x16 output tile from LDS-resident operands with arbitrary strides:
+//   A(i,k) = A[i*a_rs + k*a_ks]   (i = 0..15)        B(k,j) = B[k*b_ks + j*b_rs]   (j = 0..15)
+// K = 4*KSTEPS.  The contraction index visited by lane group g at step s is k = 4s+g.
+template <int KSTEPS>
+__device__ __forceinline__ f32x4 tile_mma(const float* __restrict__ A, int a_rs, int a_ks,
+                                          const float* __restrict__ B, int b_rs, int b_ks, f32x4 acc) {
+    const int lane = threadIdx.x & 63;
+    const int i = lane & 15, g = lane >> 4;
+    const float* ap = A + i * a_rs + g * a_ks;
+    const float* bp = B + i * b_rs + g * b_ks;
+#pragma unroll
+    for (int s = 0; s < KSTEPS; ++s) acc = mfma16(ap[4 * s * a_ks], bp[4 * s * b_ks], acc);
+    return acc;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// position of token (hh,ww) of an Hres x Wres map inside the (shifted) window layout:
+// shifted map coords h' = (hh - shift) mod H  (torch.roll(x, -shift): shifted[h'] = x[(h'+shift)%H]),
+// window id = (h'/8)*(W/8) + w'/8, token in window = (h'%8)*8 + w'%8.
+__device__ __forceinline__ int window_slot(int hh, int ww, int Hres, int Wres, int shift) {
+    int hs = hh - shift; if (hs < 0) hs += Hres;
+    int ws = ww - shift; if (ws < 0) ws += Wres;
+    return ((hs >> 3) * (Wres >> 3) + (ws >> 3)) * 64 + (hs & 7) * 8 + (ws & 7);
+}

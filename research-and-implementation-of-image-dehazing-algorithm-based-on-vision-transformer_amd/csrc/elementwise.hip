@@ -1,0 +1,535 @@
+// HBM-bound kernels around the window attention: K1 (LN + shift + partition), K4-tail (reverse +
+// un-shift + residual), K5-middle (LeFF depthwise 3x3 with both GELUs, token layout), K10 (Charbonnier)
+// and K12 (AdamW).  All are single-pass, float4-vectorised, with the roll / partition / reverse
+// permutations folded into address arithmetic (never materialised).
+#include <math.h>
+#include "common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------ K1
+// One token = C floats.  LPT lanes cooperate on a token (C/4 float4, up to 4 per lane).
+template <int VPL>   // float4 per lane
+__global__ __launch_bounds__(256) void ln_partition_fwd_kernel(const float* __restrict__ x,
+                                                               const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, float* __restrict__ xw,
+                                                               float* __restrict__ stats, int ntok, int Hres, int Wres,
+                                                               int C, int shift, int lpt, int partition) {
+    const int tpw = 64 / lpt;                                  // tokens per wave
+    const int lane = threadIdx.x & 63;
+    const int sub = lane / lpt, li = lane % lpt;
+    const int wave_global = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    const int HW = Hres * Wres;
+    const float invC = 1.0f / (float)C;
+    float4 gm[VPL], bt[VPL];
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) {
+        gm[v] = reinterpret_cast<const float4*>(gamma)[li + v * lpt];
+        bt[v] = reinterpret_cast<const float4*>(beta)[li + v * lpt];
+    }
+    for (int base = wave_global * tpw; base < ntok; base += nwaves * tpw) {
+        const int tok = base + sub;
+        const bool ok = tok < ntok;
+        float4 xv[VPL];
+        float s = 0.f;
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) {
+            xv[v] = ok ? reinterpret_cast<const float4*>(x + (size_t)tok * C)[li + v * lpt] : make_float4(0, 0, 0, 0);
+            s += xv[v].x + xv[v].y + xv[v].z + xv[v].w;
+        }
+        for (int o = 1; o < lpt; o <<= 1) s += __shfl_xor(s, o);
+        const float mean = s * invC;
+        float var = 0.f;
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) {
+            const float a = xv[v].x - mean, b = xv[v].y - mean, c = xv[v].z - mean, d = xv[v].w - mean;
+            var += a * a + b * b + c * c + d * d;
+        }
+        for (int o = 1; o < lpt; o <<= 1) var += __shfl_xor(var, o);
+        const float rstd = rsqrtf(var * invC + 1e-5f);
+        if (ok) {
+            const int bimg = tok / HW, p = tok % HW;
+            const size_t dst = partition ? (size_t)bimg * HW + window_slot(p / Wres, p % Wres, Hres, Wres, shift) : (size_t)tok;
+#pragma unroll
+            for (int v = 0; v < VPL; ++v) {
+                float4 y;
+                y.x = (xv[v].x - mean) * rstd * gm[v].x + bt[v].x;
+                y.y = (xv[v].y - mean) * rstd * gm[v].y + bt[v].y;
+                y.z = (xv[v].z - mean) * rstd * gm[v].z + bt[v].z;
+                y.w = (xv[v].w - mean) * rstd * gm[v].w + bt[v].w;
+                reinterpret_cast<float4*>(xw + dst * C)[li + v * lpt] = y;
+            }
+            if (li == 0 && stats) *reinterpret_cast<float2*>(stats + 2 * (size_t)tok) = make_float2(mean, rstd);
+        }
+    }
+}
+
+template <int VPL>
+__global__ __launch_bounds__(256) void ln_partition_bwd_kernel(const float* __restrict__ dxw,
+                                                               const float* __restrict__ x,
+                                                               const float* __restrict__ gamma,
+                                                               const float* __restrict__ stats, float* __restrict__ dx,
+                                                               float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                               int ntok, int Hres, int Wres, int C, int shift, int lpt,
+                                                               int partition, int accumulate) {
+    __shared__ float red[2 * 1024];                            // dgamma | dbeta  (C <= 1024)
+    const int tpw = 64 / lpt;
+    const int lane = threadIdx.x & 63;
+    const int sub = lane / lpt, li = lane % lpt;
+    const int wave_global = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    const int HW = Hres * Wres;
+    const float invC = 1.0f / (float)C;
+    for (int e = threadIdx.x; e < 2 * C; e += blockDim.x) red[e] = 0.f;
+    __syncthreads();
+    float4 gm[VPL], dg[VPL], db[VPL];
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) {
+        gm[v] = reinterpret_cast<const float4*>(gamma)[li + v * lpt];
+        dg[v] = make_float4(0, 0, 0, 0);
+        db[v] = make_float4(0, 0, 0, 0);
+    }
+    for (int base = wave_global * tpw; base < ntok; base += nwaves * tpw) {
+        const int tok = base + sub;
+        const bool ok = tok < ntok;
+        float4 xh[VPL], dy[VPL];
+        float mean = 0.f, rstd = 0.f;
+        size_t src = 0;
+        if (ok) {
+            const float2 st = *reinterpret_cast<const float2*>(stats + 2 * (size_t)tok);
+            mean = st.x; rstd = st.y;
+            const int bimg = tok / HW, p = tok % HW;
+            src = partition ? (size_t)bimg * HW + window_slot(p / Wres, p % Wres, Hres, Wres, shift) : (size_t)tok;
+        }
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) {
+            if (ok) {
+                const float4 xv = reinterpret_cast<const float4*>(x + (size_t)tok * C)[li + v * lpt];
+                dy[v] = reinterpret_cast<const float4*>(dxw + src * C)[li + v * lpt];
+                xh[v] = make_float4((xv.x - mean) * rstd, (xv.y - mean) * rstd, (xv.z - mean) * rstd, (xv.w - mean) * rstd);
+            } else {
+                dy[v] = make_float4(0, 0, 0, 0);
+                xh[v] = make_float4(0, 0, 0, 0);
+            }
+            dg[v].x += dy[v].x * xh[v].x; dg[v].y += dy[v].y * xh[v].y; dg[v].z += dy[v].z * xh[v].z; dg[v].w += dy[v].w * xh[v].w;
+            db[v].x += dy[v].x; db[v].y += dy[v].y; db[v].z += dy[v].z; db[v].w += dy[v].w;
+            // dxhat = dy * gamma
+            dy[v].x *= gm[v].x; dy[v].y *= gm[v].y; dy[v].z *= gm[v].z; dy[v].w *= gm[v].w;
+            s1 += dy[v].x + dy[v].y + dy[v].z + dy[v].w;
+            s2 += dy[v].x * xh[v].x + dy[v].y * xh[v].y + dy[v].z * xh[v].z + dy[v].w * xh[v].w;
+        }
+        for (int o = 1; o < lpt; o <<= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+        s1 *= invC; s2 *= invC;
+        if (ok) {
+#pragma unroll
+            for (int v = 0; v < VPL; ++v) {
+                float4 r;
+                r.x = rstd * (dy[v].x - s1 - xh[v].x * s2);
+                r.y = rstd * (dy[v].y - s1 - xh[v].y * s2);
+                r.z = rstd * (dy[v].z - s1 - xh[v].z * s2);
+                r.w = rstd * (dy[v].w - s1 - xh[v].w * s2);
+                float4* dst = reinterpret_cast<float4*>(dx + (size_t)tok * C) + li + v * lpt;
+                if (accumulate) { const float4 o4 = *dst; r.x += o4.x; r.y += o4.y; r.z += o4.z; r.w += o4.w; }
+                *dst = r;
+            }
+        }
+    }
+    // reduce dgamma/dbeta: lanes with equal li inside the wave, then waves through LDS, then one atomic per channel
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) {
+        for (int o = lpt; o < 64; o <<= 1) {
+            dg[v].x += __shfl_xor(dg[v].x, o); dg[v].y += __shfl_xor(dg[v].y, o);
+            dg[v].z += __shfl_xor(dg[v].z, o); dg[v].w += __shfl_xor(dg[v].w, o);
+            db[v].x += __shfl_xor(db[v].x, o); db[v].y += __shfl_xor(db[v].y, o);
+            db[v].z += __shfl_xor(db[v].z, o); db[v].w += __shfl_xor(db[v].w, o);
+        }
+        if (sub == 0) {
+            const int c = 4 * (li + v * lpt);
+            atomicAdd(&red[c + 0], dg[v].x); atomicAdd(&red[c + 1], dg[v].y);
+            atomicAdd(&red[c + 2], dg[v].z); atomicAdd(&red[c + 3], dg[v].w);
+            atomicAdd(&red[C + c + 0], db[v].x); atomicAdd(&red[C + c + 1], db[v].y);
+            atomicAdd(&red[C + c + 2], db[v].z); atomicAdd(&red[C + c + 3], db[v].w);
+        }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < C; e += blockDim.x) {
+        atomicAdd(dgamma + e, red[e]);
+        atomicAdd(dbeta + e, red[C + e]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ K4 tail
+template <bool BWD>
+__global__ __launch_bounds__(256) void reverse_residual_kernel(const float* __restrict__ a,        // yw (fwd) / dout (bwd)
+                                                               const float* __restrict__ shortcut,
+                                                               const float* __restrict__ scale, float* __restrict__ o,
+                                                               int ntok, int Hres, int Wres, int C4, int shift, int partition) {
+    const int HW = Hres * Wres;
+    const size_t total = (size_t)ntok * C4;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int tok = (int)(e / C4), c = (int)(e % C4);
+        const int bimg = tok / HW, p = tok % HW;
+        const size_t slot = partition ? (size_t)bimg * HW + window_slot(p / Wres, p % Wres, Hres, Wres, shift) : (size_t)tok;
+        const float sc = scale ? scale[bimg] : 1.0f;
+        if (!BWD) {
+            const float4 y = reinterpret_cast<const float4*>(a)[slot * C4 + c];
+            const float4 s = reinterpret_cast<const float4*>(shortcut)[e];
+            reinterpret_cast<float4*>(o)[e] = make_float4(s.x + sc * y.x, s.y + sc * y.y, s.z + sc * y.z, s.w + sc * y.w);
+        } else {
+            const float4 g = reinterpret_cast<const float4*>(a)[e];
+            reinterpret_cast<float4*>(o)[slot * C4 + c] = make_float4(sc * g.x, sc * g.y, sc * g.z, sc * g.w);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ K5 middle
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_grad_f(float x) {
+    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+    const float pdf = 0.39894228040143267794f * expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}
+
+constexpr int TW = 16, TH = 8;                 // spatial tile (positions)
+constexpr int HWID = TW + 2, HHGT = TH + 2;    // with halo
+constexpr int CT = 32;                         // channels per workgroup (128 B per position)
+
+// LDS tile: [HHGT][HWID][CT] floats
+__global__ __launch_bounds__(256) void leff_dwconv_fwd_kernel(const float* __restrict__ u, const float* __restrict__ w,
+                                                              const float* __restrict__ bconv, float* __restrict__ tpre,
+                                                              float* __restrict__ z, int Hres, int Wres, int Ch,
+                                                              int tiles_x, int tiles_y) {
+    __shared__ __attribute__((aligned(16))) float g[HHGT * HWID * CT];
+    const int t = threadIdx.x;
+    const int cg = blockIdx.x % (Ch / CT);
+    int rest = blockIdx.x / (Ch / CT);
+    const int tx = rest % tiles_x; rest /= tiles_x;
+    const int ty = rest % tiles_y;
+    const int bimg = rest / tiles_y;
+    const int c4 = t & 7, ch0 = cg * CT + c4 * 4;
+    const int x0 = tx * TW - 1, y0 = ty * TH - 1;
+    const float* ub = u + (size_t)bimg * Hres * Wres * Ch;
+    // stage gelu(u) with a 1-pixel halo (zero outside the image: Conv2d padding=1)
+    for (int pos = t >> 3; pos < HHGT * HWID; pos += 32) {
+        const int yy = y0 + pos / HWID, xx = x0 + pos % HWID;
+        float4 val = make_float4(0, 0, 0, 0);
+        if (yy >= 0 && yy < Hres && xx >= 0 && xx < Wres) {
+            const float4 uv = *reinterpret_cast<const float4*>(ub + ((size_t)yy * Wres + xx) * Ch + ch0);
+            val = make_float4(gelu_f(uv.x), gelu_f(uv.y), gelu_f(uv.z), gelu_f(uv.w));
+        }
+        *reinterpret_cast<float4*>(&g[pos * CT + c4 * 4]) = val;
+    }
+    float wk[4][9];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int kk = 0; kk < 9; ++kk) wk[c][kk] = w[(ch0 + c) * 9 + kk];
+    const float4 bb = *reinterpret_cast<const float4*>(bconv + ch0);
+    __syncthreads();
+    for (int pos = t >> 3; pos < TH * TW; pos += 32) {
+        const int py = pos / TW, px = pos % TW;
+        const int yy = ty * TH + py, xx = tx * TW + px;
+        if (yy >= Hres || xx >= Wres) continue;
+        float4 acc = bb;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const float4 gv = *reinterpret_cast<const float4*>(&g[((py + ky) * HWID + px + kx) * CT + c4 * 4]);
+                acc.x += wk[0][ky * 3 + kx] * gv.x; acc.y += wk[1][ky * 3 + kx] * gv.y;
+                acc.z += wk[2][ky * 3 + kx] * gv.z; acc.w += wk[3][ky * 3 + kx] * gv.w;
+            }
+        const size_t o = ((size_t)bimg * Hres * Wres + (size_t)yy * Wres + xx) * Ch + ch0;
+        if (tpre) *reinterpret_cast<float4*>(tpre + o) = acc;
+        *reinterpret_cast<float4*>(z + o) = make_float4(gelu_f(acc.x), gelu_f(acc.y), gelu_f(acc.z), gelu_f(acc.w));
+    }
+}
+
+// Backward: persistent over tiles of one channel group so that dw/db are accumulated in registers and
+// hit global memory with one atomic per (channel, tap) per workgroup.
+__global__ __launch_bounds__(256) void leff_dwconv_bwd_kernel(const float* __restrict__ dz, const float* __restrict__ u,
+                                                              const float* __restrict__ tpre, const float* __restrict__ w,
+                                                              float* __restrict__ du, float* __restrict__ dw,
+                                                              float* __restrict__ db, int B, int Hres, int Wres, int Ch,
+                                                              int tiles_x, int tiles_y, int wg_per_cg) {
+    __shared__ __attribute__((aligned(16))) float gs[HHGT * HWID * CT];    // gelu(u) with halo
+    __shared__ __attribute__((aligned(16))) float ds[HHGT * HWID * CT];    // dt = dz * gelu'(t) with halo
+    __shared__ float red[32][CT];                                           // [pos-slot][channel] reduction scratch
+    const int t = threadIdx.x;
+    const int cg = blockIdx.x % (Ch / CT);
+    const int wslot = blockIdx.x / (Ch / CT);
+    const int c4 = t & 7, ch0 = cg * CT + c4 * 4;
+    float wk[4][9], dwk[4][9], dbk[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int kk = 0; kk < 9; ++kk) { wk[c][kk] = w[(ch0 + c) * 9 + kk]; dwk[c][kk] = 0.f; }
+    const int ntiles = B * tiles_x * tiles_y;
+    for (int tile = wslot; tile < ntiles; tile += wg_per_cg) {
+        const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, bimg = tile / (tiles_x * tiles_y);
+        const int x0 = tx * TW - 1, y0 = ty * TH - 1;
+        const size_t ib = (size_t)bimg * Hres * Wres;
+        __syncthreads();
+        for (int pos = t >> 3; pos < HHGT * HWID; pos += 32) {
+            const int yy = y0 + pos / HWID, xx = x0 + pos % HWID;
+            float4 gv = make_float4(0, 0, 0, 0), dv = make_float4(0, 0, 0, 0);
+            if (yy >= 0 && yy < Hres && xx >= 0 && xx < Wres) {
+                const size_t o = (ib + (size_t)yy * Wres + xx) * Ch + ch0;
+                const float4 uv = *reinterpret_cast<const float4*>(u + o);
+                const float4 tv = *reinterpret_cast<const float4*>(tpre + o);
+                const float4 zv = *reinterpret_cast<const float4*>(dz + o);
+                gv = make_float4(gelu_f(uv.x), gelu_f(uv.y), gelu_f(uv.z), gelu_f(uv.w));
+                dv = make_float4(zv.x * gelu_grad_f(tv.x), zv.y * gelu_grad_f(tv.y), zv.z * gelu_grad_f(tv.z),
+                                 zv.w * gelu_grad_f(tv.w));
+            }
+            *reinterpret_cast<float4*>(&gs[pos * CT + c4 * 4]) = gv;
+            *reinterpret_cast<float4*>(&ds[pos * CT + c4 * 4]) = dv;
+        }
+        __syncthreads();
+        for (int pos = t >> 3; pos < TH * TW; pos += 32) {
+            const int py = pos / TW, px = pos % TW;
+            const int yy = ty * TH + py, xx = tx * TW + px;
+            if (yy >= Hres || xx >= Wres) continue;
+            // dg[p] = sum_k w[k] * dt[p - off(k)]   (transpose of the forward correlation)
+            float4 dg = make_float4(0, 0, 0, 0);
+            const float4 dtc = *reinterpret_cast<const float4*>(&ds[((py + 1) * HWID + px + 1) * CT + c4 * 4]);
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const float4 dn = *reinterpret_cast<const float4*>(&ds[((py + 2 - ky) * HWID + px + 2 - kx) * CT + c4 * 4]);
+                    dg.x += wk[0][ky * 3 + kx] * dn.x; dg.y += wk[1][ky * 3 + kx] * dn.y;
+                    dg.z += wk[2][ky * 3 + kx] * dn.z; dg.w += wk[3][ky * 3 + kx] * dn.w;
+                    const float4 gn = *reinterpret_cast<const float4*>(&gs[((py + ky) * HWID + px + kx) * CT + c4 * 4]);
+                    dwk[0][ky * 3 + kx] += dtc.x * gn.x; dwk[1][ky * 3 + kx] += dtc.y * gn.y;
+                    dwk[2][ky * 3 + kx] += dtc.z * gn.z; dwk[3][ky * 3 + kx] += dtc.w * gn.w;
+                }
+            dbk[0] += dtc.x; dbk[1] += dtc.y; dbk[2] += dtc.z; dbk[3] += dtc.w;
+            const size_t o = (ib + (size_t)yy * Wres + xx) * Ch + ch0;
+            const float4 uv = *reinterpret_cast<const float4*>(u + o);
+            *reinterpret_cast<float4*>(du + o) = make_float4(dg.x * gelu_grad_f(uv.x), dg.y * gelu_grad_f(uv.y),
+                                                             dg.z * gelu_grad_f(uv.z), dg.w * gelu_grad_f(uv.w));
+        }
+    }
+    // reduce the 32 position-slots (t>>3) that share a channel quad, one quantity at a time
+    const int ps = t >> 3;
+    for (int kk = 0; kk < 10; ++kk) {
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < 4; ++c) red[ps][c4 * 4 + c] = (kk < 9) ? dwk[c][kk] : dbk[c];
+        __syncthreads();
+        if (t < CT) {
+            float s = 0.f;
+#pragma unroll
+            for (int p = 0; p < 32; ++p) s += red[p][t];
+            if (kk < 9) atomicAdd(dw + (cg * CT + t) * 9 + kk, s);
+            else atomicAdd(db + cg * CT + t, s);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ K10
+__global__ __launch_bounds__(256) void charbonnier_fwd_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                              float* __restrict__ clampd, float* __restrict__ loss_sum,
+                                                              int64_t n4, float eps2, int clamp01) {
+    __shared__ float part[4];
+    float s = 0.f;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n4; e += (int64_t)gridDim.x * blockDim.x) {
+        float4 xv = reinterpret_cast<const float4*>(x)[e];
+        const float4 yv = reinterpret_cast<const float4*>(y)[e];
+        if (clamp01) {
+            xv.x = fminf(fmaxf(xv.x, 0.f), 1.f); xv.y = fminf(fmaxf(xv.y, 0.f), 1.f);
+            xv.z = fminf(fmaxf(xv.z, 0.f), 1.f); xv.w = fminf(fmaxf(xv.w, 0.f), 1.f);
+        }
+        if (clampd) reinterpret_cast<float4*>(clampd)[e] = xv;
+        const float a = xv.x - yv.x, b = xv.y - yv.y, c = xv.z - yv.z, d = xv.w - yv.w;
+        s += sqrtf(a * a + eps2) + sqrtf(b * b + eps2) + sqrtf(c * c + eps2) + sqrtf(d * d + eps2);
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(loss_sum, part[0] + part[1] + part[2] + part[3]);
+}
+
+__global__ __launch_bounds__(256) void charbonnier_bwd_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                              const float* __restrict__ gscale, const float* __restrict__ gclamp,
+                                                              float* __restrict__ dx, int64_t n4, float eps2, float inv_n, int clamp01) {
+    const float gs = (gscale ? gscale[0] : 1.0f) * inv_n;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n4; e += (int64_t)gridDim.x * blockDim.x) {
+        const float4 xv = reinterpret_cast<const float4*>(x)[e];
+        const float4 yv = reinterpret_cast<const float4*>(y)[e];
+        float4 gc = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (gclamp) gc = reinterpret_cast<const float4*>(gclamp)[e];
+        auto f = [&](float xx, float yy, float extra) {
+            if (clamp01 && !(xx >= 0.f && xx <= 1.f)) return 0.f;   // torch.clamp backward: pass-through on [0,1]
+            const float d = xx - yy;
+            return gs * d / sqrtf(d * d + eps2) + extra;
+        };
+        reinterpret_cast<float4*>(dx)[e] = make_float4(f(xv.x, yv.x, gc.x), f(xv.y, yv.y, gc.y), f(xv.z, yv.z, gc.z), f(xv.w, yv.w, gc.w));
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ K12
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                    float* __restrict__ m, float* __restrict__ v, int64_t n, float lr,
+                                                    float b1, float b2, float eps, float wd, float step_size,
+                                                    float bc2_sqrt, float gscale) {
+    const int64_t n4 = n >> 2;
+    auto upd = [&](float& pp, float gg, float& mm, float& vv) {
+        gg *= gscale;
+        pp *= 1.0f - lr * wd;
+        mm = b1 * mm + (1.0f - b1) * gg;
+        vv = b2 * vv + (1.0f - b2) * gg * gg;
+        const float denom = sqrtf(vv) / bc2_sqrt + eps;
+        pp -= step_size * (mm / denom);
+    };
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n4; e += (int64_t)gridDim.x * blockDim.x) {
+        float4 pv = reinterpret_cast<float4*>(p)[e], mv = reinterpret_cast<float4*>(m)[e], vv = reinterpret_cast<float4*>(v)[e];
+        const float4 gv = reinterpret_cast<const float4*>(g)[e];
+        upd(pv.x, gv.x, mv.x, vv.x); upd(pv.y, gv.y, mv.y, vv.y); upd(pv.z, gv.z, mv.z, vv.z); upd(pv.w, gv.w, mv.w, vv.w);
+        reinterpret_cast<float4*>(p)[e] = pv; reinterpret_cast<float4*>(m)[e] = mv; reinterpret_cast<float4*>(v)[e] = vv;
+    }
+    // tail
+    const int64_t e = (n4 << 2) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < n) upd(p[e], g[e], m[e], v[e]);
+}
+
+inline int grid_for(int64_t work_items, int per_block = 256, int cap = 256 * 8) {
+    int64_t g = (work_items + per_block - 1) / per_block;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (int)g;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------ C ABI
+static int ln_geometry(int C, int* lpt, int* vpl) {
+    if (C % 4 != 0 || C < 4 || C > 1024) return -1;
+    int c4 = C / 4, l = 1;
+    while (l < 64 && l < c4) l <<= 1;
+    if (l > c4) return -1;          // C/4 must be a power of two below 64 lanes ...
+    if (c4 % l != 0) return -1;
+    *lpt = l;
+    *vpl = c4 / l;                  // ... or a multiple of 64 float4 (C = 256, 512, 768, 1024)
+    return (*vpl >= 1 && *vpl <= 4) ? 0 : -1;
+}
+
+extern "C" int dhz_ln_partition_fwd(const float* x, const float* gamma, const float* beta, float* xw, float* stats,
+                                    int B, int Hres, int Wres, int C, int shift, int partition, void* stream) {
+    DHZ_REQUIRE(x && gamma && beta && xw, "dhz_ln_partition_fwd: null pointer");
+    DHZ_REQUIRE(B > 0 && Hres > 0 && Wres > 0 && (!partition || (Hres % 8 == 0 && Wres % 8 == 0 && shift >= 0 && shift < 8)),
+                "dhz_ln_partition_fwd: bad shape");
+    int lpt, vpl;
+    DHZ_REQUIRE(ln_geometry(C, &lpt, &vpl) == 0, "dhz_ln_partition_fwd: unsupported C=%d", C);
+    const int ntok = B * Hres * Wres;
+    const int grid = grid_for((int64_t)ntok * lpt);
+    hipStream_t s = (hipStream_t)stream;
+#define LAUNCH(V) hipLaunchKernelGGL(ln_partition_fwd_kernel<V>, dim3(grid), dim3(256), 0, s, x, gamma, beta, xw, stats, ntok, Hres, Wres, C, shift, lpt, partition)
+    switch (vpl) { case 1: LAUNCH(1); break; case 2: LAUNCH(2); break; case 3: LAUNCH(3); break; default: LAUNCH(4); }
+#undef LAUNCH
+    DHZ_CHECK_LAUNCH("dhz_ln_partition_fwd");
+    return DHZ_OK;
+}
+
+extern "C" int dhz_ln_partition_bwd(const float* dxw, const float* x, const float* gamma, const float* stats, float* dx,
+                                    float* dgamma, float* dbeta, int B, int Hres, int Wres, int C, int shift,
+                                    int partition, int accumulate, void* stream) {
+    DHZ_REQUIRE(dxw && x && gamma && stats && dx && dgamma && dbeta, "dhz_ln_partition_bwd: null pointer");
+    DHZ_REQUIRE(B > 0 && Hres > 0 && Wres > 0 && (!partition || (Hres % 8 == 0 && Wres % 8 == 0 && shift >= 0 && shift < 8)),
+                "dhz_ln_partition_bwd: bad shape");
+    int lpt, vpl;
+    DHZ_REQUIRE(ln_geometry(C, &lpt, &vpl) == 0, "dhz_ln_partition_bwd: unsupported C=%d", C);
+    const int ntok = B * Hres * Wres;
+    const int grid = grid_for((int64_t)ntok * lpt, 256, 1024);
+    hipStream_t s = (hipStream_t)stream;
+#define LAUNCH(V) hipLaunchKernelGGL(ln_partition_bwd_kernel<V>, dim3(grid), dim3(256), 0, s, dxw, x, gamma, stats, dx, dgamma, dbeta, ntok, Hres, Wres, C, shift, lpt, partition, accumulate)
+    switch (vpl) { case 1: LAUNCH(1); break; case 2: LAUNCH(2); break; case 3: LAUNCH(3); break; default: LAUNCH(4); }
+#undef LAUNCH
+    DHZ_CHECK_LAUNCH("dhz_ln_partition_bwd");
+    return DHZ_OK;
+}
+
+extern "C" int dhz_reverse_residual_fwd(const float* yw, const float* shortcut, const float* scale, float* out, int B,
+                                        int Hres, int Wres, int C, int shift, int partition, void* stream) {
+    DHZ_REQUIRE(yw && shortcut && out, "dhz_reverse_residual_fwd: null pointer");
+    DHZ_REQUIRE(B > 0 && C % 4 == 0 && (!partition || (Hres % 8 == 0 && Wres % 8 == 0 && shift >= 0 && shift < 8)),
+                "dhz_reverse_residual_fwd: bad shape");
+    const int ntok = B * Hres * Wres;
+    hipLaunchKernelGGL(reverse_residual_kernel<false>, dim3(grid_for((int64_t)ntok * (C / 4))), dim3(256), 0,
+                       (hipStream_t)stream, yw, shortcut, scale, out, ntok, Hres, Wres, C / 4, shift, partition);
+    DHZ_CHECK_LAUNCH("dhz_reverse_residual_fwd");
+    return DHZ_OK;
+}
+
+extern "C" int dhz_reverse_residual_bwd(const float* dout, const float* scale, float* dyw, int B, int Hres, int Wres,
+                                        int C, int shift, int partition, void* stream) {
+    DHZ_REQUIRE(dout && dyw, "dhz_reverse_residual_bwd: null pointer");
+    DHZ_REQUIRE(B > 0 && C % 4 == 0 && (!partition || (Hres % 8 == 0 && Wres % 8 == 0 && shift >= 0 && shift < 8)),
+                "dhz_reverse_residual_bwd: bad shape");
+    const int ntok = B * Hres * Wres;
+    hipLaunchKernelGGL(reverse_residual_kernel<true>, dim3(grid_for((int64_t)ntok * (C / 4))), dim3(256), 0,
+                       (hipStream_t)stream, dout, nullptr, scale, dyw, ntok, Hres, Wres, C / 4, shift, partition);
+    DHZ_CHECK_LAUNCH("dhz_reverse_residual_bwd");
+    return DHZ_OK;
+}
+
+extern "C" int dhz_leff_dwconv_fwd(const float* u, const float* w, const float* b, float* t, float* z, int B, int Hres,
+                                   int Wres, int Ch, void* stream) {
+    DHZ_REQUIRE(u && w && b && z, "dhz_leff_dwconv_fwd: null pointer");
+    DHZ_REQUIRE(B > 0 && Hres > 0 && Wres > 0 && Ch % CT == 0, "dhz_leff_dwconv_fwd: Ch=%d must be a multiple of %d", Ch, CT);
+    const int tiles_x = (Wres + TW - 1) / TW, tiles_y = (Hres + TH - 1) / TH;
+    const int grid = B * tiles_x * tiles_y * (Ch / CT);
+    hipLaunchKernelGGL(leff_dwconv_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, u, w, b, t, z, Hres, Wres,
+                       Ch, tiles_x, tiles_y);
+    DHZ_CHECK_LAUNCH("dhz_leff_dwconv_fwd");
+    return DHZ_OK;
+}
+
+extern "C" int dhz_leff_dwconv_bwd(const float* dz, const float* u, const float* t, const float* w, float* du, float* dw,
+                                   float* db, int B, int Hres, int Wres, int Ch, void* stream) {
+    DHZ_REQUIRE(dz && u && t && w && du && dw && db, "dhz_leff_dwconv_bwd: null pointer");
+    DHZ_REQUIRE(B > 0 && Hres > 0 && Wres > 0 && Ch % CT == 0, "dhz_leff_dwconv_bwd: Ch=%d must be a multiple of %d", Ch, CT);
+    const int tiles_x = (Wres + TW - 1) / TW, tiles_y = (Hres + TH - 1) / TH;
+    const int ntiles = B * tiles_x * tiles_y, ncg = Ch / CT;
+    int wg_per_cg = 1536 / ncg;
+    if (wg_per_cg < 1) wg_per_cg = 1;
+    if (wg_per_cg > ntiles) wg_per_cg = ntiles;
+    hipLaunchKernelGGL(leff_dwconv_bwd_kernel, dim3(wg_per_cg * ncg), dim3(256), 0, (hipStream_t)stream, dz, u, t, w, du,
+                       dw, db, B, Hres, Wres, Ch, tiles_x, tiles_y, wg_per_cg);
+    DHZ_CHECK_LAUNCH("dhz_leff_dwconv_bwd");
+    return DHZ_OK;
+}
+
+extern "C" int dhz_charbonnier_fwd(const float* x, const float* y, float* clampd, float* loss_sum, int64_t n, float eps,
+                                   int clamp01, void* stream) {
+    DHZ_REQUIRE(x && y && loss_sum && n > 0 && n % 4 == 0, "dhz_charbonnier_fwd: bad arguments (n must be a multiple of 4)");
+    hipLaunchKernelGGL(charbonnier_fwd_kernel, dim3(grid_for(n / 4, 256, 1024)), dim3(256), 0, (hipStream_t)stream, x, y,
+                       clampd, loss_sum, n / 4, eps * eps, clamp01);
+    DHZ_CHECK_LAUNCH("dhz_charbonnier_fwd");
+    return DHZ_OK;
+}
+
+extern "C" int dhz_charbonnier_bwd(const float* x, const float* y, const float* gscale, const float* gclamp, float* dx,
+                                   int64_t n, float eps, float inv_n, int clamp01, void* stream) {
+    DHZ_REQUIRE(x && y && dx && n > 0 && n % 4 == 0, "dhz_charbonnier_bwd: bad arguments (n must be a multiple of 4)");
+    hipLaunchKernelGGL(charbonnier_bwd_kernel, dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream, x, y, gscale, gclamp,
+                       dx, n / 4, eps * eps, inv_n, clamp01);
+    DHZ_CHECK_LAUNCH("dhz_charbonnier_bwd");
+    return DHZ_OK;
+}
+
+extern "C" int dhz_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                              float eps, float wd, int step, float grad_scale, void* stream) {
+    DHZ_REQUIRE(p && g && m && v && n > 0 && step >= 1, "dhz_adamw_step: bad arguments");
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    const float step_size = (float)((double)lr / bc1);
+    const float bc2_sqrt = (float)sqrt(bc2);
+    hipLaunchKernelGGL(adamw_kernel, dim3(grid_for((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr,
+                       beta1, beta2, eps, wd, step_size, bc2_sqrt, grad_scale);
+    DHZ_CHECK_LAUNCH("dhz_adamw_step");
+    return DHZ_OK;
+}

@@ -1,0 +1,624 @@
+// K3 - ProbSparse window attention core (forward + backward) for gfx950.
+//
+// One 256-thread workgroup (4 wave64) per (window, head).  Q, K, V of a window-head (3 x 64 x d fp32)
+// are staged once into LDS; everything else - the sampled-score sparsity measure, the top-u selection,
+// the double softmax, bias/mask addition, A.V and the mean(V) fill - happens on chip.  The reference
+// materialises K_sample[B_,H,64,25,d], bias.repeat(B_) and mask.repeat(B) in HBM for the same result
+// (ATT:88-110, 229-230, 246-258).
+//
+// Contractions run on the fp32-input matrix pipe (v_mfma_f32_16x16x4_f32):
+//   S  = Q K^T   (64x64xd)  - dense; the 25 sampled scores per query are then *read out of S in LDS*
+//                             and the 25 selected rows of S are exactly Q_reduce K^T (ATT:150), so the
+//                             reference's two score products collapse into one MFMA product.
+//   O  = P V     (32x64xd)  - 25 selected rows padded to 32; row 25 of P is the constant 1/64 so that
+//                             row 25 of O is mean(V) (ATT:168-172) for free.
+#include "common.h"
+
+namespace {
+
+constexpr int NT = 64;     // tokens per window
+constexpr int NU = 25;     // selected queries / sampled keys
+constexpr int SS = 68;     // row stride of the 64-wide score tiles
+
+template <int D>
+struct FwdSmem {
+    static constexpr int DS = D + 4;
+    float q[NT * DS];      // Q, later P (32 x SS)
+    float k[NT * DS];
+    float v[NT * DS];
+    float s[NT * SS];      // S, later O (32 x DS)
+    float m[NT];
+    int part[4 * NT];
+    int top[32];
+    uint8_t rank[NT];
+    uint8_t idx[NT * NU];
+};
+
+__device__ __forceinline__ float row8_max(float v) {
+    v = fmaxf(v, __shfl_xor(v, 1));
+    v = fmaxf(v, __shfl_xor(v, 2));
+    v = fmaxf(v, __shfl_xor(v, 4));
+    return v;
+}
+__device__ __forceinline__ float row8_sum(float v) {
+    v += __shfl_xor(v, 1);
+    v += __shfl_xor(v, 2);
+    v += __shfl_xor(v, 4);
+    return v;
+}
+
+// Double softmax of one selected row, 8 columns per thread (8 threads per row):
+//   p1 = softmax(x);  a = p1 + bias + mask;  p2 = softmax(a)          (ATT:195, 229, 251-258, 262)
+__device__ __forceinline__ void double_softmax8(const float* x, const float* brow, const float* mrow, float* p1,
+                                                float* p2) {
+    float mx = x[0];
+#pragma unroll
+    for (int i = 1; i < 8; ++i) mx = fmaxf(mx, x[i]);
+    mx = row8_max(mx);
+    float e[8], sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { e[i] = expf(x[i] - mx); sum += e[i]; }
+    sum = row8_sum(sum);
+    float a[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { p1[i] = e[i] / sum; a[i] = p1[i]; }
+    if (brow) {
+        const float4 b0 = *reinterpret_cast<const float4*>(brow), b1 = *reinterpret_cast<const float4*>(brow + 4);
+        a[0] += b0.x; a[1] += b0.y; a[2] += b0.z; a[3] += b0.w; a[4] += b1.x; a[5] += b1.y; a[6] += b1.z; a[7] += b1.w;
+    }
+    if (mrow) {
+        const float4 b0 = *reinterpret_cast<const float4*>(mrow), b1 = *reinterpret_cast<const float4*>(mrow + 4);
+        a[0] += b0.x; a[1] += b0.y; a[2] += b0.z; a[3] += b0.w; a[4] += b1.x; a[5] += b1.y; a[6] += b1.z; a[7] += b1.w;
+    }
+    float mx2 = a[0];
+#pragma unroll
+    for (int i = 1; i < 8; ++i) mx2 = fmaxf(mx2, a[i]);
+    mx2 = row8_max(mx2);
+    float sum2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { e[i] = expf(a[i] - mx2); sum2 += e[i]; }
+    sum2 = row8_sum(sum2);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) p2[i] = e[i] / sum2;
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void ps_attn_fwd_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                          const float* __restrict__ v, int ld,
+                                                          const uint8_t* __restrict__ idx,
+                                                          const float* __restrict__ bias,
+                                                          const float* __restrict__ mask, float* __restrict__ out,
+                                                          int ldo, uint8_t* __restrict__ rank_out, int H, int nW) {
+    constexpr int DS = D + 4;
+    constexpr int F = D / 4;            // float4 per row
+    constexpr int RPP = 256 / F;        // rows per load pass
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    FwdSmem<D>& sm = *reinterpret_cast<FwdSmem<D>*>(smem_raw);
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int b = blockIdx.x / H, h = blockIdx.x % H;
+    const size_t tok0 = (size_t)b * NT;
+
+    // ---- stage Q,K,V (+ the shared sample index table) into LDS
+    {
+        const int c4 = t % F;
+#pragma unroll
+        for (int p = 0; p < NT / RPP; ++p) {
+            const int row = p * RPP + t / F;
+            const size_t g = (tok0 + row) * ld + h * D + c4 * 4;
+            *reinterpret_cast<float4*>(&sm.q[row * DS + c4 * 4]) = *reinterpret_cast<const float4*>(q + g);
+            *reinterpret_cast<float4*>(&sm.k[row * DS + c4 * 4]) = *reinterpret_cast<const float4*>(k + g);
+            *reinterpret_cast<float4*>(&sm.v[row * DS + c4 * 4]) = *reinterpret_cast<const float4*>(v + g);
+        }
+        if (t < NT * NU / 16) reinterpret_cast<uint4*>(sm.idx)[t] = reinterpret_cast<const uint4*>(idx)[t];
+    }
+    __syncthreads();
+
+    // ---- S = Q K^T : wave w owns rows 16w..16w+15, all 64 columns (4 tiles)
+    {
+        const int i = lane & 15, g = lane >> 4;
+        float a[D / 4];
+#pragma unroll
+        for (int s = 0; s < D / 4; ++s) a[s] = sm.q[(16 * w + i) * DS + 4 * s + g];
+#pragma unroll
+        for (int tc = 0; tc < 4; ++tc) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < D / 4; ++s) acc = mfma16(a[s], sm.k[(16 * tc + i) * DS + 4 * s + g], acc);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sm.s[(16 * w + 4 * g + j) * SS + 16 * tc + i] = acc[j];
+        }
+    }
+    __syncthreads();
+
+    // ---- sparsity measure M[q] = max_s S[q,idx[q,s]] - sum_s S[q,idx[q,s]] / 64      (ATT:117)
+    {
+        const int qi = t >> 2, j = t & 3;
+        float mx = -INFINITY, su = 0.f;
+        for (int s = j; s < NU; s += 4) {
+            const float val = sm.s[qi * SS + sm.idx[qi * NU + s]];
+            mx = fmaxf(mx, val);
+            su += val;
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 1)); mx = fmaxf(mx, __shfl_xor(mx, 2));
+        su += __shfl_xor(su, 1); su += __shfl_xor(su, 2);
+        if (j == 0) sm.m[qi] = mx - su * (1.0f / NT);
+    }
+    __syncthreads();
+
+    // ---- top-u by rank: rank[q] = #{j : M[j] > M[q] or (M[j] == M[q] and j < q)}    (ATT:122)
+    {
+        const int qi = t & 63;
+        const float m = sm.m[qi];
+        int cnt = 0;
+#pragma unroll
+        for (int jj = 0; jj < 16; ++jj) {
+            const int j = 16 * w + jj;
+            const float mj = sm.m[j];
+            cnt += (mj > m) || (mj == m && j < qi);
+        }
+        sm.part[w * NT + qi] = cnt;
+    }
+    __syncthreads();
+    if (t < NT) {
+        const int r = sm.part[t] + sm.part[NT + t] + sm.part[2 * NT + t] + sm.part[3 * NT + t];
+        sm.rank[t] = r < NU ? (uint8_t)r : (uint8_t)255;
+        if (r < NU) sm.top[r] = t;
+    } else if (t < NT + 32 - NU) {
+        sm.top[NU + t - NT] = 0;
+    }
+    __syncthreads();
+
+    // ---- P = softmax(softmax(scale * S[top]) + bias[top] + mask[top])  -> LDS (over the dead Q tile)
+    float* P = sm.q;
+    {
+        const int r = t >> 3, c0 = (t & 7) * 8;
+        float p2[8];
+        if (r < NU) {
+            const int qrow = sm.top[r];
+            const float scale = rsqrtf((float)D);
+            float x[8], p1[8];
+            const float4 s0 = *reinterpret_cast<const float4*>(&sm.s[qrow * SS + c0]);
+            const float4 s1 = *reinterpret_cast<const float4*>(&sm.s[qrow * SS + c0 + 4]);
+            x[0] = s0.x * scale; x[1] = s0.y * scale; x[2] = s0.z * scale; x[3] = s0.w * scale;
+            x[4] = s1.x * scale; x[5] = s1.y * scale; x[6] = s1.z * scale; x[7] = s1.w * scale;
+            const float* brow = bias ? bias + ((size_t)h * NT + qrow) * NT + c0 : nullptr;
+            const float* mrow = mask ? mask + ((size_t)(b % nW) * NT + qrow) * NT + c0 : nullptr;
+            double_softmax8(x, brow, mrow, p1, p2);
+        } else {
+            const float f = (r == NU) ? (1.0f / NT) : 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) p2[i] = f;
+        }
+        *reinterpret_cast<float4*>(&P[r * SS + c0]) = make_float4(p2[0], p2[1], p2[2], p2[3]);
+        *reinterpret_cast<float4*>(&P[r * SS + c0 + 4]) = make_float4(p2[4], p2[5], p2[6], p2[7]);
+    }
+    __syncthreads();
+
+    // ---- O = P V  (32 x D): tiles (tr, tc), tr = w&1, tc = (w>>1) + 2i ; O overwrites the dead S tile
+    float* O = sm.s;
+    {
+        const int i = lane & 15, g = lane >> 4;
+        const int tr = w & 1;
+#pragma unroll
+        for (int ii = 0; ii < D / 32; ++ii) {
+            const int tc = (w >> 1) + 2 * ii;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            acc = tile_mma<16>(P + 16 * tr * SS, SS, 1, sm.v + 16 * tc, 1, DS, acc);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) O[(16 * tr + 4 * g + j) * DS + 16 * tc + i] = acc[j];
+        }
+    }
+    __syncthreads();
+
+    // ---- scatter: selected queries get their attention row, the others mean(V) (row 25)
+    {
+        const int c4 = t % F;
+#pragma unroll
+        for (int p = 0; p < NT / RPP; ++p) {
+            const int row = p * RPP + t / F;
+            const int r = sm.rank[row] < NU ? sm.rank[row] : NU;
+            *reinterpret_cast<float4*>(out + (tok0 + row) * ldo + h * D + c4 * 4) =
+                *reinterpret_cast<const float4*>(&O[r * DS + c4 * 4]);
+        }
+        if (t < NT / 4) reinterpret_cast<uint32_t*>(rank_out + (size_t)blockIdx.x * NT)[t] =
+            reinterpret_cast<const uint32_t*>(sm.rank)[t];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ backward
+template <int D>
+struct BwdSmem {
+    static constexpr int DS = D + 4;
+    float qr[32 * DS];     // Q[top] rows (25 live)
+    float k[NT * DS];      // K        ; later dK staging
+    float v[NT * DS];      // V        ; later dV staging
+    float dor[32 * DS];    // dO[top] rows, row 25 = sum of dO over unselected queries
+    float p1[32 * SS];     // scores -> P1 ; later dQ[top] staging (32 x DS)
+    float p2[32 * SS];
+    float ds[32 * SS];     // dP2 -> dS
+    float acc[NT * NT];    // per-workgroup bias-gradient accumulator
+    float dmp[4 * D];
+    int top[32];
+    uint8_t rank[NT];
+};
+
+template <int D, bool HAS_BIAS>
+__global__ __launch_bounds__(256) void ps_attn_bwd_kernel(
+    const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v, int ld,
+    const float* __restrict__ bias, const float* __restrict__ mask, const uint8_t* __restrict__ rank_in,
+    const float* __restrict__ dout, int ldo, float* __restrict__ dq, float* __restrict__ dk, float* __restrict__ dv,
+    int ldg, float* __restrict__ dbias_part, int B_, int H, int nW) {
+    constexpr int DS = D + 4;
+    constexpr int F = D / 4;
+    constexpr int RPP = 256 / F;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    BwdSmem<D>& sm = *reinterpret_cast<BwdSmem<D>*>(smem_raw);
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int i16 = lane & 15, g = lane >> 4;
+    const int h = blockIdx.x % H;
+    const int bstep = gridDim.x / H;
+    const float scale = rsqrtf((float)D);
+
+    if (HAS_BIAS) {
+        for (int e = t; e < NT * NT / 4; e += 256) reinterpret_cast<float4*>(sm.acc)[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+
+    for (int b = blockIdx.x / H; b < B_; b += bstep) {
+        const size_t tok0 = (size_t)b * NT;
+        const size_t wh = (size_t)b * H + h;
+        __syncthreads();   // previous iteration's staging reads are done
+        if (t < NT) {
+            const uint8_t r = rank_in[wh * NT + t];
+            sm.rank[t] = r;
+            if (r < NU) sm.top[r] = t;
+        } else if (t < NT + 32 - NU) {
+            sm.top[NU + t - NT] = 0;
+        }
+        // zero the padding rows of Q[top] / dO[top]
+        for (int e = t; e < (32 - NU) * DS; e += 256) { sm.qr[NU * DS + e] = 0.f; sm.dor[NU * DS + e] = 0.f; }
+        __syncthreads();
+
+        // ---- stage K, V, Q[top], dO[top]; reduce dO over the unselected queries (mean(V) path)
+        {
+            const int c4 = t % F;
+            float4 dm = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int p = 0; p < NT / RPP; ++p) {
+                const int row = p * RPP + t / F;
+                const size_t gi = (tok0 + row) * ld + h * D + c4 * 4;
+                *reinterpret_cast<float4*>(&sm.k[row * DS + c4 * 4]) = *reinterpret_cast<const float4*>(k + gi);
+                *reinterpret_cast<float4*>(&sm.v[row * DS + c4 * 4]) = *reinterpret_cast<const float4*>(v + gi);
+                const float4 go = *reinterpret_cast<const float4*>(dout + (tok0 + row) * ldo + h * D + c4 * 4);
+                const int r = sm.rank[row];
+                if (r < NU) {
+                    *reinterpret_cast<float4*>(&sm.qr[r * DS + c4 * 4]) = *reinterpret_cast<const float4*>(q + gi);
+                    *reinterpret_cast<float4*>(&sm.dor[r * DS + c4 * 4]) = go;
+                } else {
+                    dm.x += go.x; dm.y += go.y; dm.z += go.z; dm.w += go.w;
+                }
+            }
+#pragma unroll
+            for (int o = F; o < 64; o <<= 1) {
+                dm.x += __shfl_xor(dm.x, o); dm.y += __shfl_xor(dm.y, o);
+                dm.z += __shfl_xor(dm.z, o); dm.w += __shfl_xor(dm.w, o);
+            }
+            if (lane < F) *reinterpret_cast<float4*>(&sm.dmp[w * D + lane * 4]) = dm;
+        }
+        __syncthreads();
+        if (t < D) sm.dor[NU * DS + t] = sm.dmp[t] + sm.dmp[D + t] + sm.dmp[2 * D + t] + sm.dmp[3 * D + t];
+
+        // ---- recompute scores of the selected rows: Sr = Q[top] K^T (32 x 64), 8 tiles, 2 per wave
+        {
+            const int tr = w & 1;
+#pragma unroll
+            for (int ii = 0; ii < 2; ++ii) {
+                const int tc = (w >> 1) + 2 * ii;
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                acc = tile_mma<D / 4>(sm.qr + 16 * tr * DS, DS, 1, sm.k + 16 * tc * DS, DS, 1, acc);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) sm.p1[(16 * tr + 4 * g + j) * SS + 16 * tc + i16] = acc[j];
+            }
+        }
+        __syncthreads();
+
+        // ---- P1, P2
+        {
+            const int r = t >> 3, c0 = (t & 7) * 8;
+            float p1[8], p2[8];
+            if (r < NU) {
+                const int qrow = sm.top[r];
+                float x[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) x[i] = sm.p1[r * SS + c0 + i] * scale;
+                const float* brow = bias ? bias + ((size_t)h * NT + qrow) * NT + c0 : nullptr;
+                const float* mrow = mask ? mask + ((size_t)(b % nW) * NT + qrow) * NT + c0 : nullptr;
+                double_softmax8(x, brow, mrow, p1, p2);
+            } else {
+                const float f = (r == NU) ? (1.0f / NT) : 0.f;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { p1[i] = 0.f; p2[i] = f; }
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { sm.p1[r * SS + c0 + i] = p1[i]; sm.p2[r * SS + c0 + i] = p2[i]; }
+        }
+        __syncthreads();
+
+        // ---- dV = P2^T dO[top]  (64 x D; row 25 of P2 = 1/64 carries the mean(V) path)
+        //      dP2 = dO[top] V^T (32 x 64)
+        f32x4 accv[D / 16];
+        f32x4 accp[2];
+        {
+            // dV tiles: (tn, tc): tn = w (rows 16w..), tc = 0..D/16-1
+#pragma unroll
+            for (int tc = 0; tc < D / 16; ++tc) {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                // A(i=n, k=r) = P2[r][16w+n] ; B(k=r, j=c) = dOr[r][16tc + c]
+                accv[tc] = tile_mma<8>(sm.p2 + 16 * w, 1, SS, sm.dor + 16 * tc, 1, DS, acc);
+            }
+            const int tr = w & 1;
+#pragma unroll
+            for (int ii = 0; ii < 2; ++ii) {
+                const int tc = (w >> 1) + 2 * ii;
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                // A(i=r, k=e) = dOr[16tr + r][e] ; B(k=e, j=n) = V[16tc + n][e]
+                accp[ii] = tile_mma<D / 4>(sm.dor + 16 * tr * DS, DS, 1, sm.v + 16 * tc * DS, DS, 1, acc);
+            }
+        }
+        __syncthreads();   // all reads of V done -> V tile becomes the dV staging buffer
+        {
+#pragma unroll
+            for (int tc = 0; tc < D / 16; ++tc)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) sm.v[(16 * w + 4 * g + j) * DS + 16 * tc + i16] = accv[tc][j];
+            const int tr = w & 1;
+#pragma unroll
+            for (int ii = 0; ii < 2; ++ii) {
+                const int tc = (w >> 1) + 2 * ii;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) sm.ds[(16 * tr + 4 * g + j) * SS + 16 * tc + i16] = accp[ii][j];
+            }
+        }
+        __syncthreads();
+
+        // ---- softmax backward (twice), bias-gradient accumulation; dV -> global
+        {
+            const int r = t >> 3, c0 = (t & 7) * 8;
+            float dp[8], p1[8], p2[8];
+            float dot2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                dp[i] = sm.ds[r * SS + c0 + i]; p1[i] = sm.p1[r * SS + c0 + i]; p2[i] = sm.p2[r * SS + c0 + i];
+                dot2 += dp[i] * p2[i];
+            }
+            dot2 = row8_sum(dot2);
+            float da[8], dot1 = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { da[i] = p2[i] * (dp[i] - dot2); dot1 += da[i] * p1[i]; }
+            dot1 = row8_sum(dot1);
+            if (HAS_BIAS && r < NU) {
+                float* arow = sm.acc + sm.top[r] * NT + c0;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) arow[i] += da[i];
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) sm.ds[r * SS + c0 + i] = p1[i] * (da[i] - dot1) * scale;
+
+            const int c4 = t % F;
+#pragma unroll
+            for (int p = 0; p < NT / RPP; ++p) {
+                const int row = p * RPP + t / F;
+                *reinterpret_cast<float4*>(dv + (tok0 + row) * ldg + h * D + c4 * 4) =
+                    *reinterpret_cast<const float4*>(&sm.v[row * DS + c4 * 4]);
+            }
+        }
+        __syncthreads();
+
+        // ---- dQ[top] = dS K (32 x D, K = 64) ; dK = dS^T Q[top] (64 x D, K = 32)
+        f32x4 accq[D / 32];
+        f32x4 acck[D / 16];
+        {
+            const int tr = w & 1;
+#pragma unroll
+            for (int ii = 0; ii < D / 32; ++ii) {
+                const int tc = (w >> 1) + 2 * ii;
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                // A(i=r,k=n) = dS[16tr + r][n] ; B(k=n, j=e) = K[n][16tc + e]
+                accq[ii] = tile_mma<16>(sm.ds + 16 * tr * SS, SS, 1, sm.k + 16 * tc, 1, DS, acc);
+            }
+#pragma unroll
+            for (int tc = 0; tc < D / 16; ++tc) {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                // A(i=n,k=r) = dS[r][16w + n] ; B(k=r, j=e) = Qr[r][16tc + e]
+                acck[tc] = tile_mma<8>(sm.ds + 16 * w, 1, SS, sm.qr + 16 * tc, 1, DS, acc);
+            }
+        }
+        __syncthreads();   // all reads of K / P1 done
+        {
+            const int tr = w & 1;
+            float* dqs = sm.p1;   // 32 x DS
+#pragma unroll
+            for (int ii = 0; ii < D / 32; ++ii) {
+                const int tc = (w >> 1) + 2 * ii;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) dqs[(16 * tr + 4 * g + j) * DS + 16 * tc + i16] = accq[ii][j];
+            }
+#pragma unroll
+            for (int tc = 0; tc < D / 16; ++tc)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) sm.k[(16 * w + 4 * g + j) * DS + 16 * tc + i16] = acck[tc][j];
+        }
+        __syncthreads();
+        {
+            const float* dqs = sm.p1;
+            const int c4 = t % F;
+#pragma unroll
+            for (int p = 0; p < NT / RPP; ++p) {
+                const int row = p * RPP + t / F;
+                const size_t go = (tok0 + row) * ldg + h * D + c4 * 4;
+                *reinterpret_cast<float4*>(dk + go) = *reinterpret_cast<const float4*>(&sm.k[row * DS + c4 * 4]);
+                const int r = sm.rank[row];
+                float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (r < NU) val = *reinterpret_cast<const float4*>(&dqs[r * DS + c4 * 4]);
+                *reinterpret_cast<float4*>(dq + go) = val;
+            }
+        }
+    }
+
+    if (HAS_BIAS) {
+        __syncthreads();
+        float4* dst = reinterpret_cast<float4*>(dbias_part + (size_t)blockIdx.x * NT * NT);
+        for (int e = t; e < NT * NT / 4; e += 256) dst[e] = reinterpret_cast<const float4*>(sm.acc)[e];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ small helpers
+__global__ void bias_gather_kernel(const float* __restrict__ table, float* __restrict__ bias, int H) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;   // over H*64*64
+    if (e >= H * NT * NT) return;
+    const int h = e / (NT * NT), i = (e / NT) % NT, j = e % NT;
+    const int rel = ((i >> 3) - (j >> 3) + 7) * 15 + ((i & 7) - (j & 7) + 7);
+    bias[e] = table[rel * H + h];
+}
+
+// one workgroup per head: sum the per-workgroup partials, then fold (i,j) pairs onto the 225 table rows
+__global__ __launch_bounds__(256) void bias_table_grad_kernel(const float* __restrict__ part, int parts,
+                                                              float* __restrict__ dtable, int H, int accumulate) {
+    __shared__ float sum[NT * NT];
+    const int h = blockIdx.x, t = threadIdx.x;
+    for (int e = t; e < NT * NT; e += 256) {
+        float s = 0.f;
+        for (int p = h; p < parts; p += H) s += part[(size_t)p * NT * NT + e];
+        sum[e] = s;
+    }
+    __syncthreads();
+    if (t < 225) {
+        const int dh = t / 15 - 7, dw = t % 15 - 7;
+        float s = 0.f;
+        for (int ih = 0; ih < 8; ++ih) {
+            const int jh = ih - dh;
+            if (jh < 0 || jh > 7) continue;
+            for (int iw = 0; iw < 8; ++iw) {
+                const int jw = iw - dw;
+                if (jw < 0 || jw > 7) continue;
+                s += sum[(ih * 8 + iw) * NT + jh * 8 + jw];
+            }
+        }
+        if (accumulate) dtable[t * H + h] += s; else dtable[t * H + h] = s;
+    }
+}
+
+__global__ void shift_mask_kernel(float* __restrict__ mask, int Hres, int Wres, int shift) {
+    // mask[w][i][j]; one thread per element
+    const int nWw = Wres >> 3;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    const int total = (Hres >> 3) * nWw * NT * NT;
+    if (e >= total) return;
+    const int wdx = e / (NT * NT), i = (e / NT) % NT, j = e % NT;
+    const int wh = wdx / nWw, ww = wdx % nWw;
+    auto label = [&](int tok) {
+        const int hh = wh * 8 + (tok >> 3), wc = ww * 8 + (tok & 7);
+        const int lh = hh < Hres - 8 ? 0 : (hh < Hres - shift ? 1 : 2);
+        const int lw = wc < Wres - 8 ? 0 : (wc < Wres - shift ? 1 : 2);
+        return lh * 3 + lw;
+    };
+    mask[e] = (label(i) != label(j)) ? -100.0f : 0.0f;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------ C ABI
+// LDS above 64 KiB per workgroup needs an explicit opt-in; idempotent and cheap, so done per launch.
+static void allow_smem(const void* fn, size_t bytes) {
+    if (bytes > 48 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+extern "C" int dhz_ps_attn_fwd(const float* q, const float* k, const float* v, int ld, const uint8_t* idx,
+                               const float* bias, const float* mask, float* out, int ldo, uint8_t* rank, int B_,
+                               int H, int nW, int d, void* stream) {
+    DHZ_REQUIRE(q && k && v && idx && out && rank, "dhz_ps_attn_fwd: null pointer");
+    DHZ_REQUIRE(B_ > 0 && H > 0, "dhz_ps_attn_fwd: B_=%d H=%d", B_, H);
+    DHZ_REQUIRE(d == 32 || d == 64, "dhz_ps_attn_fwd: head_dim %d unsupported (32 or 64)", d);
+    DHZ_REQUIRE(ld % 4 == 0 && ldo % 4 == 0 && ld >= H * d && ldo >= H * d, "dhz_ps_attn_fwd: bad ld %d/%d", ld, ldo);
+    DHZ_REQUIRE(!mask || (nW > 0 && B_ % nW == 0), "dhz_ps_attn_fwd: B_=%d not a multiple of nW=%d", B_, nW);
+    hipStream_t s = (hipStream_t)stream;
+    if (d == 32) {
+        allow_smem(reinterpret_cast<const void*>(&ps_attn_fwd_kernel<32>), sizeof(FwdSmem<32>));
+        hipLaunchKernelGGL(ps_attn_fwd_kernel<32>, dim3(B_ * H), dim3(256), sizeof(FwdSmem<32>), s, q, k, v, ld, idx,
+                           bias, mask, out, ldo, rank, H, nW > 0 ? nW : 1);
+    } else {
+        allow_smem(reinterpret_cast<const void*>(&ps_attn_fwd_kernel<64>), sizeof(FwdSmem<64>));
+        hipLaunchKernelGGL(ps_attn_fwd_kernel<64>, dim3(B_ * H), dim3(256), sizeof(FwdSmem<64>), s, q, k, v, ld, idx,
+                           bias, mask, out, ldo, rank, H, nW > 0 ? nW : 1);
+    }
+    DHZ_CHECK_LAUNCH("dhz_ps_attn_fwd");
+    return DHZ_OK;
+}
+
+extern "C" int dhz_ps_attn_bwd_parts(int B_, int H) {
+    if (B_ <= 0 || H <= 0) return 0;
+    const int cap = 512;
+    int per_head = cap / H;
+    if (per_head < 1) per_head = 1;
+    if (per_head > B_) per_head = B_;
+    return per_head * H;
+}
+
+template <int D, bool HB>
+static void launch_bwd(int parts, hipStream_t s, const float* q, const float* k, const float* v, int ld,
+                       const float* bias, const float* mask, const uint8_t* rank, const float* dout, int ldo,
+                       float* dq, float* dk, float* dv, int ldg, float* dbias_part, int B_, int H, int nW) {
+    const size_t smem = sizeof(BwdSmem<D>);
+    allow_smem(reinterpret_cast<const void*>(&ps_attn_bwd_kernel<D, HB>), smem);
+    hipLaunchKernelGGL((ps_attn_bwd_kernel<D, HB>), dim3(parts), dim3(256), smem, s, q, k, v, ld, bias, mask, rank,
+                       dout, ldo, dq, dk, dv, ldg, dbias_part, B_, H, nW);
+}
+
+extern "C" int dhz_ps_attn_bwd(const float* q, const float* k, const float* v, int ld, const float* bias,
+                               const float* mask, const uint8_t* rank, const float* dout, int ldo, float* dq,
+                               float* dk, float* dv, int ldg, float* dbias_part, int B_, int H, int nW, int d,
+                               void* stream) {
+    DHZ_REQUIRE(q && k && v && rank && dout && dq && dk && dv, "dhz_ps_attn_bwd: null pointer");
+    DHZ_REQUIRE(d == 32 || d == 64, "dhz_ps_attn_bwd: head_dim %d unsupported (32 or 64)", d);
+    DHZ_REQUIRE(!bias || dbias_part, "dhz_ps_attn_bwd: bias given but dbias_part is NULL");
+    DHZ_REQUIRE(ld % 4 == 0 && ldo % 4 == 0 && ldg % 4 == 0, "dhz_ps_attn_bwd: leading dims must be multiples of 4");
+    DHZ_REQUIRE(!mask || (nW > 0 && B_ % nW == 0), "dhz_ps_attn_bwd: B_=%d not a multiple of nW=%d", B_, nW);
+    hipStream_t s = (hipStream_t)stream;
+    const int parts = dhz_ps_attn_bwd_parts(B_, H);
+    if (nW <= 0) nW = 1;
+    if (d == 32) {
+        if (bias) launch_bwd<32, true>(parts, s, q, k, v, ld, bias, mask, rank, dout, ldo, dq, dk, dv, ldg, dbias_part, B_, H, nW);
+        else launch_bwd<32, false>(parts, s, q, k, v, ld, bias, mask, rank, dout, ldo, dq, dk, dv, ldg, dbias_part, B_, H, nW);
+    } else {
+        if (bias) launch_bwd<64, true>(parts, s, q, k, v, ld, bias, mask, rank, dout, ldo, dq, dk, dv, ldg, dbias_part, B_, H, nW);
+        else launch_bwd<64, false>(parts, s, q, k, v, ld, bias, mask, rank, dout, ldo, dq, dk, dv, ldg, dbias_part, B_, H, nW);
+    }
+    DHZ_CHECK_LAUNCH("dhz_ps_attn_bwd");
+    return DHZ_OK;
+}
+
+extern "C" int dhz_bias_gather(const float* table, float* bias, int H, void* stream) {
+    DHZ_REQUIRE(table && bias && H > 0, "dhz_bias_gather: bad arguments");
+    const int n = H * NT * NT;
+    hipLaunchKernelGGL(bias_gather_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, table, bias, H);
+    DHZ_CHECK_LAUNCH("dhz_bias_gather");
+    return DHZ_OK;
+}
+
+extern "C" int dhz_bias_table_grad(const float* dbias_part, int parts, float* dtable, int H, int accumulate,
+                                   void* stream) {
+    DHZ_REQUIRE(dbias_part && dtable && H > 0 && parts > 0 && parts % H == 0, "dhz_bias_table_grad: bad arguments");
+    hipLaunchKernelGGL(bias_table_grad_kernel, dim3(H), dim3(256), 0, (hipStream_t)stream, dbias_part, parts, dtable,
+                       H, accumulate);
+    DHZ_CHECK_LAUNCH("dhz_bias_table_grad");
+    return DHZ_OK;
+}
+
+extern "C" int dhz_shift_mask(float* mask, int Hres, int Wres, int shift, void* stream) {
+    DHZ_REQUIRE(mask && Hres % 8 == 0 && Wres % 8 == 0 && Hres > 8 && Wres > 8 && shift > 0 && shift < 8,
+                "dhz_shift_mask: bad arguments %dx%d shift %d", Hres, Wres, shift);
+    const int n = (Hres / 8) * (Wres / 8) * NT * NT;
+    hipLaunchKernelGGL(shift_mask_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, mask, Hres, Wres,
+                       shift);
+    DHZ_CHECK_LAUNCH("dhz_shift_mask");
+    return DHZ_OK;
+}

@@ -1,0 +1,72 @@
+"""ctypes binding of libdehaze_hip.so (C-ABI declared in include/dehaze_hip.h).
+
+There is NO fallback: if the shared object is missing the import of the product fails loudly with
+the build instruction; nothing here routes to PyTorch eager or to the CPU oracle.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdehaze_hip.so")
+
+c_f = ctypes.c_void_p      # device float*
+c_p = ctypes.c_void_p
+c_i = ctypes.c_int
+c_l = ctypes.c_int64
+c_fl = ctypes.c_float
+
+# name -> argtypes  (return type is int unless listed in _RESTYPE)
+SIGNATURES = {
+    "dhz_abi_version": [],
+    "dhz_last_error": [],
+    "dhz_ps_attn_fwd": [c_f, c_f, c_f, c_i, c_p, c_f, c_f, c_f, c_i, c_p, c_i, c_i, c_i, c_i, c_p],
+    "dhz_ps_attn_bwd_parts": [c_i, c_i],
+    "dhz_ps_attn_bwd": [c_f, c_f, c_f, c_i, c_f, c_f, c_p, c_f, c_i, c_f, c_f, c_f, c_i, c_f, c_i, c_i, c_i, c_i, c_p],
+    "dhz_bias_gather": [c_f, c_f, c_i, c_p],
+    "dhz_bias_table_grad": [c_f, c_i, c_f, c_i, c_i, c_p],
+    "dhz_shift_mask": [c_f, c_i, c_i, c_i, c_p],
+    "dhz_ln_partition_fwd": [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
+    "dhz_ln_partition_bwd": [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
+    "dhz_reverse_residual_fwd": [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
+    "dhz_reverse_residual_bwd": [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
+    "dhz_leff_dwconv_fwd": [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_p],
+    "dhz_leff_dwconv_bwd": [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_p],
+    "dhz_charbonnier_fwd": [c_f, c_f, c_f, c_f, c_l, c_fl, c_i, c_p],
+    "dhz_charbonnier_bwd": [c_f, c_f, c_f, c_f, c_f, c_l, c_fl, c_fl, c_i, c_p],
+    "dhz_adamw_step": [c_f, c_f, c_f, c_f, c_l, c_fl, c_fl, c_fl, c_fl, c_fl, c_i, c_fl, c_p],
+}
+_RESTYPE = {"dhz_last_error": ctypes.c_char_p}
+
+_lib = None
+
+
+class DehazeHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the shared object (once).  Raises ImportError with the build recipe if it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: the HIP extension is mandatory (there is no PyTorch/CPU fallback). "
+            "Build it with `python __graft_entry__.py build` or `csrc/build.sh` (hipcc --offload-arch=gfx950).")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, args in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError here = header / library mismatch: fail loudly
+        fn.argtypes = args
+        fn.restype = _RESTYPE.get(name, ctypes.c_int)
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().dhz_last_error()
+        raise DehazeHipError(f"{what} failed with code {rc}: {msg.decode() if msg else ''}")
+
+
+def call(name, *args):
+    check(getattr(load(), name)(*args), name)

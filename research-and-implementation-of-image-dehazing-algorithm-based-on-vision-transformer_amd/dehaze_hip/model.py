@@ -1,0 +1,480 @@
+"""Uformer (ProbSparse and dense twins) on the MI355X kernels.
+
+The module TREE, parameter registration order, initialisation stream and `state_dict` keys are those
+of the reference (Uformer_ProbSparse/My_model_1.py and My_model.py) so checkpoints and optimizer
+states are interchangeable; the COMPUTE inside every block runs through dehaze_hip.ops (hand-written
+HIP kernels) plus rocBLAS/MIOpen calls for the plain GEMMs / strided convolutions.
+
+Reference map (M1 = My_model_1.py, M0 = My_model.py, ATT = ProbSparse/attn.py):
+  Uformer M1:955-1207 | BasicUformerLayer M1:894-946 | LeWinTransformerBlock M1:738-875 |
+  WindowAttention M1:336-415 / M0:428-518 | AttentionLayer ATT:345-461 | ProbAttention ATT:43-342 |
+  LeFF M1:477-534 | Downsample M1:606-622 | Upsample M1:633-648 | InputProj M1:659-682 |
+  OutputProj M1:696-723
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+
+# ----------------------------------------------------------------------------- small reference-surface helpers
+
+
+def to_2tuple(x):
+    return tuple(x) if isinstance(x, (tuple, list)) else (x, x)
+
+
+def trunc_normal_(t, mean=0., std=1., a=-2., b=2.):
+    return nn.init.trunc_normal_(t, mean=mean, std=std, a=a, b=b)
+
+
+class DropPath(nn.Module):
+    """Per-sample stochastic depth (timm semantics).  `sample_scale` returns the [B] keep/keep_prob
+    vector that the fused residual kernels consume; forward() keeps the stand-alone behaviour."""
+
+    def __init__(self, drop_prob=0., scale_by_keep=True):
+        super().__init__()
+        self.drop_prob = drop_prob
+        self.scale_by_keep = scale_by_keep
+
+    def sample_scale(self, x):
+        if self.drop_prob == 0. or not self.training:
+            return None
+        keep = 1 - self.drop_prob
+        r = x.new_empty((x.shape[0],)).bernoulli_(keep)
+        if keep > 0 and self.scale_by_keep:
+            r.div_(keep)
+        return r
+
+    def forward(self, x):
+        s = self.sample_scale(x)
+        return x if s is None else x * s.view((-1,) + (1,) * (x.ndim - 1))
+
+
+def n_top(L, factor=5):
+    """u = U_part = min(L, factor*ceil(ln L))  (ATT:310-315)."""
+    return min(L, factor * int(math.ceil(math.log(L))))
+
+
+def draw_sample_index(n_blocks=1, L=ops.NTOK):
+    """Sampled-key table(s) from the GLOBAL CPU generator, exactly like ATT:91 (`torch.randint(L_K,
+    (L_Q, sample_k))`); a batched draw consumes the stream identically to consecutive draws."""
+    return torch.randint(L, (n_blocks, L, n_top(L)))
+
+
+def window_partition(x, win_size, dilation_rate=1):
+    """[B,H,W,C] -> [B*nW, win, win, C]  (reference helper M1:550-574; kept for API parity - the model
+    itself never materialises this, the partition is folded into the LN kernel's store addresses)."""
+    assert dilation_rate == 1, "dilated windows are unused by the reference path"
+    B, H, W, C = x.shape
+    x = x.reshape(B, H // win_size, win_size, W // win_size, win_size, C)
+    return x.permute(0, 1, 3, 2, 4, 5).reshape(-1, win_size, win_size, C)
+
+
+def window_reverse(windows, win_size, H, W, dilation_rate=1):
+    """inverse of window_partition (M1:577-601)."""
+    assert dilation_rate == 1
+    C = windows.shape[-1]
+    x = windows.reshape(-1, H // win_size, W // win_size, win_size, win_size, C)
+    return x.permute(0, 1, 3, 2, 4, 5).reshape(-1, H, W, C)
+
+
+# ----------------------------------------------------------------------------- attention
+
+class ProbAttention(nn.Module):
+    """Parameter-free holder mirroring ATT:43-69 (the dropout it owns is never applied, ATT:68)."""
+
+    def __init__(self, mask_flag=False, factor=5, scale=None, attention_dropout=0.1, output_attention=False):
+        super().__init__()
+        self.factor, self.scale, self.mask_flag, self.output_attention = factor, scale, mask_flag, output_attention
+        self.dropout = nn.Dropout(attention_dropout)
+        self.softmax = nn.Softmax(dim=-1)
+
+
+class AttentionLayer(nn.Module):
+    """Q/K/V/out projections around the ProbSparse core (ATT:345-461)."""
+
+    def __init__(self, d_model, n_heads, d_keys=None, d_values=None, mix=False):
+        super().__init__()
+        d_keys = d_keys or (d_model // n_heads)
+        d_values = d_values or (d_model // n_heads)
+        self.inner_attention = ProbAttention(False, 5, None, 0.1, False)
+        self.query_projection = nn.Linear(d_model, d_keys * n_heads)
+        self.key_projection = nn.Linear(d_model, d_keys * n_heads)
+        self.value_projection = nn.Linear(d_model, d_values * n_heads)
+        self.out_projection = nn.Linear(d_values * n_heads, d_model)
+        self.n_heads = n_heads
+        self.mix = mix
+
+    def forward(self, queries, keys, values, table, SW_mask, attn_mask=None, idx=None):
+        """queries (= keys = values): [B_, 64, C] window tokens.  `table` is the [225,H] bias table (or
+        None when options.is_relative_position_bias is False); returns ([B_,64,C], None)."""
+        assert keys is queries and values is queries, "self-attention only (M1:413 passes x, x, x)"
+        B_, N, C = queries.shape
+        H = self.n_heads
+        w = torch.cat([self.query_projection.weight, self.key_projection.weight, self.value_projection.weight], 0)
+        b = torch.cat([self.query_projection.bias, self.key_projection.bias, self.value_projection.bias], 0)
+        qkv = F.linear(queries.reshape(B_ * N, C), w, b)                        # one rocBLAS GEMM [T,3C]
+        if idx is None:
+            idx = draw_sample_index(1, N)[0]
+        if idx.device != qkv.device or idx.dtype != torch.uint8:
+            idx = idx.to(device=qkv.device, dtype=torch.uint8)
+        ctx = ops.ps_window_attention(qkv, table, idx.contiguous(), SW_mask, H, C // H)
+        out = F.linear(ctx, self.out_projection.weight, self.out_projection.bias)
+        return out.view(B_, N, C), None
+
+
+class LinearProjection(nn.Module):
+    """to_q / to_kv of the dense twin (M0:264-300); present-but-dead in the ProbSparse model (M1:389)."""
+
+    def __init__(self, dim, heads=8, dim_head=64, dropout=0., bias=True):
+        super().__init__()
+        inner = dim_head * heads
+        self.heads = heads
+        self.to_q = nn.Linear(dim, inner, bias=bias)
+        self.to_kv = nn.Linear(dim, inner * 2, bias=bias)
+        self.dim, self.inner_dim = dim, inner
+
+    def forward(self, x, attn_kv=None):
+        B_, N, C = x.shape
+        attn_kv = x if attn_kv is None else attn_kv
+        q = self.to_q(x).reshape(B_, N, 1, self.heads, C // self.heads).permute(2, 0, 3, 1, 4)[0]
+        kv = self.to_kv(attn_kv).reshape(B_, N, 2, self.heads, C // self.heads).permute(2, 0, 3, 1, 4)
+        return q, kv[0], kv[1]
+
+
+def relative_position_index(win):
+    c = torch.arange(win)
+    hh, ww = torch.meshgrid(c, c, indexing="ij")
+    coords = torch.stack([hh.reshape(-1), ww.reshape(-1)])
+    rel = coords[:, :, None] - coords[:, None, :] + (win - 1)
+    return rel[0] * (2 * win - 1) + rel[1]
+
+
+class WindowAttention(nn.Module):
+    """M1:336-415 (variant='probsparse') / M0:428-518 (variant='dense')."""
+
+    def __init__(self, dim, win_size, num_heads, token_projection='linear', qkv_bias=True, qk_scale=None,
+                 attn_drop=0., proj_drop=0., se_layer=False, variant="probsparse"):
+        super().__init__()
+        if token_projection != 'linear' or se_layer:
+            raise NotImplementedError("only token_projection='linear', se_layer=False are on the accelerated path")
+        self.dim, self.win_size, self.num_heads, self.variant = dim, win_size, num_heads, variant
+        head_dim = dim // num_heads
+        self.scale = qk_scale or head_dim ** -0.5
+        if variant == "probsparse":
+            self.ProbSpare = AttentionLayer(dim, num_heads)
+        self.relative_position_bias_table = nn.Parameter(
+            torch.zeros((2 * win_size[0] - 1) * (2 * win_size[1] - 1), num_heads))
+        self.register_buffer("relative_position_index", relative_position_index(win_size[0]))
+        self.qkv = LinearProjection(dim, num_heads, dim // num_heads, bias=qkv_bias)
+        self.token_projection = token_projection
+        self.attn_drop = nn.Dropout(attn_drop)
+        self.proj = nn.Linear(dim, dim)
+        self.se_layer = nn.Identity()
+        self.proj_drop = nn.Dropout(proj_drop)
+        trunc_normal_(self.relative_position_bias_table, std=.02)
+        self.softmax = nn.Softmax(dim=-1)
+
+    def forward(self, x, attn_kv=None, mask=None, idx=None):
+        if self.win_size[0] * self.win_size[1] != ops.NTOK:
+            raise NotImplementedError("the HIP kernels are specialised to 8x8 windows")
+        if self.variant == "probsparse":
+            import options                                         # read at call time, like ATT:227
+            table = self.relative_position_bias_table if options.is_relative_position_bias else None
+            out, _ = self.ProbSpare(x, x, x, table, mask, idx=idx)
+            return out
+        return self._dense(x, mask)
+
+    def _dense(self, x, mask):
+        # TODO(next round): dedicated dense-window HIP kernel; the dense twin is an f4 "next" row of SURVEY §8.
+        raise NotImplementedError("dense My_model.Uformer attention kernel is not built yet (SURVEY §8 f4)")
+
+    def extra_repr(self):
+        return f'dim={self.dim}, win_size={self.win_size}, num_heads={self.num_heads}'
+
+
+# ----------------------------------------------------------------------------- feed-forward
+
+class LeFF(nn.Module):
+    """M1:477-534.  Linear+GELU -> depthwise3x3+GELU -> Linear; the middle stage runs in token (NHWC)
+    layout in one HIP kernel, so neither GELU nor the NCHW rearranges touch HBM."""
+
+    def __init__(self, dim=32, hidden_dim=128, act_layer=nn.GELU, drop=0.):
+        super().__init__()
+        self.linear1 = nn.Sequential(nn.Linear(dim, hidden_dim), act_layer())
+        self.dwconv = nn.Sequential(nn.Conv2d(hidden_dim, hidden_dim, groups=hidden_dim, kernel_size=3, stride=1, padding=1),
+                                    act_layer())
+        self.linear2 = nn.Sequential(nn.Linear(hidden_dim, dim))
+        self.dim, self.hidden_dim = dim, hidden_dim
+
+    def forward(self, x):
+        B, L, C = x.shape
+        hh = int(math.sqrt(L))
+        u = F.linear(x.reshape(B * L, C), self.linear1[0].weight, self.linear1[0].bias).view(B, L, self.hidden_dim)
+        z = ops.leff_dwconv(u, self.dwconv[0].weight, self.dwconv[0].bias, hh, hh)
+        y = F.linear(z.view(B * L, self.hidden_dim), self.linear2[0].weight, self.linear2[0].bias)
+        return y.view(B, L, C)
+
+
+# ----------------------------------------------------------------------------- block
+
+class LeWinTransformerBlock(nn.Module):
+    """M1:738-875."""
+
+    def __init__(self, dim, input_resolution, num_heads, win_size=8, shift_size=0, mlp_ratio=4., qkv_bias=True,
+                 qk_scale=None, drop=0., attn_drop=0., drop_path=0., act_layer=nn.GELU, norm_layer=nn.LayerNorm,
+                 token_projection='linear', token_mlp='leff', se_layer=False, variant="probsparse"):
+        super().__init__()
+        if token_mlp != 'leff':
+            raise NotImplementedError("only token_mlp='leff' is on the accelerated path (options.py default)")
+        self.dim, self.input_resolution, self.num_heads = dim, input_resolution, num_heads
+        self.win_size, self.shift_size, self.mlp_ratio, self.token_mlp = win_size, shift_size, mlp_ratio, token_mlp
+        if min(self.input_resolution) <= self.win_size:                     # M1:764-766
+            self.shift_size = 0
+            self.win_size = min(self.input_resolution)
+        assert 0 <= self.shift_size < self.win_size, "shift_size must in 0-win_size"
+        self.norm1 = norm_layer(dim)
+        self.attn = WindowAttention(dim, win_size=to_2tuple(self.win_size), num_heads=num_heads, qkv_bias=qkv_bias,
+                                    qk_scale=qk_scale, attn_drop=attn_drop, proj_drop=drop,
+                                    token_projection=token_projection, se_layer=se_layer, variant=variant)
+        self.drop_path = DropPath(drop_path) if drop_path > 0. else nn.Identity()
+        self.norm2 = norm_layer(dim)
+        self.mlp = LeFF(dim, int(dim * mlp_ratio), act_layer=act_layer, drop=drop)
+        self._mask_cache = {}
+        self._staged_idx = None      # set by Uformer.forward (one batched host draw per model forward)
+
+    def extra_repr(self):
+        return (f"dim={self.dim}, input_resolution={self.input_resolution}, num_heads={self.num_heads}, "
+                f"win_size={self.win_size}, shift_size={self.shift_size}, mlp_ratio={self.mlp_ratio}")
+
+    def _shift_mask(self, H, W, device):
+        key = (H, W, str(device))
+        m = self._mask_cache.get(key)
+        if m is None:
+            m = ops.shift_mask(H, W, self.shift_size, device)
+            self._mask_cache[key] = m
+        return m
+
+    def _scale(self, x):
+        return self.drop_path.sample_scale(x) if isinstance(self.drop_path, DropPath) else None
+
+    def forward(self, x, mask=None):
+        B, L, C = x.shape
+        H = W = int(math.sqrt(L))
+        attn_mask = None
+        if mask is not None:                                                 # input-mask path, M1:791-800
+            im = F.interpolate(mask, size=(H, W)).permute(0, 2, 3, 1)
+            am = window_partition(im, self.win_size).view(-1, self.win_size * self.win_size)
+            am = am.unsqueeze(2) * am.unsqueeze(1)
+            attn_mask = am.masked_fill(am != 0, float(-100.0)).masked_fill(am == 0, float(0.0))
+        if self.shift_size > 0:
+            sm = self._shift_mask(H, W, x.device)
+            attn_mask = attn_mask + sm if attn_mask is not None else sm
+        idx, self._staged_idx = self._staged_idx, None
+
+        xw = ops.ln_partition(x, self.norm1.weight, self.norm1.bias, H, W, self.shift_size)   # LN+roll+partition
+        aw = self.attn(xw.view(-1, self.win_size * self.win_size, C), mask=attn_mask, idx=idx)
+        x = ops.reverse_residual(aw.reshape(-1, C), x, self._scale(x), H, W, self.shift_size)  # reverse+unroll+res
+        y = self.mlp(ops.layer_norm_tokens(x, self.norm2.weight, self.norm2.bias).view(B, L, C))
+        return ops.residual_scale(y.reshape(-1, C), x, self._scale(x))
+
+
+class BasicUformerLayer(nn.Module):
+    """M1:894-946."""
+
+    def __init__(self, dim, output_dim, input_resolution, depth, num_heads, win_size, mlp_ratio=4., qkv_bias=True,
+                 qk_scale=None, drop=0., attn_drop=0., drop_path=0., norm_layer=nn.LayerNorm, use_checkpoint=False,
+                 token_projection='linear', token_mlp='ffn', se_layer=False, variant="probsparse"):
+        super().__init__()
+        self.dim, self.input_resolution, self.depth, self.use_checkpoint = dim, input_resolution, depth, use_checkpoint
+        self.blocks = nn.ModuleList([
+            LeWinTransformerBlock(dim=dim, input_resolution=input_resolution, num_heads=num_heads, win_size=win_size,
+                                  shift_size=0 if (i % 2 == 0) else win_size // 2, mlp_ratio=mlp_ratio,
+                                  qkv_bias=qkv_bias, qk_scale=qk_scale, drop=drop, attn_drop=attn_drop,
+                                  drop_path=drop_path[i] if isinstance(drop_path, list) else drop_path,
+                                  norm_layer=norm_layer, token_projection=token_projection, token_mlp=token_mlp,
+                                  se_layer=se_layer, variant=variant)
+            for i in range(depth)])
+
+    def extra_repr(self):
+        return f"dim={self.dim}, input_resolution={self.input_resolution}, depth={self.depth}"
+
+    def forward(self, x, mask=None):
+        for blk in self.blocks:
+            if self.use_checkpoint:
+                x = torch.utils.checkpoint.checkpoint(blk, x)
+            else:
+                x = blk(x, mask)
+        return x
+
+
+# ----------------------------------------------------------------------------- resampling / projections
+
+def _tokens_to_map(x):
+    B, L, C = x.shape
+    s = int(math.sqrt(L))
+    return x.transpose(1, 2).contiguous().view(B, C, s, s)
+
+
+class Downsample(nn.Module):
+    """Conv k4 s2 p1 on the token map (M1:606-622)."""
+
+    def __init__(self, in_channel, out_channel):
+        super().__init__()
+        self.conv = nn.Sequential(nn.Conv2d(in_channel, out_channel, kernel_size=4, stride=2, padding=1))
+        self.in_channel, self.out_channel = in_channel, out_channel
+
+    def forward(self, x):
+        return self.conv(_tokens_to_map(x)).flatten(2).transpose(1, 2).contiguous()
+
+
+class Upsample(nn.Module):
+    """ConvTranspose k2 s2 (M1:633-648)."""
+
+    def __init__(self, in_channel, out_channel):
+        super().__init__()
+        self.deconv = nn.Sequential(nn.ConvTranspose2d(in_channel, out_channel, kernel_size=2, stride=2))
+        self.in_channel, self.out_channel = in_channel, out_channel
+
+    def forward(self, x):
+        return self.deconv(_tokens_to_map(x)).flatten(2).transpose(1, 2).contiguous()
+
+
+class InputProj(nn.Module):
+    """Conv3x3 + LeakyReLU -> tokens (M1:659-682)."""
+
+    def __init__(self, in_channel=3, out_channel=64, kernel_size=3, stride=1, norm_layer=None, act_layer=nn.LeakyReLU):
+        super().__init__()
+        self.proj = nn.Sequential(nn.Conv2d(in_channel, out_channel, kernel_size=3, stride=stride, padding=kernel_size // 2),
+                                  act_layer(inplace=True))
+        self.norm = norm_layer(out_channel) if norm_layer is not None else None
+        self.in_channel, self.out_channel = in_channel, out_channel
+
+    def forward(self, x):
+        x = self.proj(x).flatten(2).transpose(1, 2).contiguous()
+        return self.norm(x) if self.norm is not None else x
+
+
+class OutputProj(nn.Module):
+    """tokens -> Conv3x3 -> image (M1:696-723)."""
+
+    def __init__(self, in_channel=64, out_channel=3, kernel_size=3, stride=1, norm_layer=None, act_layer=None):
+        super().__init__()
+        self.proj = nn.Sequential(nn.Conv2d(in_channel, out_channel, kernel_size=3, stride=stride, padding=kernel_size // 2))
+        if act_layer is not None:
+            self.proj.add_module("act", act_layer(inplace=True))
+        self.norm = norm_layer(out_channel) if norm_layer is not None else None
+        self.in_channel, self.out_channel = in_channel, out_channel
+
+    def forward(self, x):
+        x = self.proj(_tokens_to_map(x))
+        return self.norm(x) if self.norm is not None else x
+
+
+# ----------------------------------------------------------------------------- the model
+
+class Uformer(nn.Module):
+    """U-shaped encoder/decoder of LeWin blocks (M1:955-1207); constructor signature of M1:961-967."""
+
+    variant = "probsparse"
+
+    def __init__(self, img_size=128, in_chans=3, embed_dim=32, depths=[2, 2, 2, 2, 2, 2, 2, 2, 2],
+                 num_heads=[1, 2, 4, 8, 16, 16, 8, 4, 2], win_size=8, mlp_ratio=4., qkv_bias=True, qk_scale=None,
+                 drop_rate=0., attn_drop_rate=0., drop_path_rate=0.1, norm_layer=nn.LayerNorm, patch_norm=True,
+                 use_checkpoint=False, token_projection='linear', token_mlp='ffn', se_layer=False,
+                 dowsample=Downsample, upsample=Upsample, **kwargs):
+        super().__init__()
+        self.num_enc_layers = self.num_dec_layers = len(depths) // 2
+        self.embed_dim, self.patch_norm, self.mlp_ratio = embed_dim, patch_norm, mlp_ratio
+        self.token_projection, self.mlp, self.win_size, self.reso = token_projection, token_mlp, win_size, img_size
+        self.pos_drop = nn.Dropout(p=drop_rate)
+        enc_dpr = [x.item() for x in torch.linspace(0, drop_path_rate, sum(depths[:self.num_enc_layers]))]
+        conv_dpr = [drop_path_rate] * depths[4]
+        dec_dpr = enc_dpr[::-1]
+
+        def layer(i, dim, res, dpr):
+            return BasicUformerLayer(dim=dim, output_dim=dim, input_resolution=(res, res), depth=depths[i],
+                                     num_heads=num_heads[i], win_size=win_size, mlp_ratio=mlp_ratio, qkv_bias=qkv_bias,
+                                     qk_scale=qk_scale, drop=drop_rate, attn_drop=attn_drop_rate, drop_path=dpr,
+                                     norm_layer=norm_layer, use_checkpoint=use_checkpoint,
+                                     token_projection=token_projection, token_mlp=token_mlp, se_layer=se_layer,
+                                     variant=self.variant)
+
+        self.input_proj = InputProj(in_channel=in_chans, out_channel=embed_dim, kernel_size=3, stride=1, act_layer=nn.LeakyReLU)
+        self.output_proj = OutputProj(in_channel=2 * embed_dim, out_channel=in_chans, kernel_size=3, stride=1)
+        for s in range(4):                                                   # encoder: dim E*2^s at res/2^s
+            lo, hi = sum(depths[:s]), sum(depths[:s + 1])
+            setattr(self, f"encoderlayer_{s}", layer(s, embed_dim * 2 ** s, img_size // 2 ** s, enc_dpr[lo:hi]))
+            setattr(self, f"dowsample_{s}", dowsample(embed_dim * 2 ** s, embed_dim * 2 ** (s + 1)))
+        self.conv = layer(4, embed_dim * 16, img_size // 16, conv_dpr)
+        up_io = [(16, 8), (16, 4), (8, 2), (4, 1)]                           # M1:1082,1098,1114,1130
+        dec_dim = [16, 8, 4, 2]
+        for s in range(4):
+            lo, hi = sum(depths[5:5 + s]), sum(depths[5:6 + s])
+            setattr(self, f"upsample_{s}", upsample(embed_dim * up_io[s][0], embed_dim * up_io[s][1]))
+            setattr(self, f"decoderlayer_{s}", layer(5 + s, embed_dim * dec_dim[s], img_size // 2 ** (3 - s), dec_dpr[lo:hi]))
+        self.apply(self._init_weights)
+
+    def _init_weights(self, m):
+        if isinstance(m, nn.Linear):
+            trunc_normal_(m.weight, std=.02)
+            if m.bias is not None:
+                nn.init.constant_(m.bias, 0)
+        elif isinstance(m, nn.LayerNorm):
+            nn.init.constant_(m.bias, 0)
+            nn.init.constant_(m.weight, 1.0)
+
+    @torch.jit.ignore
+    def no_weight_decay(self):
+        return {'absolute_pos_embed'}
+
+    @torch.jit.ignore
+    def no_weight_decay_keywords(self):
+        return {'relative_position_bias_table'}
+
+    def extra_repr(self):
+        return (f"embed_dim={self.embed_dim}, token_projection={self.token_projection}, token_mlp={self.mlp},"
+                f"win_size={self.win_size}")
+
+    def stages(self):
+        names = [f"encoderlayer_{s}" for s in range(4)] + ["conv"] + [f"decoderlayer_{s}" for s in range(4)]
+        return [getattr(self, n) for n in names]
+
+    def live_parameters(self):
+        """Parameters that receive gradients (the reference keeps 108 dead tensors - attn.qkv.*, attn.proj.* -
+        in parameters() and in the optimizer; they are excluded from gradient buckets)."""
+        dead = ("attn.qkv.", "attn.proj.") if self.variant == "probsparse" else ()
+        return [(n, p) for n, p in self.named_parameters() if not any(d in n for d in dead)]
+
+    def _stage_sample_indices(self, device):
+        """One host draw for all ProbSparse blocks of this forward (same CPU-generator stream as the
+        reference's 18 per-block draws), one H2D copy, handed to the blocks in execution order."""
+        blocks = [b for st in self.stages() for b in st.blocks]
+        if self.variant != "probsparse":
+            return
+        idx = draw_sample_index(len(blocks)).to(torch.uint8)
+        idx = idx.pin_memory().to(device, non_blocking=True) if device.type == "cuda" else idx
+        for i, b in enumerate(blocks):
+            b._staged_idx = idx[i]
+
+    def forward(self, x, mask=None):
+        self._stage_sample_indices(x.device)
+        y = self.pos_drop(self.input_proj(x))
+        skips = []
+        for s in range(4):
+            y = getattr(self, f"encoderlayer_{s}")(y, mask=mask)
+            skips.append(y)
+            y = getattr(self, f"dowsample_{s}")(y)
+        y = self.conv(y, mask=mask)
+        for s in range(4):
+            y = getattr(self, f"upsample_{s}")(y)
+            y = torch.cat([y, skips[3 - s]], -1)
+            y = getattr(self, f"decoderlayer_{s}")(y, mask=mask)
+        return x + self.output_proj(y)
+
+
+class UformerDense(Uformer):
+    variant = "dense"

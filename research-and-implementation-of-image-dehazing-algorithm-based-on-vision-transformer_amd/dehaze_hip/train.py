@@ -1,0 +1,234 @@
+"""Training-step machinery: flat-buffer AdamW on the HIP kernel, bucketed RCCL gradient all-reduce
+(one process per GPU over xGMI - replaces the reference's nn.DataParallel, TR:97), synthetic haze
+batches and the step body of My_train.py (TR:212-250).
+"""
+import math
+
+import torch
+import torch.distributed as dist
+
+from . import ops
+
+
+# ----------------------------------------------------------------------------- flat AdamW (K12)
+class FlatAdamW(torch.optim.Optimizer):
+    """torch.optim.AdamW semantics (TR:90-92: lr 2e-4, betas (0.9,0.999), eps 1e-8, wd 0.02) with all LIVE
+    parameters, their gradients and both moments living in four flat fp32 buffers, updated by ONE launch
+    of dhz_adamw_step.  Parameters that never receive a gradient (the reference's 108 dead attn.qkv.* /
+    attn.proj.* tensors) are skipped exactly like torch skips `grad is None` params.
+
+    The flat layout is in REVERSE registration order so that gradient buckets (contiguous slices of the
+    flat gradient) complete in backward order.  state_dict()/load_state_dict() speak torch.optim.AdamW's
+    positional format, so reference checkpoints ('optimizer' entry, TR:296) round-trip.
+
+    Flattening happens lazily at the first zero_grad()/step() - i.e. after the model has been moved to its
+    device, mirroring the reference's order (optimizer built before .cuda(), TR:90-98).  Moving the model
+    afterwards would detach the parameters from the flat buffers (don't).
+    """
+
+    def __init__(self, model_or_params, lr=2e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.02, live=None):
+        if isinstance(model_or_params, torch.nn.Module):
+            params = list(model_or_params.parameters())
+            if live is None and hasattr(model_or_params, "live_parameters"):
+                live = [p for _, p in model_or_params.live_parameters()]
+        else:
+            params = list(model_or_params)
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self._all = params
+        self._live = live if live is not None else [p for p in params if p.requires_grad]
+        self._flat = None
+        self._step = 0
+        self.grad_scale = 1.0          # set to 1/world_size by the gradient reducer (SUM all-reduce)
+
+    # -- flat buffers
+    def _ensure_flat(self):
+        if self._flat is not None:
+            return
+        order = list(reversed(self._live))
+        dev = order[0].device
+        n = sum(p.numel() for p in order)
+        npad = (n + 3) // 4 * 4
+        fp = torch.zeros(npad, device=dev, dtype=torch.float32)
+        fg = torch.zeros(npad, device=dev, dtype=torch.float32)
+        self._offsets = {}
+        off = 0
+        for p in order:
+            k = p.numel()
+            fp[off:off + k].copy_(p.data.reshape(-1))
+            if p.grad is not None:
+                fg[off:off + k].copy_(p.grad.reshape(-1))
+            p.data = fp[off:off + k].view_as(p)
+            p.grad = fg[off:off + k].view_as(p)
+            self._offsets[id(p)] = (off, k)
+            off += k
+        self._flat = dict(p=fp, g=fg, m=torch.zeros_like(fp), v=torch.zeros_like(fp), n=n)
+
+    @property
+    def flat_grad(self):
+        self._ensure_flat()
+        return self._flat["g"]
+
+    def param_slices(self):
+        """[(param, offset, numel)] in flat (= reverse registration) order."""
+        self._ensure_flat()
+        return [(p,) + self._offsets[id(p)] for p in reversed(self._live)]
+
+    def zero_grad(self, set_to_none=False):
+        self._ensure_flat()
+        self._flat["g"].zero_()
+        for p in self._all:
+            if id(p) not in self._offsets:
+                p.grad = None
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        self._ensure_flat()
+        g = self.param_groups[0]
+        self._step += 1
+        f = self._flat
+        ops.adamw_step_(f["p"], f["g"], f["m"], f["v"], g["lr"], g["betas"][0], g["betas"][1], g["eps"],
+                        g["weight_decay"], self._step, self.grad_scale)
+
+    # -- torch.optim.AdamW-compatible (positional) state
+    def state_dict(self):
+        self._ensure_flat()
+        index = {id(p): i for i, p in enumerate(self._all)}
+        state = {}
+        if self._step > 0:
+            for p in self._live:
+                off, k = self._offsets[id(p)]
+                state[index[id(p)]] = {"step": torch.tensor(float(self._step)),
+                                       "exp_avg": self._flat["m"][off:off + k].view_as(p).clone(),
+                                       "exp_avg_sq": self._flat["v"][off:off + k].view_as(p).clone()}
+        groups = [{k: v for k, v in g.items() if k != "params"} for g in self.param_groups]
+        groups[0]["params"] = list(range(len(self._all)))
+        return {"state": state, "param_groups": groups}
+
+    def load_state_dict(self, sd):
+        self._ensure_flat()
+        for k, v in sd["param_groups"][0].items():
+            if k != "params":
+                self.param_groups[0][k] = v
+        steps = set()
+        for i, st in sd["state"].items():
+            p = self._all[int(i)]
+            if id(p) not in self._offsets:
+                continue
+            off, k = self._offsets[id(p)]
+            self._flat["m"][off:off + k].copy_(st["exp_avg"].reshape(-1))
+            self._flat["v"][off:off + k].copy_(st["exp_avg_sq"].reshape(-1))
+            steps.add(int(float(st["step"])))
+        if steps:
+            self._step = max(steps)
+
+
+# ----------------------------------------------------------------------------- C1: bucketed gradient all-reduce
+class GradReducer:
+    """DDP-style gradient exchange for one-process-per-GPU data parallelism.
+
+    Gradients live in one flat buffer (FlatAdamW.flat_grad, or a private one when used stand-alone);
+    it is cut into ~bucket_mb contiguous buckets in backward order.  A post-accumulate hook on every
+    live parameter counts arrivals; when a bucket is complete its slice is all-reduced (SUM) asynchronously
+    on the process group's own stream (RCCL over xGMI on GPUs, gloo in the CPU tests) while backward
+    continues.  wait() joins the outstanding collectives; the 1/world_size factor is folded into the
+    optimizer kernel (FlatAdamW.grad_scale) instead of a separate pass over the 82.5 MB gradient.
+    Dead parameters never enter a bucket (find_unused_parameters-equivalent).
+    """
+
+    def __init__(self, optimizer=None, params=None, bucket_mb=25.0, group=None):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.opt = optimizer
+        if optimizer is not None:
+            slices = optimizer.param_slices()
+            self.flat = optimizer.flat_grad
+            optimizer.grad_scale = 1.0 / self.world
+        else:
+            params = [p for p in reversed(list(params)) if p.requires_grad]
+            n = sum(p.numel() for p in params)
+            self.flat = torch.zeros(n, device=params[0].device, dtype=params[0].dtype)
+            slices, off = [], 0
+            for p in params:
+                p.grad = self.flat[off:off + p.numel()].view_as(p)
+                slices.append((p, off, p.numel()))
+                off += p.numel()
+        cap = int(bucket_mb * 1024 * 1024 / 4)
+        self.buckets = []            # [lo, hi, n_params]
+        self.bucket_of = {}
+        lo, cnt = 0, 0
+        for p, off, k in slices:
+            self.bucket_of[id(p)] = len(self.buckets)
+            cnt += 1
+            if off + k - lo >= cap:
+                self.buckets.append([lo, off + k, cnt])
+                lo, cnt = off + k, 0
+        if cnt:
+            self.buckets.append([lo, slices[-1][1] + slices[-1][2], cnt])
+        self._pending = [0] * len(self.buckets)
+        self._handles = []
+        self._hooks = []
+        if self.world > 1:
+            for p, _, _ in slices:
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
+
+    def _on_grad(self, p):
+        b = self.bucket_of[id(p)]
+        self._pending[b] += 1
+        if self._pending[b] == self.buckets[b][2]:
+            lo, hi, _ = self.buckets[b]
+            self._handles.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def wait(self):
+        """Join all bucket all-reduces of this backward pass (call before optimizer.step())."""
+        if self.world > 1:
+            # buckets whose hooks did not all fire (a parameter unused this step) are reduced here
+            for b, (lo, hi, n) in enumerate(self.buckets):
+                if 0 < self._pending[b] < n or (self._pending[b] == 0 and n > 0):
+                    self._handles.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group,
+                                                         async_op=True))
+            for h in self._handles:
+                h.wait()
+        self._handles = []
+        self._pending = [0] * len(self.buckets)
+
+    def average_(self):
+        """Stand-alone use (no FlatAdamW): turn the summed gradients into the mean."""
+        if self.world > 1:
+            self.flat.div_(self.world)
+
+
+# ----------------------------------------------------------------------------- data + step
+def synthetic_batch(batch, ps=128, seed=1234, device="cpu"):
+    """Synthetic haze pairs: gt ~ U[0,1); hazy = clamp(t*gt + (1-t)*A, 0, 1) with
+    per-sample transmission t ~ U(0.3,0.9) and airlight A ~ U(0.6,1.0).  Returns (target, input_)."""
+    g = torch.Generator().manual_seed(seed)
+    gt = torch.rand(batch, 3, ps, ps, generator=g)
+    t = 0.3 + 0.6 * torch.rand(batch, 1, 1, 1, generator=g)
+    A = 0.6 + 0.4 * torch.rand(batch, 1, 1, 1, generator=g)
+    hazy = (t * gt + (1 - t) * A).clamp(0, 1)
+    return gt.to(device), hazy.to(device)
+
+
+def train_step(model, char_loss, cr_loss, optimizer, reducer, input_, target, w_char=1.0, w_cr=1.0):
+    """One optimisation step, the body of TR:212-250 in fp32: zero_grad -> restored = model(input_) ->
+    clamp(0,1) -> w_char*Charbonnier + w_cr*Contrast -> backward (bucketed all-reduce overlapped) ->
+    AdamW.  Returns (loss, loss_rec, loss_cr) as device scalars (no host sync here; the reference's
+    per-step .item() calls, TR:250-254, are left to the caller's logging cadence)."""
+    optimizer.zero_grad()
+    restored = model(input_)
+    loss_rec, clamped = char_loss.forward_clamped(restored, target)
+    loss = w_char * loss_rec if w_char > 0 else 0
+    loss_cr = None
+    if w_cr > 0 and cr_loss is not None:
+        loss_cr, _, _ = cr_loss(clamped, target, input_)
+        loss = loss + w_cr * loss_cr
+    loss.backward()
+    if reducer is not None:
+        reducer.wait()
+    optimizer.step()
+    return loss.detach(), loss_rec.detach(), (loss_cr.detach() if loss_cr is not None else None)
+
+
+def psnr(a, b):
+    mse = torch.mean((a.double() - b.double()) ** 2).item()
+    return 10.0 * math.log10(1.0 / max(mse, 1e-20))

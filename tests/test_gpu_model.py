@@ -1,0 +1,135 @@
+"""-m gpu parity of the assembled path: LeWin block, whole Uformer (forward, gradients, PSNR vs the
+reference output) and short training trajectories, against golden vectors from the reference and
+against the CPU oracle."""
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import uformer_oracle as O
+
+pytestmark = pytest.mark.gpu
+T = torch.from_numpy
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "needs an MI355X"
+    return torch.device("cuda:0")
+
+
+def seed_all(s):
+    random.seed(s)
+    np.random.seed(s)
+    torch.manual_seed(s)
+
+
+@pytest.mark.parametrize("name,heads,shift,C", [("block_m1_c32_shift0", 1, 0, 32), ("block_m1_c32_shift4", 1, 4, 32),
+                                                ("block_m1_c64_shift4", 2, 4, 64)])
+def test_block_vs_reference_golden(golden, dev, name, heads, shift, C):
+    import My_model_1 as M1
+    g = golden(name)
+    blk = M1.LeWinTransformerBlock(dim=C, input_resolution=(16, 16), num_heads=heads, win_size=8, shift_size=shift,
+                                   token_mlp='leff', drop_path=0.)
+    sd = {k[3:]: T(g[k]) for k in g.files if k.startswith("sd/")}
+    blk.load_state_dict(sd)
+    blk.to(dev)
+    x = T(g["x"]).to(dev).requires_grad_()
+    blk._staged_idx = T(g["idx"].astype(np.uint8)).to(dev)
+    y = blk(x)
+    assert torch.allclose(y.cpu(), T(g["y"]), atol=3e-5, rtol=1e-4), (y.cpu() - T(g["y"])).abs().max()
+    (y * T(g["gout"]).to(dev)).sum().backward()
+    assert torch.allclose(x.grad.cpu(), T(g["dx"]), atol=5e-5, rtol=1e-3)
+    for n, p in blk.named_parameters():
+        ref = g["g/" + n]
+        if ref.size == 0:
+            assert p.grad is None, n
+        else:
+            assert p.grad is not None, n
+            err = (p.grad.cpu() - T(ref)).abs().max().item()
+            assert err <= 2e-4 + 2e-3 * np.abs(ref).max(), (n, err)
+
+
+def test_full_model_vs_reference_golden(golden, dev):
+    """Whole E=32 model, reference seed recipe: eval output and Charbonnier gradients vs the reference's
+    own numbers; PSNR(build, reference) on the stored crop must be far above the 0.01 dB contract."""
+    import My_model_1 as M1
+    from losses import CharbonnierLoss
+    g = golden("full_m1_e32")
+    seed_all(1234)
+    model = M1.Uformer(img_size=128, embed_dim=32, win_size=8, token_projection='linear', token_mlp='leff').to(dev)
+    gt, hazy = T(g["gt"]).float().to(dev), T(g["hazy"]).float().to(dev)
+    model.eval()
+    torch.manual_seed(99)
+    with torch.no_grad():
+        y = model(hazy)
+    crop = y[0, :, 40:72, 40:72].cpu()
+    ref_crop = T(g["y_eval_crop"])
+    assert torch.allclose(crop, ref_crop, atol=2e-4, rtol=1e-3), (crop - ref_crop).abs().max()
+    low = torch.nn.functional.avg_pool2d(y, 4).cpu()
+    assert torch.allclose(low, T(g["y_eval_lowres"]), atol=1e-4, rtol=1e-3)
+    assert abs(float(y.double().sum()) - float(g["y_eval_sum"])) < 1e-3 * float(g["y_eval_abs"])
+    mse = torch.mean((crop.double() - ref_crop.double()) ** 2).item()
+    assert mse < 1e-7           # PSNR(build vs reference) > 70 dB on [0,1] data
+    # gradients (eval-mode forward with grad, exactly as the golden generator did)
+    torch.manual_seed(99)
+    out = model(hazy)
+    loss, _ = CharbonnierLoss().forward_clamped(out, gt)
+    assert abs(loss.item() - float(g["loss"])) < 2e-6
+    loss.backward()
+    gn = np.array([float(p.grad.double().norm()) if p.grad is not None else -1.0 for p in model.parameters()])
+    ref = g["gnorm"]
+    assert np.array_equal(gn < 0, ref < 0)                          # same 108 dead tensors
+    live = ref >= 0
+    rel = np.abs(gn[live] - ref[live]) / (ref[live] + 1e-8)
+    assert rel.max() < 5e-3, rel.max()
+
+
+def test_training_steps_vs_oracle(dev):
+    """3 AdamW steps (Charbonnier only, DropPath off so that host and device RNG use is identical):
+    product on GPU vs CPU oracle + torch.optim.AdamW, same seeds, same sampled-key stream."""
+    import My_model_1 as M1
+    from dehaze_hip.train import FlatAdamW
+    from losses import CharbonnierLoss
+    seed_all(1234)
+    model = M1.Uformer(img_size=128, embed_dim=32, win_size=8, token_projection='linear', token_mlp='leff',
+                       drop_path_rate=0.).to(dev)
+    P = {k: v.detach().cpu().clone().requires_grad_(v.dtype.is_floating_point) for k, v in model.state_dict().items()}
+    ref_params = [P[n] for n, _ in model.named_parameters()]
+    opt_ref = torch.optim.AdamW(ref_params, lr=2e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.02)
+    opt = FlatAdamW(model, lr=2e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.02)
+    g = torch.Generator().manual_seed(7)
+    gt = torch.rand(2, 3, 128, 128, generator=g)
+    hazy = (0.6 * gt + 0.4 * torch.rand(2, 1, 1, 1, generator=g)).clamp(0, 1)
+    crit = CharbonnierLoss()
+    model.train()
+    for step in range(3):
+        torch.manual_seed(500 + step)
+        opt.zero_grad()
+        loss, _ = crit.forward_clamped(model(hazy.to(dev)), gt.to(dev))
+        loss.backward()
+        opt.step()
+        torch.manual_seed(500 + step)
+        opt_ref.zero_grad()
+        loss_ref, _ = O.train_step_loss(P, hazy, gt, training=True, drop_path_rate=0.)
+        loss_ref.backward()
+        opt_ref.step()
+        assert abs(loss.item() - loss_ref.item()) < 5e-5, (step, loss.item(), loss_ref.item())
+    sd = model.state_dict()
+    worst = max((sd[k].cpu() - P[k].detach()).abs().max().item() for k in P if P[k].dtype.is_floating_point)
+    assert worst < 5e-4, worst
+
+
+def test_contrast_loss_vs_oracle(golden, dev):
+    import My_CR
+    g = golden("losses")
+    cl = My_CR.ContrastLoss(ablation=False).to(dev)
+    assert torch.equal(cl.vgg.slice1[0].weight.cpu(), T(g["cr/vgg_w0"]))
+    for tag, ab in (("cr", False), ("cr_ab", True)):
+        cl.ab = ab
+        a = T(g[tag + "/a"]).to(dev).requires_grad_()
+        loss, ap, an = cl(a, T(g[tag + "/p"]).to(dev), T(g[tag + "/n"]).to(dev))
+        assert abs(loss.item() - float(g[tag + "/loss"])) < 1e-4 * max(1.0, abs(float(g[tag + "/loss"])))
+        loss.backward()
+        assert torch.allclose(a.grad.cpu(), T(g[tag + "/da"]), atol=1e-6, rtol=2e-2)

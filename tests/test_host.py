@@ -1,0 +1,116 @@
+"""CPU-side (-m "not gpu") checks of the host logic: the C-ABI library loads and exports every symbol the
+header declares, the drop-in surface matches the reference (state_dict keys, parameter order, init
+stream, options), and the product refuses CPU tensors instead of silently falling back."""
+import argparse
+import os
+import random
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from dehaze_hip import _lib
+    lib = _lib.load()
+    hdr = open(os.path.join(ROOT, "include", "dehaze_hip.h")).read()
+    declared = set(re.findall(r"\b(dhz_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/dehaze_hip.h but not exported"
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    assert lib.dhz_abi_version() == 1
+    assert lib.dhz_ps_attn_bwd_parts(8192, 1) == 512 and lib.dhz_ps_attn_bwd_parts(4, 16) == 64
+
+
+def test_argument_validation_without_gpu():
+    """Bad arguments are rejected before any launch (safe on a GPU-less host)."""
+    from dehaze_hip import _lib
+    lib = _lib.load()
+    rc = lib.dhz_ps_attn_fwd(None, None, None, 32, None, None, None, None, 32, None, 1, 1, 1, 32, None)
+    assert rc == -22 and b"null pointer" in lib.dhz_last_error()
+    rc = lib.dhz_ps_attn_fwd(8, 8, 8, 32, 8, None, None, 8, 32, 8, 1, 1, 1, 48, None)
+    assert rc == -22 and b"head_dim" in lib.dhz_last_error()
+
+
+@pytest.mark.parametrize("modname,gname", [("My_model_1", "full_m1_e32"), ("My_model", "full_m0_e32")])
+def test_state_dict_and_init_stream_match_reference(golden, modname, gname):
+    mod = __import__(modname)
+    g = golden(gname)
+    random.seed(1234); np.random.seed(1234); torch.manual_seed(1234)
+    m = mod.Uformer(img_size=128, embed_dim=32, win_size=8, token_projection='linear', token_mlp='leff')
+    sd = m.state_dict()
+    assert list(sd.keys()) == list(g["keys"])
+    assert [n for n, _ in m.named_parameters()] == list(g["pnames"])
+    assert [str(tuple(v.shape)) for v in sd.values()] == list(g["shapes"])
+    stats = np.array([[float(v.double().sum()), float(v.double().abs().sum())] for v in sd.values()])
+    assert np.array_equal(stats, g["sd_stats"])          # same init RNG stream, bit for bit
+    assert sum(p.numel() for p in m.parameters()) == 26222685 if modname == "My_model_1" else True
+    if modname == "My_model_1":
+        live = m.live_parameters()
+        assert sum(p.numel() for _, p in live) == 20628317 and len(list(m.parameters())) - len(live) == 108
+
+
+def test_options_match_reference(golden):
+    import options
+    g = golden("options")
+    p = options.Options().init(argparse.ArgumentParser())
+    mine = {a.dest: (str(a.default), str(a.type.__name__ if a.type else None), a.__class__.__name__)
+            for a in p._actions if a.dest != "help"}
+    assert list(mine) == list(g["dests"])
+    for d, dflt, ty, kind in zip(g["dests"], g["defaults"], g["types"], g["kinds"]):
+        if d in ("pretrain_weights",):                 # machine-specific absolute path in the reference
+            continue
+        assert mine[d] == (dflt, ty, kind), d
+    assert options.is_relative_position_bias is True and int(g["is_relative_position_bias"]) == 1
+
+
+def test_misc_host_helpers(golden):
+    import utils
+    from warmup_scheduler import GradualWarmupScheduler
+    g = golden("misc")
+    torch.manual_seed(5)
+    mix = utils.MixUp_AUG()
+    a, b = mix.aug(torch.from_numpy(g["mix_gt"]), torch.from_numpy(g["mix_nz"]))
+    assert torch.allclose(a, torch.from_numpy(g["mix_out_gt"])) and torch.allclose(b, torch.from_numpy(g["mix_out_nz"]))
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.AdamW([p], lr=2e-4)
+    cos = torch.optim.lr_scheduler.CosineAnnealingLR(opt, 20 - 3, eta_min=1e-6)
+    sch = GradualWarmupScheduler(opt, multiplier=1, total_epoch=3, after_scheduler=cos)
+    lrs = []
+    for ep in range(20):
+        lrs.append(opt.param_groups[0]['lr'])
+        opt.step()
+        sch.step()
+    assert np.allclose(lrs, g["lrs"], rtol=1e-9, atol=0)
+
+
+def test_product_refuses_cpu_tensors():
+    import My_model_1 as M1
+    from losses import CharbonnierLoss
+    blk = M1.LeWinTransformerBlock(dim=32, input_resolution=(16, 16), num_heads=1, win_size=8, shift_size=0, token_mlp='leff')
+    with pytest.raises(RuntimeError, match="no CPU"):
+        blk(torch.zeros(1, 256, 32))
+    with pytest.raises(RuntimeError, match="no CPU"):
+        CharbonnierLoss()(torch.zeros(4), torch.zeros(4))
+
+
+def test_get_arch_and_checkpoint_roundtrip(tmp_path):
+    import utils
+    ns = argparse.Namespace(arch="Uformer", train_ps=128, embed_dim=32, win_size=8, token_projection="linear", token_mlp="leff")
+    torch.manual_seed(0)
+    m = utils.get_arch(ns)
+    assert type(m).__name__ == "Uformer" and m.variant == "probsparse"
+    with pytest.raises(Exception, match="Arch error"):
+        utils.get_arch(argparse.Namespace(arch="nope", train_ps=128, embed_dim=32, win_size=8, token_projection="linear", token_mlp="leff"))
+    # reference checkpoints carry DataParallel's 'module.' prefix (TR:294-297)
+    path = str(tmp_path / "ck.pth")
+    torch.save({"epoch": 7, "state_dict": {"module." + k: v for k, v in m.state_dict().items()}, "optimizer": {}}, path)
+    torch.manual_seed(1)
+    m2 = utils.get_arch(ns)
+    utils.load_checkpoint(m2, path)
+    assert utils.load_start_epoch(path) == 7
+    assert all(torch.equal(a, b) for a, b in zip(m.state_dict().values(), m2.state_dict().values()))
