@@ -248,6 +248,8 @@ def gen_full(M1, M0, losses):
         g = torch.Generator().manual_seed(7)
         gt = torch.rand(1, 3, 128, 128, generator=g)
         hazy = (0.6 * gt + 0.4 * torch.rand(1, 1, 1, 1, generator=g)).clamp(0, 1)
+        # inputs are stored as fp16 to keep the fixture small: make them exactly fp16-representable
+        gt, hazy = gt.half().float(), hazy.half().float()
         # per-stage activation means via hooks
         acts = {}
         hooks = []

@@ -116,3 +116,89 @@ def test_losses(golden):
         assert torch.allclose(a.grad, T(g[tag + "/da"]), atol=1e-7, rtol=1e-3)
     feats = O.vgg19_features(T(g["cr/a"]), W)
     assert [list(f.shape) for f in feats] == g["cr/feat_shapes"].tolist()
+
+
+# ----------------------------------------------------------------------------- plain-C oracle (oracle/ps_attn_oracle.c)
+def _c_oracle():
+    import ctypes
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    so = os.path.join(root, "oracle", "libps_attn_oracle.so")
+    if not os.path.exists(so):
+        subprocess.run(["make", "-s", "-C", os.path.join(root, "oracle")], check=True)
+    return ctypes.CDLL(so)
+
+
+@pytest.mark.parametrize("case", ["h1_nomask_bias", "h2_mask_bias", "h16_nomask_nobias", "h2_mask_nobias",
+                                  "h2_mask_bias_d64"])
+def test_c_oracle_prob_attention(golden, case):
+    """The double-precision C restatement reproduces the reference's outputs and gradients."""
+    import ctypes
+    lib = _c_oracle()
+    g = golden("probattn_" + case)
+    q, k, v = (np.ascontiguousarray(g[n].transpose(0, 2, 1, 3)) for n in "qkv")           # B_,H,N,d
+    B_, H, N, d = q.shape
+    use_bias = bool(g["use_bias"])
+    bias = np.ascontiguousarray(g["bias"]) if use_bias else None
+    mask = np.ascontiguousarray(g["mask"]) if g["mask"].size else None
+    idx = np.ascontiguousarray(g["idx"].astype(np.int32))
+    ctx = np.empty_like(q)
+    top = np.empty((B_, H, 25), np.int32)
+    P = lambda a: a.ctypes.data_as(ctypes.c_void_p) if a is not None else None
+    nW = mask.shape[0] if mask is not None else 1
+    lib.ps_attn_oracle_fwd(P(q), P(k), P(v), P(idx), P(bias), P(mask), B_, H, nW, N, d, 25, P(ctx), P(top), None)
+    assert np.array_equal(np.sort(top, -1), np.sort(g["top"].astype(np.int32), -1))
+    assert np.allclose(ctx, g["ctx"].transpose(0, 2, 1, 3), atol=2e-6, rtol=1e-5)
+    dctx = np.ascontiguousarray(g["gout"].transpose(0, 2, 1, 3))
+    dq, dk, dv = np.empty_like(q), np.empty_like(q), np.empty_like(q)
+    dbias = np.zeros((H, N, N), np.float32) if use_bias else None
+    lib.ps_attn_oracle_bwd(P(q), P(k), P(v), P(bias), P(mask), P(top), P(dctx), B_, H, nW, N, d, 25, P(dq), P(dk),
+                           P(dv), P(dbias))
+    for name, arr in (("dq", dq), ("dk", dk), ("dv", dv)):
+        assert np.allclose(arr, g[name].transpose(0, 2, 1, 3), atol=5e-6, rtol=1e-4), name
+    if use_bias:
+        assert np.allclose(dbias, g["dbias"], atol=5e-6, rtol=1e-4)
+
+
+def test_train_trajectory(golden):
+    """seed recipe -> the reference's 6-step loss trajectory (pins the order in which the
+    sampling indices and the DropPath masks consume the global CPU generator)."""
+    import random
+    import My_model_1 as M1
+    g = golden("train_trajectory")
+    random.seed(1234); np.random.seed(1234); torch.manual_seed(1234)
+    model = M1.Uformer(img_size=128, embed_dim=32, win_size=8, token_projection='linear', token_mlp='leff')
+    P = {k: v.detach().clone().requires_grad_(v.dtype.is_floating_point) for k, v in model.state_dict().items()}
+    opt = torch.optim.AdamW([P[n] for n, _ in model.named_parameters()], lr=2e-4, betas=(0.9, 0.999), eps=1e-8,
+                            weight_decay=0.02)
+    gen = torch.Generator().manual_seed(7)
+    gt = torch.rand(4, 3, 128, 128, generator=gen)
+    hazy = (0.6 * gt + 0.4 * torch.rand(4, 1, 1, 1, generator=gen)).clamp(0, 1)
+
+    def step(a, b):
+        opt.zero_grad()
+        loss, _ = O.train_step_loss(P, hazy[a:b], gt[a:b], training=True)
+        loss.backward()
+        opt.step()
+        return loss.item()
+
+    step(0, 2)
+    traj = [step(2 * s, 2 * s + 2) for _ in range(3) for s in range(2)]
+    assert np.allclose(traj, g["losses"], atol=2e-5), (traj, g["losses"])
+
+
+@pytest.mark.parametrize("gname,variant", [("full_m1_e32", "probsparse"), ("full_m0_e32", "dense")])
+def test_full_model_oracle(golden, gname, variant):
+    import random
+    mod = __import__("My_model_1" if variant == "probsparse" else "My_model")
+    g = golden(gname)
+    random.seed(1234); np.random.seed(1234); torch.manual_seed(1234)
+    model = mod.Uformer(img_size=128, embed_dim=32, win_size=8, token_projection='linear', token_mlp='leff')
+    P = {k: v.detach() for k, v in model.state_dict().items()}
+    hazy = T(g["hazy"]).float()
+    torch.manual_seed(99)
+    with torch.no_grad():
+        y = O.uformer_forward(P, hazy, variant=variant)
+    assert torch.allclose(y[0, :, 40:72, 40:72], T(g["y_eval_crop"]), atol=1e-5, rtol=1e-4)
+    assert abs(float(y.double().sum()) - float(g["y_eval_sum"])) < 1e-4 * float(g["y_eval_abs"])
