@@ -73,6 +73,15 @@ int dhz_bias_gather(const float* table, float* bias, int H, void* stream);
 int dhz_bias_table_grad(const float* dbias_part, int parts, float* dtable, int H, int accumulate,
                         void* stream);
 
+/* K2/K4/K5 (backward)  weight + bias gradient of every token-major nn.Linear on the path
+ *     (query/key/value/out projections ATT:420-422,454-458; LeFF linear1/linear2 M1:487-492):
+ *     dw[N,K] += dy^T[N,T] . x[T,K]        db[N] += sum_t dy[t,:]        (ACCUMULATED: caller zeroes,
+ *     which lets the gradients land directly in the optimizer's flat gradient buffer).
+ *     dy: [T,N] with row stride ldy, x: [T,K] with row stride ldx; T % 32 == 0, N % 32 == 0, K % 32 == 0.
+ *     db may be NULL.  Summation order over T is not deterministic (fp32 atomics). */
+int dhz_linear_wgrad(const float* dy, int ldy, const float* x, int ldx, int T, int N, int K,
+                     float* dw, float* db, void* stream);
+
 /* K6  shift mask builder: mask[nW,64,64] in {0,-100}  (M1:803-836), Hres x Wres map, win 8. */
 int dhz_shift_mask(float* mask, int Hres, int Wres, int shift, void* stream);
 

@@ -481,30 +481,17 @@ __global__ void bias_gather_kernel(const float* __restrict__ table, float* __res
 }
 
 // one workgroup per head: sum the per-workgroup partials, then fold (i,j) pairs onto the 225 table rows
+// grid = (16 element-chunks, H heads, Z part-slices): every thread sums one (i,j) element over its slice of
+// the per-workgroup partials (coalesced across the 256 threads) and adds it onto the table row rel(i,j).
 __global__ __launch_bounds__(256) void bias_table_grad_kernel(const float* __restrict__ part, int parts,
-                                                              float* __restrict__ dtable, int H, int accumulate) {
-    __shared__ float sum[NT * NT];
-    const int h = blockIdx.x, t = threadIdx.x;
-    for (int e = t; e < NT * NT; e += 256) {
-        float s = 0.f;
-        for (int p = h; p < parts; p += H) s += part[(size_t)p * NT * NT + e];
-        sum[e] = s;
-    }
-    __syncthreads();
-    if (t < 225) {
-        const int dh = t / 15 - 7, dw = t % 15 - 7;
-        float s = 0.f;
-        for (int ih = 0; ih < 8; ++ih) {
-            const int jh = ih - dh;
-            if (jh < 0 || jh > 7) continue;
-            for (int iw = 0; iw < 8; ++iw) {
-                const int jw = iw - dw;
-                if (jw < 0 || jw > 7) continue;
-                s += sum[(ih * 8 + iw) * NT + jh * 8 + jw];
-            }
-        }
-        if (accumulate) dtable[t * H + h] += s; else dtable[t * H + h] = s;
-    }
+                                                              float* __restrict__ dtable, int H) {
+    const int h = blockIdx.y;
+    const int e = blockIdx.x * 256 + threadIdx.x;          // 0..4095
+    float s = 0.f;
+    for (int p = h + H * blockIdx.z; p < parts; p += H * gridDim.z) s += part[(size_t)p * NT * NT + e];
+    const int i = e >> 6, j = e & 63;
+    const int rel = ((i >> 3) - (j >> 3) + 7) * 15 + ((i & 7) - (j & 7) + 7);
+    atomicAdd(dtable + rel * H + h, s);
 }
 
 __global__ void shift_mask_kernel(float* __restrict__ mask, int Hres, int Wres, int shift) {
@@ -607,8 +594,12 @@ extern "C" int dhz_bias_gather(const float* table, float* bias, int H, void* str
 extern "C" int dhz_bias_table_grad(const float* dbias_part, int parts, float* dtable, int H, int accumulate,
                                    void* stream) {
     DHZ_REQUIRE(dbias_part && dtable && H > 0 && parts > 0 && parts % H == 0, "dhz_bias_table_grad: bad arguments");
-    hipLaunchKernelGGL(bias_table_grad_kernel, dim3(H), dim3(256), 0, (hipStream_t)stream, dbias_part, parts, dtable,
-                       H, accumulate);
+    hipStream_t s = (hipStream_t)stream;
+    if (!accumulate) (void)hipMemsetAsync(dtable, 0, sizeof(float) * 225 * H, s);
+    int z = parts / H / 8;            // >= 8 partials per thread
+    if (z < 1) z = 1;
+    if (z > 32) z = 32;
+    hipLaunchKernelGGL(bias_table_grad_kernel, dim3(NT * NT / 256, H, z), dim3(256), 0, s, dbias_part, parts, dtable, H);
     DHZ_CHECK_LAUNCH("dhz_bias_table_grad");
     return DHZ_OK;
 }

@@ -114,15 +114,15 @@ class AttentionLayer(nn.Module):
         assert keys is queries and values is queries, "self-attention only (M1:413 passes x, x, x)"
         B_, N, C = queries.shape
         H = self.n_heads
-        w = torch.cat([self.query_projection.weight, self.key_projection.weight, self.value_projection.weight], 0)
-        b = torch.cat([self.query_projection.bias, self.key_projection.bias, self.value_projection.bias], 0)
-        qkv = F.linear(queries.reshape(B_ * N, C), w, b)                        # one rocBLAS GEMM [T,3C]
+        qp, kp, vp = self.query_projection, self.key_projection, self.value_projection
+        qkv = ops.linear_tokens(queries.reshape(B_ * N, C), qp.weight, qp.bias, kp.weight, kp.bias,
+                                vp.weight, vp.bias)                              # one library GEMM [T,3C]
         if idx is None:
             idx = draw_sample_index(1, N)[0]
         if idx.device != qkv.device or idx.dtype != torch.uint8:
             idx = idx.to(device=qkv.device, dtype=torch.uint8)
         ctx = ops.ps_window_attention(qkv, table, idx.contiguous(), SW_mask, H, C // H)
-        out = F.linear(ctx, self.out_projection.weight, self.out_projection.bias)
+        out = ops.linear_tokens(ctx, self.out_projection.weight, self.out_projection.bias)
         return out.view(B_, N, C), None
 
 
@@ -213,9 +213,9 @@ class LeFF(nn.Module):
     def forward(self, x):
         B, L, C = x.shape
         hh = int(math.sqrt(L))
-        u = F.linear(x.reshape(B * L, C), self.linear1[0].weight, self.linear1[0].bias).view(B, L, self.hidden_dim)
+        u = ops.linear_tokens(x.reshape(B * L, C), self.linear1[0].weight, self.linear1[0].bias).view(B, L, self.hidden_dim)
         z = ops.leff_dwconv(u, self.dwconv[0].weight, self.dwconv[0].bias, hh, hh)
-        y = F.linear(z.view(B * L, self.hidden_dim), self.linear2[0].weight, self.linear2[0].bias)
+        y = ops.linear_tokens(z.view(B * L, self.hidden_dim), self.linear2[0].weight, self.linear2[0].bias)
         return y.view(B, L, C)
 
 

@@ -120,6 +120,91 @@ def shift_mask(Hres, Wres, shift, device):
     return m
 
 
+# ----------------------------------------------------------------------------- token-major Linear (K2 / K4 / K5 GEMMs)
+# Called with every parameter whose gradient has just been accumulated IN PLACE by a wgrad kernel (autograd's
+# AccumulateGrad - and therefore its post-accumulate hooks - is bypassed for those); the gradient reducer
+# installs itself here to keep its bucket bookkeeping.
+GRAD_READY = None
+
+
+def _accumulate_param_grads(dy, ldy_off, x, params):
+    """dW += dy[:, off:off+N]^T x, db += colsum for every (W, b) pair, straight into .grad (zero-init)."""
+    T, K = x.shape
+    off = ldy_off
+    for W, b in params:
+        N = W.shape[0]
+        for p in (W, b):
+            if p is not None and p.grad is None:
+                p.grad = torch.zeros_like(p, memory_format=torch.contiguous_format)
+        assert W.grad.is_contiguous()
+        _lib.call("dhz_linear_wgrad", dy.data_ptr() + 4 * off, dy.stride(0), _p(x), x.stride(0), T, N, K, _p(W.grad),
+                  _p(b.grad) if b is not None else None, _stream())
+        if GRAD_READY is not None:
+            GRAD_READY(W)
+            if b is not None:
+                GRAD_READY(b)
+        off += N
+
+
+class _LinearTokens(Function):
+    """y = x [W_1;..;W_n]^T + [b_1;..;b_n] for token-major x [T,K].  Forward and dgrad are plain library
+    GEMMs (rocBLAS/hipBLASLt run them near the fp32 MFMA peak); the weight/bias gradients - skinny TN
+    GEMMs over T tokens that the library runs at 5-20 TFLOP/s - use dhz_linear_wgrad and are accumulated
+    in place into the parameters' .grad (the optimizer's flat gradient buffer)."""
+
+    @staticmethod
+    def forward(ctx, x, *wb):
+        _require_gpu(x)
+        params = [(wb[i], wb[i + 1]) for i in range(0, len(wb), 2)]
+        if len(params) == 1:
+            W, b = params[0]
+        else:
+            W = torch.cat([w for w, _ in params], 0)
+            b = torch.cat([b_ for _, b_ in params], 0)
+        y = torch.addmm(b, x, W.t()) if b is not None else x @ W.t()
+        ctx.save_for_backward(x, W)
+        ctx.params = params
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, W = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = dy @ W if ctx.needs_input_grad[0] else None
+        T, K = x.shape
+        grads = []
+        off = 0
+        for w, b in ctx.params:
+            N = w.shape[0]
+            # measured on MI355X (tools/bench_wgrad.py): the split-T kernel wins 2-18x for T >= 16k tokens and
+            # for small N*K; the library's TN GEMM wins (1.2-1.7x) only on the deep stages (T <= 8k, N*K >= 256k)
+            mine = T >= 16384 or N * K < 200000
+            if mine and w.is_leaf and (b is None or b.is_leaf):
+                _accumulate_param_grads(dy, off, x, [(w, b)])
+                grads += [None, None]
+            elif mine:
+                dw = torch.zeros_like(w, memory_format=torch.contiguous_format)
+                db = torch.zeros_like(b) if b is not None else None
+                _lib.call("dhz_linear_wgrad", dy.data_ptr() + 4 * off, dy.shape[1], _p(x), K, T, N, K, _p(dw), _p(db),
+                          _stream())
+                grads += [dw, db]
+            else:
+                dys = dy[:, off:off + N]
+                grads += [dys.t() @ x, dys.sum(0) if b is not None else None]
+            off += N
+        return (dx,) + tuple(grads)
+
+
+def linear_tokens(x, *wb):
+    """x [T,K] (contiguous); wb = W1, b1, W2, b2, ...  ->  [T, sum N_i]."""
+    if not torch.is_grad_enabled() or not any(t is not None and t.requires_grad for t in (x,) + wb):
+        params = [(wb[i], wb[i + 1]) for i in range(0, len(wb), 2)]
+        W = params[0][0] if len(params) == 1 else torch.cat([w for w, _ in params], 0)
+        b = params[0][1] if len(params) == 1 else torch.cat([b_ for _, b_ in params], 0)
+        return torch.addmm(b, x, W.t())
+    return _LinearTokens.apply(x.contiguous(), *wb)
+
+
 # ----------------------------------------------------------------------------- K1
 class _LNPartition(Function):
     @staticmethod

@@ -170,6 +170,11 @@ class GradReducer:
         if self.world > 1:
             for p, _, _ in slices:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
+            ops.GRAD_READY = self._on_grad_inplace      # wgrad kernels accumulate in place, bypassing autograd hooks
+
+    def _on_grad_inplace(self, p):
+        if id(p) in self.bucket_of:
+            self._on_grad(p)
 
     def _on_grad(self, p):
         b = self.bucket_of[id(p)]

@@ -1,0 +1,58 @@
+"""-m gpu: dhz_linear_wgrad (skinny TN GEMM over tokens) and the token-major Linear wrapper vs torch."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("T,N,K", [(4096, 32, 32), (8192, 96, 32), (4096, 128, 32), (4096, 32, 128), (2048, 192, 64),
+                                   (2048, 256, 64), (1024, 384, 128), (1024, 512, 128), (512, 1536, 512),
+                                   (256, 2048, 512), (512, 512, 2048), (64, 64, 64)])
+def test_linear_tokens_grads(T, N, K):
+    from dehaze_hip import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(T + N + K)
+    x = torch.randn(T, K, generator=g)
+    W = torch.randn(N, K, generator=g) * 0.1
+    b = torch.randn(N, generator=g) * 0.1
+    go = torch.randn(T, N, generator=g)
+    xr, Wr, br = x.double().requires_grad_(), W.double().requires_grad_(), b.double().requires_grad_()
+    (torch.nn.functional.linear(xr, Wr, br) * go.double()).sum().backward()
+    xd = x.to(dev).requires_grad_()
+    Wd = torch.nn.Parameter(W.to(dev))
+    bd = torch.nn.Parameter(b.to(dev))
+    y = ops.linear_tokens(xd, Wd, bd)
+    (y * go.to(dev)).sum().backward()
+    assert torch.allclose(y.detach().cpu().double(), torch.nn.functional.linear(xr, Wr, br).detach(), atol=1e-4, rtol=1e-4)
+    scale = (T ** 0.5)
+    assert torch.allclose(xd.grad.cpu().double(), xr.grad, atol=1e-4, rtol=1e-4)
+    assert (Wd.grad.cpu().double() - Wr.grad).abs().max() < 2e-5 * scale
+    assert (bd.grad.cpu().double() - br.grad).abs().max() < 2e-5 * scale
+    # second backward accumulates in place
+    y2 = ops.linear_tokens(xd, Wd, bd)
+    (y2 * go.to(dev)).sum().backward()
+    assert (Wd.grad.cpu().double() - 2 * Wr.grad).abs().max() < 4e-5 * scale
+
+
+def test_packed_qkv_grads():
+    from dehaze_hip import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(3)
+    T, C = 2048, 64
+    x = torch.randn(T, C, generator=g)
+    Ws = [torch.randn(C, C, generator=g) * 0.1 for _ in range(3)]
+    bs = [torch.randn(C, generator=g) * 0.1 for _ in range(3)]
+    go = torch.randn(T, 3 * C, generator=g)
+    xr = x.double().requires_grad_()
+    Wr = [w.double().requires_grad_() for w in Ws]
+    br = [b.double().requires_grad_() for b in bs]
+    (torch.nn.functional.linear(xr, torch.cat(Wr), torch.cat(br)) * go.double()).sum().backward()
+    Wd = [torch.nn.Parameter(w.to(dev)) for w in Ws]
+    bd = [torch.nn.Parameter(b.to(dev)) for b in bs]
+    xd = x.to(dev).requires_grad_()
+    y = ops.linear_tokens(xd, Wd[0], bd[0], Wd[1], bd[1], Wd[2], bd[2])
+    (y * go.to(dev)).sum().backward()
+    for i in range(3):
+        assert (Wd[i].grad.cpu().double() - Wr[i].grad).abs().max() < 1e-3
+        assert (bd[i].grad.cpu().double() - br[i].grad).abs().max() < 1e-3
+    assert torch.allclose(xd.grad.cpu().double(), xr.grad, atol=1e-4, rtol=1e-4)
