@@ -154,9 +154,17 @@ def main():
             bytes_alg = wh * (4 * 64 * d * 4)                   # Q,K,V in + ctx out, fp32
             flops_alg = wh * 3 * 2 * 25 * 64 * d                # 307.2 KFLOP / window-head
             gbs = bytes_alg / (ms * 1e-3) / 1e9
+            # HBM bytes per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
+            # separate runs of this same command; FETCH doubled per the gfx950 correction) - tools/pmc_summary.py
+            traffic = None
+            try:
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+                traffic = round(pmc["ps_attn_fwd_kernel<32>"]["hbm_bytes_per_launch"])
+            except Exception:
+                pass
             out["roofline"] = {"kernel": "ps_attn_fwd_kernel<32> (dhz_ps_attn_fwd)", "bound": "hbm",
                                "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
+                               "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
                                "launches": len(ev), "avg_launch_us": round(1e3 * ms / len(ev), 2),
                                "alg_bytes_per_launch": bytes_alg // len(ev),
                                "alg_tflops": round(flops_alg / (ms * 1e-3) / 1e12, 2),

@@ -8,6 +8,7 @@
 // (v_mfma_f32_16x16x4_f32, A = dY^T and B = X both read "row = token, lanes along the feature", which is
 // conflict-free with a +16 float row pad), reduces db on the fly from the staged dY registers, and
 // finally adds its partial tile into dW with full-line fp32 atomics.
+#include <stdlib.h>
 #include "common.h"
 
 namespace {
@@ -146,7 +147,11 @@ int launch(const float* dy, int ldy, const float* x, int ldx, int T, int N, int 
     constexpr size_t stage = (size_t)TK * (BM + 16 + BN + 16) * sizeof(float);
     constexpr size_t smem = 2 * stage > (size_t)BM * BN * 4 ? 2 * stage : (size_t)BM * BN * 4;
     const int tiles = (N / BM) * (K / BN);
-    int nsplit = (1536 + tiles - 1) / tiles;
+    // Every workgroup ends with BM*BN fp32 atomics (chip-wide ~1.3 TB/s of added bytes): large tiles want
+    // fewer, longer token slabs.  DHZ_WGRAD_TARGET overrides the workgroup target (tuning aid).
+    static const int env_target = getenv("DHZ_WGRAD_TARGET") ? atoi(getenv("DHZ_WGRAD_TARGET")) : 0;
+    const int target = env_target > 0 ? env_target : 512;      // 2 workgroups per CU measured best on every shape
+    int nsplit = (target + tiles - 1) / tiles;
     const int max_split = T / (TK * 4) > 0 ? T / (TK * 4) : 1;     // at least 4 stages per workgroup
     if (nsplit > max_split) nsplit = max_split;
     if (nsplit < 1) nsplit = 1;

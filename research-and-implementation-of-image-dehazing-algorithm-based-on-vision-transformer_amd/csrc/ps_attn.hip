@@ -483,15 +483,28 @@ __global__ void bias_gather_kernel(const float* __restrict__ table, float* __res
 // one workgroup per head: sum the per-workgroup partials, then fold (i,j) pairs onto the 225 table rows
 // grid = (16 element-chunks, H heads, Z part-slices): every thread sums one (i,j) element over its slice of
 // the per-workgroup partials (coalesced across the 256 threads) and adds it onto the table row rel(i,j).
+// grid = (Z part-slices, H heads): a workgroup sums its slice of the per-workgroup partials (coalesced float4
+// reads), folds the 4096 (i,j) elements onto the 225 table rows with LDS atomics and issues 225 global atomics.
 __global__ __launch_bounds__(256) void bias_table_grad_kernel(const float* __restrict__ part, int parts,
                                                               float* __restrict__ dtable, int H) {
-    const int h = blockIdx.y;
-    const int e = blockIdx.x * 256 + threadIdx.x;          // 0..4095
-    float s = 0.f;
-    for (int p = h + H * blockIdx.z; p < parts; p += H * gridDim.z) s += part[(size_t)p * NT * NT + e];
-    const int i = e >> 6, j = e & 63;
-    const int rel = ((i >> 3) - (j >> 3) + 7) * 15 + ((i & 7) - (j & 7) + 7);
-    atomicAdd(dtable + rel * H + h, s);
+    __shared__ float tab[225];
+    const int h = blockIdx.y, t = threadIdx.x;
+    if (t < 225) tab[t] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int e4 = q * 256 + t;                            // float4 index 0..1023
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int p = h + H * blockIdx.x; p < parts; p += H * gridDim.x) {
+            const float4 v = reinterpret_cast<const float4*>(part + (size_t)p * NT * NT)[e4];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        const int e = e4 * 4, i = e >> 6, j = e & 63;          // 4 consecutive j in the same row i
+        const int rel = ((i >> 3) - (j >> 3) + 7) * 15 + ((i & 7) - (j & 7) + 7);
+        atomicAdd(&tab[rel], s.x); atomicAdd(&tab[rel - 1], s.y); atomicAdd(&tab[rel - 2], s.z); atomicAdd(&tab[rel - 3], s.w);
+    }
+    __syncthreads();
+    if (t < 225) atomicAdd(dtable + t * H + h, tab[t]);
 }
 
 __global__ void shift_mask_kernel(float* __restrict__ mask, int Hres, int Wres, int shift) {
@@ -596,10 +609,10 @@ extern "C" int dhz_bias_table_grad(const float* dbias_part, int parts, float* dt
     DHZ_REQUIRE(dbias_part && dtable && H > 0 && parts > 0 && parts % H == 0, "dhz_bias_table_grad: bad arguments");
     hipStream_t s = (hipStream_t)stream;
     if (!accumulate) (void)hipMemsetAsync(dtable, 0, sizeof(float) * 225 * H, s);
-    int z = parts / H / 8;            // >= 8 partials per thread
+    int z = parts / H / 4;            // >= 4 partials (64 KiB) per workgroup
     if (z < 1) z = 1;
-    if (z > 32) z = 32;
-    hipLaunchKernelGGL(bias_table_grad_kernel, dim3(NT * NT / 256, H, z), dim3(256), 0, s, dbias_part, parts, dtable, H);
+    if (z > 128) z = 128;
+    hipLaunchKernelGGL(bias_table_grad_kernel, dim3(z, H), dim3(256), 0, s, dbias_part, parts, dtable, H);
     DHZ_CHECK_LAUNCH("dhz_bias_table_grad");
     return DHZ_OK;
 }

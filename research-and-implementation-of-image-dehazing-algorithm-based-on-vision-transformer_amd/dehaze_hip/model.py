@@ -314,9 +314,17 @@ class BasicUformerLayer(nn.Module):
 # ----------------------------------------------------------------------------- resampling / projections
 
 def _tokens_to_map(x):
+    """[B, H*W, C] tokens -> logical NCHW map that ALIASES the token buffer (channels_last strides): the
+    token layout is NHWC already, so no transpose kernel runs and MIOpen picks its NHWC kernels directly."""
     B, L, C = x.shape
     s = int(math.sqrt(L))
-    return x.transpose(1, 2).contiguous().view(B, C, s, s)
+    return x.contiguous().view(B, s, s, C).permute(0, 3, 1, 2)
+
+
+def _map_to_tokens(y):
+    """NCHW-logical conv output (channels_last in memory) -> [B, H*W, C] tokens, copy-free when possible."""
+    B, C, H, W = y.shape
+    return y.permute(0, 2, 3, 1).reshape(B, H * W, C)
 
 
 class Downsample(nn.Module):
@@ -328,7 +336,7 @@ class Downsample(nn.Module):
         self.in_channel, self.out_channel = in_channel, out_channel
 
     def forward(self, x):
-        return self.conv(_tokens_to_map(x)).flatten(2).transpose(1, 2).contiguous()
+        return _map_to_tokens(self.conv(_tokens_to_map(x)))
 
 
 class Upsample(nn.Module):
@@ -340,7 +348,7 @@ class Upsample(nn.Module):
         self.in_channel, self.out_channel = in_channel, out_channel
 
     def forward(self, x):
-        return self.deconv(_tokens_to_map(x)).flatten(2).transpose(1, 2).contiguous()
+        return _map_to_tokens(self.deconv(_tokens_to_map(x)))
 
 
 class InputProj(nn.Module):
@@ -354,7 +362,7 @@ class InputProj(nn.Module):
         self.in_channel, self.out_channel = in_channel, out_channel
 
     def forward(self, x):
-        x = self.proj(x).flatten(2).transpose(1, 2).contiguous()
+        x = _map_to_tokens(self.proj(x.contiguous(memory_format=torch.channels_last)))
         return self.norm(x) if self.norm is not None else x
 
 
