@@ -65,6 +65,19 @@ int dhz_ps_attn_bwd(const float* q, const float* k, const float* v, int ld, cons
                     float* dk, float* dv, int ldg, float* dbias_part, int B_, int H, int nW, int d,
                     void* stream);
 
+/* K3-dense  Dense window attention of the My_model.Uformer twin.  Replaces WindowAttention.forward
+ *     M0:428-492:  out = softmax(scale * q k^T + bias[h] + mask[b % nW]) v   per (window, head).
+ *     Same layouts as dhz_ps_attn_fwd (q,k,v [B_,64,H,d] with token stride ld; bias [H,64,64] or NULL;
+ *     mask [nW,64,64] or NULL).  Nothing is saved: the backward recomputes the probabilities.
+ *     dbias_part: [dhz_ps_attn_bwd_parts(B_,H), 64, 64] partials, reduced by dhz_bias_table_grad. */
+int dhz_dense_attn_fwd(const float* q, const float* k, const float* v, int ld, const float* bias,
+                       const float* mask, float* out, int ldo, int B_, int H, int nW, int d,
+                       float scale, void* stream);
+int dhz_dense_attn_bwd(const float* q, const float* k, const float* v, int ld, const float* bias,
+                       const float* mask, const float* dout, int ldo, float* dq, float* dk, float* dv,
+                       int ldg, float* dbias_part, int B_, int H, int nW, int d, float scale,
+                       void* stream);
+
 /* K7  relative-position bias:  bias[h,i,j] = table[rel_index(i,j), h]   (M1:408-410, win = 8).
  * table: [225, H].  bias: [H,64,64]. */
 int dhz_bias_gather(const float* table, float* bias, int H, void* stream);

@@ -22,6 +22,8 @@ SIGNATURES = {
     "dhz_ps_attn_fwd": [c_f, c_f, c_f, c_i, c_p, c_f, c_f, c_f, c_i, c_p, c_i, c_i, c_i, c_i, c_p],
     "dhz_ps_attn_bwd_parts": [c_i, c_i],
     "dhz_ps_attn_bwd": [c_f, c_f, c_f, c_i, c_f, c_f, c_p, c_f, c_i, c_f, c_f, c_f, c_i, c_f, c_i, c_i, c_i, c_i, c_p],
+    "dhz_dense_attn_fwd": [c_f, c_f, c_f, c_i, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_fl, c_p],
+    "dhz_dense_attn_bwd": [c_f, c_f, c_f, c_i, c_f, c_f, c_f, c_i, c_f, c_f, c_f, c_i, c_f, c_i, c_i, c_i, c_i, c_fl, c_p],
     "dhz_bias_gather": [c_f, c_f, c_i, c_p],
     "dhz_bias_table_grad": [c_f, c_i, c_f, c_i, c_i, c_p],
     "dhz_shift_mask": [c_f, c_i, c_i, c_i, c_p],

@@ -189,8 +189,13 @@ class WindowAttention(nn.Module):
         return self._dense(x, mask)
 
     def _dense(self, x, mask):
-        # TODO(next round): dedicated dense-window HIP kernel; the dense twin is an f4 "next" row of SURVEY §8.
-        raise NotImplementedError("dense My_model.Uformer attention kernel is not built yet (SURVEY §8 f4)")
+        """M0:428-518: q = to_q(x), [k|v] = to_kv(x) as ONE packed GEMM, fused dense window attention, proj."""
+        B_, N, C = x.shape
+        H = self.num_heads
+        qkv = ops.linear_tokens(x.reshape(B_ * N, C), self.qkv.to_q.weight, self.qkv.to_q.bias,
+                                self.qkv.to_kv.weight, self.qkv.to_kv.bias)
+        ctx = ops.dense_window_attention(qkv, self.relative_position_bias_table, mask, H, C // H, self.scale)
+        return ops.linear_tokens(ctx, self.proj.weight, self.proj.bias).view(B_, N, C)
 
     def extra_repr(self):
         return f'dim={self.dim}, win_size={self.win_size}, num_heads={self.num_heads}'

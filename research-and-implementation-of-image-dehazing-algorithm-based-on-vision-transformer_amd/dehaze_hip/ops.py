@@ -113,6 +113,48 @@ def ps_window_attention_rank(qkv, table, idx, mask, H, d):
     return out, rank
 
 
+class _DenseWindowAttention(Function):
+    """Dense window attention (My_model twin, M0:428-492) on a packed [T,3C] QKV buffer."""
+
+    @staticmethod
+    def forward(ctx, qkv, table, mask, H, d, scale):
+        _require_gpu(qkv, table, mask)
+        T, C3 = qkv.shape
+        C = H * d
+        assert C3 == 3 * C and T % NTOK == 0 and qkv.is_contiguous()
+        B_ = T // NTOK
+        out = torch.empty((T, C), device=qkv.device, dtype=torch.float32)
+        bias = torch.empty((H, NTOK, NTOK), device=qkv.device, dtype=torch.float32)
+        _lib.call("dhz_bias_gather", _p(table.contiguous()), _p(bias), H, _stream())
+        nW = mask.shape[0] if mask is not None else 1
+        base = qkv.data_ptr()
+        _lib.call("dhz_dense_attn_fwd", base, base + 4 * C, base + 8 * C, 3 * C, _p(bias), _p(mask), _p(out), C, B_, H,
+                  nW, d, float(scale), _stream())
+        ctx.save_for_backward(qkv, bias, mask)
+        ctx.dims = (B_, H, d, nW, float(scale))
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv, bias, mask = ctx.saved_tensors
+        B_, H, d, nW, scale = ctx.dims
+        C = H * d
+        dout = dout.contiguous()
+        dqkv = torch.empty_like(qkv)
+        parts = _lib.load().dhz_ps_attn_bwd_parts(B_, H)
+        dpart = torch.empty((parts, NTOK, NTOK), device=qkv.device, dtype=torch.float32)
+        base, gb = qkv.data_ptr(), dqkv.data_ptr()
+        _lib.call("dhz_dense_attn_bwd", base, base + 4 * C, base + 8 * C, 3 * C, _p(bias), _p(mask), _p(dout), C,
+                  gb, gb + 4 * C, gb + 8 * C, 3 * C, _p(dpart), B_, H, nW, d, scale, _stream())
+        dtable = torch.empty((225, H), device=qkv.device, dtype=torch.float32)
+        _lib.call("dhz_bias_table_grad", _p(dpart), parts, _p(dtable), H, 0, _stream())
+        return dqkv, dtable, None, None, None, None
+
+
+def dense_window_attention(qkv, table, mask, H, d, scale):
+    return _DenseWindowAttention.apply(qkv, table, mask, H, d, scale)
+
+
 def shift_mask(Hres, Wres, shift, device):
     """[nW,64,64] 0/-100 mask of M1:803-836 (cached by callers; depends only on the geometry)."""
     m = torch.empty(((Hres // 8) * (Wres // 8), NTOK, NTOK), device=device, dtype=torch.float32)

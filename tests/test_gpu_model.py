@@ -137,3 +137,40 @@ def test_contrast_loss_vs_oracle(golden, dev):
         ref = T(g[tag + "/da"])
         err = (a.grad.cpu() - ref).abs().max().item()
         assert err < 2e-2 * ref.abs().max().item(), err
+
+
+# ----------------------------------------------------------------------------- dense twin (My_model.Uformer)
+@pytest.mark.parametrize("name,heads,shift,C", [("block_m0_c32_shift0", 1, 0, 32), ("block_m0_c32_shift4", 1, 4, 32),
+                                                ("block_m0_c64_shift4", 2, 4, 64)])
+def test_dense_block_vs_reference_golden(golden, dev, name, heads, shift, C):
+    import My_model as M0
+    g = golden(name)
+    blk = M0.LeWinTransformerBlock(dim=C, input_resolution=(16, 16), num_heads=heads, win_size=8, shift_size=shift,
+                                   token_mlp='leff', drop_path=0., variant="dense")
+    blk.load_state_dict({k[3:]: T(g[k]) for k in g.files if k.startswith("sd/")})
+    blk.to(dev)
+    x = T(g["x"]).to(dev).requires_grad_()
+    y = blk(x)
+    assert torch.allclose(y.cpu(), T(g["y"]), atol=3e-5, rtol=1e-4), (y.cpu() - T(g["y"])).abs().max()
+    (y * T(g["gout"]).to(dev)).sum().backward()
+    assert torch.allclose(x.grad.cpu(), T(g["dx"]), atol=5e-5, rtol=1e-3)
+    for n, p in blk.named_parameters():
+        ref = g["g/" + n]
+        if ref.size == 0:
+            assert p.grad is None, n
+        else:
+            err = (p.grad.cpu() - T(ref)).abs().max().item()
+            assert err <= 2e-4 + 2e-3 * np.abs(ref).max(), (n, err)
+
+
+def test_dense_full_model_vs_reference_golden(golden, dev):
+    import My_model as M0
+    g = golden("full_m0_e32")
+    seed_all(1234)
+    model = M0.Uformer(img_size=128, embed_dim=32, win_size=8, token_projection='linear', token_mlp='leff').to(dev)
+    model.eval()
+    with torch.no_grad():
+        y = model(T(g["hazy"]).float().to(dev))
+    crop = y[0, :, 40:72, 40:72].cpu()
+    assert torch.allclose(crop, T(g["y_eval_crop"]), atol=2e-4, rtol=1e-3), (crop - T(g["y_eval_crop"])).abs().max()
+    assert abs(float(y.double().sum()) - float(g["y_eval_sum"])) < 1e-3 * float(g["y_eval_abs"])

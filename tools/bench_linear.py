@@ -1,0 +1,19 @@
+"""Library GEMM efficiency on the model's token-major Linear shapes (forward and dgrad), bs=32."""
+import torch
+dev = torch.device("cuda:0")
+print(f"{'T':>7} {'K':>5} {'N':>5} | fwd us   GB/s    TF | dgrad us  GB/s    TF")
+for T, C in [(524288, 32), (131072, 64), (32768, 128), (8192, 256), (2048, 512), (8192, 512), (32768, 256), (131072, 128), (524288, 64)]:
+    for K, N in [(C, 3 * C), (C, C), (C, 4 * C), (4 * C, C)]:
+        x = torch.randn(T, K, device=dev); W = torch.randn(N, K, device=dev); b = torch.randn(N, device=dev)
+        dy = torch.randn(T, N, device=dev)
+        res = []
+        for f in (lambda: torch.addmm(b, x, W.t()), lambda: dy @ W):
+            for _ in range(3): f()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10): f()
+            e1.record(); torch.cuda.synchronize()
+            res.append(e0.elapsed_time(e1) / 10 * 1e3)
+        gb = T * (N + K) * 4 / 1e9; tf = 2 * T * N * K / 1e12
+        print(f"{T:7d} {K:5d} {N:5d} | {res[0]:7.1f} {gb/res[0]*1e6:6.0f} {tf/res[0]*1e6:5.1f} | {res[1]:7.1f} {gb/res[1]*1e6:6.0f} {tf/res[1]*1e6:5.1f}")
