@@ -128,7 +128,10 @@ int dhz_reverse_residual_bwd(const float* dout, const float* scale, float* dyw, 
  * K5 (middle)  LeFF depthwise stage in token (NHWC) layout.  Replaces the NHWC<->NCHW rearranges,
  *     the GELU after linear1, the depthwise 3x3 conv and its GELU  (M1:488,514-520).
  *     u: [B, Hres*Wres, Ch] = linear1 output BEFORE GELU.  w: [Ch,1,3,3] (PyTorch layout), b: [Ch].
- *     t = dwconv3x3(gelu(u)) + b   (pre-activation, saved when t != NULL)      z = gelu(t).
+ *     z = gelu(dwconv3x3(gelu(u)) + b).   When t != NULL the kernel also stores t = gelu'(pre-activation),
+ *     the only thing the backward needs from the second GELU (same bytes as saving the pre-activation,
+ *     one exponential fewer per element in the backward).  GELU is the exact-erf form evaluated with the
+ *     Abramowitz-Stegun 7.1.26 rational approximation of erf (|error| <= 1.5e-7, i.e. fp32 rounding level).
  */
 int dhz_leff_dwconv_fwd(const float* u, const float* w, const float* b, float* t, float* z, int B,
                         int Hres, int Wres, int Ch, void* stream);

@@ -185,12 +185,22 @@ __global__ __launch_bounds__(256) void reverse_residual_kernel(const float* __re
 }
 
 // ------------------------------------------------------------------------------------------------ K5 middle
-__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
-__device__ __forceinline__ float gelu_grad_f(float x) {
-    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
-    const float pdf = 0.39894228040143267794f * expf(-0.5f * x * x);
-    return cdf + x * pdf;
+// GELU (exact-erf form, nn.GELU default) and its derivative from ONE exponential:
+//   erf(|x|/sqrt2) = 1 - (a1 t + ... + a5 t^5) exp(-x^2/2),  t = 1/(1 + p|x|/sqrt2)   (Abramowitz-Stegun 7.1.26,
+//   |error| <= 1.5e-7 - at the fp32 rounding level of the cdf), and the same exponential is the Gaussian pdf
+//   needed by the derivative.  ~15 VALU instructions for both values instead of ~45 with erff()+expf().
+__device__ __forceinline__ void gelu_both(float x, float& g, float& gp) {
+    const float ax = fabsf(x) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * ax);       // v_rcp_f32 (1 ulp), no IEEE division sequence
+    const float e = __expf(-ax * ax);                                    // = exp(-x^2/2)
+    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    const float erf_abs = 1.0f - poly * e;
+    const float cdf = 0.5f * (1.0f + copysignf(erf_abs, x));
+    g = x * cdf;
+    gp = cdf + x * (0.39894228040143267794f * e);
 }
+__device__ __forceinline__ float gelu_f(float x) { float g, gp; gelu_both(x, g, gp); return g; }
+__device__ __forceinline__ float gelu_grad_f(float x) { float g, gp; gelu_both(x, g, gp); return gp; }
 
 constexpr int TW = 16, TH = 8;                 // spatial tile (positions)
 constexpr int HWID = TW + 2, HHGT = TH + 2;    // with halo
@@ -212,14 +222,28 @@ __global__ __launch_bounds__(256) void leff_dwconv_fwd_kernel(const float* __res
     const int x0 = tx * TW - 1, y0 = ty * TH - 1;
     const float* ub = u + (size_t)bimg * Hres * Wres * Ch;
     // stage gelu(u) with a 1-pixel halo (zero outside the image: Conv2d padding=1)
-    for (int pos = t >> 3; pos < HHGT * HWID; pos += 32) {
-        const int yy = y0 + pos / HWID, xx = x0 + pos % HWID;
-        float4 val = make_float4(0, 0, 0, 0);
-        if (yy >= 0 && yy < Hres && xx >= 0 && xx < Wres) {
-            const float4 uv = *reinterpret_cast<const float4*>(ub + ((size_t)yy * Wres + xx) * Ch + ch0);
-            val = make_float4(gelu_f(uv.x), gelu_f(uv.y), gelu_f(uv.z), gelu_f(uv.w));
+    {
+        constexpr int NPOS = HHGT * HWID, NIT = (NPOS + 31) / 32;
+        float4 ru[NIT];
+        bool ok[NIT];
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {                       // all loads in flight before the first GELU
+            const int pos = (t >> 3) + 32 * i;
+            const int pc = pos < NPOS ? pos : NPOS - 1;
+            const int yy = y0 + pc / HWID, xx = x0 + pc % HWID;
+            ok[i] = pos < NPOS && yy >= 0 && yy < Hres && xx >= 0 && xx < Wres;
+            const int yc = min(max(yy, 0), Hres - 1), xc = min(max(xx, 0), Wres - 1);
+            ru[i] = *reinterpret_cast<const float4*>(ub + ((size_t)yc * Wres + xc) * Ch + ch0);
         }
-        *reinterpret_cast<float4*>(&g[pos * CT + c4 * 4]) = val;
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+            const int pos = (t >> 3) + 32 * i;
+            if (pos < NPOS) {
+                float4 val = make_float4(0, 0, 0, 0);
+                if (ok[i]) val = make_float4(gelu_f(ru[i].x), gelu_f(ru[i].y), gelu_f(ru[i].z), gelu_f(ru[i].w));
+                *reinterpret_cast<float4*>(&g[pos * CT + c4 * 4]) = val;
+            }
+        }
     }
     float wk[4][9];
 #pragma unroll
@@ -242,8 +266,10 @@ __global__ __launch_bounds__(256) void leff_dwconv_fwd_kernel(const float* __res
                 acc.z += wk[2][ky * 3 + kx] * gv.z; acc.w += wk[3][ky * 3 + kx] * gv.w;
             }
         const size_t o = ((size_t)bimg * Hres * Wres + (size_t)yy * Wres + xx) * Ch + ch0;
-        if (tpre) *reinterpret_cast<float4*>(tpre + o) = acc;
-        *reinterpret_cast<float4*>(z + o) = make_float4(gelu_f(acc.x), gelu_f(acc.y), gelu_f(acc.z), gelu_f(acc.w));
+        float4 zz, zp;
+        gelu_both(acc.x, zz.x, zp.x); gelu_both(acc.y, zz.y, zp.y); gelu_both(acc.z, zz.z, zp.z); gelu_both(acc.w, zz.w, zp.w);
+        if (tpre) *reinterpret_cast<float4*>(tpre + o) = zp;      // saved for backward: gelu'(t), not t itself
+        *reinterpret_cast<float4*>(z + o) = zz;
     }
 }
 
@@ -272,23 +298,51 @@ __global__ __launch_bounds__(256) void leff_dwconv_bwd_kernel(const float* __res
         const int x0 = tx * TW - 1, y0 = ty * TH - 1;
         const size_t ib = (size_t)bimg * Hres * Wres;
         __syncthreads();
-        for (int pos = t >> 3; pos < HHGT * HWID; pos += 32) {
-            const int yy = y0 + pos / HWID, xx = x0 + pos % HWID;
-            float4 gv = make_float4(0, 0, 0, 0), dv = make_float4(0, 0, 0, 0);
-            if (yy >= 0 && yy < Hres && xx >= 0 && xx < Wres) {
-                const size_t o = (ib + (size_t)yy * Wres + xx) * Ch + ch0;
-                const float4 uv = *reinterpret_cast<const float4*>(u + o);
-                const float4 tv = *reinterpret_cast<const float4*>(tpre + o);
-                const float4 zv = *reinterpret_cast<const float4*>(dz + o);
-                gv = make_float4(gelu_f(uv.x), gelu_f(uv.y), gelu_f(uv.z), gelu_f(uv.w));
-                dv = make_float4(zv.x * gelu_grad_f(tv.x), zv.y * gelu_grad_f(tv.y), zv.z * gelu_grad_f(tv.z),
-                                 zv.w * gelu_grad_f(tv.w));
+        // staging in two batches of 3 positions per thread: all 9 loads of a batch are issued before any is
+        // consumed (branch-free, addresses clamped into the image) so that their latencies overlap
+        constexpr int NPOS = HHGT * HWID;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            float4 ru[3], rt[3], rz[3];
+            bool ok[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const int pos = (t >> 3) + 32 * (3 * half + i);
+                const int pc = pos < NPOS ? pos : NPOS - 1;
+                const int yy = y0 + pc / HWID, xx = x0 + pc % HWID;
+                ok[i] = pos < NPOS && yy >= 0 && yy < Hres && xx >= 0 && xx < Wres;
+                const int yc = min(max(yy, 0), Hres - 1), xc = min(max(xx, 0), Wres - 1);
+                const size_t o = (ib + (size_t)yc * Wres + xc) * Ch + ch0;
+                ru[i] = *reinterpret_cast<const float4*>(u + o);
+                rt[i] = *reinterpret_cast<const float4*>(tpre + o);
+                rz[i] = *reinterpret_cast<const float4*>(dz + o);
             }
-            *reinterpret_cast<float4*>(&gs[pos * CT + c4 * 4]) = gv;
-            *reinterpret_cast<float4*>(&ds[pos * CT + c4 * 4]) = dv;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const int pos = (t >> 3) + 32 * (3 * half + i);
+                if (pos < NPOS) {
+                    float4 gv = make_float4(0, 0, 0, 0), dv = make_float4(0, 0, 0, 0);
+                    if (ok[i]) {
+                        gv = make_float4(gelu_f(ru[i].x), gelu_f(ru[i].y), gelu_f(ru[i].z), gelu_f(ru[i].w));
+                        dv = make_float4(rz[i].x * rt[i].x, rz[i].y * rt[i].y, rz[i].z * rt[i].z, rz[i].w * rt[i].w);
+                    }
+                    *reinterpret_cast<float4*>(&gs[pos * CT + c4 * 4]) = gv;      // tpre holds gelu'(t)
+                    *reinterpret_cast<float4*>(&ds[pos * CT + c4 * 4]) = dv;
+                }
+            }
+        }
+        // centre values of u (for gelu'(u)): issued before the barrier, consumed after the tap loop (L2 hits)
+        float4 uc[TH * TW / 32];
+#pragma unroll
+        for (int i = 0; i < TH * TW / 32; ++i) {
+            const int pos = (t >> 3) + 32 * i;
+            const int yc = min(ty * TH + pos / TW, Hres - 1), xc = min(tx * TW + pos % TW, Wres - 1);
+            uc[i] = *reinterpret_cast<const float4*>(u + (ib + (size_t)yc * Wres + xc) * Ch + ch0);
         }
         __syncthreads();
-        for (int pos = t >> 3; pos < TH * TW; pos += 32) {
+#pragma unroll
+        for (int it = 0; it < TH * TW / 32; ++it) {
+            const int pos = (t >> 3) + 32 * it;
             const int py = pos / TW, px = pos % TW;
             const int yy = ty * TH + py, xx = tx * TW + px;
             if (yy >= Hres || xx >= Wres) continue;
@@ -308,7 +362,7 @@ __global__ __launch_bounds__(256) void leff_dwconv_bwd_kernel(const float* __res
                 }
             dbk[0] += dtc.x; dbk[1] += dtc.y; dbk[2] += dtc.z; dbk[3] += dtc.w;
             const size_t o = (ib + (size_t)yy * Wres + xx) * Ch + ch0;
-            const float4 uv = *reinterpret_cast<const float4*>(u + o);
+            const float4 uv = uc[it];
             *reinterpret_cast<float4*>(du + o) = make_float4(dg.x * gelu_grad_f(uv.x), dg.y * gelu_grad_f(uv.y),
                                                              dg.z * gelu_grad_f(uv.z), dg.w * gelu_grad_f(uv.w));
         }
