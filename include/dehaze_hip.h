@@ -65,6 +65,27 @@ int dhz_ps_attn_bwd(const float* q, const float* k, const float* v, int ld, cons
                     float* dk, float* dv, int ldg, float* dbias_part, int B_, int H, int nW, int d,
                     void* stream);
 
+/* K1+K2+K3+K4  Fused attention branch of a LeWin block, forward, for C = 32, 64, 128 (head_dim 32):
+ *     out = x + drop_scale[b] * out_projection(ProbAttention(Q,K,V = projections(window(roll(norm1(x))))))
+ *     Replaces M1:839-872 + ATT:385-461 in one kernel (one workgroup per 8x8 window, per-head QKV GEMM and
+ *     the out-projection on the fp32 matrix pipe around the LDS-resident ProbSparse core).
+ * dhz_fused_attn_prepack: reorders the four [C,C] projection weights into MFMA B-fragment order
+ *     (wqkv_p: 3*C*C floats, wo_p: C*C floats); call whenever the weights change.
+ * x,out: [B, Hres*Wres, C] tokens.  bqkv = [bq|bk|bv] (3C), bo (C).  idx [64,25] uint8.  bias [H,64,64] or
+ *     NULL.  mask [nW,64,64] (shifted blocks) or NULL.  drop_scale [B] or NULL (DropPath keep/keep_prob).
+ * Training mode - all five save pointers non-NULL, window-ordered rows r = (b*nW + w)*64 + token:
+ *     xn_save [T,C] (LayerNorm output), qkv_save [T,3C], ctx_save [T,C], stats_save [B*HW,2] (mean, rstd by
+ *     source token), rank_save [B*nW, H, 64] - exactly what dhz_ps_attn_bwd / dhz_linear_wgrad /
+ *     dhz_ln_partition_bwd consume.  Inference mode: pass NULL for all five. */
+int dhz_fused_attn_prepack(const float* wq, const float* wk, const float* wv, const float* wo,
+                           float* wqkv_p, float* wo_p, int C, void* stream);
+int dhz_fused_window_attn_fwd(const float* x, const float* gamma, const float* beta, const float* wqkv_p,
+                              const float* bqkv, const float* wo_p, const float* bo, const uint8_t* idx,
+                              const float* bias, const float* mask, const float* drop_scale, float* out,
+                              float* xn_save, float* qkv_save, float* ctx_save, float* stats_save,
+                              uint8_t* rank_save, int B, int Hres, int Wres, int C, int shift,
+                              void* stream);
+
 /* K3-dense  Dense window attention of the My_model.Uformer twin.  Replaces WindowAttention.forward
  *     M0:428-492:  out = softmax(scale * q k^T + bias[h] + mask[b % nW]) v   per (window, head).
  *     Same layouts as dhz_ps_attn_fwd (q,k,v [B_,64,H,d] with token stride ld; bias [H,64,64] or NULL;
@@ -107,11 +128,11 @@ int dhz_shift_mask(float* mask, int Hres, int Wres, int shift, void* stream);
 int dhz_ln_partition_fwd(const float* x, const float* gamma, const float* beta, float* xw,
                          float* stats, int B, int Hres, int Wres, int C, int shift, int partition,
                          void* stream);
-/* dxw: [B*nW,64,C] -> dx: [B,HW,C] (overwritten, or accumulated into when accumulate != 0);
- * dgamma,dbeta [C] are ACCUMULATED (caller zeroes). */
+/* dxw: [B*nW,64,C] -> dx: [B,HW,C] = LN-backward(dxw) (+ dres when dres != NULL: the gradient that reaches x
+ * through the residual shortcut, M1:872 - dx may alias dres);  dgamma,dbeta [C] are ACCUMULATED (caller zeroes). */
 int dhz_ln_partition_bwd(const float* dxw, const float* x, const float* gamma, const float* stats,
-                         float* dx, float* dgamma, float* dbeta, int B, int Hres, int Wres, int C,
-                         int shift, int partition, int accumulate, void* stream);
+                         const float* dres, float* dx, float* dgamma, float* dbeta, int B, int Hres,
+                         int Wres, int C, int shift, int partition, void* stream);
 
 /* K4 (tail)  window reverse + un-shift + residual with per-sample DropPath scale.
  *     Replaces window_reverse M1:577-601, roll M1:866, shortcut + drop_path(x) M1:872.

@@ -69,10 +69,11 @@ template <int VPL>
 __global__ __launch_bounds__(256) void ln_partition_bwd_kernel(const float* __restrict__ dxw,
                                                                const float* __restrict__ x,
                                                                const float* __restrict__ gamma,
-                                                               const float* __restrict__ stats, float* __restrict__ dx,
+                                                               const float* __restrict__ stats,
+                                                               const float* dres, float* dx,
                                                                float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                                int ntok, int Hres, int Wres, int C, int shift, int lpt,
-                                                               int partition, int accumulate) {
+                                                               int partition) {
     __shared__ float red[2 * 1024];                            // dgamma | dbeta  (C <= 1024)
     const int tpw = 64 / lpt;
     const int lane = threadIdx.x & 63;
@@ -131,7 +132,10 @@ __global__ __launch_bounds__(256) void ln_partition_bwd_kernel(const float* __re
                 r.z = rstd * (dy[v].z - s1 - xh[v].z * s2);
                 r.w = rstd * (dy[v].w - s1 - xh[v].w * s2);
                 float4* dst = reinterpret_cast<float4*>(dx + (size_t)tok * C) + li + v * lpt;
-                if (accumulate) { const float4 o4 = *dst; r.x += o4.x; r.y += o4.y; r.z += o4.z; r.w += o4.w; }
+                if (dres) {
+                    const float4 o4 = reinterpret_cast<const float4*>(dres + (size_t)tok * C)[li + v * lpt];
+                    r.x += o4.x; r.y += o4.y; r.z += o4.z; r.w += o4.w;
+                }
                 *dst = r;
             }
         }
@@ -488,9 +492,9 @@ extern "C" int dhz_ln_partition_fwd(const float* x, const float* gamma, const fl
     return DHZ_OK;
 }
 
-extern "C" int dhz_ln_partition_bwd(const float* dxw, const float* x, const float* gamma, const float* stats, float* dx,
-                                    float* dgamma, float* dbeta, int B, int Hres, int Wres, int C, int shift,
-                                    int partition, int accumulate, void* stream) {
+extern "C" int dhz_ln_partition_bwd(const float* dxw, const float* x, const float* gamma, const float* stats,
+                                    const float* dres, float* dx, float* dgamma, float* dbeta, int B, int Hres, int Wres,
+                                    int C, int shift, int partition, void* stream) {
     DHZ_REQUIRE(dxw && x && gamma && stats && dx && dgamma && dbeta, "dhz_ln_partition_bwd: null pointer");
     DHZ_REQUIRE(B > 0 && Hres > 0 && Wres > 0 && (!partition || (Hres % 8 == 0 && Wres % 8 == 0 && shift >= 0 && shift < 8)),
                 "dhz_ln_partition_bwd: bad shape");
@@ -499,7 +503,7 @@ extern "C" int dhz_ln_partition_bwd(const float* dxw, const float* x, const floa
     const int ntok = B * Hres * Wres;
     const int grid = grid_for((int64_t)ntok * lpt, 256, 1024);
     hipStream_t s = (hipStream_t)stream;
-#define LAUNCH(V) hipLaunchKernelGGL(ln_partition_bwd_kernel<V>, dim3(grid), dim3(256), 0, s, dxw, x, gamma, stats, dx, dgamma, dbeta, ntok, Hres, Wres, C, shift, lpt, partition, accumulate)
+#define LAUNCH(V) hipLaunchKernelGGL(ln_partition_bwd_kernel<V>, dim3(grid), dim3(256), 0, s, dxw, x, gamma, stats, dres, dx, dgamma, dbeta, ntok, Hres, Wres, C, shift, lpt, partition)
     switch (vpl) { case 1: LAUNCH(1); break; case 2: LAUNCH(2); break; case 3: LAUNCH(3); break; default: LAUNCH(4); }
 #undef LAUNCH
     DHZ_CHECK_LAUNCH("dhz_ln_partition_bwd");

@@ -1,0 +1,494 @@
+// Fused window-attention branch of a LeWin block (forward), C = 32 / 64 / 128 (head_dim 32):
+//
+//   out = x + drop_scale[b] * OutProj( ProbSparseAttention( QKV( roll+partition( LayerNorm(x) ) ) ) )   un-rolled
+//
+// i.e. M1:839-872 (norm1, roll, window_partition, WindowAttention -> AttentionLayer -> ProbAttention,
+// window_reverse, roll back, shortcut + drop_path) in ONE kernel.  One 256-thread workgroup per 8x8 window:
+//   0. the window's 64 token rows are gathered with the cyclic shift folded into the addresses, normalised
+//      (4 lanes per token) and kept in LDS (xn);
+//   per head h (d = 32):
+//   1. [Q_h|K_h|V_h] = xn W_h^T + b_h on the fp32 matrix pipe; A fragments from LDS, B fragments straight from
+//      a fragment-ordered ("prepacked") copy of the weights with coalesced float4 loads (L1/L2 resident);
+//   2. S = Q_h K_h^T, sparsity measure, top-u ranks, double softmax, O = P V_h (+ mean(V) row) exactly as
+//      ps_attn_fwd_kernel, all operands already in LDS;
+//   3. the out-projection is accumulated head by head in registers: acc += ctx_h Wo[:, 32h:32h+32]^T with the
+//      "selected row or mean row" choice folded into the A-fragment row index;
+//   4. epilogue: + bias, * drop-path scale, + shortcut (re-read of x, L2 hit), scatter back to token order.
+// In training mode (SAVE) the kernel additionally writes what the (unfused) backward kernels consume:
+// LN statistics, xn, the packed QKV rows, the attention context and the selection ranks - 7C floats of HBM
+// traffic per token instead of the 15C of the unfused forward chain; in inference mode only x is read and
+// out written (2C per token) and the kernel is bound by the fp32 MFMA rate (AI 50.7 FLOP/B at C = 32).
+#include "common.h"
+
+namespace {
+
+constexpr int NT = 64;
+constexpr int NU = 25;
+constexpr int SS = 68;     // row stride of 64-wide score tiles
+constexpr int HS = 36;     // row stride of the per-head 32-wide tiles
+
+__device__ __forceinline__ float r8max(float v) {
+    v = fmaxf(v, __shfl_xor(v, 1)); v = fmaxf(v, __shfl_xor(v, 2)); return fmaxf(v, __shfl_xor(v, 4));
+}
+__device__ __forceinline__ float r8sum(float v) {
+    v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); return v + __shfl_xor(v, 4);
+}
+
+template <int C>
+struct FusedSmem {
+    static constexpr int XS = C + 4;
+    float xn[NT * XS];         // LN output; later the out-projection staging tile
+    float q[NT * HS];          // Q_h | K_h are contiguous: S (64 x SS = 4352 floats) overlays them (4608 floats)
+    float k[NT * HS];
+    float v[NT * HS];
+    float p[32 * SS];          // P (rows 0..24 selected queries, row 25 = 1/64)
+    float m[NT];
+    int part[4 * NT];
+    int top[32];
+    uint8_t rank[NT];
+    uint8_t idx[NT * NU];
+};
+
+template <int C, bool SAVE>
+__global__ __launch_bounds__(256) void fused_window_attn_fwd_kernel(
+    const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+    const float4* __restrict__ wqkv_p, const float* __restrict__ bqkv, const float4* __restrict__ wo_p,
+    const float* __restrict__ bo, const uint8_t* __restrict__ idx, const float* __restrict__ bias,
+    const float* __restrict__ mask, const float* __restrict__ dscale, float* __restrict__ out,
+    float* __restrict__ xn_save, float* __restrict__ qkv_save, float* __restrict__ ctx_save,
+    float* __restrict__ stats_save, uint8_t* __restrict__ rank_save, int Hres, int Wres, int shift, int nwin) {
+    constexpr int XS = C + 4;
+    constexpr int H = C / 32;
+    constexpr int CPT = C / 4;            // floats per thread in the token-row phases (4 threads per token)
+    constexpr int KS = C / 4;             // k-steps of the QKV GEMM
+    constexpr int KS4 = KS / 4;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    FusedSmem<C>& sm = *reinterpret_cast<FusedSmem<C>*>(smem_raw);
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int i16 = lane & 15, g = lane >> 4;
+    const int nWw = Wres >> 3, nW = (Hres >> 3) * nWw;
+    const int tl = t >> 2, qd = t & 3;    // token row / channel quarter of this thread in the row phases
+    const float scale = 0.17677669529663687f;      // 1/sqrt(32)
+
+    // token this thread's row comes from (and goes back to) for window `win`: cyclic shift folded in
+    auto src_token = [&](int win) -> size_t {
+        const int bimg = win / nW, wdx = win % nW;
+        int hh = (wdx / nWw) * 8 + (tl >> 3) + shift; if (hh >= Hres) hh -= Hres;
+        int ww = (wdx % nWw) * 8 + (tl & 7) + shift; if (ww >= Wres) ww -= Wres;
+        return (size_t)bimg * Hres * Wres + (size_t)hh * Wres + ww;
+    };
+
+    // C == 32: all projection weights (64 VGPRs of B fragments) stay in registers for the kernel's lifetime
+    float4 wr_qkv[C == 32 ? 12 : 1], wr_o[C == 32 ? 4 : 1];
+    if constexpr (C == 32) {
+#pragma unroll
+        for (int i = 0; i < 12; ++i) wr_qkv[i] = wqkv_p[i * 64 + lane];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) wr_o[i] = wo_p[i * 64 + lane];
+    }
+    if (t < NT * NU / 16) reinterpret_cast<uint4*>(sm.idx)[t] = reinterpret_cast<const uint4*>(idx)[t];
+
+    float4 xv[CPT / 4], xnext[CPT / 4];
+    int win = blockIdx.x;
+    if (win < nwin) {
+        const float4* xp = reinterpret_cast<const float4*>(x + src_token(win) * C + qd * CPT);
+#pragma unroll
+        for (int i = 0; i < CPT / 4; ++i) xv[i] = xp[i];
+    }
+#pragma unroll 1
+    for (; win < nwin; win += gridDim.x) {
+        const int bimg = win / nW, wdx = win % nW;
+        const size_t src_tok = src_token(win);
+        // prefetch the next window's rows: their HBM latency hides under this window's compute
+        if (C == 32 && win + (int)gridDim.x < nwin) {
+            const float4* xp = reinterpret_cast<const float4*>(x + src_token(win + gridDim.x) * C + qd * CPT);
+#pragma unroll
+            for (int i = 0; i < CPT / 4; ++i) xnext[i] = xp[i];
+        }
+        // ---- 0. LayerNorm of the gathered rows (4 lanes per token)
+        {
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < CPT / 4; ++i) s += xv[i].x + xv[i].y + xv[i].z + xv[i].w;
+            s += __shfl_xor(s, 1); s += __shfl_xor(s, 2);
+            const float mean = s * (1.0f / C);
+            float var = 0.f;
+#pragma unroll
+            for (int i = 0; i < CPT / 4; ++i) {
+                const float a0 = xv[i].x - mean, a1 = xv[i].y - mean, a2 = xv[i].z - mean, a3 = xv[i].w - mean;
+                var += a0 * a0 + a1 * a1 + a2 * a2 + a3 * a3;
+            }
+            var += __shfl_xor(var, 1); var += __shfl_xor(var, 2);
+            const float rstd = rsqrtf(var * (1.0f / C) + 1e-5f);
+#pragma unroll
+            for (int i = 0; i < CPT / 4; ++i) {
+                const float4 gm = reinterpret_cast<const float4*>(gamma + qd * CPT)[i];
+                const float4 bt = reinterpret_cast<const float4*>(beta + qd * CPT)[i];
+                float4 y;
+                y.x = (xv[i].x - mean) * rstd * gm.x + bt.x;
+                y.y = (xv[i].y - mean) * rstd * gm.y + bt.y;
+                y.z = (xv[i].z - mean) * rstd * gm.z + bt.z;
+                y.w = (xv[i].w - mean) * rstd * gm.w + bt.w;
+                *reinterpret_cast<float4*>(&sm.xn[tl * XS + qd * CPT + 4 * i]) = y;
+                if (SAVE) reinterpret_cast<float4*>(xn_save + ((size_t)win * NT + tl) * C + qd * CPT)[i] = y;
+            }
+            if (SAVE && qd == 0) *reinterpret_cast<float2*>(stats_save + 2 * src_tok) = make_float2(mean, rstd);
+        }
+        __syncthreads();
+
+        f32x4 oacc[C / 16];                    // out-projection accumulators: rows 16w.., all C columns
+#pragma unroll
+        for (int i = 0; i < C / 16; ++i) oacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll 1
+        for (int h = 0; h < H; ++h) {
+            // ---- 1. [Q_h | K_h | V_h] = xn W_h^T + b_h : wave w -> rows 16w..16w+15, 6 column tiles, interleaved chains
+            {
+                float a[KS];
+#pragma unroll
+                for (int s = 0; s < KS; ++s) a[s] = sm.xn[(16 * w + i16) * XS + 4 * s + g];
+                f32x4 acc[6];
+#pragma unroll
+                for (int j = 0; j < 6; ++j) {
+                    const float bj = bqkv[(j >> 1) * C + 32 * h + 16 * (j & 1) + i16];
+                    acc[j] = f32x4{bj, bj, bj, bj};
+                }
+                if constexpr (C == 32) {
+#pragma unroll
+                    for (int s4 = 0; s4 < 2; ++s4) {
+#pragma unroll
+                        for (int j = 0; j < 6; ++j) acc[j] = mfma16(a[4 * s4 + 0], wr_qkv[j * 2 + s4].x, acc[j]);
+#pragma unroll
+                        for (int j = 0; j < 6; ++j) acc[j] = mfma16(a[4 * s4 + 1], wr_qkv[j * 2 + s4].y, acc[j]);
+#pragma unroll
+                        for (int j = 0; j < 6; ++j) acc[j] = mfma16(a[4 * s4 + 2], wr_qkv[j * 2 + s4].z, acc[j]);
+#pragma unroll
+                        for (int j = 0; j < 6; ++j) acc[j] = mfma16(a[4 * s4 + 3], wr_qkv[j * 2 + s4].w, acc[j]);
+                    }
+                } else {
+                    const float4* wp = wqkv_p + (size_t)h * 6 * KS4 * 64 + lane;
+                    float4 bc[6], bn[6];
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) bc[j] = wp[(j * KS4) * 64];
+#pragma unroll
+                    for (int s4 = 0; s4 < KS4; ++s4) {
+                        if (s4 + 1 < KS4) {
+#pragma unroll
+                            for (int j = 0; j < 6; ++j) bn[j] = wp[(j * KS4 + s4 + 1) * 64];
+                        }
+#pragma unroll
+                        for (int j = 0; j < 6; ++j) acc[j] = mfma16(a[4 * s4 + 0], bc[j].x, acc[j]);
+#pragma unroll
+                        for (int j = 0; j < 6; ++j) acc[j] = mfma16(a[4 * s4 + 1], bc[j].y, acc[j]);
+#pragma unroll
+                        for (int j = 0; j < 6; ++j) acc[j] = mfma16(a[4 * s4 + 2], bc[j].z, acc[j]);
+#pragma unroll
+                        for (int j = 0; j < 6; ++j) acc[j] = mfma16(a[4 * s4 + 3], bc[j].w, acc[j]);
+#pragma unroll
+                        for (int j = 0; j < 6; ++j) bc[j] = bn[j];
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 6; ++j) {
+                    float* dst = (j < 2 ? sm.q : (j < 4 ? sm.k : sm.v)) + 16 * (j & 1) + i16;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) dst[(16 * w + 4 * g + r) * HS] = acc[j][r];
+                }
+            }
+            __syncthreads();
+            if (SAVE) {   // packed QKV rows for the backward kernels: [win*64 + row][3C], head slice 32h..32h+31
+                const int row = t >> 2, c8 = (t & 3) * 8;
+                float* dst = qkv_save + ((size_t)win * NT + row) * 3 * C + 32 * h + c8;
+                *reinterpret_cast<float4*>(dst) = *reinterpret_cast<const float4*>(&sm.q[row * HS + c8]);
+                *reinterpret_cast<float4*>(dst + 4) = *reinterpret_cast<const float4*>(&sm.q[row * HS + c8 + 4]);
+                *reinterpret_cast<float4*>(dst + C) = *reinterpret_cast<const float4*>(&sm.k[row * HS + c8]);
+                *reinterpret_cast<float4*>(dst + C + 4) = *reinterpret_cast<const float4*>(&sm.k[row * HS + c8 + 4]);
+                *reinterpret_cast<float4*>(dst + 2 * C) = *reinterpret_cast<const float4*>(&sm.v[row * HS + c8]);
+                *reinterpret_cast<float4*>(dst + 2 * C + 4) = *reinterpret_cast<const float4*>(&sm.v[row * HS + c8 + 4]);
+            }
+            // ---- 2a. S = Q_h K_h^T in registers (4 interleaved chains), then over the dead Q|K tiles
+            f32x4 sacc[4];
+            {
+                float a[8];
+#pragma unroll
+                for (int s = 0; s < 8; ++s) a[s] = sm.q[(16 * w + i16) * HS + 4 * s + g];
+#pragma unroll
+                for (int tc = 0; tc < 4; ++tc) sacc[tc] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s = 0; s < 8; ++s)
+#pragma unroll
+                    for (int tc = 0; tc < 4; ++tc)
+                        sacc[tc] = mfma16(a[s], sm.k[(16 * tc + i16) * HS + 4 * s + g], sacc[tc]);
+            }
+            __syncthreads();
+            float* S = sm.q;                       // 64 x SS overlay on q|k
+#pragma unroll
+            for (int tc = 0; tc < 4; ++tc)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) S[(16 * w + 4 * g + r) * SS + 16 * tc + i16] = sacc[tc][r];
+            __syncthreads();
+            // ---- 2b. sparsity measure + ranks (ATT:117,122)
+            {
+                const int qi = t >> 2, j = t & 3;
+                float mx = -INFINITY, su = 0.f;
+                for (int s = j; s < NU; s += 4) {
+                    const float val = S[qi * SS + sm.idx[qi * NU + s]];
+                    mx = fmaxf(mx, val);
+                    su += val;
+                }
+                mx = fmaxf(mx, __shfl_xor(mx, 1)); mx = fmaxf(mx, __shfl_xor(mx, 2));
+                su += __shfl_xor(su, 1); su += __shfl_xor(su, 2);
+                if (j == 0) sm.m[qi] = mx - su * (1.0f / NT);
+            }
+            __syncthreads();
+            {
+                const int qi = t & 63;
+                const float mq = sm.m[qi];
+                int cnt = 0;
+#pragma unroll
+                for (int jj = 0; jj < 16; ++jj) {
+                    const int j = 16 * w + jj;
+                    const float mj = sm.m[j];
+                    cnt += (mj > mq) || (mj == mq && j < qi);
+                }
+                sm.part[w * NT + qi] = cnt;
+            }
+            __syncthreads();
+            if (t < NT) {
+                const int r = sm.part[t] + sm.part[NT + t] + sm.part[2 * NT + t] + sm.part[3 * NT + t];
+                sm.rank[t] = r < NU ? (uint8_t)r : (uint8_t)255;
+                if (r < NU) sm.top[r] = t;
+            } else if (t < NT + 32 - NU) {
+                sm.top[NU + t - NT] = 0;
+            }
+            __syncthreads();
+            // ---- 2c. P = softmax(softmax(scale S[top]) + bias + mask)
+            {
+                const int r = t >> 3, c0 = (t & 7) * 8;
+                float p2[8];
+                if (r < NU) {
+                    const int qrow = sm.top[r];
+                    float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0, m0 = b0, m1 = b0;
+                    if (bias) {      // issue the (L2-resident) bias / mask row loads before the first softmax
+                        const float* br = bias + ((size_t)h * NT + qrow) * NT + c0;
+                        b0 = *reinterpret_cast<const float4*>(br); b1 = *reinterpret_cast<const float4*>(br + 4);
+                    }
+                    if (mask) {
+                        const float* mr = mask + ((size_t)wdx * NT + qrow) * NT + c0;
+                        m0 = *reinterpret_cast<const float4*>(mr); m1 = *reinterpret_cast<const float4*>(mr + 4);
+                    }
+                    float xr[8], a2[8];
+                    const float4 s0 = *reinterpret_cast<const float4*>(&S[qrow * SS + c0]);
+                    const float4 s1 = *reinterpret_cast<const float4*>(&S[qrow * SS + c0 + 4]);
+                    xr[0] = s0.x * scale; xr[1] = s0.y * scale; xr[2] = s0.z * scale; xr[3] = s0.w * scale;
+                    xr[4] = s1.x * scale; xr[5] = s1.y * scale; xr[6] = s1.z * scale; xr[7] = s1.w * scale;
+                    float mx = xr[0];
+#pragma unroll
+                    for (int i = 1; i < 8; ++i) mx = fmaxf(mx, xr[i]);
+                    mx = r8max(mx);
+                    float sum = 0.f;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) { xr[i] = __expf(xr[i] - mx); sum += xr[i]; }
+                    sum = __builtin_amdgcn_rcpf(r8sum(sum));
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) a2[i] = xr[i] * sum;
+                    a2[0] += b0.x + m0.x; a2[1] += b0.y + m0.y; a2[2] += b0.z + m0.z; a2[3] += b0.w + m0.w;
+                    a2[4] += b1.x + m1.x; a2[5] += b1.y + m1.y; a2[6] += b1.z + m1.z; a2[7] += b1.w + m1.w;
+                    float mx2 = a2[0];
+#pragma unroll
+                    for (int i = 1; i < 8; ++i) mx2 = fmaxf(mx2, a2[i]);
+                    mx2 = r8max(mx2);
+                    float sum2 = 0.f;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) { a2[i] = __expf(a2[i] - mx2); sum2 += a2[i]; }
+                    sum2 = __builtin_amdgcn_rcpf(r8sum(sum2));
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) p2[i] = a2[i] * sum2;
+                } else {
+                    const float f = (r == NU) ? (1.0f / NT) : 0.f;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) p2[i] = f;
+                }
+                *reinterpret_cast<float4*>(&sm.p[r * SS + c0]) = make_float4(p2[0], p2[1], p2[2], p2[3]);
+                *reinterpret_cast<float4*>(&sm.p[r * SS + c0 + 4]) = make_float4(p2[4], p2[5], p2[6], p2[7]);
+            }
+            __syncthreads();
+            // ---- 2d. O_h = P V_h (32 x 32): one 16x16 tile per wave, written over the dead S tile
+            float* O = sm.q;                       // 32 x HS
+            {
+                const int tr = w & 1, tc = w >> 1;
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                acc = tile_mma<16>(sm.p + 16 * tr * SS, SS, 1, sm.v + 16 * tc, 1, HS, acc);
+                // S (under O) was last read by the softmax phase, which ended at the barrier above: safe to overwrite
+#pragma unroll
+                for (int r = 0; r < 4; ++r) O[(16 * tr + 4 * g + r) * HS + 16 * tc + i16] = acc[r];
+            }
+            __syncthreads();
+            // ---- 3. out-projection partial: oacc += ctx_h Wo[:, 32h:32h+32]^T ; ctx row = selected row or mean row
+            {
+                const int rk = sm.rank[16 * w + i16];
+                const int srow = rk < NU ? rk : NU;
+                float a[8];
+#pragma unroll
+                for (int s = 0; s < 8; ++s) a[s] = O[srow * HS + 4 * s + g];
+                if constexpr (C == 32) {
+#pragma unroll
+                    for (int s4 = 0; s4 < 2; ++s4) {
+#pragma unroll
+                        for (int tn = 0; tn < 2; ++tn) oacc[tn] = mfma16(a[4 * s4 + 0], wr_o[tn * 2 + s4].x, oacc[tn]);
+#pragma unroll
+                        for (int tn = 0; tn < 2; ++tn) oacc[tn] = mfma16(a[4 * s4 + 1], wr_o[tn * 2 + s4].y, oacc[tn]);
+#pragma unroll
+                        for (int tn = 0; tn < 2; ++tn) oacc[tn] = mfma16(a[4 * s4 + 2], wr_o[tn * 2 + s4].z, oacc[tn]);
+#pragma unroll
+                        for (int tn = 0; tn < 2; ++tn) oacc[tn] = mfma16(a[4 * s4 + 3], wr_o[tn * 2 + s4].w, oacc[tn]);
+                    }
+                } else {
+                    const float4* wp = wo_p + (size_t)h * (C / 16) * 2 * 64 + lane;
+                    float4 b4[C / 16][2];
+#pragma unroll
+                    for (int tn = 0; tn < C / 16; ++tn) { b4[tn][0] = wp[(tn * 2) * 64]; b4[tn][1] = wp[(tn * 2 + 1) * 64]; }
+#pragma unroll
+                    for (int s4 = 0; s4 < 2; ++s4) {
+#pragma unroll
+                        for (int tn = 0; tn < C / 16; ++tn) oacc[tn] = mfma16(a[4 * s4 + 0], b4[tn][s4].x, oacc[tn]);
+#pragma unroll
+                        for (int tn = 0; tn < C / 16; ++tn) oacc[tn] = mfma16(a[4 * s4 + 1], b4[tn][s4].y, oacc[tn]);
+#pragma unroll
+                        for (int tn = 0; tn < C / 16; ++tn) oacc[tn] = mfma16(a[4 * s4 + 2], b4[tn][s4].z, oacc[tn]);
+#pragma unroll
+                        for (int tn = 0; tn < C / 16; ++tn) oacc[tn] = mfma16(a[4 * s4 + 3], b4[tn][s4].w, oacc[tn]);
+                    }
+                }
+                if (SAVE) {
+                    const int row = t >> 2, c8 = (t & 3) * 8;
+                    const int rr = sm.rank[row] < NU ? sm.rank[row] : NU;
+                    float* dst = ctx_save + ((size_t)win * NT + row) * C + 32 * h + c8;
+                    *reinterpret_cast<float4*>(dst) = *reinterpret_cast<const float4*>(&O[rr * HS + c8]);
+                    *reinterpret_cast<float4*>(dst + 4) = *reinterpret_cast<const float4*>(&O[rr * HS + c8 + 4]);
+                    if (t < NT / 4)
+                        reinterpret_cast<uint32_t*>(rank_save + ((size_t)win * H + h) * NT)[t] =
+                            reinterpret_cast<const uint32_t*>(sm.rank)[t];
+                }
+            }
+            __syncthreads();                       // q/k/v/p/rank are rewritten by the next head
+        }
+
+        // ---- 4. epilogue: stage the 64 x C projection through LDS (xn is dead), add bias + shortcut (x is still in
+        //         registers), scatter to token order
+#pragma unroll
+        for (int tn = 0; tn < C / 16; ++tn)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sm.xn[(16 * w + 4 * g + r) * XS + 16 * tn + i16] = oacc[tn][r];
+        __syncthreads();
+        {
+            const float sc = dscale ? dscale[bimg] : 1.0f;
+            float4* op = reinterpret_cast<float4*>(out + src_tok * C + qd * CPT);
+#pragma unroll
+            for (int i = 0; i < CPT / 4; ++i) {
+                const float4 y = *reinterpret_cast<const float4*>(&sm.xn[tl * XS + qd * CPT + 4 * i]);
+                const float4 b4 = reinterpret_cast<const float4*>(bo + qd * CPT)[i];
+                op[i] = make_float4(xv[i].x + sc * (y.x + b4.x), xv[i].y + sc * (y.y + b4.y), xv[i].z + sc * (y.z + b4.z),
+                                    xv[i].w + sc * (y.w + b4.w));
+            }
+        }
+        if constexpr (C == 32) {
+#pragma unroll
+            for (int i = 0; i < CPT / 4; ++i) xv[i] = xnext[i];
+        } else if (win + (int)gridDim.x < nwin) {  // (only reached when the grid is smaller than the window count)
+            const float4* xp = reinterpret_cast<const float4*>(x + src_token(win + gridDim.x) * C + qd * CPT);
+#pragma unroll
+            for (int i = 0; i < CPT / 4; ++i) xv[i] = xp[i];
+        }
+        __syncthreads();                           // the staging tile is rewritten by the next window's LayerNorm
+    }
+}
+
+// weight prepack: fragment order for the 16x16x4 MFMA B operand (lane = 16 g + i16 holds B[k = 4 s + g][j = i16]);
+// four consecutive k-steps are packed into one float4 so that a wave reads 1 KiB contiguous per instruction.
+//   wqkv_p[h][j(6)][s4(C/16)][lane(64)] (float4 over r)  = W_m[32h + 16(j&1) + i16][16 s4 + 4 r + g],  m = j>>1
+//   wo_p  [h][tn(C/16)][s4(2)][lane(64)] (float4 over r) = Wo[16 tn + i16][32 h + 16 s4 + 4 r + g]
+__global__ void prepack_weights_kernel(const float* __restrict__ wq, const float* __restrict__ wk,
+                                       const float* __restrict__ wv, const float* __restrict__ wo,
+                                       float* __restrict__ wqkv_p, float* __restrict__ wo_p, int C) {
+    const int H = C / 32, KS4 = C / 16;
+    const int nq = H * 6 * KS4 * 64 * 4, no = H * (C / 16) * 2 * 64 * 4;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < nq) {
+        const int r = e & 3, lane = (e >> 2) & 63;
+        int rest = e >> 8;
+        const int s4 = rest % KS4; rest /= KS4;
+        const int j = rest % 6, h = rest / 6;
+        const int i16 = lane & 15, g = lane >> 4;
+        const float* W = (j >> 1) == 0 ? wq : ((j >> 1) == 1 ? wk : wv);
+        wqkv_p[e] = W[(size_t)(32 * h + 16 * (j & 1) + i16) * C + 16 * s4 + 4 * r + g];
+    } else if (e < nq + no) {
+        const int f = e - nq;
+        const int r = f & 3, lane = (f >> 2) & 63;
+        int rest = f >> 8;
+        const int s4 = rest & 1; rest >>= 1;
+        const int tn = rest % (C / 16), h = rest / (C / 16);
+        const int i16 = lane & 15, g = lane >> 4;
+        wo_p[f] = wo[(size_t)(16 * tn + i16) * C + 32 * h + 16 * s4 + 4 * r + g];
+    }
+}
+
+template <int C, bool SAVE>
+void launch_fused(hipStream_t s, int nwin, const float* x, const float* gamma, const float* beta, const float* wqkv_p,
+                  const float* bqkv, const float* wo_p, const float* bo, const uint8_t* idx, const float* bias,
+                  const float* mask, const float* dscale, float* out, float* xn_save, float* qkv_save, float* ctx_save,
+                  float* stats_save, uint8_t* rank_save, int Hres, int Wres, int shift) {
+    const size_t smem = sizeof(FusedSmem<C>);
+    if (smem > 48 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_window_attn_fwd_kernel<C, SAVE>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    // persistent workgroups: as many as fit the chip at this LDS footprint (3 per CU at C = 32, 2 above)
+    const int per_cu = (int)(160 * 1024 / smem) > 0 ? (int)(160 * 1024 / smem) : 1;
+    int grid = (C == 32) ? 256 * (per_cu > 3 ? 3 : per_cu) : nwin;     // C == 32: persistent (weights live in registers)
+    if (grid > nwin) grid = nwin;
+    hipLaunchKernelGGL((fused_window_attn_fwd_kernel<C, SAVE>), dim3(grid), dim3(256), smem, s, x, gamma, beta,
+                       reinterpret_cast<const float4*>(wqkv_p), bqkv, reinterpret_cast<const float4*>(wo_p), bo, idx,
+                       bias, mask, dscale, out, xn_save, qkv_save, ctx_save, stats_save, rank_save, Hres, Wres, shift,
+                       nwin);
+}
+
+}  // namespace
+
+extern "C" int dhz_fused_attn_prepack(const float* wq, const float* wk, const float* wv, const float* wo, float* wqkv_p,
+                                      float* wo_p, int C, void* stream) {
+    DHZ_REQUIRE(wq && wk && wv && wo && wqkv_p && wo_p, "dhz_fused_attn_prepack: null pointer");
+    DHZ_REQUIRE(C == 32 || C == 64 || C == 128, "dhz_fused_attn_prepack: C=%d unsupported (32, 64, 128)", C);
+    const int n = 4 * C * C;
+    hipLaunchKernelGGL(prepack_weights_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, wq, wk, wv, wo,
+                       wqkv_p, wo_p, C);
+    DHZ_CHECK_LAUNCH("dhz_fused_attn_prepack");
+    return DHZ_OK;
+}
+
+extern "C" int dhz_fused_window_attn_fwd(const float* x, const float* gamma, const float* beta, const float* wqkv_p,
+                                         const float* bqkv, const float* wo_p, const float* bo, const uint8_t* idx,
+                                         const float* bias, const float* mask, const float* drop_scale, float* out,
+                                         float* xn_save, float* qkv_save, float* ctx_save, float* stats_save,
+                                         uint8_t* rank_save, int B, int Hres, int Wres, int C, int shift, void* stream) {
+    DHZ_REQUIRE(x && gamma && beta && wqkv_p && bqkv && wo_p && bo && idx && out, "dhz_fused_window_attn_fwd: null pointer");
+    DHZ_REQUIRE(C == 32 || C == 64 || C == 128, "dhz_fused_window_attn_fwd: C=%d unsupported (32, 64, 128)", C);
+    DHZ_REQUIRE(B > 0 && Hres % 8 == 0 && Wres % 8 == 0 && Hres >= 8 && Wres >= 8 && shift >= 0 && shift < 8,
+                "dhz_fused_window_attn_fwd: bad geometry %dx%d shift %d", Hres, Wres, shift);
+    const bool save = xn_save || qkv_save || ctx_save || stats_save || rank_save;
+    DHZ_REQUIRE(!save || (xn_save && qkv_save && ctx_save && stats_save && rank_save),
+                "dhz_fused_window_attn_fwd: training mode needs all five save buffers");
+    DHZ_REQUIRE(!mask || shift > 0, "dhz_fused_window_attn_fwd: a mask is only meaningful for shifted windows");
+    hipStream_t s = (hipStream_t)stream;
+    const int nwin = B * (Hres / 8) * (Wres / 8);
+#define GO(CC)                                                                                                      \
+    do {                                                                                                            \
+        if (save) launch_fused<CC, true>(s, nwin, x, gamma, beta, wqkv_p, bqkv, wo_p, bo, idx, bias, mask, drop_scale, \
+                                         out, xn_save, qkv_save, ctx_save, stats_save, rank_save, Hres, Wres, shift);   \
+        else launch_fused<CC, false>(s, nwin, x, gamma, beta, wqkv_p, bqkv, wo_p, bo, idx, bias, mask, drop_scale, out, \
+                                     nullptr, nullptr, nullptr, nullptr, nullptr, Hres, Wres, shift);                \
+    } while (0)
+    if (C == 32) GO(32); else if (C == 64) GO(64); else GO(128);
+#undef GO
+    DHZ_CHECK_LAUNCH("dhz_fused_window_attn_fwd");
+    return DHZ_OK;
+}

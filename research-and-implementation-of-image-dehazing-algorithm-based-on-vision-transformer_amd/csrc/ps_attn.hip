@@ -57,11 +57,11 @@ __device__ __forceinline__ void double_softmax8(const float* x, const float* bro
     mx = row8_max(mx);
     float e[8], sum = 0.f;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) { e[i] = expf(x[i] - mx); sum += e[i]; }
-    sum = row8_sum(sum);
+    for (int i = 0; i < 8; ++i) { e[i] = __expf(x[i] - mx); sum += e[i]; }
+    sum = __builtin_amdgcn_rcpf(row8_sum(sum));          // v_exp_f32 / v_rcp_f32: ~1 ulp each, 10x fewer instructions
     float a[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) { p1[i] = e[i] / sum; a[i] = p1[i]; }
+    for (int i = 0; i < 8; ++i) { p1[i] = e[i] * sum; a[i] = p1[i]; }
     if (brow) {
         const float4 b0 = *reinterpret_cast<const float4*>(brow), b1 = *reinterpret_cast<const float4*>(brow + 4);
         a[0] += b0.x; a[1] += b0.y; a[2] += b0.z; a[3] += b0.w; a[4] += b1.x; a[5] += b1.y; a[6] += b1.z; a[7] += b1.w;
@@ -76,10 +76,10 @@ __device__ __forceinline__ void double_softmax8(const float* x, const float* bro
     mx2 = row8_max(mx2);
     float sum2 = 0.f;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) { e[i] = expf(a[i] - mx2); sum2 += e[i]; }
-    sum2 = row8_sum(sum2);
+    for (int i = 0; i < 8; ++i) { e[i] = __expf(a[i] - mx2); sum2 += e[i]; }
+    sum2 = __builtin_amdgcn_rcpf(row8_sum(sum2));
 #pragma unroll
-    for (int i = 0; i < 8; ++i) p2[i] = e[i] / sum2;
+    for (int i = 0; i < 8; ++i) p2[i] = e[i] * sum2;
 }
 
 template <int D>

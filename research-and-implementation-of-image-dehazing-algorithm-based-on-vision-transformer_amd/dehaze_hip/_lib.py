@@ -22,6 +22,9 @@ SIGNATURES = {
     "dhz_ps_attn_fwd": [c_f, c_f, c_f, c_i, c_p, c_f, c_f, c_f, c_i, c_p, c_i, c_i, c_i, c_i, c_p],
     "dhz_ps_attn_bwd_parts": [c_i, c_i],
     "dhz_ps_attn_bwd": [c_f, c_f, c_f, c_i, c_f, c_f, c_p, c_f, c_i, c_f, c_f, c_f, c_i, c_f, c_i, c_i, c_i, c_i, c_p],
+    "dhz_fused_attn_prepack": [c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_p],
+    "dhz_fused_window_attn_fwd": [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_p, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_p,
+                                  c_i, c_i, c_i, c_i, c_i, c_p],
     "dhz_dense_attn_fwd": [c_f, c_f, c_f, c_i, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_fl, c_p],
     "dhz_dense_attn_bwd": [c_f, c_f, c_f, c_i, c_f, c_f, c_f, c_i, c_f, c_f, c_f, c_i, c_f, c_i, c_i, c_i, c_i, c_fl, c_p],
     "dhz_bias_gather": [c_f, c_f, c_i, c_p],
@@ -29,7 +32,7 @@ SIGNATURES = {
     "dhz_shift_mask": [c_f, c_i, c_i, c_i, c_p],
     "dhz_linear_wgrad": [c_f, c_i, c_f, c_i, c_i, c_i, c_i, c_f, c_f, c_p],
     "dhz_ln_partition_fwd": [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
-    "dhz_ln_partition_bwd": [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
+    "dhz_ln_partition_bwd": [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
     "dhz_reverse_residual_fwd": [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
     "dhz_reverse_residual_bwd": [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
     "dhz_leff_dwconv_fwd": [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_p],

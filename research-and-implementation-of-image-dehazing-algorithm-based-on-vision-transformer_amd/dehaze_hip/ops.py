@@ -270,8 +270,8 @@ class _LNPartition(Function):
         dy = dy.contiguous()
         dx = torch.empty_like(x)
         dgb = torch.zeros((2, C), device=x.device, dtype=torch.float32)
-        _lib.call("dhz_ln_partition_bwd", _p(dy), _p(x), _p(gamma), _p(stats), _p(dx), dgb[0].data_ptr(),
-                  dgb[1].data_ptr(), B, Hres, Wres, C, shift, partition, 0, _stream())
+        _lib.call("dhz_ln_partition_bwd", _p(dy), _p(x), _p(gamma), _p(stats), None, _p(dx), dgb[0].data_ptr(),
+                  dgb[1].data_ptr(), B, Hres, Wres, C, shift, partition, _stream())
         return dx, dgb[0], dgb[1], None, None, None, None
 
 

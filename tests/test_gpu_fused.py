@@ -1,0 +1,93 @@
+"""-m gpu: the fused attention-branch kernel (dhz_fused_window_attn_fwd) against the unfused kernel chain and
+against the reference goldens, forward and backward, for every supported width."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+T = torch.from_numpy
+
+
+@pytest.fixture(scope="module")
+def dev():
+    return torch.device("cuda:0")
+
+
+def _run_block(blk, x, idx, gout, fused_on):
+    from dehaze_hip import fused
+    fused.ENABLED = fused_on
+    try:
+        for p in blk.parameters():
+            p.grad = None
+        xx = x.clone().requires_grad_()
+        blk._staged_idx = idx
+        y = blk(xx)
+        (y * gout).sum().backward()
+        grads = {n: (p.grad.clone() if p.grad is not None else None) for n, p in blk.named_parameters()}
+        return y.detach(), xx.grad.clone(), grads
+    finally:
+        fused.ENABLED = True
+
+
+@pytest.mark.parametrize("C,heads,res,shift,B", [(32, 1, 16, 0, 2), (32, 1, 32, 4, 2), (64, 2, 16, 4, 3), (64, 2, 32, 0, 1),
+                                               (128, 4, 16, 4, 2), (128, 4, 24, 0, 1)])
+def test_fused_equals_unfused_chain(dev, C, heads, res, shift, B):
+    import My_model_1 as M1
+    torch.manual_seed(C + res + shift)
+    blk = M1.LeWinTransformerBlock(dim=C, input_resolution=(res, res), num_heads=heads, win_size=8, shift_size=shift,
+                                   token_mlp='leff', drop_path=0.1).to(dev)
+    with torch.no_grad():
+        for p in blk.parameters():
+            if p.ndim == 1:
+                p.add_(0.1 * torch.randn_like(p))
+    blk.train()
+    x = torch.randn(B, res * res, C, device=dev)
+    gout = torch.randn(B, res * res, C, device=dev)
+    idx = torch.randint(64, (64, 25)).to(torch.uint8).to(dev)
+    torch.manual_seed(1); torch.cuda.manual_seed(1)
+    y0, dx0, g0 = _run_block(blk, x, idx, gout, False)
+    torch.manual_seed(1); torch.cuda.manual_seed(1)
+    y1, dx1, g1 = _run_block(blk, x, idx, gout, True)
+    assert torch.allclose(y1, y0, atol=2e-5, rtol=1e-4), (y1 - y0).abs().max()
+    assert torch.allclose(dx1, dx0, atol=5e-5, rtol=1e-3), (dx1 - dx0).abs().max()
+    for n in g0:
+        if g0[n] is None:
+            assert g1[n] is None, n
+        else:
+            err = (g1[n] - g0[n]).abs().max().item()
+            assert err <= 2e-4 + 2e-3 * g0[n].abs().max().item(), (n, err)
+    # inference mode (no saves)
+    blk.eval()
+    with torch.no_grad():
+        blk._staged_idx = idx
+        ye = blk(x)
+        from dehaze_hip import fused
+        fused.ENABLED = False
+        blk._staged_idx = idx
+        yu = blk(x)
+        fused.ENABLED = True
+    assert torch.allclose(ye, yu, atol=2e-5, rtol=1e-4)
+
+
+@pytest.mark.parametrize("name,heads,shift,C", [("block_m1_c32_shift0", 1, 0, 32), ("block_m1_c32_shift4", 1, 4, 32),
+                                                ("block_m1_c64_shift4", 2, 4, 64)])
+def test_fused_block_vs_reference_golden(golden, dev, name, heads, shift, C):
+    import My_model_1 as M1
+    from dehaze_hip import fused
+    assert fused.ENABLED
+    g = golden(name)
+    blk = M1.LeWinTransformerBlock(dim=C, input_resolution=(16, 16), num_heads=heads, win_size=8, shift_size=shift,
+                                   token_mlp='leff', drop_path=0.)
+    blk.load_state_dict({k[3:]: T(g[k]) for k in g.files if k.startswith("sd/")})
+    blk.to(dev)
+    x = T(g["x"]).to(dev).requires_grad_()
+    blk._staged_idx = T(g["idx"].astype(np.uint8)).to(dev)
+    y = blk(x)
+    assert torch.allclose(y.cpu(), T(g["y"]), atol=3e-5, rtol=1e-4), (y.cpu() - T(g["y"])).abs().max()
+    (y * T(g["gout"]).to(dev)).sum().backward()
+    assert torch.allclose(x.grad.cpu(), T(g["dx"]), atol=5e-5, rtol=1e-3)
+    for n, p in blk.named_parameters():
+        ref = g["g/" + n]
+        if ref.size:
+            err = (p.grad.cpu() - T(ref)).abs().max().item()
+            assert err <= 2e-4 + 2e-3 * np.abs(ref).max(), (n, err)
