@@ -125,3 +125,170 @@ def fused_attn_branch(x, norm, layer, table, idx, mask, dscale, Hres, Wres, shif
     q, k, v, o = layer.query_projection, layer.key_projection, layer.value_projection, layer.out_projection
     return _FusedAttnBranch.apply(x, norm.weight, norm.bias, q.weight, q.bias, k.weight, k.bias, v.weight, v.bias,
                                   o.weight, o.bias, table, idx, mask, dscale, Hres, Wres, shift, heads)
+
+
+# ----------------------------------------------------------------------------- unfused forward, same hand-sequenced backward
+class _AttnBranchChain(Function):
+    """Attention branch for the widths the fused kernel does not cover (C >= 256) or where the kernel chain is
+    faster: forward = dhz_ln_partition_fwd -> library GEMM -> dhz_ps_attn_fwd -> library GEMM ->
+    dhz_reverse_residual_fwd, as ONE autograd node whose backward is the same sequence as _FusedAttnBranch's
+    (shortcut gradient folded into the LayerNorm backward, weight gradients accumulated in place)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, wq, bq, wk, bk, wv, bv, wo, bo, table, idx, mask, dscale, Hres, Wres, shift, H):
+        _require_gpu(x, gamma, beta, wq, wo, table, idx, mask, dscale)
+        x = x.contiguous()
+        B, L, C = x.shape
+        d = C // H
+        dev = x.device
+        T = B * L
+        f32 = dict(device=dev, dtype=torch.float32)
+        xn = torch.empty((T, C), **f32)
+        stats = torch.empty((T, 2), **f32)
+        _lib.call("dhz_ln_partition_fwd", _p(x), _p(gamma), _p(beta), _p(xn), _p(stats), B, Hres, Wres, C, shift, 1,
+                  _stream())
+        wcat = torch.cat([wq, wk, wv], 0)
+        qkv = torch.addmm(torch.cat([bq, bk, bv]), xn, wcat.t())
+        bias = None
+        if table is not None:
+            bias = torch.empty((H, NTOK, NTOK), **f32)
+            _lib.call("dhz_bias_gather", _p(table.contiguous()), _p(bias), H, _stream())
+        cx = torch.empty((T, C), **f32)
+        rank = torch.empty(((T // NTOK) * H * NTOK,), device=dev, dtype=torch.uint8)
+        nW = mask.shape[0] if mask is not None else 1
+        base = qkv.data_ptr()
+        timing = ops.KERNEL_TIMING.get("dhz_ps_attn_fwd") if ops.KERNEL_TIMING is not None else None
+        if timing is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        _lib.call("dhz_ps_attn_fwd", base, base + 4 * C, base + 8 * C, 3 * C, _p(idx), _p(bias), _p(mask), _p(cx), C,
+                  _p(rank), T // NTOK, H, nW, d, _stream())
+        if timing is not None:
+            e1.record()
+            timing.append((e0, e1, (T // NTOK) * H))
+        aw = torch.addmm(bo, cx, wo.t())
+        out = torch.empty_like(x)
+        _lib.call("dhz_reverse_residual_fwd", _p(aw), _p(x), _p(dscale), _p(out), B, Hres, Wres, C, shift, 1, _stream())
+        if any(ctx.needs_input_grad):
+            ctx.save_for_backward(x, gamma, stats, xn, qkv, cx, rank, bias, mask, dscale, wq, wk, wv, wo)
+            ctx.params = (wq, bq, wk, bk, wv, bv, wo, bo)
+            ctx.geom = (B, Hres, Wres, C, shift, H)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, gamma, stats, xn, qkv, cx, rank, bias, mask, dscale, wq_, wk_, wv_, wo_ = ctx.saved_tensors
+        wq, bq, wk, bk, wv, bv, wo, bo = ctx.params
+        B, Hres, Wres, C, shift, H = ctx.geom
+        d = C // H
+        dout = dout.contiguous()
+        dev = x.device
+        T = B * Hres * Wres
+        B_ = T // NTOK
+        f32 = dict(device=dev, dtype=torch.float32)
+        daw = torch.empty((T, C), **f32)
+        _lib.call("dhz_reverse_residual_bwd", _p(dout), _p(dscale), _p(daw), B, Hres, Wres, C, shift, 1, _stream())
+        dctx = daw @ wo_
+        g_wo, g_bo = _wgrad(daw, 0, cx, wo, bo)
+        dqkv = torch.empty_like(qkv)
+        parts = _lib.load().dhz_ps_attn_bwd_parts(B_, H)
+        dpart = torch.empty((parts, NTOK, NTOK), **f32) if bias is not None else None
+        nW = mask.shape[0] if mask is not None else 1
+        base, gb = qkv.data_ptr(), dqkv.data_ptr()
+        _lib.call("dhz_ps_attn_bwd", base, base + 4 * C, base + 8 * C, 3 * C, _p(bias), _p(mask), _p(rank), _p(dctx), C,
+                  gb, gb + 4 * C, gb + 8 * C, 3 * C, _p(dpart), B_, H, nW, d, _stream())
+        dtable = None
+        if bias is not None:
+            dtable = torch.empty((225, H), **f32)
+            _lib.call("dhz_bias_table_grad", _p(dpart), parts, _p(dtable), H, 0, _stream())
+        dxn = dqkv @ torch.cat([wq_, wk_, wv_], 0)
+        g_wq, g_bq = _wgrad(dqkv, 0, xn, wq, bq)
+        g_wk, g_bk = _wgrad(dqkv, C, xn, wk, bk)
+        g_wv, g_bv = _wgrad(dqkv, 2 * C, xn, wv, bv)
+        dx = torch.empty_like(x)
+        dgb = torch.zeros((2, C), **f32)
+        _lib.call("dhz_ln_partition_bwd", _p(dxn), _p(x), _p(gamma), _p(stats), _p(dout), _p(dx), dgb[0].data_ptr(),
+                  dgb[1].data_ptr(), B, Hres, Wres, C, shift, 1, _stream())
+        return (dx, dgb[0], dgb[1], g_wq, g_bq, g_wk, g_bk, g_wv, g_bv, g_wo, g_bo, dtable,
+                None, None, None, None, None, None, None)
+
+
+def attn_branch(x, norm, layer, table, idx, mask, dscale, Hres, Wres, shift, heads):
+    """Dispatch: fused kernel where it wins (measured, tools/bench_fused.py), kernel chain elsewhere."""
+    C = x.shape[-1]
+    q, k, v, o = layer.query_projection, layer.key_projection, layer.value_projection, layer.out_projection
+    args = (x, norm.weight, norm.bias, q.weight, q.bias, k.weight, k.bias, v.weight, v.bias, o.weight, o.bias, table, idx,
+            mask, dscale, Hres, Wres, shift, heads)
+    use_fused = ENABLED and C == 32 * heads and (C in (32, 64) or (C == 128 and Hres * Wres <= 1024))
+    return (_FusedAttnBranch if use_fused else _AttnBranchChain).apply(*args)
+
+
+# ----------------------------------------------------------------------------- LeFF branch as one autograd node
+class _LeffBranch(Function):
+    """out = x + drop_scale * linear2(gelu(dwconv3x3(gelu(linear1(LayerNorm(x))))))       (M1:873 + M1:496-534)
+    forward : dhz_ln_partition_fwd (plain LN) -> library GEMM -> dhz_leff_dwconv_fwd -> library GEMM ->
+              dhz_reverse_residual_fwd (token order)
+    backward: the mirror sequence with in-place weight gradients and the shortcut gradient folded into the
+              LayerNorm backward (no autograd accumulation kernels)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, w1, b1, wd, bd, w2, b2, dscale, Hres, Wres):
+        _require_gpu(x, gamma, beta, w1, wd, w2, dscale)
+        x = x.contiguous()
+        B, L, C = x.shape
+        Ch = w1.shape[0]
+        T = B * L
+        dev = x.device
+        f32 = dict(device=dev, dtype=torch.float32)
+        train = any(ctx.needs_input_grad)
+        xn = torch.empty((T, C), **f32)
+        stats = torch.empty((T, 2), **f32)
+        _lib.call("dhz_ln_partition_fwd", _p(x), _p(gamma), _p(beta), _p(xn), _p(stats), B, L, 1, C, 0, 0, _stream())
+        u = torch.addmm(b1, xn, w1.t())
+        z = torch.empty_like(u)
+        tg = torch.empty_like(u) if train else None
+        wdc = wd.contiguous()
+        _lib.call("dhz_leff_dwconv_fwd", _p(u), _p(wdc), _p(bd), _p(tg), _p(z), B, Hres, Wres, Ch, _stream())
+        y = torch.addmm(b2, z, w2.t())
+        out = torch.empty_like(x)
+        _lib.call("dhz_reverse_residual_fwd", _p(y), _p(x), _p(dscale), _p(out), B, L, 1, C, 0, 0, _stream())
+        if train:
+            ctx.save_for_backward(x, gamma, stats, xn, u, tg, z, dscale, w1, wdc, w2)
+            ctx.params = (w1, b1, wd, bd, w2, b2)
+            ctx.geom = (B, L, C, Ch, Hres, Wres)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, gamma, stats, xn, u, tg, z, dscale, w1_, wdc, w2_ = ctx.saved_tensors
+        w1, b1, wd, bd, w2, b2 = ctx.params
+        B, L, C, Ch, Hres, Wres = ctx.geom
+        T = B * L
+        dout = dout.contiguous()
+        dev = x.device
+        f32 = dict(device=dev, dtype=torch.float32)
+        if dscale is not None:
+            dy = torch.empty((T, C), **f32)
+            _lib.call("dhz_reverse_residual_bwd", _p(dout), _p(dscale), _p(dy), B, L, 1, C, 0, 0, _stream())
+        else:
+            dy = dout.view(T, C)
+        dz = dy @ w2_
+        g_w2, g_b2 = _wgrad(dy, 0, z, w2, b2)
+        du = torch.empty_like(u)
+        dwb = torch.zeros((Ch * 10,), **f32)
+        _lib.call("dhz_leff_dwconv_bwd", _p(dz), _p(u), _p(tg), _p(wdc), _p(du), dwb.data_ptr(),
+                  dwb.data_ptr() + 4 * Ch * 9, B, Hres, Wres, Ch, _stream())
+        dxn = du @ w1_
+        g_w1, g_b1 = _wgrad(du, 0, xn, w1, b1)
+        dx = torch.empty_like(x)
+        dgb = torch.zeros((2, C), **f32)
+        _lib.call("dhz_ln_partition_bwd", _p(dxn), _p(x), _p(gamma), _p(stats), _p(dout), _p(dx), dgb[0].data_ptr(),
+                  dgb[1].data_ptr(), B, L, 1, C, 0, 0, _stream())
+        return (dx, dgb[0], dgb[1], g_w1, g_b1, dwb[:Ch * 9].view(Ch, 1, 3, 3), dwb[Ch * 9:], g_w2, g_b2,
+                None, None, None)
+
+
+def leff_branch(x, norm, mlp, dscale, Hres, Wres):
+    return _LeffBranch.apply(x, norm.weight, norm.bias, mlp.linear1[0].weight, mlp.linear1[0].bias,
+                             mlp.dwconv[0].weight, mlp.dwconv[0].bias, mlp.linear2[0].weight, mlp.linear2[0].bias,
+                             dscale, Hres, Wres)

@@ -280,23 +280,23 @@ class LeWinTransformerBlock(nn.Module):
             attn_mask = attn_mask + sm if attn_mask is not None else sm
         idx, self._staged_idx = self._staged_idx, None
 
-        if (fused.ENABLED and self.attn.variant == "probsparse" and C in fused.SUPPORTED_C and self.win_size == 8
-                and C == 32 * self.num_heads and (mask is None)):
-            # whole attention branch in one kernel (LN, roll, partition, QKV, ProbSparse core, out-proj, residual)
+        if self.attn.variant == "probsparse" and self.win_size == 8 and C == 32 * self.num_heads and mask is None:
+            # attention branch as ONE autograd node: the fused kernel (LN, roll, partition, QKV, ProbSparse core,
+            # out-proj, residual) where it wins, the kernel chain elsewhere; hand-sequenced backward in both cases
             import options
             table = self.attn.relative_position_bias_table if options.is_relative_position_bias else None
             if idx is None:
                 idx = draw_sample_index(1, ops.NTOK)[0]
             if idx.device != x.device or idx.dtype != torch.uint8:
                 idx = idx.to(device=x.device, dtype=torch.uint8)
-            x = fused.fused_attn_branch(x, self.norm1, self.attn.ProbSpare, table, idx.contiguous(), attn_mask,
-                                        self._scale(x), H, W, self.shift_size, self.num_heads)
+            x = fused.attn_branch(x, self.norm1, self.attn.ProbSpare, table, idx.contiguous(), attn_mask,
+                                  self._scale(x), H, W, self.shift_size, self.num_heads)
         else:
             xw = ops.ln_partition(x, self.norm1.weight, self.norm1.bias, H, W, self.shift_size)   # LN+roll+partition
             aw = self.attn(xw.view(-1, self.win_size * self.win_size, C), mask=attn_mask, idx=idx)
             x = ops.reverse_residual(aw.reshape(-1, C), x, self._scale(x), H, W, self.shift_size)  # reverse+unroll+res
-        y = self.mlp(ops.layer_norm_tokens(x, self.norm2.weight, self.norm2.bias).view(B, L, C))
-        return ops.residual_scale(y.reshape(-1, C), x, self._scale(x))
+        # LeFF branch (norm2 -> linear1 -> dwconv -> linear2 -> residual) as one autograd node
+        return fused.leff_branch(x, self.norm2, self.mlp, self._scale(x), H, W)
 
 
 class BasicUformerLayer(nn.Module):
