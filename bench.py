@@ -115,7 +115,7 @@ def main():
     for _ in range(args.warmup):
         step()
     if not args.no_kernel_timing:
-        ops.KERNEL_TIMING = {"dhz_ps_attn_fwd": []}
+        ops.KERNEL_TIMING = {"dhz_ps_attn_fwd": [], "dhz_fused_window_attn_fwd": []}
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -146,29 +146,39 @@ def main():
                        "global_batch": args.batch * world, "parallelism": f"dp{world}",
                        "loss_last_step": round(float(loss), 6)},
         }
+        pmc = {}
+        try:    # HBM bytes per launch from the committed PMC passes (tools/pmc_summary.py; FETCH doubled per the
+            # gfx950 correction of MI355X_MICROARCH.md, WRITE exact; separate --pmc runs of this same command)
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        except Exception:
+            pass
+        if timing and timing.get("dhz_fused_window_attn_fwd"):
+            # the window-attention kernel of the north star: LN + QKV + ProbSparse core + out-proj + residual, fused.
+            # algorithmic FLOPs per window = 2*64*(4C^2 + 75C) (four CxC projections + 3x(25x64x32) core)
+            ev = timing["dhz_fused_window_attn_fwd"]
+            ms = sum(a.elapsed_time(b) for a, b, _, _ in ev)
+            flops = sum(n * 2 * 64 * (4 * c * c + 75 * c) for _, _, n, c in ev)
+            tf = flops / (ms * 1e-3) / 1e12
+            traffic = pmc.get("fused_window_attn_fwd_kernel", {}).get("hbm_bytes_per_launch")
+            out["roofline"] = {"kernel": "fused_window_attn_fwd_kernel<C,SAVE> (dhz_fused_window_attn_fwd), C in {32,64,128}",
+                               "bound": "mfma", "achieved": round(tf, 2), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
+                               "frac": round(tf / MFMA_F32_PEAK_TF, 4),
+                               "traffic": round(traffic) if traffic else None, "launches": len(ev),
+                               "avg_launch_us": round(1e3 * ms / len(ev), 2),
+                               "alg_flops_per_launch": flops // len(ev)}
         if timing and timing.get("dhz_ps_attn_fwd"):
+            # the stand-alone ProbSparse core (stages the fused kernel does not cover): HBM-bound, 32 KiB / window-head
             ev = timing["dhz_ps_attn_fwd"]
             ms = sum(a.elapsed_time(b) for a, b, _ in ev)
-            wh = sum(n for _, _, n in ev)                       # window-heads processed
-            d = 32
-            bytes_alg = wh * (4 * 64 * d * 4)                   # Q,K,V in + ctx out, fp32
-            flops_alg = wh * 3 * 2 * 25 * 64 * d                # 307.2 KFLOP / window-head
+            wh = sum(n for _, _, n in ev)
+            bytes_alg = wh * (4 * 64 * 32 * 4)
             gbs = bytes_alg / (ms * 1e-3) / 1e9
-            # HBM bytes per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
-            # separate runs of this same command; FETCH doubled per the gfx950 correction) - tools/pmc_summary.py
-            traffic = None
-            try:
-                pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-                traffic = round(pmc["ps_attn_fwd_kernel<32>"]["hbm_bytes_per_launch"])
-            except Exception:
-                pass
-            out["roofline"] = {"kernel": "ps_attn_fwd_kernel<32> (dhz_ps_attn_fwd)", "bound": "hbm",
-                               "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
-                               "launches": len(ev), "avg_launch_us": round(1e3 * ms / len(ev), 2),
-                               "alg_bytes_per_launch": bytes_alg // len(ev),
-                               "alg_tflops": round(flops_alg / (ms * 1e-3) / 1e12, 2),
-                               "mfma_f32_peak_tflops": MFMA_F32_PEAK_TF}
+            traffic = pmc.get("ps_attn_fwd_kernel<32>", {}).get("hbm_bytes_per_launch")
+            entry = {"kernel": "ps_attn_fwd_kernel<32> (dhz_ps_attn_fwd)", "bound": "hbm", "achieved": round(gbs, 1),
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                     "traffic": round(traffic) if traffic else None, "launches": len(ev),
+                     "avg_launch_us": round(1e3 * ms / len(ev), 2), "alg_bytes_per_launch": bytes_alg // len(ev)}
+            out["roofline" if "roofline" not in out else "roofline_core_unfused"] = entry
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

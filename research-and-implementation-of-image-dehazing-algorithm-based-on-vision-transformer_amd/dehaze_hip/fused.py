@@ -35,6 +35,49 @@ def _wgrad(dy, off, x, w, b):
     return dys.t() @ x, (dys.sum(0) if b is not None else None)
 
 
+def _grad_buf(p):
+    """Zero-initialised, contiguous .grad of a leaf parameter (the optimizer's flat-buffer view when FlatAdamW is in
+    use), or None when in-place accumulation is not possible."""
+    if not (p.is_leaf and p.requires_grad):
+        return None
+    if p.grad is None:
+        p.grad = torch.zeros_like(p, memory_format=torch.contiguous_format)
+    return p.grad if p.grad.is_contiguous() else None
+
+
+def _ready(*params):
+    if ops.GRAD_READY is not None:
+        for p in params:
+            ops.GRAD_READY(p)
+
+
+def _ln_backward(dxn, x, gamma_p, beta_p, gamma, stats, dres, B, Hres, Wres, C, shift, partition):
+    """LayerNorm backward with the shortcut gradient folded in; d(gamma), d(beta) accumulated in place when the
+    parameters are leaves (returns (dx, dgamma, dbeta) with None for gradients already accumulated)."""
+    dx = torch.empty_like(x)
+    gg, gb = _grad_buf(gamma_p), _grad_buf(beta_p)
+    if gg is not None and gb is not None:
+        _lib.call("dhz_ln_partition_bwd", _p(dxn), _p(x), _p(gamma), _p(stats), _p(dres), _p(dx), _p(gg), _p(gb),
+                  B, Hres, Wres, C, shift, partition, _stream())
+        _ready(gamma_p, beta_p)
+        return dx, None, None
+    dgb = torch.zeros((2, C), device=x.device, dtype=torch.float32)
+    _lib.call("dhz_ln_partition_bwd", _p(dxn), _p(x), _p(gamma), _p(stats), _p(dres), _p(dx), dgb[0].data_ptr(),
+              dgb[1].data_ptr(), B, Hres, Wres, C, shift, partition, _stream())
+    return dx, dgb[0], dgb[1]
+
+
+def _table_backward(dpart, parts, table_p, H, dev):
+    gt = _grad_buf(table_p)
+    if gt is not None:
+        _lib.call("dhz_bias_table_grad", _p(dpart), parts, _p(gt), H, 1, _stream())
+        _ready(table_p)
+        return None
+    dtable = torch.empty((225, H), device=dev, dtype=torch.float32)
+    _lib.call("dhz_bias_table_grad", _p(dpart), parts, _p(dtable), H, 0, _stream())
+    return dtable
+
+
 class _FusedAttnBranch(Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, wq, bq, wk, bk, wv, bv, wo, bo, table, idx, mask, dscale, Hres, Wres, shift, H):
@@ -74,14 +117,14 @@ class _FusedAttnBranch(Function):
             timing.append((e0, e1, T // NTOK, C))
         if train:
             ctx.save_for_backward(x, gamma, stats, xn, qkv, cx, rank, bias, mask, dscale, wq, wk, wv, wo)
-            ctx.params = (wq, bq, wk, bk, wv, bv, wo, bo)
+            ctx.params = (wq, bq, wk, bk, wv, bv, wo, bo, gamma, beta, table)
             ctx.geom = (B, Hres, Wres, C, shift, H)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         x, gamma, stats, xn, qkv, cx, rank, bias, mask, dscale, wq_, wk_, wv_, wo_ = ctx.saved_tensors
-        wq, bq, wk, bk, wv, bv, wo, bo = ctx.params
+        wq, bq, wk, bk, wv, bv, wo, bo, gamma_p, beta_p, table_p = ctx.params
         B, Hres, Wres, C, shift, H = ctx.geom
         dout = dout.contiguous()
         dev = x.device
@@ -102,21 +145,15 @@ class _FusedAttnBranch(Function):
         base, gb = qkv.data_ptr(), dqkv.data_ptr()
         _lib.call("dhz_ps_attn_bwd", base, base + 4 * C, base + 8 * C, 3 * C, _p(bias), _p(mask), _p(rank), _p(dctx), C,
                   gb, gb + 4 * C, gb + 8 * C, 3 * C, _p(dpart), B_, H, nW, 32, _stream())
-        dtable = None
-        if bias is not None:
-            dtable = torch.empty((225, H), **f32)
-            _lib.call("dhz_bias_table_grad", _p(dpart), parts, _p(dtable), H, 0, _stream())
+        dtable = _table_backward(dpart, parts, table_p, H, dev) if bias is not None else None
         # (4) QKV projection
         dxn = dqkv @ torch.cat([wq_, wk_, wv_], 0)
         g_wq, g_bq = _wgrad(dqkv, 0, xn, wq, bq)
         g_wk, g_bk = _wgrad(dqkv, C, xn, wk, bk)
         g_wv, g_bv = _wgrad(dqkv, 2 * C, xn, wv, bv)
         # (5) LayerNorm backward + shortcut gradient in one pass
-        dx = torch.empty_like(x)
-        dgb = torch.zeros((2, C), **f32)
-        _lib.call("dhz_ln_partition_bwd", _p(dxn), _p(x), _p(gamma), _p(stats), _p(dout), _p(dx), dgb[0].data_ptr(),
-                  dgb[1].data_ptr(), B, Hres, Wres, C, shift, 1, _stream())
-        return (dx, dgb[0], dgb[1], g_wq, g_bq, g_wk, g_bk, g_wv, g_bv, g_wo, g_bo, dtable,
+        dx, dgamma, dbeta = _ln_backward(dxn, x, gamma_p, beta_p, gamma, stats, dout, B, Hres, Wres, C, shift, 1)
+        return (dx, dgamma, dbeta, g_wq, g_bq, g_wk, g_bk, g_wv, g_bv, g_wo, g_bo, dtable,
                 None, None, None, None, None, None, None)
 
 
@@ -171,14 +208,14 @@ class _AttnBranchChain(Function):
         _lib.call("dhz_reverse_residual_fwd", _p(aw), _p(x), _p(dscale), _p(out), B, Hres, Wres, C, shift, 1, _stream())
         if any(ctx.needs_input_grad):
             ctx.save_for_backward(x, gamma, stats, xn, qkv, cx, rank, bias, mask, dscale, wq, wk, wv, wo)
-            ctx.params = (wq, bq, wk, bk, wv, bv, wo, bo)
+            ctx.params = (wq, bq, wk, bk, wv, bv, wo, bo, gamma, beta, table)
             ctx.geom = (B, Hres, Wres, C, shift, H)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         x, gamma, stats, xn, qkv, cx, rank, bias, mask, dscale, wq_, wk_, wv_, wo_ = ctx.saved_tensors
-        wq, bq, wk, bk, wv, bv, wo, bo = ctx.params
+        wq, bq, wk, bk, wv, bv, wo, bo, gamma_p, beta_p, table_p = ctx.params
         B, Hres, Wres, C, shift, H = ctx.geom
         d = C // H
         dout = dout.contiguous()
@@ -197,19 +234,13 @@ class _AttnBranchChain(Function):
         base, gb = qkv.data_ptr(), dqkv.data_ptr()
         _lib.call("dhz_ps_attn_bwd", base, base + 4 * C, base + 8 * C, 3 * C, _p(bias), _p(mask), _p(rank), _p(dctx), C,
                   gb, gb + 4 * C, gb + 8 * C, 3 * C, _p(dpart), B_, H, nW, d, _stream())
-        dtable = None
-        if bias is not None:
-            dtable = torch.empty((225, H), **f32)
-            _lib.call("dhz_bias_table_grad", _p(dpart), parts, _p(dtable), H, 0, _stream())
+        dtable = _table_backward(dpart, parts, table_p, H, dev) if bias is not None else None
         dxn = dqkv @ torch.cat([wq_, wk_, wv_], 0)
         g_wq, g_bq = _wgrad(dqkv, 0, xn, wq, bq)
         g_wk, g_bk = _wgrad(dqkv, C, xn, wk, bk)
         g_wv, g_bv = _wgrad(dqkv, 2 * C, xn, wv, bv)
-        dx = torch.empty_like(x)
-        dgb = torch.zeros((2, C), **f32)
-        _lib.call("dhz_ln_partition_bwd", _p(dxn), _p(x), _p(gamma), _p(stats), _p(dout), _p(dx), dgb[0].data_ptr(),
-                  dgb[1].data_ptr(), B, Hres, Wres, C, shift, 1, _stream())
-        return (dx, dgb[0], dgb[1], g_wq, g_bq, g_wk, g_bk, g_wv, g_bv, g_wo, g_bo, dtable,
+        dx, dgamma, dbeta = _ln_backward(dxn, x, gamma_p, beta_p, gamma, stats, dout, B, Hres, Wres, C, shift, 1)
+        return (dx, dgamma, dbeta, g_wq, g_bq, g_wk, g_bk, g_wv, g_bv, g_wo, g_bo, dtable,
                 None, None, None, None, None, None, None)
 
 
@@ -254,14 +285,14 @@ class _LeffBranch(Function):
         _lib.call("dhz_reverse_residual_fwd", _p(y), _p(x), _p(dscale), _p(out), B, L, 1, C, 0, 0, _stream())
         if train:
             ctx.save_for_backward(x, gamma, stats, xn, u, tg, z, dscale, w1, wdc, w2)
-            ctx.params = (w1, b1, wd, bd, w2, b2)
+            ctx.params = (w1, b1, wd, bd, w2, b2, gamma, beta)
             ctx.geom = (B, L, C, Ch, Hres, Wres)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         x, gamma, stats, xn, u, tg, z, dscale, w1_, wdc, w2_ = ctx.saved_tensors
-        w1, b1, wd, bd, w2, b2 = ctx.params
+        w1, b1, wd, bd, w2, b2, gamma_p, beta_p = ctx.params
         B, L, C, Ch, Hres, Wres = ctx.geom
         T = B * L
         dout = dout.contiguous()
@@ -275,17 +306,21 @@ class _LeffBranch(Function):
         dz = dy @ w2_
         g_w2, g_b2 = _wgrad(dy, 0, z, w2, b2)
         du = torch.empty_like(u)
-        dwb = torch.zeros((Ch * 10,), **f32)
-        _lib.call("dhz_leff_dwconv_bwd", _p(dz), _p(u), _p(tg), _p(wdc), _p(du), dwb.data_ptr(),
-                  dwb.data_ptr() + 4 * Ch * 9, B, Hres, Wres, Ch, _stream())
+        gwd, gbd = _grad_buf(wd), _grad_buf(bd)
+        if gwd is not None and gbd is not None:          # depthwise weight / bias gradients straight into .grad
+            _lib.call("dhz_leff_dwconv_bwd", _p(dz), _p(u), _p(tg), _p(wdc), _p(du), _p(gwd), _p(gbd), B, Hres, Wres, Ch,
+                      _stream())
+            _ready(wd, bd)
+            g_wd = g_bd = None
+        else:
+            dwb = torch.zeros((Ch * 10,), **f32)
+            _lib.call("dhz_leff_dwconv_bwd", _p(dz), _p(u), _p(tg), _p(wdc), _p(du), dwb.data_ptr(),
+                      dwb.data_ptr() + 4 * Ch * 9, B, Hres, Wres, Ch, _stream())
+            g_wd, g_bd = dwb[:Ch * 9].view(Ch, 1, 3, 3), dwb[Ch * 9:]
         dxn = du @ w1_
         g_w1, g_b1 = _wgrad(du, 0, xn, w1, b1)
-        dx = torch.empty_like(x)
-        dgb = torch.zeros((2, C), **f32)
-        _lib.call("dhz_ln_partition_bwd", _p(dxn), _p(x), _p(gamma), _p(stats), _p(dout), _p(dx), dgb[0].data_ptr(),
-                  dgb[1].data_ptr(), B, L, 1, C, 0, 0, _stream())
-        return (dx, dgb[0], dgb[1], g_w1, g_b1, dwb[:Ch * 9].view(Ch, 1, 3, 3), dwb[Ch * 9:], g_w2, g_b2,
-                None, None, None)
+        dx, dgamma, dbeta = _ln_backward(dxn, x, gamma_p, beta_p, gamma, stats, dout, B, L, 1, C, 0, 0)
+        return (dx, dgamma, dbeta, g_w1, g_b1, g_wd, g_bd, g_w2, g_b2, None, None, None)
 
 
 def leff_branch(x, norm, mlp, dscale, Hres, Wres):
