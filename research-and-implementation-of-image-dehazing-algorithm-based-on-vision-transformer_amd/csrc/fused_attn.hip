@@ -18,45 +18,58 @@
 // LN statistics, xn, the packed QKV rows, the attention context and the selection ranks - 7C floats of HBM
 // traffic per token instead of the 15C of the unfused forward chain; in inference mode only x is read and
 // out written (2C per token) and the kernel is bound by the fp32 MFMA rate (AI 50.7 FLOP/B at C = 32).
+#include <stdlib.h>
 #include "common.h"
 
 namespace {
 
+#ifndef FUSED_PERSIST_C32
+#define FUSED_PERSIST_C32 1
+#endif
 constexpr int NT = 64;
 constexpr int NU = 25;
 constexpr int SS = 68;     // row stride of 64-wide score tiles
 constexpr int HS = 36;     // row stride of the per-head 32-wide tiles
 
-__device__ __forceinline__ float r8max(float v) {
-    v = fmaxf(v, __shfl_xor(v, 1)); v = fmaxf(v, __shfl_xor(v, 2)); return fmaxf(v, __shfl_xor(v, 4));
+// Cross-lane exchanges inside aligned groups of 4 / 8 lanes on the VALU (DPP), not through the LDS crossbar
+// (ds_bpermute costs an LDS round trip per step; a softmax row needs 12 dependent steps):
+//   quad_perm [1,0,3,2] = xor 1, quad_perm [2,3,0,1] = xor 2, row_half_mirror = lane i <-> 7-i within 8 lanes.
+template <int CTRL>
+__device__ __forceinline__ float dpp(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
 }
-__device__ __forceinline__ float r8sum(float v) {
-    v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); return v + __shfl_xor(v, 4);
+__device__ __forceinline__ float r4max(float v) { v = fmaxf(v, dpp<0xB1>(v)); return fmaxf(v, dpp<0x4E>(v)); }
+__device__ __forceinline__ float r4sum(float v) { v += dpp<0xB1>(v); return v + dpp<0x4E>(v); }
+__device__ __forceinline__ float r8max(float v) { v = r4max(v); return fmaxf(v, dpp<0x141>(v)); }
+__device__ __forceinline__ float r8sum(float v) { v = r4sum(v); return v + dpp<0x141>(v); }
+
+__device__ __forceinline__ void ld4(const float* p, float* dst) {
+    const float4 v = *reinterpret_cast<const float4*>(p);
+    dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
 }
 
 template <int C>
 struct FusedSmem {
     static constexpr int XS = C + 4;
-    float xn[NT * XS];         // LN output; later the out-projection staging tile
-    float q[NT * HS];          // Q_h | K_h are contiguous: S (64 x SS = 4352 floats) overlays them (4608 floats)
+    float xn[NT * XS];         // LN output (rows of wave w are produced and consumed by wave w); later the out-proj staging tile
+    float q[NT * HS];          // Q_h, later O_h (32 x HS)
     float k[NT * HS];
     float v[NT * HS];
+    float s[NT * SS];          // S = Q_h K_h^T
     float p[32 * SS];          // P (rows 0..24 selected queries, row 25 = 1/64)
-    float m[NT];
-    int part[4 * NT];
-    int top[32];
-    uint8_t rank[NT];
+    float m[NT];               // sparsity measure
+    int top[4][32];            // per-wave copy of the selected-query list (every wave derives the full ranking itself)
     uint8_t idx[NT * NU];
 };
 
 template <int C, bool SAVE>
-__global__ __launch_bounds__(256) void fused_window_attn_fwd_kernel(
+__global__ __launch_bounds__(256, C == 128 ? 1 : 2) void fused_window_attn_fwd_kernel(
     const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
     const float4* __restrict__ wqkv_p, const float* __restrict__ bqkv, const float4* __restrict__ wo_p,
     const float* __restrict__ bo, const uint8_t* __restrict__ idx, const float* __restrict__ bias,
     const float* __restrict__ mask, const float* __restrict__ dscale, float* __restrict__ out,
     float* __restrict__ xn_save, float* __restrict__ qkv_save, float* __restrict__ ctx_save,
-    float* __restrict__ stats_save, uint8_t* __restrict__ rank_save, int Hres, int Wres, int shift, int nwin) {
+    float* __restrict__ stats_save, uint8_t* __restrict__ rank_save, int Hres, int Wres, int shift, int nwin, int abl) {
     constexpr int XS = C + 4;
     constexpr int H = C / 32;
     constexpr int CPT = C / 4;            // floats per thread in the token-row phases (4 threads per token)
@@ -79,8 +92,9 @@ __global__ __launch_bounds__(256) void fused_window_attn_fwd_kernel(
     };
 
     // C == 32: all projection weights (64 VGPRs of B fragments) stay in registers for the kernel's lifetime
-    float4 wr_qkv[C == 32 ? 12 : 1], wr_o[C == 32 ? 4 : 1];
-    if constexpr (C == 32) {
+    constexpr bool WREG = (C == 32) && FUSED_PERSIST_C32;
+    float4 wr_qkv[WREG ? 12 : 1], wr_o[WREG ? 4 : 1];
+    if constexpr (WREG) {
 #pragma unroll
         for (int i = 0; i < 12; ++i) wr_qkv[i] = wqkv_p[i * 64 + lane];
 #pragma unroll
@@ -88,6 +102,15 @@ __global__ __launch_bounds__(256) void fused_window_attn_fwd_kernel(
     }
     if (t < NT * NU / 16) reinterpret_cast<uint4*>(sm.idx)[t] = reinterpret_cast<const uint4*>(idx)[t];
 
+    // loop-invariant vectors in registers: nothing inside the window loop waits on a global load except the bias /
+    // mask rows (vmcnt is an in-order counter - a waited load also waits for every older load and store)
+    float4 gmr[CPT / 4], btr[CPT / 4], bor[CPT / 4];
+#pragma unroll
+    for (int i = 0; i < CPT / 4; ++i) {
+        gmr[i] = reinterpret_cast<const float4*>(gamma + qd * CPT)[i];
+        btr[i] = reinterpret_cast<const float4*>(beta + qd * CPT)[i];
+        bor[i] = reinterpret_cast<const float4*>(bo + qd * CPT)[i];
+    }
     float4 xv[CPT / 4], xnext[CPT / 4];
     int win = blockIdx.x;
     if (win < nwin) {
@@ -99,18 +122,12 @@ __global__ __launch_bounds__(256) void fused_window_attn_fwd_kernel(
     for (; win < nwin; win += gridDim.x) {
         const int bimg = win / nW, wdx = win % nW;
         const size_t src_tok = src_token(win);
-        // prefetch the next window's rows: their HBM latency hides under this window's compute
-        if (C == 32 && win + (int)gridDim.x < nwin) {
-            const float4* xp = reinterpret_cast<const float4*>(x + src_token(win + gridDim.x) * C + qd * CPT);
-#pragma unroll
-            for (int i = 0; i < CPT / 4; ++i) xnext[i] = xp[i];
-        }
         // ---- 0. LayerNorm of the gathered rows (4 lanes per token)
         {
             float s = 0.f;
 #pragma unroll
             for (int i = 0; i < CPT / 4; ++i) s += xv[i].x + xv[i].y + xv[i].z + xv[i].w;
-            s += __shfl_xor(s, 1); s += __shfl_xor(s, 2);
+            s = r4sum(s);
             const float mean = s * (1.0f / C);
             float var = 0.f;
 #pragma unroll
@@ -118,12 +135,11 @@ __global__ __launch_bounds__(256) void fused_window_attn_fwd_kernel(
                 const float a0 = xv[i].x - mean, a1 = xv[i].y - mean, a2 = xv[i].z - mean, a3 = xv[i].w - mean;
                 var += a0 * a0 + a1 * a1 + a2 * a2 + a3 * a3;
             }
-            var += __shfl_xor(var, 1); var += __shfl_xor(var, 2);
+            var = r4sum(var);
             const float rstd = rsqrtf(var * (1.0f / C) + 1e-5f);
 #pragma unroll
             for (int i = 0; i < CPT / 4; ++i) {
-                const float4 gm = reinterpret_cast<const float4*>(gamma + qd * CPT)[i];
-                const float4 bt = reinterpret_cast<const float4*>(beta + qd * CPT)[i];
+                const float4 gm = gmr[i], bt = btr[i];
                 float4 y;
                 y.x = (xv[i].x - mean) * rstd * gm.x + bt.x;
                 y.y = (xv[i].y - mean) * rstd * gm.y + bt.y;
@@ -134,7 +150,7 @@ __global__ __launch_bounds__(256) void fused_window_attn_fwd_kernel(
             }
             if (SAVE && qd == 0) *reinterpret_cast<float2*>(stats_save + 2 * src_tok) = make_float2(mean, rstd);
         }
-        __syncthreads();
+        // no barrier: wave w normalised exactly the 16 rows (tokens 16w..16w+15) whose A fragments it reads next
 
         f32x4 oacc[C / 16];                    // out-projection accumulators: rows 16w.., all C columns
 #pragma unroll
@@ -143,17 +159,17 @@ __global__ __launch_bounds__(256) void fused_window_attn_fwd_kernel(
 #pragma unroll 1
         for (int h = 0; h < H; ++h) {
             // ---- 1. [Q_h | K_h | V_h] = xn W_h^T + b_h : wave w -> rows 16w..16w+15, 6 column tiles, interleaved chains
-            {
+            if (!(abl & 1)) {
                 float a[KS];
 #pragma unroll
-                for (int s = 0; s < KS; ++s) a[s] = sm.xn[(16 * w + i16) * XS + 4 * s + g];
+                for (int s4 = 0; s4 < KS4; ++s4) ld4(&sm.xn[(16 * w + i16) * XS + g * KS + 4 * s4], &a[4 * s4]);
                 f32x4 acc[6];
 #pragma unroll
                 for (int j = 0; j < 6; ++j) {
                     const float bj = bqkv[(j >> 1) * C + 32 * h + 16 * (j & 1) + i16];
                     acc[j] = f32x4{bj, bj, bj, bj};
                 }
-                if constexpr (C == 32) {
+                if constexpr (WREG) {
 #pragma unroll
                     for (int s4 = 0; s4 < 2; ++s4) {
 #pragma unroll
@@ -206,80 +222,82 @@ __global__ __launch_bounds__(256) void fused_window_attn_fwd_kernel(
                 *reinterpret_cast<float4*>(dst + 2 * C) = *reinterpret_cast<const float4*>(&sm.v[row * HS + c8]);
                 *reinterpret_cast<float4*>(dst + 2 * C + 4) = *reinterpret_cast<const float4*>(&sm.v[row * HS + c8 + 4]);
             }
-            // ---- 2a. S = Q_h K_h^T in registers (4 interleaved chains), then over the dead Q|K tiles
-            f32x4 sacc[4];
-            {
-                float a[8];
+            // ---- 2a. S = Q_h K_h^T (4 interleaved chains); wave w writes its own 16 rows of S
+            if (!(abl & 2)) {
+                float a[8], kb[4][8];
+                f32x4 sacc[4];
+                ld4(&sm.q[(16 * w + i16) * HS + 8 * g], &a[0]);
+                ld4(&sm.q[(16 * w + i16) * HS + 8 * g + 4], &a[4]);
 #pragma unroll
-                for (int s = 0; s < 8; ++s) a[s] = sm.q[(16 * w + i16) * HS + 4 * s + g];
-#pragma unroll
-                for (int tc = 0; tc < 4; ++tc) sacc[tc] = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int tc = 0; tc < 4; ++tc) {
+                    ld4(&sm.k[(16 * tc + i16) * HS + 8 * g], &kb[tc][0]);
+                    ld4(&sm.k[(16 * tc + i16) * HS + 8 * g + 4], &kb[tc][4]);
+                    sacc[tc] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
 #pragma unroll
                 for (int s = 0; s < 8; ++s)
 #pragma unroll
-                    for (int tc = 0; tc < 4; ++tc)
-                        sacc[tc] = mfma16(a[s], sm.k[(16 * tc + i16) * HS + 4 * s + g], sacc[tc]);
+                    for (int tc = 0; tc < 4; ++tc) sacc[tc] = mfma16(a[s], kb[tc][s], sacc[tc]);
+#pragma unroll
+                for (int tc = 0; tc < 4; ++tc)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) sm.s[(16 * w + 4 * g + r) * SS + 16 * tc + i16] = sacc[tc][r];
             }
-            __syncthreads();
-            float* S = sm.q;                       // 64 x SS overlay on q|k
-#pragma unroll
-            for (int tc = 0; tc < 4; ++tc)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) S[(16 * w + 4 * g + r) * SS + 16 * tc + i16] = sacc[tc][r];
-            __syncthreads();
-            // ---- 2b. sparsity measure + ranks (ATT:117,122)
-            {
+            // ---- 2b. sparsity measure of the wave's own 16 queries (reads only its own rows of S: no barrier)
+            if (!(abl & 4)) {
                 const int qi = t >> 2, j = t & 3;
-                float mx = -INFINITY, su = 0.f;
-                for (int s = j; s < NU; s += 4) {
-                    const float val = S[qi * SS + sm.idx[qi * NU + s]];
-                    mx = fmaxf(mx, val);
-                    su += val;
+                float val[7];
+#pragma unroll
+                for (int i = 0; i < 7; ++i) {           // samples j, j+4, .., j+24 (25 per query); all 7 gathers in flight
+                    const int sidx = j + 4 * i < NU ? j + 4 * i : j;
+                    val[i] = sm.s[qi * SS + sm.idx[qi * NU + sidx]];
                 }
-                mx = fmaxf(mx, __shfl_xor(mx, 1)); mx = fmaxf(mx, __shfl_xor(mx, 2));
-                su += __shfl_xor(su, 1); su += __shfl_xor(su, 2);
+                float mx = val[0], su = val[0];
+#pragma unroll
+                for (int i = 1; i < 7; ++i) {
+                    const bool ok = j + 4 * i < NU;
+                    mx = ok ? fmaxf(mx, val[i]) : mx;
+                    su += ok ? val[i] : 0.f;
+                }
+                mx = r4max(mx);
+                su = r4sum(su);
                 if (j == 0) sm.m[qi] = mx - su * (1.0f / NT);
             }
-            __syncthreads();
-            {
-                const int qi = t & 63;
-                const float mq = sm.m[qi];
+            __syncthreads();                       // S and M complete
+            // ---- 2c. every wave ranks all 64 queries itself (lane q <-> query q): no partial-count exchange
+            int myrank = lane;
+            if (!(abl & 8)) {
+                const float mq = sm.m[lane];
                 int cnt = 0;
+#pragma unroll 2
+                for (int jj = 0; jj < NT; jj += 4) {
+                    float mv[4];
+                    ld4(&sm.m[jj], mv);
 #pragma unroll
-                for (int jj = 0; jj < 16; ++jj) {
-                    const int j = 16 * w + jj;
-                    const float mj = sm.m[j];
-                    cnt += (mj > mq) || (mj == mq && j < qi);
+                    for (int u = 0; u < 4; ++u) cnt += (mv[u] > mq) || (mv[u] == mq && (jj + u) < lane);
                 }
-                sm.part[w * NT + qi] = cnt;
+                myrank = cnt;
+                if (cnt < NU) sm.top[w][cnt] = lane;
+                if (lane >= NU && lane < 32) sm.top[w][lane] = 0;
             }
-            __syncthreads();
-            if (t < NT) {
-                const int r = sm.part[t] + sm.part[NT + t] + sm.part[2 * NT + t] + sm.part[3 * NT + t];
-                sm.rank[t] = r < NU ? (uint8_t)r : (uint8_t)255;
-                if (r < NU) sm.top[r] = t;
-            } else if (t < NT + 32 - NU) {
-                sm.top[NU + t - NT] = 0;
-            }
-            __syncthreads();
-            // ---- 2c. P = softmax(softmax(scale S[top]) + bias + mask)
-            {
+            // ---- 2d. P = softmax(softmax(scale S[top]) + bias + mask): wave w -> rows 8w..8w+7
+            if (!(abl & 16)) {
                 const int r = t >> 3, c0 = (t & 7) * 8;
                 float p2[8];
                 if (r < NU) {
-                    const int qrow = sm.top[r];
+                    const int qrow = sm.top[w][r];
                     float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0, m0 = b0, m1 = b0;
                     if (bias) {      // issue the (L2-resident) bias / mask row loads before the first softmax
                         const float* br = bias + ((size_t)h * NT + qrow) * NT + c0;
                         b0 = *reinterpret_cast<const float4*>(br); b1 = *reinterpret_cast<const float4*>(br + 4);
                     }
-                    if (mask) {
+                    if (mask && ((wdx / nWw) == (Hres >> 3) - 1 || (wdx % nWw) == nWw - 1)) {   // elsewhere the mask is all zero
                         const float* mr = mask + ((size_t)wdx * NT + qrow) * NT + c0;
                         m0 = *reinterpret_cast<const float4*>(mr); m1 = *reinterpret_cast<const float4*>(mr + 4);
                     }
                     float xr[8], a2[8];
-                    const float4 s0 = *reinterpret_cast<const float4*>(&S[qrow * SS + c0]);
-                    const float4 s1 = *reinterpret_cast<const float4*>(&S[qrow * SS + c0 + 4]);
+                    const float4 s0 = *reinterpret_cast<const float4*>(&sm.s[qrow * SS + c0]);
+                    const float4 s1 = *reinterpret_cast<const float4*>(&sm.s[qrow * SS + c0 + 4]);
                     xr[0] = s0.x * scale; xr[1] = s0.y * scale; xr[2] = s0.z * scale; xr[3] = s0.w * scale;
                     xr[4] = s1.x * scale; xr[5] = s1.y * scale; xr[6] = s1.z * scale; xr[7] = s1.w * scale;
                     float mx = xr[0];
@@ -312,26 +330,36 @@ __global__ __launch_bounds__(256) void fused_window_attn_fwd_kernel(
                 *reinterpret_cast<float4*>(&sm.p[r * SS + c0]) = make_float4(p2[0], p2[1], p2[2], p2[3]);
                 *reinterpret_cast<float4*>(&sm.p[r * SS + c0 + 4]) = make_float4(p2[4], p2[5], p2[6], p2[7]);
             }
-            __syncthreads();
-            // ---- 2d. O_h = P V_h (32 x 32): one 16x16 tile per wave, written over the dead S tile
-            float* O = sm.q;                       // 32 x HS
-            {
+            // prefetch the next window's rows HERE: younger than every load this window still waits for, so the
+            // in-order vmcnt never makes a wait of this window sit out the prefetch's HBM latency
+            if (WREG && h == H - 1 && win + (int)gridDim.x < nwin) {
+                const float4* xp = reinterpret_cast<const float4*>(x + src_token(win + gridDim.x) * C + qd * CPT);
+#pragma unroll
+                for (int i = 0; i < CPT / 4; ++i) xnext[i] = xp[i];
+            }
+            __syncthreads();                       // P complete
+            // ---- 2e. O_h = P V_h (32 x 32): one 16x16 tile per wave, into the dead Q tile
+            float* O = sm.q;                       // 32 x HS (Q_h was last read before the first barrier of this head)
+            if (!(abl & 32)) {
                 const int tr = w & 1, tc = w >> 1;
                 f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-                acc = tile_mma<16>(sm.p + 16 * tr * SS, SS, 1, sm.v + 16 * tc, 1, HS, acc);
-                // S (under O) was last read by the softmax phase, which ended at the barrier above: safe to overwrite
+                float pa[16];
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) ld4(&sm.p[(16 * tr + i16) * SS + 16 * g + 4 * s4], &pa[4 * s4]);
+#pragma unroll
+                for (int s = 0; s < 16; ++s) acc = mfma16(pa[s], sm.v[(16 * g + s) * HS + 16 * tc + i16], acc);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) O[(16 * tr + 4 * g + r) * HS + 16 * tc + i16] = acc[r];
             }
-            __syncthreads();
+            __syncthreads();                       // O complete
             // ---- 3. out-projection partial: oacc += ctx_h Wo[:, 32h:32h+32]^T ; ctx row = selected row or mean row
-            {
-                const int rk = sm.rank[16 * w + i16];
+            if (!(abl & 64)) {
+                const int rk = __shfl(myrank, 16 * w + i16);
                 const int srow = rk < NU ? rk : NU;
                 float a[8];
-#pragma unroll
-                for (int s = 0; s < 8; ++s) a[s] = O[srow * HS + 4 * s + g];
-                if constexpr (C == 32) {
+                ld4(&O[srow * HS + 8 * g], &a[0]);
+                ld4(&O[srow * HS + 8 * g + 4], &a[4]);
+                if constexpr (WREG) {
 #pragma unroll
                     for (int s4 = 0; s4 < 2; ++s4) {
 #pragma unroll
@@ -362,16 +390,15 @@ __global__ __launch_bounds__(256) void fused_window_attn_fwd_kernel(
                 }
                 if (SAVE) {
                     const int row = t >> 2, c8 = (t & 3) * 8;
-                    const int rr = sm.rank[row] < NU ? sm.rank[row] : NU;
+                    const int rkr = __shfl(myrank, row);
+                    const int rr = rkr < NU ? rkr : NU;
                     float* dst = ctx_save + ((size_t)win * NT + row) * C + 32 * h + c8;
                     *reinterpret_cast<float4*>(dst) = *reinterpret_cast<const float4*>(&O[rr * HS + c8]);
                     *reinterpret_cast<float4*>(dst + 4) = *reinterpret_cast<const float4*>(&O[rr * HS + c8 + 4]);
-                    if (t < NT / 4)
-                        reinterpret_cast<uint32_t*>(rank_save + ((size_t)win * H + h) * NT)[t] =
-                            reinterpret_cast<const uint32_t*>(sm.rank)[t];
+                    if (w == 0) rank_save[((size_t)win * H + h) * NT + lane] = myrank < NU ? (uint8_t)myrank : (uint8_t)255;
                 }
             }
-            __syncthreads();                       // q/k/v/p/rank are rewritten by the next head
+            __syncthreads();                       // O (in the Q tile), K, V, S, P are rewritten by the next head / window
         }
 
         // ---- 4. epilogue: stage the 64 x C projection through LDS (xn is dead), add bias + shortcut (x is still in
@@ -380,19 +407,18 @@ __global__ __launch_bounds__(256) void fused_window_attn_fwd_kernel(
         for (int tn = 0; tn < C / 16; ++tn)
 #pragma unroll
             for (int r = 0; r < 4; ++r) sm.xn[(16 * w + 4 * g + r) * XS + 16 * tn + i16] = oacc[tn][r];
-        __syncthreads();
-        {
+        {   // wave-local again: wave w staged rows 16w..16w+15 and reads exactly those (tl = t >> 2)
             const float sc = dscale ? dscale[bimg] : 1.0f;
             float4* op = reinterpret_cast<float4*>(out + src_tok * C + qd * CPT);
 #pragma unroll
             for (int i = 0; i < CPT / 4; ++i) {
                 const float4 y = *reinterpret_cast<const float4*>(&sm.xn[tl * XS + qd * CPT + 4 * i]);
-                const float4 b4 = reinterpret_cast<const float4*>(bo + qd * CPT)[i];
+                const float4 b4 = bor[i];
                 op[i] = make_float4(xv[i].x + sc * (y.x + b4.x), xv[i].y + sc * (y.y + b4.y), xv[i].z + sc * (y.z + b4.z),
                                     xv[i].w + sc * (y.w + b4.w));
             }
         }
-        if constexpr (C == 32) {
+        if constexpr (WREG) {
 #pragma unroll
             for (int i = 0; i < CPT / 4; ++i) xv[i] = xnext[i];
         } else if (win + (int)gridDim.x < nwin) {  // (only reached when the grid is smaller than the window count)
@@ -400,14 +426,16 @@ __global__ __launch_bounds__(256) void fused_window_attn_fwd_kernel(
 #pragma unroll
             for (int i = 0; i < CPT / 4; ++i) xv[i] = xp[i];
         }
-        __syncthreads();                           // the staging tile is rewritten by the next window's LayerNorm
+        // no barrier: the staging tile is rewritten by this same wave's LayerNorm of the next window
     }
 }
 
 // weight prepack: fragment order for the 16x16x4 MFMA B operand (lane = 16 g + i16 holds B[k = 4 s + g][j = i16]);
 // four consecutive k-steps are packed into one float4 so that a wave reads 1 KiB contiguous per instruction.
-//   wqkv_p[h][j(6)][s4(C/16)][lane(64)] (float4 over r)  = W_m[32h + 16(j&1) + i16][16 s4 + 4 r + g],  m = j>>1
-//   wo_p  [h][tn(C/16)][s4(2)][lane(64)] (float4 over r) = Wo[16 tn + i16][32 h + 16 s4 + 4 r + g]
+// The contraction index is permuted so that lane group g owns a CONTIGUOUS k range (the A fragments then come out
+// of LDS with ds_read_b128; any permutation is valid as long as A and B agree):
+//   wqkv_p[h][j(6)][s4(C/16)][lane(64)] (float4 over r)  = W_m[32h + 16(j&1) + i16][g*C/4 + 4 s4 + r],  m = j>>1
+//   wo_p  [h][tn(C/16)][s4(2)][lane(64)] (float4 over r) = Wo[16 tn + i16][32 h + 8 g + 4 s4 + r]
 __global__ void prepack_weights_kernel(const float* __restrict__ wq, const float* __restrict__ wk,
                                        const float* __restrict__ wv, const float* __restrict__ wo,
                                        float* __restrict__ wqkv_p, float* __restrict__ wo_p, int C) {
@@ -421,7 +449,7 @@ __global__ void prepack_weights_kernel(const float* __restrict__ wq, const float
         const int j = rest % 6, h = rest / 6;
         const int i16 = lane & 15, g = lane >> 4;
         const float* W = (j >> 1) == 0 ? wq : ((j >> 1) == 1 ? wk : wv);
-        wqkv_p[e] = W[(size_t)(32 * h + 16 * (j & 1) + i16) * C + 16 * s4 + 4 * r + g];
+        wqkv_p[e] = W[(size_t)(32 * h + 16 * (j & 1) + i16) * C + g * (C / 4) + 4 * s4 + r];
     } else if (e < nq + no) {
         const int f = e - nq;
         const int r = f & 3, lane = (f >> 2) & 63;
@@ -429,7 +457,7 @@ __global__ void prepack_weights_kernel(const float* __restrict__ wq, const float
         const int s4 = rest & 1; rest >>= 1;
         const int tn = rest % (C / 16), h = rest / (C / 16);
         const int i16 = lane & 15, g = lane >> 4;
-        wo_p[f] = wo[(size_t)(16 * tn + i16) * C + 32 * h + 16 * s4 + 4 * r + g];
+        wo_p[f] = wo[(size_t)(16 * tn + i16) * C + 32 * h + 8 * g + 4 * s4 + r];
     }
 }
 
@@ -438,18 +466,19 @@ void launch_fused(hipStream_t s, int nwin, const float* x, const float* gamma, c
                   const float* bqkv, const float* wo_p, const float* bo, const uint8_t* idx, const float* bias,
                   const float* mask, const float* dscale, float* out, float* xn_save, float* qkv_save, float* ctx_save,
                   float* stats_save, uint8_t* rank_save, int Hres, int Wres, int shift) {
+    static const int abl = getenv("DHZ_FUSED_ABLATE") ? atoi(getenv("DHZ_FUSED_ABLATE")) : 0;   // timing diagnostics only
     const size_t smem = sizeof(FusedSmem<C>);
     if (smem > 48 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_window_attn_fwd_kernel<C, SAVE>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     // persistent workgroups: as many as fit the chip at this LDS footprint (3 per CU at C = 32, 2 above)
     const int per_cu = (int)(160 * 1024 / smem) > 0 ? (int)(160 * 1024 / smem) : 1;
-    int grid = (C == 32) ? 256 * (per_cu > 3 ? 3 : per_cu) : nwin;     // C == 32: persistent (weights live in registers)
+    int grid = (C == 32 && FUSED_PERSIST_C32) ? 256 * (per_cu > 3 ? 3 : per_cu) : nwin;   // persistent only with register-resident weights
     if (grid > nwin) grid = nwin;
     hipLaunchKernelGGL((fused_window_attn_fwd_kernel<C, SAVE>), dim3(grid), dim3(256), smem, s, x, gamma, beta,
                        reinterpret_cast<const float4*>(wqkv_p), bqkv, reinterpret_cast<const float4*>(wo_p), bo, idx,
                        bias, mask, dscale, out, xn_save, qkv_save, ctx_save, stats_save, rank_save, Hres, Wres, shift,
-                       nwin);
+                       nwin, abl);
 }
 
 }  // namespace
