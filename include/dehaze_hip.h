@@ -116,6 +116,19 @@ int dhz_bias_table_grad(const float* dbias_part, int parts, float* dtable, int H
 int dhz_linear_wgrad(const float* dy, int ldy, const float* x, int ldx, int T, int N, int K,
                      float* dw, float* db, void* stream);
 
+/* K11  3x3 / stride 1 / pad 1 convolution of the VGG19 feature stack (My_CR.py:56-86) as Winograd F(2x2,3x3) on the
+ *      fp32 matrix pipe.  Tensors are channel-blocked NCHW8c: x[b][c/8][h][w][c%8] (dhz_layout_blocked8 converts).
+ *      dhz_winograd_prepack: weight [Kout,Cin,3,3] -> transform-domain filters upack (16*Kout*Cin floats);
+ *        transposed_rot != 0 builds the backward-data filters from the forward weight [Cin,Kout,3,3] (the roles of
+ *        the two channel counts swap, taps rotate by 180 degrees).  The VGG weights are frozen: prepack once.
+ *      dhz_winograd_conv3x3: y = conv(x (* [act_mask > 0]), W) + bias, optional ReLU.  act_mask (same shape as x) is the
+ *        saved post-ReLU activation of the layer whose gradient is being propagated (backward-data pass) or NULL.
+ *        H % 16 == 0, W % 16 == 0, C % 8 == 0, K % 32 == 0. */
+int dhz_winograd_prepack(const float* weight, float* upack, int Kout, int Cin, int transposed_rot, void* stream);
+int dhz_winograd_conv3x3(const float* x, const float* act_mask, const float* upack, const float* bias, float* y,
+                         int B, int H, int W, int C, int K, int relu, void* stream);
+int dhz_layout_blocked8(const float* src, float* dst, int B, int C, int HW, int to_blocked, void* stream);
+
 /* K6  shift mask builder: mask[nW,64,64] in {0,-100}  (M1:803-836), Hres x Wres map, win 8. */
 int dhz_shift_mask(float* mask, int Hres, int Wres, int shift, void* stream);
 

@@ -15,15 +15,18 @@ namespace {
 
 constexpr int TK = 32;   // tokens per LDS stage
 
-template <int WM, int WN>   // 16x16 tiles per wave along N (rows of dW) and K (cols of dW); waves are 2 x 2
-__global__ __launch_bounds__(256) void linear_wgrad_kernel(const float* __restrict__ dy, int ldy,
+// WM, WN: 16x16 tiles per wave along N (rows of dW) and K (cols of dW); waves are NWM x 2 (NWM = 2: 256 threads,
+// NWM = 4: 512 threads and a 256-row tile - twice the FLOP per staged byte for the compute-bound shapes)
+template <int WM, int WN, int NWM>
+__global__ __launch_bounds__(128 * NWM) void linear_wgrad_kernel(const float* __restrict__ dy, int ldy,
                                                            const float* __restrict__ x, int ldx, int T, int N,
                                                            int K, float* __restrict__ dw, float* __restrict__ db,
                                                            int nsplit) {
-    constexpr int BM = 32 * WM, BN = 32 * WN;
+    constexpr int NTHR = 128 * NWM;
+    constexpr int BM = 16 * WM * NWM, BN = 32 * WN;
     constexpr int SA = BM + 16, SB = BN + 16;          // LDS row strides (floats): stride % 32 == 16
     constexpr int A4 = BM / 4, B4 = BN / 4;            // float4 per staged row
-    constexpr int NA = (TK * A4 + 255) / 256, NB = (TK * B4 + 255) / 256;   // float4 per thread per stage
+    constexpr int NA = (TK * A4 + NTHR - 1) / NTHR, NB = (TK * B4 + NTHR - 1) / NTHR;   // float4 per thread per stage
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int STAGE = TK * (SA + SB);              // floats per stage: [A | B]
     auto As = [&](int buf) -> float* { return smem + buf * STAGE; };
@@ -56,30 +59,30 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(const float* __restri
         const size_t tok0 = (size_t)st * TK;
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
-            const int e = t + 256 * i;
-            if (TK * A4 % 256 == 0 || e < TK * A4)
+            const int e = t + NTHR * i;
+            if (TK * A4 % NTHR == 0 || e < TK * A4)
                 ra[i] = *reinterpret_cast<const float4*>(dy + (tok0 + e / A4) * ldy + n0 + (e % A4) * 4);
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
-            const int e = t + 256 * i;
-            if (TK * B4 % 256 == 0 || e < TK * B4)
+            const int e = t + NTHR * i;
+            if (TK * B4 % NTHR == 0 || e < TK * B4)
                 rb[i] = *reinterpret_cast<const float4*>(x + (tok0 + e / B4) * ldx + k0 + (e % B4) * 4);
         }
     };
     auto swrite = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
-            const int e = t + 256 * i;
-            if (TK * A4 % 256 == 0 || e < TK * A4) {
+            const int e = t + NTHR * i;
+            if (TK * A4 % NTHR == 0 || e < TK * A4) {
                 *reinterpret_cast<float4*>(&As(buf)[(e / A4) * SA + (e % A4) * 4]) = ra[i];
                 dbacc[i].x += ra[i].x; dbacc[i].y += ra[i].y; dbacc[i].z += ra[i].z; dbacc[i].w += ra[i].w;
             }
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
-            const int e = t + 256 * i;
-            if (TK * B4 % 256 == 0 || e < TK * B4)
+            const int e = t + NTHR * i;
+            if (TK * B4 % NTHR == 0 || e < TK * B4)
                 *reinterpret_cast<float4*>(&Bs(buf)[(e / B4) * SB + (e % B4) * 4]) = rb[i];
         }
     };
@@ -120,7 +123,7 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(const float* __restri
             for (int j = 0; j < 4; ++j)
                 Cs[(wm * WM * 16 + a * 16 + 4 * g + j) * BN + wn * WN * 16 + b * 16 + i16] = acc[a][b][j];
     __syncthreads();
-    for (int e = t; e < BM * BN; e += 256) {
+    for (int e = t; e < BM * BN; e += NTHR) {
         const int r = e / BN, c = e % BN;
         atomicAdd(dw + (size_t)(n0 + r) * K + k0 + c, Cs[e]);
     }
@@ -130,7 +133,8 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(const float* __restri
         __syncthreads();
         float* red = smem;                                // [TK*A4][4] floats = TK*BM <= one stage
 #pragma unroll
-        for (int i = 0; i < NA; ++i) *reinterpret_cast<float4*>(&red[(t + 256 * i) * 4]) = dbacc[i];
+        for (int i = 0; i < NA; ++i)
+            if (TK * A4 % NTHR == 0 || t + NTHR * i < TK * A4) *reinterpret_cast<float4*>(&red[(t + NTHR * i) * 4]) = dbacc[i];
         __syncthreads();
         if (t < BM) {
             const int c4 = t / 4, comp = t % 4;
@@ -141,24 +145,24 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(const float* __restri
     }
 }
 
-template <int WM, int WN>
+template <int WM, int WN, int NWM = 2>
 int launch(const float* dy, int ldy, const float* x, int ldx, int T, int N, int K, float* dw, float* db, hipStream_t s) {
-    constexpr int BM = 32 * WM, BN = 32 * WN;
+    constexpr int BM = 16 * WM * NWM, BN = 32 * WN;
     constexpr size_t stage = (size_t)TK * (BM + 16 + BN + 16) * sizeof(float);
     constexpr size_t smem = 2 * stage > (size_t)BM * BN * 4 ? 2 * stage : (size_t)BM * BN * 4;
     const int tiles = (N / BM) * (K / BN);
     // Every workgroup ends with BM*BN fp32 atomics (chip-wide ~1.3 TB/s of added bytes): large tiles want
     // fewer, longer token slabs.  DHZ_WGRAD_TARGET overrides the workgroup target (tuning aid).
     static const int env_target = getenv("DHZ_WGRAD_TARGET") ? atoi(getenv("DHZ_WGRAD_TARGET")) : 0;
-    const int target = env_target > 0 ? env_target : 512;      // 2 workgroups per CU measured best on every shape
+    const int target = env_target > 0 ? env_target : (NWM == 4 ? 256 : 512);   // 2 (1 for the 512-thread tile) workgroups per CU
     int nsplit = (target + tiles - 1) / tiles;
     const int max_split = T / (TK * 4) > 0 ? T / (TK * 4) : 1;     // at least 4 stages per workgroup
     if (nsplit > max_split) nsplit = max_split;
     if (nsplit < 1) nsplit = 1;
     if (smem > 48 * 1024)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_wgrad_kernel<WM, WN>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_wgrad_kernel<WM, WN, NWM>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    hipLaunchKernelGGL((linear_wgrad_kernel<WM, WN>), dim3(tiles * nsplit), dim3(256), smem, s, dy, ldy, x, ldx, T, N, K,
+    hipLaunchKernelGGL((linear_wgrad_kernel<WM, WN, NWM>), dim3(tiles * nsplit), dim3(128 * NWM), smem, s, dy, ldy, x, ldx, T, N, K,
                        dw, db, nsplit);
     return 0;
 }
@@ -174,6 +178,12 @@ extern "C" int dhz_linear_wgrad(const float* dy, int ldy, const float* x, int ld
     hipStream_t s = (hipStream_t)stream;
     const int wm = (N % 128 == 0) ? 4 : (N % 96 == 0) ? 3 : (N % 64 == 0) ? 2 : 1;
     const int wn = (K % 128 == 0) ? 4 : (K % 64 == 0) ? 2 : 1;
+    static const int big_env = getenv("DHZ_WGRAD_BIG") ? atoi(getenv("DHZ_WGRAD_BIG")) : 0;   // measured: +-5 %, not worth it by default
+    if (big_env && N % 256 == 0 && K % 128 == 0) {          // compute-bound shapes: 256 x 128 tile on 8 waves
+        launch<4, 4, 4>(dy, ldy, x, ldx, T, N, K, dw, db, s);
+        DHZ_CHECK_LAUNCH("dhz_linear_wgrad");
+        return DHZ_OK;
+    }
 #define CASE(a, b) if (wm == a && wn == b) launch<a, b>(dy, ldy, x, ldx, T, N, K, dw, db, s);
     CASE(1, 1) CASE(1, 2) CASE(1, 4) CASE(2, 1) CASE(2, 2) CASE(2, 4) CASE(3, 1) CASE(3, 2) CASE(3, 4)
     CASE(4, 1) CASE(4, 2) CASE(4, 4)

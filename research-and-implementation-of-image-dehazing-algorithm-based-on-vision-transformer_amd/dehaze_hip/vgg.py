@@ -1,0 +1,174 @@
+"""VGG19[:30] feature stack of the contrastive loss (My_CR.py:56-86) on the Winograd-MFMA convolution kernel.
+
+conv 0 (3 -> 64) and conv 12 (512 -> 512 on 8x8 maps) stay on the library (negligible work / a map smaller than the
+kernel's 16x16 block); convs 1..11 - 99 % of the FLOPs - run dhz_winograd_conv3x3 with bias + ReLU fused, in the
+channel-blocked NCHW8c layout end to end.  The filters are frozen (My_CR.py:75-77), so their transform-domain
+forms (forward and backward-data) are prepacked once per device.
+
+Forward-only passes (target / hazy input, My_CR.py:102) save nothing; the pass on the restored image is one autograd
+node whose backward walks the stack with the same kernel (rotated/transposed filters, ReLU mask fused into the patch
+load) - weight gradients are never formed (the reference freezes the VGG, My_CR.py:75-77).
+"""
+import torch
+import torch.nn.functional as F
+from torch.autograd import Function
+
+from . import _lib
+from .ops import _p, _stream
+
+CONVS = ((3, 64), (64, 64), (64, 128), (128, 128), (128, 256), (256, 256), (256, 256), (256, 256), (256, 512),
+         (512, 512), (512, 512), (512, 512), (512, 512))
+POOL_AFTER = (1, 3, 7, 11)
+TAPS = (0, 2, 4, 8, 12)          # relu1_1, relu2_1, relu3_1, relu4_1, relu5_1
+
+
+def to_blocked(x):
+    B, C, H, W = x.shape
+    out = torch.empty((B, C // 8, H, W, 8), device=x.device, dtype=torch.float32)
+    _lib.call("dhz_layout_blocked8", _p(x.contiguous()), _p(out), B, C, H * W, 1, _stream())
+    return out
+
+
+def to_plain(xb):
+    B, CG, H, W, _ = xb.shape
+    out = torch.empty((B, CG * 8, H, W), device=xb.device, dtype=torch.float32)
+    _lib.call("dhz_layout_blocked8", _p(xb), _p(out), B, CG * 8, H * W, 0, _stream())
+    return out
+
+
+def _pool_view(xb):
+    """blocked [B,CG,H,W,8] viewed as an [N = B*CG, 8, H, W] channels_last tensor (no copy)."""
+    B, CG, H, W, _ = xb.shape
+    return xb.view(B * CG, H, W, 8).permute(0, 3, 1, 2)
+
+
+def pool_fwd(xb, want_indices):
+    B, CG, H, W, _ = xb.shape
+    v = _pool_view(xb)
+    if want_indices:
+        y, ind = F.max_pool2d(v, 2, 2, return_indices=True)
+    else:
+        y, ind = F.max_pool2d(v, 2, 2), None
+    yb = y.permute(0, 2, 3, 1).contiguous().view(B, CG, H // 2, W // 2, 8)
+    return yb, ind
+
+
+def pool_bwd(gb, xb, ind):
+    B, CG, H, W, _ = xb.shape
+    g = gb.view(B * CG, H // 2, W // 2, 8).permute(0, 3, 1, 2)
+    gx = torch.ops.aten.max_pool2d_with_indices_backward(g, _pool_view(xb), [2, 2], [2, 2], [0, 0], [1, 1], False, ind)
+    return gx.permute(0, 2, 3, 1).contiguous().view(B, CG, H, W, 8)
+
+
+class VggEngine:
+    def __init__(self, convs):
+        """convs: the 13 nn.Conv2d modules of vgg19.features[0:30]."""
+        self.convs = convs
+        self._packed = {}
+
+    def packed(self, i, device):
+        key = (i, str(device), self.convs[i].weight.data_ptr(), self.convs[i].weight._version)
+        hit = self._packed.get(i)
+        if hit is None or hit[0] != key:
+            w = self.convs[i].weight.detach().contiguous()
+            K, C = w.shape[0], w.shape[1]
+            uf = torch.empty(16 * K * C, device=device, dtype=torch.float32)
+            ub = torch.empty(16 * K * C, device=device, dtype=torch.float32)
+            _lib.call("dhz_winograd_prepack", _p(w), _p(uf), K, C, 0, _stream())
+            _lib.call("dhz_winograd_prepack", _p(w), _p(ub), C, K, 1, _stream())
+            hit = (key, uf, ub)
+            self._packed[i] = hit
+        return hit[1], hit[2]
+
+    # ---- one Winograd layer
+    def conv(self, i, xb):
+        B, CG, H, W, _ = xb.shape
+        C, K = CONVS[i]
+        uf, _ = self.packed(i, xb.device)
+        yb = torch.empty((B, K // 8, H, W, 8), device=xb.device, dtype=torch.float32)
+        _lib.call("dhz_winograd_conv3x3", _p(xb), None, _p(uf), _p(self.convs[i].bias), _p(yb), B, H, W, C, K, 1, _stream())
+        return yb
+
+    def conv_dgrad(self, i, gb, actb):
+        """gradient w.r.t. the input of conv i from the gradient w.r.t. its post-ReLU output (ReLU mask fused)."""
+        B, KG, H, W, _ = gb.shape
+        C, K = CONVS[i]
+        _, ub = self.packed(i, gb.device)
+        dxb = torch.empty((B, C // 8, H, W, 8), device=gb.device, dtype=torch.float32)
+        _lib.call("dhz_winograd_conv3x3", _p(gb), _p(actb), _p(ub), None, _p(dxb), B, H, W, K, C, 0, _stream())
+        return dxb
+
+    # ---- full stack, forward only
+    def forward_taps(self, x, save=None):
+        """x: [B,3,H,W] NCHW.  Returns the 5 tap features: taps 1-4 blocked [B,C/8,H,W,8], tap 5 NCHW.
+        `save` (dict) receives what the backward needs."""
+        c0, c12 = self.convs[0], self.convs[12]
+        a0 = F.relu(F.conv2d(x, c0.weight, c0.bias, padding=1))
+        cur = to_blocked(a0)
+        acts = {0: cur}
+        taps = [cur]
+        pools = {}
+        for i in range(1, 12):
+            cur = self.conv(i, cur)
+            acts[i] = cur
+            if i in TAPS:
+                taps.append(cur)
+            if i in POOL_AFTER:
+                pooled, ind = pool_fwd(cur, save is not None)
+                pools[i] = (pooled, ind)
+                cur = pooled
+        x12 = to_plain(cur)
+        a12 = F.relu(F.conv2d(x12, c12.weight, c12.bias, padding=1))
+        taps.append(a12)
+        if save is not None:
+            save.update(x=x, a0=a0, acts=acts, pools=pools, x12=x12, a12=a12)
+        return taps
+
+
+class _VggTaps(Function):
+    """taps(x) with gradient w.r.t. x only (frozen weights)."""
+
+    @staticmethod
+    def forward(ctx, engine, x):
+        saved = {}
+        with torch.no_grad():
+            taps = engine.forward_taps(x, save=saved)
+        ctx.engine, ctx.saved = engine, saved
+        return tuple(taps)
+
+    @staticmethod
+    def backward(ctx, g1, g2, g3, g4, g5):
+        eng, sv = ctx.engine, ctx.saved
+        acts, pools = sv["acts"], sv["pools"]
+        tap_grad = {0: g1, 2: g2, 4: g3, 8: g4}
+        c0, c12 = eng.convs[0], eng.convs[12]
+        with torch.no_grad():
+            # conv 12 (library) : gradient to its (pooled) input
+            G = None
+            if g5 is not None:
+                g12 = g5 * (sv["a12"] > 0)
+                gx12 = torch.ops.aten.convolution_backward(g12, sv["x12"], c12.weight, None, [1, 1], [1, 1], [1, 1], False,
+                                                           [0, 0], 1, [True, False, False])[0]
+                G = pool_bwd(to_blocked(gx12), acts[11], pools[11][1])       # gradient at a11 (post-ReLU)
+            for i in range(11, 0, -1):
+                if i in tap_grad and tap_grad[i] is not None:
+                    G = tap_grad[i].contiguous() if G is None else G + tap_grad[i]
+                if G is None:
+                    continue
+                G = eng.conv_dgrad(i, G.contiguous(), acts[i])               # -> gradient at conv i's input
+                if (i - 1) in POOL_AFTER:                                    # that input was a pooled map
+                    G = pool_bwd(G, acts[i - 1], pools[i - 1][1])
+            if g1 is not None:
+                G = g1.contiguous() if G is None else G + g1
+            g0 = to_plain(G) * (sv["a0"] > 0)
+            gx = torch.ops.aten.convolution_backward(g0, sv["x"], c0.weight, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
+                                                     [True, False, False])[0]
+        ctx.saved = None
+        return None, gx
+
+
+def vgg_taps(engine, x):
+    if torch.is_grad_enabled() and x.requires_grad:
+        return list(_VggTaps.apply(engine, x))
+    with torch.no_grad():
+        return engine.forward_taps(x)

@@ -3,6 +3,7 @@ import os, sys, time, warnings
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "research-and-implementation-of-image-dehazing-algorithm-based-on-vision-transformer_amd"))
 import torch
+if os.environ.get("CUDNN_BENCH"): torch.backends.cudnn.benchmark = True
 warnings.simplefilter("ignore")
 import My_CR
 dev = torch.device("cuda:0")
