@@ -76,8 +76,26 @@ class Vgg19(nn.Module):
         if not requires_grad:
             for p in self.parameters():
                 p.requires_grad = False
+        self._frozen = not requires_grad
+        self._engine = None
+
+    def engine_for(self, X):
+        """The Winograd-MFMA feature engine (dehaze_hip/vgg.py) when it applies: frozen filters, fp32 on the GPU, maps
+        that stay multiples of 16 down to relu4_4 (H, W multiples of 128); None -> library convolutions."""
+        if not (self._frozen and X.is_cuda and X.dtype == torch.float32 and X.dim() == 4 and X.shape[1] == 3
+                and X.shape[2] % 128 == 0 and X.shape[3] % 128 == 0):
+            return None
+        if self._engine is None:
+            from dehaze_hip.vgg import VggEngine
+            self._engine = VggEngine([m for m in self.modules() if isinstance(m, nn.Conv2d)])
+        return self._engine
 
     def forward(self, X):
+        eng = self.engine_for(X)
+        if eng is not None:
+            from dehaze_hip import vgg as _v
+            taps = _v.vgg_taps(eng, X)
+            return [_v.to_plain_tap(t) for t in taps]
         h1 = self.slice1(X)
         h2 = self.slice2(h1)
         h3 = self.slice3(h2)
@@ -99,9 +117,17 @@ class ContrastLoss(nn.Module):
 
     def forward(self, a, p, n):
         # p and n never need gradients: one batched VGG pass for both, one (with grad) for a
-        with torch.no_grad():
-            pn = self.vgg(torch.cat([p, n], 0)) if not self.ab else self.vgg(p)
-        a_vgg = self.vgg(a)
+        eng = self.vgg.engine_for(a)
+        if eng is not None:
+            # features stay in the engine's channel-blocked layout: the L1 means do not care about element order
+            from dehaze_hip.vgg import vgg_taps
+            with torch.no_grad():
+                pn = vgg_taps(eng, torch.cat([p, n], 0) if not self.ab else p)
+            a_vgg = vgg_taps(eng, a)
+        else:
+            with torch.no_grad():
+                pn = self.vgg(torch.cat([p, n], 0)) if not self.ab else self.vgg(p)
+            a_vgg = self.vgg(a)
         B = a.shape[0]
         loss, all_ap, all_an = 0, 0, 0
         for i in range(len(a_vgg)):

@@ -25,17 +25,25 @@ namespace {
 constexpr int TILES = 64;          // tiles per workgroup (8 x 8)
 constexpr int KB = 32;             // output channels per workgroup
 constexpr int CC = 8;              // input channels per step (= the layout's channel block)
-constexpr int PR = 20;             // patch row stride (18 used)
-constexpr int PPL = 18 * PR + 8;   // patch plane stride (floats)
-constexpr int VS = 80;             // V row stride: [xi][c][tile(64) + pad]
-constexpr int US = 48;             // U row stride: [xi][c][k(32) + pad]
+constexpr int PR = 24;             // patch row stride (18 used): 2*PR % 64 == 48 keeps the b64 transform reads conflict-free
+constexpr int PPL = 18 * PR + 8;   // patch plane stride (floats); 4*PPL % 64 == 32
+constexpr int VROW = 160;          // V row [xi][channel pair]: 64 tiles x 2 channels + 32 pad (row stride % 64 == 32)
+constexpr int YS = 260;            // output staging stride per output channel (16x16 px + pad)
+constexpr int NP4 = (18 * 18 * 2 + 255) / 256;    // float4 patch loads per thread (3)
+constexpr int NU4 = 16 * CC * KB / 4 / 256;       // float4 filter loads per thread (4)
 
 struct WinoSmem {
-    float patch[CC * PPL];         //  11.8 KB
-    float u[16 * CC * US];         //  24.6 KB
-    float v[16 * CC * VS];         //  41.0 KB ; later the output staging tile [32 k][16*16 px] (32 KB)
+    float patch[CC * PPL];         //  14.1 KB  planar [c][py][px]
+    float u[16 * 4 * 64];          //  16.4 KB  [xi][channel pair g][k & 15][k >> 4][c & 1]  (= the prepacked order)
+    float v[16 * 4 * VROW];        //  41.0 KB  [xi][channel pair][tile][c & 1]; later the output staging tile
 };
 
+// Pipeline per 8-channel group cb (2 barriers):
+//   transform(patch -> V) ; filters(cb) registers -> LDS ; barrier ; issue global loads of group cb+1 (patch, mask,
+//   filters -> registers) ; 64 MFMA per wave over U,V (b128 / b64 fragment reads) ; patch(cb+1) registers -> LDS ; barrier
+// so the global-load latency of the next group hides behind the MFMA phase of the current one.
+// MFMA contraction mapping: step s in {0,1}, lane group g  <->  channel 2g+s (any bijection works as long as A and B agree),
+// which makes a lane's two B values (and its four A values) contiguous in LDS.
 template <bool RELU, bool MASKED>
 __global__ __launch_bounds__(256, 2) void winograd_conv3x3_kernel(const float* __restrict__ x,
                                                               const float* __restrict__ act_mask,
@@ -59,37 +67,59 @@ __global__ __launch_bounds__(256, 2) void winograd_conv3x3_kernel(const float* _
 #pragma unroll
     for (int xi = 0; xi < 16; ++xi) { acc[xi][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[xi][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
-    for (int cb = 0; cb < CBn; ++cb) {
-        // ---- 1. halo patch (18 x 18 px x 8 ch) -> planar LDS; filters of (kb, cb) -> LDS
+    // per-thread patch slots: element e = t + 256 i -> (pixel p = e >> 1, channel half e & 1)
+    int poff[NP4];            // offset inside a plane (floats), -1 = outside the image (zero padding) or unused slot
+    int pdst[NP4];            // LDS destination
+#pragma unroll
+    for (int i = 0; i < NP4; ++i) {
+        const int e = t + 256 * i;
+        const int half = e & 1, p = e >> 1;
+        const int py = p / 18, px = p % 18;
+        const int iy = oy0 - 1 + py, ix = ox0 - 1 + px;
+        const bool ok = e < 18 * 18 * 2 && iy >= 0 && iy < H && ix >= 0 && ix < W;
+        poff[i] = ok ? (iy * W + ix) * 8 + half * 4 : -1;
+        pdst[i] = e < 18 * 18 * 2 ? (half * 4) * PPL + py * PR + px : -1;
+    }
+    float4 rp[NP4], rm[NP4], ru[NU4];
+    auto gload = [&](int cb) {
         const float* xp = x + ((size_t)bimg * CBn + cb) * plane;
         const float* mp = MASKED ? act_mask + ((size_t)bimg * CBn + cb) * plane : nullptr;
-        for (int e = t; e < 18 * 18 * 2; e += 256) {
-            const int half = e & 1, p = e >> 1;
-            const int py = p / 18, px = p % 18;
-            const int iy = oy0 - 1 + py, ix = ox0 - 1 + px;
-            float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
-                const size_t o = ((size_t)iy * W + ix) * 8 + half * 4;
-                val = *reinterpret_cast<const float4*>(xp + o);
-                if (MASKED) {
-                    const float4 m = *reinterpret_cast<const float4*>(mp + o);
-                    val.x = m.x > 0.f ? val.x : 0.f; val.y = m.y > 0.f ? val.y : 0.f;
-                    val.z = m.z > 0.f ? val.z : 0.f; val.w = m.w > 0.f ? val.w : 0.f;
-                }
+#pragma unroll
+        for (int i = 0; i < NP4; ++i) {
+            rp[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (poff[i] >= 0) {
+                rp[i] = *reinterpret_cast<const float4*>(xp + poff[i]);
+                if (MASKED) rm[i] = *reinterpret_cast<const float4*>(mp + poff[i]);
             }
-            float* dst = sm.patch + (half * 4) * PPL + py * PR + px;
+        }
+        const float4* up = reinterpret_cast<const float4*>(upack + ((size_t)kb * CBn + cb) * (16 * CC * KB));
+#pragma unroll
+        for (int i = 0; i < NU4; ++i) ru[i] = up[t + 256 * i];
+    };
+    auto write_patch = [&]() {
+#pragma unroll
+        for (int i = 0; i < NP4; ++i) {
+            if (pdst[i] < 0) continue;
+            float4 val = rp[i];
+            if (MASKED && poff[i] >= 0) {
+                val.x = rm[i].x > 0.f ? val.x : 0.f; val.y = rm[i].y > 0.f ? val.y : 0.f;
+                val.z = rm[i].z > 0.f ? val.z : 0.f; val.w = rm[i].w > 0.f ? val.w : 0.f;
+            }
+            float* dst = sm.patch + pdst[i];
             dst[0] = val.x; dst[PPL] = val.y; dst[2 * PPL] = val.z; dst[3 * PPL] = val.w;
         }
-        {
-            const float4* up = reinterpret_cast<const float4*>(upack + ((size_t)kb * CBn + cb) * (16 * CC * KB));
-            for (int e = t; e < 16 * CC * KB / 4; e += 256) {       // [xi][c][k32] rows of 32 floats -> stride US
-                const float4 v4 = up[e];
-                const int row = e >> 3, q = e & 7;
-                *reinterpret_cast<float4*>(&sm.u[row * US + q * 4]) = v4;
-            }
-        }
-        __syncthreads();
-        // ---- 2. input transform V = B^T d B ; thread = (channel c, tile): 2 tiles per thread
+    };
+    auto write_u = [&]() {
+#pragma unroll
+        for (int i = 0; i < NU4; ++i) *reinterpret_cast<float4*>(&sm.u[(t + 256 * i) * 4]) = ru[i];
+    };
+
+    gload(0);
+    write_patch();
+    __syncthreads();
+
+    for (int cb = 0; cb < CBn; ++cb) {
+        // ---- input transform V = B^T d B ; thread = (channel c, tile): 2 tiles per thread
         {
             const int c = t >> 5;
 #pragma unroll
@@ -99,9 +129,11 @@ __global__ __launch_bounds__(256, 2) void winograd_conv3x3_kernel(const float* _
                 const float* pp = sm.patch + c * PPL + (2 * ty) * PR + 2 * tx;
                 float d[4][4];
 #pragma unroll
-                for (int a = 0; a < 4; ++a)
-#pragma unroll
-                    for (int b = 0; b < 4; ++b) d[a][b] = pp[a * PR + b];
+                for (int a = 0; a < 4; ++a) {
+                    const float2 lo = *reinterpret_cast<const float2*>(pp + a * PR);
+                    const float2 hi = *reinterpret_cast<const float2*>(pp + a * PR + 2);
+                    d[a][0] = lo.x; d[a][1] = lo.y; d[a][2] = hi.x; d[a][3] = hi.y;
+                }
                 float tmp[4][4];                    // B^T d
 #pragma unroll
                 for (int b = 0; b < 4; ++b) {
@@ -110,34 +142,39 @@ __global__ __launch_bounds__(256, 2) void winograd_conv3x3_kernel(const float* _
                     tmp[2][b] = d[2][b] - d[1][b];
                     tmp[3][b] = d[1][b] - d[3][b];
                 }
-                float* vp = sm.v + c * VS + tile;
+                float* vp = sm.v + (c >> 1) * VROW + tile * 2 + (c & 1);
 #pragma unroll
                 for (int a = 0; a < 4; ++a) {       // (B^T d) B
-                    vp[(4 * a + 0) * CC * VS] = tmp[a][0] - tmp[a][2];
-                    vp[(4 * a + 1) * CC * VS] = tmp[a][1] + tmp[a][2];
-                    vp[(4 * a + 2) * CC * VS] = tmp[a][2] - tmp[a][1];
-                    vp[(4 * a + 3) * CC * VS] = tmp[a][1] - tmp[a][3];
+                    vp[(4 * a + 0) * 4 * VROW] = tmp[a][0] - tmp[a][2];
+                    vp[(4 * a + 1) * 4 * VROW] = tmp[a][1] + tmp[a][2];
+                    vp[(4 * a + 2) * 4 * VROW] = tmp[a][2] - tmp[a][1];
+                    vp[(4 * a + 3) * 4 * VROW] = tmp[a][1] - tmp[a][3];
                 }
             }
         }
+        write_u();                                   // filters of this group (loaded one MFMA phase ago)
         __syncthreads();
-        // ---- 3. M_xi += U_xi V_xi for the wave's 16 tiles, all 16 xi, both 16-row halves of the 32 output channels
-#pragma unroll
-        for (int s = 0; s < CC / 4; ++s) {
+        if (cb + 1 < CBn) gload(cb + 1);
+        // ---- M_xi += U_xi V_xi for the wave's 16 tiles, all 16 xi, both 16-row halves of the 32 output channels
+        {
+            const float* up = sm.u + (g * 16 + i16) * 4;
+            const float* vp = sm.v + g * VROW + (16 * w + i16) * 2;
 #pragma unroll
             for (int xi = 0; xi < 16; ++xi) {
-                const float b = sm.v[(xi * CC + 4 * s + g) * VS + 16 * w + i16];
-                const float a0 = sm.u[(xi * CC + 4 * s + g) * US + i16];
-                const float a1 = sm.u[(xi * CC + 4 * s + g) * US + 16 + i16];
-                acc[xi][0] = mfma16(a0, b, acc[xi][0]);
-                acc[xi][1] = mfma16(a1, b, acc[xi][1]);
+                const float4 a = *reinterpret_cast<const float4*>(up + xi * 256);          // {k lo,c0},{k lo,c1},{k hi,c0},{k hi,c1}
+                const float2 b = *reinterpret_cast<const float2*>(vp + xi * 4 * VROW);      // {c0},{c1}
+                acc[xi][0] = mfma16(a.x, b.x, acc[xi][0]);
+                acc[xi][1] = mfma16(a.z, b.x, acc[xi][1]);
+                acc[xi][0] = mfma16(a.y, b.y, acc[xi][0]);
+                acc[xi][1] = mfma16(a.w, b.y, acc[xi][1]);
             }
         }
+        if (cb + 1 < CBn) write_patch();
         __syncthreads();
     }
 
     // ---- epilogue: Y = A^T M A (lane-local), + bias, ReLU; stage [32 k][16 x 16 px] in LDS; coalesced stores
-    float* ys = sm.v;                                   // [k 32][py 16][px 16]  (8192 floats)
+    float* ys = sm.v;                                   // [k 32][py 16][px 16] stride YS
     {
         const int tile = 16 * w + i16, ty = tile >> 3, tx = tile & 7;
 #pragma unroll
@@ -158,8 +195,9 @@ __global__ __launch_bounds__(256, 2) void winograd_conv3x3_kernel(const float* _
                 float y00 = t0[0] + t0[1] + t0[2] + bk, y01 = t0[1] - t0[2] - t0[3] + bk;
                 float y10 = t1[0] + t1[1] + t1[2] + bk, y11 = t1[1] - t1[2] - t1[3] + bk;
                 if (RELU) { y00 = fmaxf(y00, 0.f); y01 = fmaxf(y01, 0.f); y10 = fmaxf(y10, 0.f); y11 = fmaxf(y11, 0.f); }
-                float* o = ys + k * 256 + (2 * ty) * 16 + 2 * tx;
-                o[0] = y00; o[1] = y01; o[16] = y10; o[17] = y11;
+                float* o = ys + k * YS + (2 * ty) * 16 + 2 * tx;
+                *reinterpret_cast<float2*>(o) = make_float2(y00, y01);
+                *reinterpret_cast<float2*>(o + 16) = make_float2(y10, y11);
             }
     }
     __syncthreads();
@@ -169,15 +207,16 @@ __global__ __launch_bounds__(256, 2) void winograd_conv3x3_kernel(const float* _
         for (int e = t; e < 4 * 256 * 2; e += 256) {
             const int half = e & 1, p = (e >> 1) & 255, kg = e >> 9;
             const int py = p >> 4, px = p & 15;
-            const float* s0 = ys + (kg * 8 + half * 4) * 256 + p;
-            const float4 v4 = make_float4(s0[0], s0[256], s0[512], s0[768]);
+            const float* s0 = ys + (kg * 8 + half * 4) * YS + p;
+            const float4 v4 = make_float4(s0[0], s0[YS], s0[2 * YS], s0[3 * YS]);
             *reinterpret_cast<float4*>(y + (((size_t)bimg * KG + kb * 4 + kg) * H + oy0 + py) * W * 8 +
                                        (size_t)(ox0 + px) * 8 + half * 4) = v4;
         }
     }
 }
 
-// U = G g G^T for every (k, c), packed [k/32][c/8][xi 16][c%8][k%32]; `transposed_rot` selects the backward-data
+// U = G g G^T for every (k, c), packed [k/32][c/8][xi 16][(c%8)/2][k%16][(k%32)/16][c%2] (the kernel's LDS order);
+// `transposed_rot` selects the backward-data
 // filters g'[c][k][i][j] = g[k][c][2-i][2-j] (the roles of C and K swap).
 __global__ void winograd_prepack_kernel(const float* __restrict__ wgt, float* __restrict__ upack, int Kout, int Cin,
                                         int transposed_rot) {
@@ -199,7 +238,9 @@ __global__ void winograd_prepack_kernel(const float* __restrict__ wgt, float* __
         tg[2][j] = 0.5f * (gk[0][j] - gk[1][j] + gk[2][j]);
         tg[3][j] = gk[2][j];
     }
-    float* dst = upack + (((size_t)(k / KB) * (Cin / CC) + c / CC) * 16) * (CC * KB) + (c % CC) * KB + (k % KB);
+    const int kk = k % KB, cc = c % CC;
+    float* dst = upack + (((size_t)(k / KB) * (Cin / CC) + c / CC) * 16) * (CC * KB) +
+                 (((cc >> 1) * 16 + (kk & 15)) * 4 + (kk >> 4) * 2 + (cc & 1));
 #pragma unroll
     for (int i = 0; i < 4; ++i) {                             // (G g) G^T
         dst[(4 * i + 0) * CC * KB] = tg[i][0];

@@ -172,3 +172,18 @@ def vgg_taps(engine, x):
         return list(_VggTaps.apply(engine, x))
     with torch.no_grad():
         return engine.forward_taps(x)
+
+
+class _ToPlain(Function):
+    @staticmethod
+    def forward(ctx, xb):
+        return to_plain(xb)
+
+    @staticmethod
+    def backward(ctx, g):
+        return to_blocked(g)
+
+
+def to_plain_tap(t):
+    """tap feature -> NCHW (differentiable); tap 5 already is."""
+    return _ToPlain.apply(t) if t.dim() == 5 else t

@@ -51,3 +51,71 @@ def test_winograd_forward_and_dgrad(B, C, K, H):
         dx = _plain(dxb, C)
         refdx = F.conv_transpose2d((dy * (ref > 0)).double(), w.double(), padding=1).float()
         assert torch.allclose(dx, refdx, atol=5e-5, rtol=1e-4), (dx - refdx).abs().max()
+
+
+@pytest.mark.parametrize("ablation", [False, True])
+def test_contrast_loss_engine_vs_oracle(ablation):
+    """ContrastLoss on the Winograd feature engine (128x128 patches) vs the CPU oracle in float64: value, the two L1
+    sums, and the gradient w.r.t. the restored image; and Vgg19.forward's NCHW features vs the oracle's."""
+    import warnings
+    import My_CR
+    from oracle import uformer_oracle as O
+    dev = torch.device("cuda:0")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        cl = My_CR.ContrastLoss(ablation=ablation).to(dev)
+    g = torch.Generator().manual_seed(77)
+    a, p, n = (torch.rand(2, 3, 128, 128, generator=g) for _ in range(3))
+    W = O.seeded_vgg_weights(dtype=torch.float64)
+    a64 = a.double().requires_grad_()
+    loss_o, ap_o, an_o = O.contrast_loss(a64, p.double(), n.double(), W, ablation=ablation)
+    loss_o.backward()
+
+    ad = a.to(dev).requires_grad_()
+    assert cl.vgg.engine_for(ad) is not None
+    loss, ap, an = cl(ad, p.to(dev), n.to(dev))
+    loss.backward()
+    assert abs(loss.item() - loss_o.item()) < 2e-4 * abs(loss_o.item()), (loss.item(), loss_o.item())
+    assert abs(float(ap) - float(ap_o)) < 2e-4 * float(ap_o)
+    if not ablation:
+        assert abs(float(an) - float(an_o)) < 2e-4 * float(an_o)
+    # d|fa - fp| = sign(fa - fp): an fp32-vs-fp64 rounding difference flips a few signs / ReLU masks among the ~10^6
+    # feature elements, so the max error is loose (the smooth-loss test below pins the backward chain tightly)
+    ref = a64.grad.float()
+    err = (ad.grad.cpu() - ref).abs()
+    assert err.max().item() < 3e-2 * ref.abs().max().item(), (err.max().item(), ref.abs().max().item())
+    assert err.mean().item() < 3e-3 * ref.abs().mean().item(), (err.mean().item(), ref.abs().mean().item())
+
+    feats = cl.vgg(a.to(dev))
+    feats_o = O.vgg19_features(a.double(), W)
+    for f, fo in zip(feats, feats_o):
+        assert f.shape == fo.shape
+        assert (f.cpu() - fo.float()).abs().max().item() < 2e-3 * fo.abs().max().item()
+
+
+def test_vgg_engine_backward_smooth_loss():
+    """The engine's hand-sequenced backward (Winograd backward-data + ReLU masks + pool scatter + library ends) against
+    float64 autograd of the oracle on a smooth functional: sum_i <R_i, tap_i(a)>."""
+    import warnings
+    import My_CR
+    from dehaze_hip import vgg as V
+    from oracle import uformer_oracle as O
+    dev = torch.device("cuda:0")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        net = My_CR.Vgg19().to(dev)
+    g = torch.Generator().manual_seed(5)
+    a = torch.rand(1, 3, 128, 128, generator=g)
+    W = O.seeded_vgg_weights(dtype=torch.float64)
+    a64 = a.double().requires_grad_()
+    feats_o = O.vgg19_features(a64, W)
+    R = [torch.randn(f.shape, generator=g) for f in feats_o]
+    sum((f * r.double()).sum() for f, r in zip(feats_o, R)).backward()
+
+    ad = a.to(dev).requires_grad_()
+    feats = net(ad)                                   # engine taps -> NCHW through the differentiable layout op
+    assert net.engine_for(ad) is not None
+    sum((f * r.to(dev)).sum() for f, r in zip(feats, R)).backward()
+    ref = a64.grad.float()
+    err = (ad.grad.cpu() - ref).abs().max().item()
+    assert err < 2e-4 * ref.abs().max().item(), (err, ref.abs().max().item())
