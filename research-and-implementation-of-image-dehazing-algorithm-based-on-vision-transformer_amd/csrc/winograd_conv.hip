@@ -67,52 +67,60 @@ __global__ __launch_bounds__(256, 2) void winograd_conv3x3_kernel(const float* _
 #pragma unroll
     for (int xi = 0; xi < 16; ++xi) { acc[xi][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[xi][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
-    // per-thread patch slots: element e = t + 256 i -> (pixel p = e >> 1, channel half e & 1)
-    int poff[NP4];            // offset inside a plane (floats), -1 = outside the image (zero padding) or unused slot
-    int pdst[NP4];            // LDS destination
+    // per-thread patch slots: element e = t + 256 i -> (pixel p = e >> 1, channel half e & 1).  The loads are
+    // unconditional (out-of-image / unused slots read offset 0 and are zeroed or skipped when written to LDS): a
+    // predicated load would make the compiler wait for it right away instead of across the MFMA phase.
+    int poff[NP4];            // offset inside a plane (floats)
+    int pdst[NP4];            // LDS destination, -1 = unused slot
+    bool pin[NP4];            // inside the image
 #pragma unroll
     for (int i = 0; i < NP4; ++i) {
         const int e = t + 256 * i;
         const int half = e & 1, p = e >> 1;
         const int py = p / 18, px = p % 18;
         const int iy = oy0 - 1 + py, ix = ox0 - 1 + px;
-        const bool ok = e < 18 * 18 * 2 && iy >= 0 && iy < H && ix >= 0 && ix < W;
-        poff[i] = ok ? (iy * W + ix) * 8 + half * 4 : -1;
+        pin[i] = e < 18 * 18 * 2 && iy >= 0 && iy < H && ix >= 0 && ix < W;
+        poff[i] = pin[i] ? (iy * W + ix) * 8 + half * 4 : 0;
         pdst[i] = e < 18 * 18 * 2 ? (half * 4) * PPL + py * PR + px : -1;
     }
-    float4 rp[NP4], rm[NP4], ru[NU4];
+    float4 rp[NP4], rm[NP4];
+    float4 ru0, ru1, ru2, ru3;                          // NU4 == 4 filter float4 per thread
+    static_assert(NU4 == 4, "filter prefetch registers");
     auto gload = [&](int cb) {
         const float* xp = x + ((size_t)bimg * CBn + cb) * plane;
         const float* mp = MASKED ? act_mask + ((size_t)bimg * CBn + cb) * plane : nullptr;
 #pragma unroll
         for (int i = 0; i < NP4; ++i) {
-            rp[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (poff[i] >= 0) {
-                rp[i] = *reinterpret_cast<const float4*>(xp + poff[i]);
-                if (MASKED) rm[i] = *reinterpret_cast<const float4*>(mp + poff[i]);
-            }
+            rp[i] = *reinterpret_cast<const float4*>(xp + poff[i]);
+            if (MASKED) rm[i] = *reinterpret_cast<const float4*>(mp + poff[i]);
         }
         const float4* up = reinterpret_cast<const float4*>(upack + ((size_t)kb * CBn + cb) * (16 * CC * KB));
-#pragma unroll
-        for (int i = 0; i < NU4; ++i) ru[i] = up[t + 256 * i];
+        ru0 = up[t]; ru1 = up[t + 256]; ru2 = up[t + 512]; ru3 = up[t + 768];
     };
     auto write_patch = [&]() {
 #pragma unroll
         for (int i = 0; i < NP4; ++i) {
             if (pdst[i] < 0) continue;
             float4 val = rp[i];
-            if (MASKED && poff[i] >= 0) {
+            if (MASKED) {
                 val.x = rm[i].x > 0.f ? val.x : 0.f; val.y = rm[i].y > 0.f ? val.y : 0.f;
                 val.z = rm[i].z > 0.f ? val.z : 0.f; val.w = rm[i].w > 0.f ? val.w : 0.f;
             }
+            if (!pin[i]) val = make_float4(0.f, 0.f, 0.f, 0.f);
             float* dst = sm.patch + pdst[i];
             dst[0] = val.x; dst[PPL] = val.y; dst[2 * PPL] = val.z; dst[3 * PPL] = val.w;
         }
     };
     auto write_u = [&]() {
-#pragma unroll
-        for (int i = 0; i < NU4; ++i) *reinterpret_cast<float4*>(&sm.u[(t + 256 * i) * 4]) = ru[i];
+        float4* us = reinterpret_cast<float4*>(sm.u);
+        us[t] = ru0; us[t + 256] = ru1; us[t + 512] = ru2; us[t + 768] = ru3;
     };
+
+    float bk[2][4];                                      // bias of this lane's 8 output channels (16 tr + 4 g + r)
+#pragma unroll
+    for (int tr = 0; tr < 2; ++tr)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bk[tr][r] = bias ? bias[kb * KB + 16 * tr + 4 * g + r] : 0.f;
 
     gload(0);
     write_patch();
@@ -159,14 +167,21 @@ __global__ __launch_bounds__(256, 2) void winograd_conv3x3_kernel(const float* _
         {
             const float* up = sm.u + (g * 16 + i16) * 4;
             const float* vp = sm.v + g * VROW + (16 * w + i16) * 2;
+            // fragments of position xi+1 are requested before the 4 MFMAs of xi are issued (two register sets)
+            float4 a = *reinterpret_cast<const float4*>(up);                                // {k lo,c0},{k lo,c1},{k hi,c0},{k hi,c1}
+            float2 b = *reinterpret_cast<const float2*>(vp);                                // {c0},{c1}
 #pragma unroll
             for (int xi = 0; xi < 16; ++xi) {
-                const float4 a = *reinterpret_cast<const float4*>(up + xi * 256);          // {k lo,c0},{k lo,c1},{k hi,c0},{k hi,c1}
-                const float2 b = *reinterpret_cast<const float2*>(vp + xi * 4 * VROW);      // {c0},{c1}
+                float4 an = a; float2 bn = b;
+                if (xi + 1 < 16) {
+                    an = *reinterpret_cast<const float4*>(up + (xi + 1) * 256);
+                    bn = *reinterpret_cast<const float2*>(vp + (xi + 1) * 4 * VROW);
+                }
                 acc[xi][0] = mfma16(a.x, b.x, acc[xi][0]);
                 acc[xi][1] = mfma16(a.z, b.x, acc[xi][1]);
                 acc[xi][0] = mfma16(a.y, b.y, acc[xi][0]);
                 acc[xi][1] = mfma16(a.w, b.y, acc[xi][1]);
+                a = an; b = bn;
             }
         }
         if (cb + 1 < CBn) write_patch();
@@ -191,9 +206,9 @@ __global__ __launch_bounds__(256, 2) void winograd_conv3x3_kernel(const float* _
                     t0[b] = m[b] + m[4 + b] + m[8 + b];
                     t1[b] = m[4 + b] - m[8 + b] - m[12 + b];
                 }
-                const float bk = bias ? bias[kb * KB + k] : 0.f;
-                float y00 = t0[0] + t0[1] + t0[2] + bk, y01 = t0[1] - t0[2] - t0[3] + bk;
-                float y10 = t1[0] + t1[1] + t1[2] + bk, y11 = t1[1] - t1[2] - t1[3] + bk;
+                const float bv = bk[tr][r];
+                float y00 = t0[0] + t0[1] + t0[2] + bv, y01 = t0[1] - t0[2] - t0[3] + bv;
+                float y10 = t1[0] + t1[1] + t1[2] + bv, y11 = t1[1] - t1[2] - t1[3] + bv;
                 if (RELU) { y00 = fmaxf(y00, 0.f); y01 = fmaxf(y01, 0.f); y10 = fmaxf(y10, 0.f); y11 = fmaxf(y11, 0.f); }
                 float* o = ys + k * YS + (2 * ty) * 16 + 2 * tx;
                 *reinterpret_cast<float2*>(o) = make_float2(y00, y01);
