@@ -8,112 +8,158 @@
 // Layout: channel-blocked NCHW8c - x[b][c/8][h][w][c%8] - so that a pixel's 8-channel group is 32 contiguous
 // bytes and an image row of a group is one contiguous run (coalesced halo-patch loads, coalesced stores).
 //
-// One 256-thread workgroup = 64 output tiles (8x8 tiles = 16x16 pixels of one image) x 32 output channels.
-// Loop over input-channel groups of 8:
-//   1. the 18x18 halo patch of the group (optionally multiplied by the ReLU mask of a saved activation - the
-//      backward-data pass) and the group's pre-transformed filters U[16][8][32] go to LDS;
-//   2. input transform V = B^T d B: thread = (channel, tile), 16 LDS reads -> 16 LDS writes, V[xi][c][tile];
-//   3. for each of the 16 transform positions xi: M_xi[32 x 64] += U_xi[32 x 8] V_xi[8 x 64] on MFMA; wave w owns
-//      the 16 tiles 16w..16w+15 for ALL xi, so the inverse transform Y = A^T M A is lane-local in the end.
-// Epilogue: inverse transform, + bias, optional ReLU, staging through LDS, coalesced 32-byte-group stores.
+// One 512-thread workgroup = two 16x16-pixel output blocks (waves 0-3 / 4-7) x 32 output channels.  Wave w owns 16
+// tiles (4 x 16 output pixels) of its block for ALL 16 transform positions xi, so
+//   * its halo patch (6 x 18 px x 8 ch) and its transformed input V live in a wave-private LDS region: patch
+//     load, input transform and MFMA of a wave need no workgroup barrier, and the inverse transform Y = A^T M A
+//     and the output staging are lane- / wave-local;
+//   * only the pre-transformed filters U (16 KB per 8-channel group, shared by the 8 waves) go through a
+//     workgroup-wide ring of 3 LDS buffers: ONE barrier per channel group.
+// Per channel group cb a wave issues 64 MFMAs (M_xi[32 k x 16 tiles] += U_xi[32 x 8] V_xi[8 x 16], 16 xi).  Measured
+// on gfx950: VALU/LDS instructions of the *partner* wave on a SIMD get ~1 issue slot per 20 cycles beside an fp32
+// MFMA stream (a separate transform phase - in the same wave or ping-ponged against the partner - ran the matrix
+// pipe at 56 %), while a wave's OWN independent instructions between its MFMAs are nearly free.  So the whole
+// input transform of group cb+1 (patch registers -> LDS, next global loads, patch reads, B^T d B in packed fp32,
+// filters -> LDS) is spread over the 32 gaps between MFMA pairs of group cb, its 16 x float2 results are held in
+// registers and stored to V once the last MFMA of cb has read V.  The barrier sits at a different position of
+// the stream in the two halves (pair-step 1 / 5), which staggers the SIMD partners by half a group so that one
+// wave's V-store burst falls into the other's MFMA stream.
+// MFMA contraction mapping: step s in {0,1}, lane group g  <->  channel 2g+s (any bijection works as long as A and
+// B agree), which makes a lane's two B values (and its four A values) contiguous in LDS (b64 / b128 reads).
 // The backward-data convolution is the same kernel with rotated / transposed filters (prepacked once: the VGG
-// weights are frozen, My_CR.py:75-77).
+// weights are frozen, My_CR.py:75-77) and the ReLU mask of the saved activation applied to the patch.
+#include <stdlib.h>
 #include "common.h"
 
 namespace {
 
-constexpr int TILES = 64;          // tiles per workgroup (8 x 8)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 constexpr int KB = 32;             // output channels per workgroup
 constexpr int CC = 8;              // input channels per step (= the layout's channel block)
-constexpr int PR = 24;             // patch row stride (18 used): 2*PR % 64 == 48 keeps the b64 transform reads conflict-free
-constexpr int PPL = 18 * PR + 8;   // patch plane stride (floats); 4*PPL % 64 == 32
-constexpr int VROW = 160;          // V row [xi][channel pair]: 64 tiles x 2 channels + 32 pad (row stride % 64 == 32)
-constexpr int YS = 260;            // output staging stride per output channel (16x16 px + pad)
-constexpr int NP4 = (18 * 18 * 2 + 255) / 256;    // float4 patch loads per thread (3)
-constexpr int NU4 = 16 * CC * KB / 4 / 256;       // float4 filter loads per thread (4)
+constexpr int RS = 48;             // patch row stride (floats): 18 px x 2 channels used; 2*RS % 64 == 32
+constexpr int PPL = 320;           // patch plane (channel pair) stride: 6 rows x 48 = 288 used; % 64 == 0
+constexpr int UF = 16 * CC * KB;   // floats of one (kb, cb) filter slice (4096)
+constexpr int VW = 16 * 4 * 32;    // floats of one wave's V: [xi][channel pair][16 tiles x 2 channels]
+constexpr int WAVE_LDS = VW + 4 * PPL;    // V + patch, contiguous per wave (3328 floats = 13 KB)
+constexpr int YS = 68;             // output staging stride per output channel (4 x 16 px + pad); 32 * YS <= WAVE_LDS
+constexpr int NP4 = 4;             // float4 patch slots per lane: 6 x 18 px x 2 halves = 216 of 256
+constexpr int NUBUF = 3;           // filter ring
+constexpr size_t WINO_SMEM = (size_t)(NUBUF * UF + 8 * WAVE_LDS) * sizeof(float);   // 152 KB: one workgroup per CU
 
-struct WinoSmem {
-    float patch[CC * PPL];         //  14.1 KB  planar [c][py][px]
-    float u[16 * 4 * 64];          //  16.4 KB  [xi][channel pair g][k & 15][k >> 4][c & 1]  (= the prepacked order)
-    float v[16 * 4 * VROW];        //  41.0 KB  [xi][channel pair][tile][c & 1]; later the output staging tile
-};
+__device__ __forceinline__ void wave_sync() {
+    // LDS operations of one wave execute in order; only the compiler must not move accesses across phase boundaries
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
-// Pipeline per 8-channel group cb (2 barriers):
-//   transform(patch -> V) ; filters(cb) registers -> LDS ; barrier ; issue global loads of group cb+1 (patch, mask,
-//   filters -> registers) ; 64 MFMA per wave over U,V (b128 / b64 fragment reads) ; patch(cb+1) registers -> LDS ; barrier
-// so the global-load latency of the next group hides behind the MFMA phase of the current one.
-// MFMA contraction mapping: step s in {0,1}, lane group g  <->  channel 2g+s (any bijection works as long as A and B agree),
-// which makes a lane's two B values (and its four A values) contiguous in LDS.
 template <bool RELU, bool MASKED>
-__global__ __launch_bounds__(256, 2) void winograd_conv3x3_kernel(const float* __restrict__ x,
-                                                              const float* __restrict__ act_mask,
-                                                              const float* __restrict__ upack,
-                                                              const float* __restrict__ bias, float* __restrict__ y,
-                                                              int H, int W, int C, int K) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    WinoSmem& sm = *reinterpret_cast<WinoSmem*>(smem_raw);
-    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+__global__ __launch_bounds__(512) void winograd_conv3x3_kernel(const float* __restrict__ x,
+                                                           const float* __restrict__ act_mask,
+                                                           const float* __restrict__ upack,
+                                                           const float* __restrict__ bias, float* __restrict__ y,
+                                                           int H, int W, int C, int K, int nblk) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6, half = w >> 2, wl = w & 3;
     const int i16 = lane & 15, g = lane >> 4;
+    float* us = smem;                                   // filters [NUBUF][UF]: [xi][channel pair][k & 15][k >> 4][c & 1]
+    float* vw = smem + NUBUF * UF + w * WAVE_LDS;       // this wave's V
+    float* pw = vw + VW;                                // this wave's patch [channel pair][6][RS]: (px, c & 1) interleaved
     const int KBn = K / KB, CBn = C / CC;
     const int kb = blockIdx.x % KBn;
-    const int blk = blockIdx.x / KBn;
+    int blk = (blockIdx.x / KBn) * 2 + half;
+    const bool live = blk < nblk;                       // odd block count: the last workgroup's second half recomputes, stores nothing
+    if (!live) blk = nblk - 1;
     const int bx_n = W / 16, by_n = H / 16;
     const int bimg = blk / (bx_n * by_n);
     const int by = (blk / bx_n) % by_n, bx = blk % bx_n;
-    const int oy0 = by * 16, ox0 = bx * 16;                 // output block origin; patch origin is (oy0-1, ox0-1)
+    const int wy0 = by * 16 + 4 * wl, ox0 = bx * 16;        // the wave's output rows wy0..wy0+3; patch origin (wy0-1, ox0-1)
     const size_t plane = (size_t)H * W * 8;                 // floats per (image, channel-group) plane
+    const int pbar = half ? 5 : 1;                          // pair-step that carries the workgroup barrier
 
     f32x4 acc[16][2];
 #pragma unroll
     for (int xi = 0; xi < 16; ++xi) { acc[xi][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[xi][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
-    // per-thread patch slots: element e = t + 256 i -> (pixel p = e >> 1, channel half e & 1).  The loads are
-    // unconditional (out-of-image / unused slots read offset 0 and are zeroed or skipped when written to LDS): a
-    // predicated load would make the compiler wait for it right away instead of across the MFMA phase.
-    int poff[NP4];            // offset inside a plane (floats)
-    int pdst[NP4];            // LDS destination, -1 = unused slot
-    bool pin[NP4];            // inside the image
+    // per-lane patch slots: element e = lane + 64 i -> (pixel p = e >> 1 of the 6 x 18 patch, channel half e & 1).
+    // Out-of-image pixels are zero padding: their LDS slots are zeroed once below and never written again; the
+    // global loads stay unconditional (such slots read offset 0) so that no load is waited for at its issue point.
+    unsigned poff[NP4];       // offset inside a plane (floats)
+    int pdst[NP4];            // LDS destination, -1 = not written (unused slot or zero padding)
 #pragma unroll
     for (int i = 0; i < NP4; ++i) {
-        const int e = t + 256 * i;
-        const int half = e & 1, p = e >> 1;
+        const int e = lane + 64 * i;
+        const int hf = e & 1, p = e >> 1;
         const int py = p / 18, px = p % 18;
-        const int iy = oy0 - 1 + py, ix = ox0 - 1 + px;
-        pin[i] = e < 18 * 18 * 2 && iy >= 0 && iy < H && ix >= 0 && ix < W;
-        poff[i] = pin[i] ? (iy * W + ix) * 8 + half * 4 : 0;
-        pdst[i] = e < 18 * 18 * 2 ? (half * 4) * PPL + py * PR + px : -1;
+        const int iy = wy0 - 1 + py, ix = ox0 - 1 + px;
+        const bool in = e < 6 * 18 * 2 && iy >= 0 && iy < H && ix >= 0 && ix < W;
+        poff[i] = in ? (unsigned)((iy * W + ix) * 8 + hf * 4) : 0u;
+        pdst[i] = in ? (2 * hf) * PPL + py * RS + px * 2 : -1;
+    }
+    {
+        float4* z = reinterpret_cast<float4*>(pw);
+#pragma unroll
+        for (int i = 0; i < 4 * PPL / 4 / 64; ++i) z[lane + 64 * i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     float4 rp[NP4], rm[NP4];
-    float4 ru0, ru1, ru2, ru3;                          // NU4 == 4 filter float4 per thread
-    static_assert(NU4 == 4, "filter prefetch registers");
-    auto gload = [&](int cb) {
-        const float* xp = x + ((size_t)bimg * CBn + cb) * plane;
-        const float* mp = MASKED ? act_mask + ((size_t)bimg * CBn + cb) * plane : nullptr;
+    float4 ru0, ru1;                                     // UF / 4 / 512 = 2 filter float4 per thread
+    const float* xbase = x + (size_t)bimg * CBn * plane;
+    const float* mbase = MASKED ? act_mask + (size_t)bimg * CBn * plane : nullptr;
+    const float4* ubase = reinterpret_cast<const float4*>(upack + (size_t)kb * CBn * UF) + t;
+    auto gload_patch = [&](int cb) {
+        const float* xp = xbase + (size_t)cb * plane;
+        const float* mp = MASKED ? mbase + (size_t)cb * plane : nullptr;
 #pragma unroll
         for (int i = 0; i < NP4; ++i) {
             rp[i] = *reinterpret_cast<const float4*>(xp + poff[i]);
             if (MASKED) rm[i] = *reinterpret_cast<const float4*>(mp + poff[i]);
         }
-        const float4* up = reinterpret_cast<const float4*>(upack + ((size_t)kb * CBn + cb) * (16 * CC * KB));
-        ru0 = up[t]; ru1 = up[t + 256]; ru2 = up[t + 512]; ru3 = up[t + 768];
     };
-    auto write_patch = [&]() {
-#pragma unroll
-        for (int i = 0; i < NP4; ++i) {
-            if (pdst[i] < 0) continue;
-            float4 val = rp[i];
-            if (MASKED) {
-                val.x = rm[i].x > 0.f ? val.x : 0.f; val.y = rm[i].y > 0.f ? val.y : 0.f;
-                val.z = rm[i].z > 0.f ? val.z : 0.f; val.w = rm[i].w > 0.f ? val.w : 0.f;
-            }
-            if (!pin[i]) val = make_float4(0.f, 0.f, 0.f, 0.f);
-            float* dst = sm.patch + pdst[i];
-            dst[0] = val.x; dst[PPL] = val.y; dst[2 * PPL] = val.z; dst[3 * PPL] = val.w;
+    auto gload_u = [&](int cb) {
+        const float4* up = ubase + (size_t)cb * (UF / 4);
+        ru0 = up[0]; ru1 = up[512];
+    };
+    auto write_patch_slot = [&](int i) {
+        if (pdst[i] < 0) return;
+        float4 val = rp[i];
+        if (MASKED) {
+            val.x = rm[i].x > 0.f ? val.x : 0.f; val.y = rm[i].y > 0.f ? val.y : 0.f;
+            val.z = rm[i].z > 0.f ? val.z : 0.f; val.w = rm[i].w > 0.f ? val.w : 0.f;
         }
+        float* dst = pw + pdst[i];
+        *reinterpret_cast<float2*>(dst) = make_float2(val.x, val.y);
+        *reinterpret_cast<float2*>(dst + PPL) = make_float2(val.z, val.w);
     };
-    auto write_u = [&]() {
-        float4* us = reinterpret_cast<float4*>(sm.u);
-        us[t] = ru0; us[t + 256] = ru1; us[t + 512] = ru2; us[t + 768] = ru3;
+    auto write_u = [&](int buf) {
+        float4* ud = reinterpret_cast<float4*>(us + buf * UF);
+        ud[t] = ru0; ud[t + 512] = ru1;
+    };
+
+    // ---- input transform of the lane's (channel pair g, tile i16), both channels packed: d rows -> B^T d -> (B^T d) B
+    f32x2 d[4][4];                                       // patch values, then B^T d, then the 16 V values (in place)
+    const float* pread = pw + g * PPL + (2 * (i16 >> 3)) * RS + (i16 & 7) * 4;
+    auto read_row = [&](int a) {
+        const float4 q0 = *reinterpret_cast<const float4*>(pread + a * RS);       // px 0,1 x (c0,c1)
+        const float4 q1 = *reinterpret_cast<const float4*>(pread + a * RS + 4);   // px 2,3
+        d[a][0] = f32x2{q0.x, q0.y}; d[a][1] = f32x2{q0.z, q0.w};
+        d[a][2] = f32x2{q1.x, q1.y}; d[a][3] = f32x2{q1.z, q1.w};
+    };
+    auto col_transform = [&](int b) {                    // B^T d, column b
+        const f32x2 d0 = d[0][b], d1 = d[1][b], d2 = d[2][b], d3 = d[3][b];
+        d[0][b] = d0 - d2; d[1][b] = d1 + d2; d[2][b] = d2 - d1; d[3][b] = d1 - d3;
+    };
+    auto row_transform = [&](int a) {                    // (B^T d) B, row a
+        const f32x2 t0 = d[a][0], t1 = d[a][1], t2 = d[a][2], t3 = d[a][3];
+        d[a][0] = t0 - t2; d[a][1] = t1 + t2; d[a][2] = t2 - t1; d[a][3] = t1 - t3;
+    };
+    float* vdst = vw + g * 32 + i16 * 2;
+    auto write_v = [&]() {
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+                *reinterpret_cast<float2*>(vdst + (4 * a + b) * 128) = make_float2(d[a][b].x, d[a][b].y);
     };
 
     float bk[2][4];                                      // bias of this lane's 8 output channels (16 tr + 4 g + r)
@@ -122,76 +168,105 @@ __global__ __launch_bounds__(256, 2) void winograd_conv3x3_kernel(const float* _
 #pragma unroll
         for (int r = 0; r < 4; ++r) bk[tr][r] = bias ? bias[kb * KB + 16 * tr + 4 * g + r] : 0.f;
 
-    gload(0);
-    write_patch();
+    // ---- prologue: group 0 transformed and in V, filters 0 in ring slot 0, loads of group 1 in flight
+    gload_patch(0);
+    gload_u(0);
+    wave_sync();                                         // zero fill before the patch stores
+#pragma unroll
+    for (int i = 0; i < NP4; ++i) write_patch_slot(i);
+    write_u(0);
+    if (CBn > 1) { gload_patch(1); gload_u(1); }
+    wave_sync();
+#pragma unroll
+    for (int a = 0; a < 4; ++a) read_row(a);
+#pragma unroll
+    for (int b = 0; b < 4; ++b) col_transform(b);
+#pragma unroll
+    for (int a = 0; a < 4; ++a) row_transform(a);
+    write_v();
     __syncthreads();
 
+    const float* ufrag = us + (g * 16 + i16) * 4;
+    const float* vfrag = vw + g * 32 + i16 * 2;
     for (int cb = 0; cb < CBn; ++cb) {
-        // ---- input transform V = B^T d B ; thread = (channel c, tile): 2 tiles per thread
-        {
-            const int c = t >> 5;
-#pragma unroll
-            for (int pass = 0; pass < 2; ++pass) {
-                const int tile = (t & 31) + 32 * pass;
-                const int ty = tile >> 3, tx = tile & 7;
-                const float* pp = sm.patch + c * PPL + (2 * ty) * PR + 2 * tx;
-                float d[4][4];
-#pragma unroll
-                for (int a = 0; a < 4; ++a) {
-                    const float2 lo = *reinterpret_cast<const float2*>(pp + a * PR);
-                    const float2 hi = *reinterpret_cast<const float2*>(pp + a * PR + 2);
-                    d[a][0] = lo.x; d[a][1] = lo.y; d[a][2] = hi.x; d[a][3] = hi.y;
-                }
-                float tmp[4][4];                    // B^T d
-#pragma unroll
-                for (int b = 0; b < 4; ++b) {
-                    tmp[0][b] = d[0][b] - d[2][b];
-                    tmp[1][b] = d[1][b] + d[2][b];
-                    tmp[2][b] = d[2][b] - d[1][b];
-                    tmp[3][b] = d[1][b] - d[3][b];
-                }
-                float* vp = sm.v + (c >> 1) * VROW + tile * 2 + (c & 1);
-#pragma unroll
-                for (int a = 0; a < 4; ++a) {       // (B^T d) B
-                    vp[(4 * a + 0) * 4 * VROW] = tmp[a][0] - tmp[a][2];
-                    vp[(4 * a + 1) * 4 * VROW] = tmp[a][1] + tmp[a][2];
-                    vp[(4 * a + 2) * 4 * VROW] = tmp[a][2] - tmp[a][1];
-                    vp[(4 * a + 3) * 4 * VROW] = tmp[a][1] - tmp[a][3];
-                }
+        const bool next = cb + 1 < CBn, next2 = cb + 2 < CBn;
+        const float* up = ufrag + (cb % NUBUF) * UF;
+        const int nbuf = (cb + 1) % NUBUF;
+        // the work of group cb+1, in 32 slots (4 per pair-step) that go between the MFMA pairs of group cb
+        auto slot = [&](int sidx) {
+            if (!next) return;
+            switch (sidx) {
+                case 0: write_u(nbuf); break;                                  // loaded during the previous group
+                case 1: if (next2) gload_u(cb + 2); break;
+                case 2: write_patch_slot(0); break;
+                case 3: write_patch_slot(1); break;
+                case 4: write_patch_slot(2); break;
+                case 5: write_patch_slot(3); break;
+                case 6: wave_sync(); if (next2) gload_patch(cb + 2); break;
+                case 8: read_row(0); break;
+                case 9: read_row(1); break;
+                case 10: read_row(2); break;
+                case 11: read_row(3); break;
+                case 13: col_transform(0); break;
+                case 14: col_transform(1); break;
+                case 15: col_transform(2); break;
+                case 16: col_transform(3); break;
+                case 18: row_transform(0); break;
+                case 19: row_transform(1); break;
+                case 20: row_transform(2); break;
+                case 21: row_transform(3); break;
+                default: break;
             }
-        }
-        write_u();                                   // filters of this group (loaded one MFMA phase ago)
-        __syncthreads();
-        if (cb + 1 < CBn) gload(cb + 1);
-        // ---- M_xi += U_xi V_xi for the wave's 16 tiles, all 16 xi, both 16-row halves of the 32 output channels
-        {
-            const float* up = sm.u + (g * 16 + i16) * 4;
-            const float* vp = sm.v + g * VROW + (16 * w + i16) * 2;
-            // fragments of position xi+1 are requested before the 4 MFMAs of xi are issued (two register sets)
-            float4 a = *reinterpret_cast<const float4*>(up);                                // {k lo,c0},{k lo,c1},{k hi,c0},{k hi,c1}
-            float2 b = *reinterpret_cast<const float2*>(vp);                                // {c0},{c1}
+        };
+        // fragments of the next PAIR of positions are requested before the 8 MFMAs of this pair are issued
+        float4 a0 = *reinterpret_cast<const float4*>(up);                       // {k lo,c0},{k lo,c1},{k hi,c0},{k hi,c1}
+        float4 a1 = *reinterpret_cast<const float4*>(up + 256);
+        float2 b0 = *reinterpret_cast<const float2*>(vfrag);                    // {c0},{c1}
+        float2 b1 = *reinterpret_cast<const float2*>(vfrag + 128);
 #pragma unroll
-            for (int xi = 0; xi < 16; ++xi) {
-                float4 an = a; float2 bn = b;
-                if (xi + 1 < 16) {
-                    an = *reinterpret_cast<const float4*>(up + (xi + 1) * 256);
-                    bn = *reinterpret_cast<const float2*>(vp + (xi + 1) * 4 * VROW);
-                }
-                acc[xi][0] = mfma16(a.x, b.x, acc[xi][0]);
-                acc[xi][1] = mfma16(a.z, b.x, acc[xi][1]);
-                acc[xi][0] = mfma16(a.y, b.y, acc[xi][0]);
-                acc[xi][1] = mfma16(a.w, b.y, acc[xi][1]);
-                a = an; b = bn;
+        for (int j = 0; j < 8; ++j) {
+            const int xi = 2 * j;
+            float4 a0n = a0, a1n = a1; float2 b0n = b0, b1n = b1;
+            if (j + 1 < 8) {
+                a0n = *reinterpret_cast<const float4*>(up + (xi + 2) * 256);
+                a1n = *reinterpret_cast<const float4*>(up + (xi + 3) * 256);
+                b0n = *reinterpret_cast<const float2*>(vfrag + (xi + 2) * 128);
+                b1n = *reinterpret_cast<const float2*>(vfrag + (xi + 3) * 128);
             }
+            if (j == 1 || j == 5) { if (j == pbar) __syncthreads(); }
+            __builtin_amdgcn_sched_barrier(0);
+            acc[xi][0] = mfma16(a0.x, b0.x, acc[xi][0]);
+            acc[xi][1] = mfma16(a0.z, b0.x, acc[xi][1]);
+            __builtin_amdgcn_sched_barrier(0);
+            slot(4 * j + 0);
+            __builtin_amdgcn_sched_barrier(0);
+            acc[xi + 1][0] = mfma16(a1.x, b1.x, acc[xi + 1][0]);
+            acc[xi + 1][1] = mfma16(a1.z, b1.x, acc[xi + 1][1]);
+            __builtin_amdgcn_sched_barrier(0);
+            slot(4 * j + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            acc[xi][0] = mfma16(a0.y, b0.y, acc[xi][0]);
+            acc[xi][1] = mfma16(a0.w, b0.y, acc[xi][1]);
+            __builtin_amdgcn_sched_barrier(0);
+            slot(4 * j + 2);
+            __builtin_amdgcn_sched_barrier(0);
+            acc[xi + 1][0] = mfma16(a1.y, b1.y, acc[xi + 1][0]);
+            acc[xi + 1][1] = mfma16(a1.w, b1.y, acc[xi + 1][1]);
+            __builtin_amdgcn_sched_barrier(0);
+            slot(4 * j + 3);
+            __builtin_amdgcn_sched_barrier(0);
+            a0 = a0n; a1 = a1n; b0 = b0n; b1 = b1n;
         }
-        if (cb + 1 < CBn) write_patch();
-        __syncthreads();
+        wave_sync();                                     // every MFMA of this group has read V
+        if (next) write_v();
+        wave_sync();
     }
 
-    // ---- epilogue: Y = A^T M A (lane-local), + bias, ReLU; stage [32 k][16 x 16 px] in LDS; coalesced stores
-    float* ys = sm.v;                                   // [k 32][py 16][px 16] stride YS
+    // ---- epilogue, wave-local: Y = A^T M A (lane-local), + bias, ReLU -> staging [32 k][4 x 16 px] over the wave's own
+    //      V/patch region; then 32-byte-group stores, 512 contiguous bytes per (channel group, row)
+    float* ys = vw;
     {
-        const int tile = 16 * w + i16, ty = tile >> 3, tx = tile & 7;
+        const int ty = i16 >> 3, tx = i16 & 7;
 #pragma unroll
         for (int tr = 0; tr < 2; ++tr)
 #pragma unroll
@@ -215,17 +290,17 @@ __global__ __launch_bounds__(256, 2) void winograd_conv3x3_kernel(const float* _
                 *reinterpret_cast<float2*>(o + 16) = make_float2(y10, y11);
             }
     }
-    __syncthreads();
-    {
-        // output group kg (4 per workgroup) : y[b][kb*4 + kg][oy][ox][8]; one float4 = half a pixel group
+    wave_sync();
+    if (live) {
         const int KG = K / 8;
-        for (int e = t; e < 4 * 256 * 2; e += 256) {
-            const int half = e & 1, p = (e >> 1) & 255, kg = e >> 9;
-            const int py = p >> 4, px = p & 15;
-            const float* s0 = ys + (kg * 8 + half * 4) * YS + p;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int e = lane + 64 * i;
+            const int hf = e & 1, px = (e >> 1) & 15, py = (e >> 5) & 3, kg = e >> 7;
+            const float* s0 = ys + (kg * 8 + hf * 4) * YS + py * 16 + px;
             const float4 v4 = make_float4(s0[0], s0[YS], s0[2 * YS], s0[3 * YS]);
-            *reinterpret_cast<float4*>(y + (((size_t)bimg * KG + kb * 4 + kg) * H + oy0 + py) * W * 8 +
-                                       (size_t)(ox0 + px) * 8 + half * 4) = v4;
+            *reinterpret_cast<float4*>(y + (((size_t)bimg * KG + kb * 4 + kg) * H + wy0 + py) * W * 8 +
+                                       (size_t)(ox0 + px) * 8 + hf * 4) = v4;
         }
     }
 }
@@ -298,15 +373,16 @@ extern "C" int dhz_winograd_conv3x3(const float* x, const float* act_mask, const
     DHZ_REQUIRE(x && upack && y, "dhz_winograd_conv3x3: null pointer");
     DHZ_REQUIRE(B > 0 && H % 16 == 0 && W % 16 == 0 && C % CC == 0 && K % KB == 0,
                 "dhz_winograd_conv3x3: unsupported shape B=%d H=%d W=%d C=%d K=%d", B, H, W, C, K);
-    const int grid = B * (H / 16) * (W / 16) * (K / KB);
-    const size_t smem = sizeof(WinoSmem);
+    const int nblk = B * (H / 16) * (W / 16);                     // 16x16-pixel output blocks, two per workgroup
+    const int grid = ((nblk + 1) / 2) * (K / KB);
+    const size_t smem = WINO_SMEM;
     hipStream_t s = (hipStream_t)stream;
 #define GO(R, M)                                                                                                   \
     do {                                                                                                           \
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&winograd_conv3x3_kernel<R, M>),                   \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);                          \
-        hipLaunchKernelGGL((winograd_conv3x3_kernel<R, M>), dim3(grid), dim3(256), smem, s, x, act_mask, upack, bias, \
-                           y, H, W, C, K);                                                                         \
+        hipLaunchKernelGGL((winograd_conv3x3_kernel<R, M>), dim3(grid), dim3(512), smem, s, x, act_mask, upack, bias, \
+                           y, H, W, C, K, nblk);                                                                         \
     } while (0)
     if (relu) { if (act_mask) GO(true, true); else GO(true, false); }
     else { if (act_mask) GO(false, true); else GO(false, false); }
