@@ -121,12 +121,20 @@ int dhz_linear_wgrad(const float* dy, int ldy, const float* x, int ldx, int T, i
  *      dhz_winograd_prepack: weight [Kout,Cin,3,3] -> transform-domain filters upack (16*Kout*Cin floats);
  *        transposed_rot != 0 builds the backward-data filters from the forward weight [Cin,Kout,3,3] (the roles of
  *        the two channel counts swap, taps rotate by 180 degrees).  The VGG weights are frozen: prepack once.
- *      dhz_winograd_conv3x3: y = conv(x (* [act_mask > 0]), W) + bias, optional ReLU.  act_mask (same shape as x) is the
- *        saved post-ReLU activation of the layer whose gradient is being propagated (backward-data pass) or NULL.
- *        H % 16 == 0, W % 16 == 0, C % 8 == 0, K % 32 == 0. */
+ *      dhz_winograd_conv3x3: forward  y = conv(x, W) [+ bias] [ReLU]                (out_mask = out_addend = NULL)
+ *                            backward y = out_mask > 0 ? conv(x, W') + out_addend : 0   (bias = NULL, relu = 0)
+ *        where W' are the backward-data filters, out_mask (shape of y, may be NULL) is the saved post-ReLU activation
+ *        at the OUTPUT positions - the ReLU of the layer below, fused into the store - and out_addend (shape of y, may
+ *        be NULL) the gradient reaching that activation from a loss tap.
+ *        H % 16 == 0, W % 16 == 0, C % 8 == 0, K % 32 == 0.
+ *      dhz_maxpool2x2_blocked_fwd / _bwd: the 2x2/stride-2 max pooling between VGG stages in the same layout
+ *        (N = B*C/8 planes of [H][W][8]); the backward routes gy to the first maximum of each window of the saved
+ *        post-ReLU map `act` and applies that map's ReLU (act > 0) in the same pass. */
 int dhz_winograd_prepack(const float* weight, float* upack, int Kout, int Cin, int transposed_rot, void* stream);
-int dhz_winograd_conv3x3(const float* x, const float* act_mask, const float* upack, const float* bias, float* y,
-                         int B, int H, int W, int C, int K, int relu, void* stream);
+int dhz_winograd_conv3x3(const float* x, const float* upack, const float* bias, int relu, const float* out_mask,
+                         const float* out_addend, float* y, int B, int H, int W, int C, int K, void* stream);
+int dhz_maxpool2x2_blocked_fwd(const float* x, float* y, int N, int H, int W, void* stream);
+int dhz_maxpool2x2_blocked_bwd(const float* gy, const float* act, float* gx, int N, int H, int W, void* stream);
 int dhz_layout_blocked8(const float* src, float* dst, int B, int C, int HW, int to_blocked, void* stream);
 
 /* K6  shift mask builder: mask[nW,64,64] in {0,-100}  (M1:803-836), Hres x Wres map, win 8. */

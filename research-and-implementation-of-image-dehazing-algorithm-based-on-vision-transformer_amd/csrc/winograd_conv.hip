@@ -45,7 +45,7 @@ constexpr int WAVE_LDS = VW + 4 * PPL;    // V + patch, contiguous per wave (332
 constexpr int YS = 68;             // output staging stride per output channel (4 x 16 px + pad); 32 * YS <= WAVE_LDS
 constexpr int NP4 = 4;             // float4 patch slots per lane: 6 x 18 px x 2 halves = 216 of 256
 constexpr int NUBUF = 3;           // filter ring
-constexpr size_t WINO_SMEM = (size_t)(NUBUF * UF + 8 * WAVE_LDS) * sizeof(float);   // 152 KB: one workgroup per CU
+constexpr size_t WINO_SMEM = (size_t)(NUBUF * UF + 8 * WAVE_LDS + KB) * sizeof(float);   // 152 KB: one workgroup per CU
 
 __device__ __forceinline__ void wave_sync() {
     // LDS operations of one wave execute in order; only the compiler must not move accesses across phase boundaries
@@ -54,12 +54,16 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-template <bool RELU, bool MASKED>
+// Epilogue: y = conv(x) [+ bias] [ReLU]  (forward)   or   y = mask > 0 ? conv(x) + addend : 0  (backward data: `mask` is
+// the saved post-ReLU activation at the OUTPUT positions, i.e. the ReLU of the layer below, `addend` the gradient that
+// reaches that activation from a loss tap) - so the hot loop is the same for both passes.
+template <bool FWD>
 __global__ __launch_bounds__(512) void winograd_conv3x3_kernel(const float* __restrict__ x,
-                                                           const float* __restrict__ act_mask,
                                                            const float* __restrict__ upack,
-                                                           const float* __restrict__ bias, float* __restrict__ y,
-                                                           int H, int W, int C, int K, int nblk) {
+                                                           const float* __restrict__ bias, int relu,
+                                                           const float* __restrict__ out_mask,
+                                                           const float* __restrict__ out_addend,
+                                                           float* __restrict__ y, int H, int W, int C, int K, int nblk) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int t = threadIdx.x, lane = t & 63, w = t >> 6, half = w >> 2, wl = w & 3;
     const int i16 = lane & 15, g = lane >> 4;
@@ -102,19 +106,14 @@ __global__ __launch_bounds__(512) void winograd_conv3x3_kernel(const float* __re
 #pragma unroll
         for (int i = 0; i < 4 * PPL / 4 / 64; ++i) z[lane + 64 * i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    float4 rp[NP4], rm[NP4];
+    float4 rp[NP4];
     float4 ru0, ru1;                                     // UF / 4 / 512 = 2 filter float4 per thread
     const float* xbase = x + (size_t)bimg * CBn * plane;
-    const float* mbase = MASKED ? act_mask + (size_t)bimg * CBn * plane : nullptr;
     const float4* ubase = reinterpret_cast<const float4*>(upack + (size_t)kb * CBn * UF) + t;
     auto gload_patch = [&](int cb) {
         const float* xp = xbase + (size_t)cb * plane;
-        const float* mp = MASKED ? mbase + (size_t)cb * plane : nullptr;
 #pragma unroll
-        for (int i = 0; i < NP4; ++i) {
-            rp[i] = *reinterpret_cast<const float4*>(xp + poff[i]);
-            if (MASKED) rm[i] = *reinterpret_cast<const float4*>(mp + poff[i]);
-        }
+        for (int i = 0; i < NP4; ++i) rp[i] = *reinterpret_cast<const float4*>(xp + poff[i]);
     };
     auto gload_u = [&](int cb) {
         const float4* up = ubase + (size_t)cb * (UF / 4);
@@ -122,11 +121,7 @@ __global__ __launch_bounds__(512) void winograd_conv3x3_kernel(const float* __re
     };
     auto write_patch_slot = [&](int i) {
         if (pdst[i] < 0) return;
-        float4 val = rp[i];
-        if (MASKED) {
-            val.x = rm[i].x > 0.f ? val.x : 0.f; val.y = rm[i].y > 0.f ? val.y : 0.f;
-            val.z = rm[i].z > 0.f ? val.z : 0.f; val.w = rm[i].w > 0.f ? val.w : 0.f;
-        }
+        const float4 val = rp[i];
         float* dst = pw + pdst[i];
         *reinterpret_cast<float2*>(dst) = make_float2(val.x, val.y);
         *reinterpret_cast<float2*>(dst + PPL) = make_float2(val.z, val.w);
@@ -162,11 +157,8 @@ __global__ __launch_bounds__(512) void winograd_conv3x3_kernel(const float* __re
                 *reinterpret_cast<float2*>(vdst + (4 * a + b) * 128) = make_float2(d[a][b].x, d[a][b].y);
     };
 
-    float bk[2][4];                                      // bias of this lane's 8 output channels (16 tr + 4 g + r)
-#pragma unroll
-    for (int tr = 0; tr < 2; ++tr)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) bk[tr][r] = bias ? bias[kb * KB + 16 * tr + 4 * g + r] : 0.f;
+    float* bias_s = smem + NUBUF * UF + 8 * WAVE_LDS;    // the 32 biases of this output-channel block
+    if (FWD && t < KB) bias_s[t] = bias ? bias[kb * KB + t] : 0.f;
 
     // ---- prologue: group 0 transformed and in V, filters 0 in ring slot 0, loads of group 1 in flight
     gload_patch(0);
@@ -281,10 +273,10 @@ __global__ __launch_bounds__(512) void winograd_conv3x3_kernel(const float* __re
                     t0[b] = m[b] + m[4 + b] + m[8 + b];
                     t1[b] = m[4 + b] - m[8 + b] - m[12 + b];
                 }
-                const float bv = bk[tr][r];
+                const float bv = FWD ? bias_s[k] : 0.f;
                 float y00 = t0[0] + t0[1] + t0[2] + bv, y01 = t0[1] - t0[2] - t0[3] + bv;
                 float y10 = t1[0] + t1[1] + t1[2] + bv, y11 = t1[1] - t1[2] - t1[3] + bv;
-                if (RELU) { y00 = fmaxf(y00, 0.f); y01 = fmaxf(y01, 0.f); y10 = fmaxf(y10, 0.f); y11 = fmaxf(y11, 0.f); }
+                if (FWD && relu) { y00 = fmaxf(y00, 0.f); y01 = fmaxf(y01, 0.f); y10 = fmaxf(y10, 0.f); y11 = fmaxf(y11, 0.f); }
                 float* o = ys + k * YS + (2 * ty) * 16 + 2 * tx;
                 *reinterpret_cast<float2*>(o) = make_float2(y00, y01);
                 *reinterpret_cast<float2*>(o + 16) = make_float2(y10, y11);
@@ -298,9 +290,20 @@ __global__ __launch_bounds__(512) void winograd_conv3x3_kernel(const float* __re
             const int e = lane + 64 * i;
             const int hf = e & 1, px = (e >> 1) & 15, py = (e >> 5) & 3, kg = e >> 7;
             const float* s0 = ys + (kg * 8 + hf * 4) * YS + py * 16 + px;
-            const float4 v4 = make_float4(s0[0], s0[YS], s0[2 * YS], s0[3 * YS]);
-            *reinterpret_cast<float4*>(y + (((size_t)bimg * KG + kb * 4 + kg) * H + wy0 + py) * W * 8 +
-                                       (size_t)(ox0 + px) * 8 + hf * 4) = v4;
+            float4 v4 = make_float4(s0[0], s0[YS], s0[2 * YS], s0[3 * YS]);
+            const size_t o = (((size_t)bimg * KG + kb * 4 + kg) * H + wy0 + py) * W * 8 + (size_t)(ox0 + px) * 8 + hf * 4;
+            if (!FWD) {
+                if (out_addend) {
+                    const float4 ad = *reinterpret_cast<const float4*>(out_addend + o);
+                    v4.x += ad.x; v4.y += ad.y; v4.z += ad.z; v4.w += ad.w;
+                }
+                if (out_mask) {
+                    const float4 m = *reinterpret_cast<const float4*>(out_mask + o);
+                    v4.x = m.x > 0.f ? v4.x : 0.f; v4.y = m.y > 0.f ? v4.y : 0.f;
+                    v4.z = m.z > 0.f ? v4.z : 0.f; v4.w = m.w > 0.f ? v4.w : 0.f;
+                }
+            }
+            *reinterpret_cast<float4*>(y + o) = v4;
         }
     }
 }
@@ -356,6 +359,56 @@ __global__ void nchw_to_blocked_kernel(const float* __restrict__ src, float* __r
     if (to_blocked) dst[e] = src[plain]; else dst[plain] = src[e];
 }
 
+// 2x2 / stride 2 max pooling in the blocked layout ([n = b * C/8][h][w][8]); one thread = 4 channels of one pooled pixel.
+__global__ void maxpool2x2_blocked_fwd_kernel(const float4* __restrict__ x, float4* __restrict__ y, size_t total, int Ho,
+                                              int Wo) {
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;     // over [n][ho][wo][2 halves]
+    if (e >= total) return;
+    const int hf = e & 1;
+    const size_t p = e >> 1;
+    const int wo = p % Wo;
+    const size_t r = p / Wo;
+    const int ho = r % Ho;
+    const size_t n = r / Ho;
+    const int W = 2 * Wo;
+    const float4* src = x + ((n * (2 * Ho) + 2 * ho) * W + 2 * wo) * 2 + hf;
+    const float4 a = src[0], b = src[2], c = src[2 * W], d = src[2 * W + 2];
+    float4 m;
+    m.x = fmaxf(fmaxf(a.x, b.x), fmaxf(c.x, d.x)); m.y = fmaxf(fmaxf(a.y, b.y), fmaxf(c.y, d.y));
+    m.z = fmaxf(fmaxf(a.z, b.z), fmaxf(c.z, d.z)); m.w = fmaxf(fmaxf(a.w, b.w), fmaxf(c.w, d.w));
+    y[e] = m;
+}
+
+// Backward of the pooling of a post-ReLU map `act`: the gradient goes to the first maximum of each window (the
+// library's tie rule) and, fused, through the ReLU below it (act > 0) - a window of zeros passes nothing.
+__global__ void maxpool2x2_blocked_bwd_kernel(const float4* __restrict__ gy, const float4* __restrict__ act,
+                                              float4* __restrict__ gx, size_t total, int Ho, int Wo) {
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    const int hf = e & 1;
+    const size_t p = e >> 1;
+    const int wo = p % Wo;
+    const size_t r = p / Wo;
+    const int ho = r % Ho;
+    const size_t n = r / Ho;
+    const int W = 2 * Wo;
+    const size_t o = ((n * (2 * Ho) + 2 * ho) * W + 2 * wo) * 2 + hf;
+    const float4 a = act[o], b = act[o + 2], c = act[o + 2 * W], d = act[o + 2 * W + 2];
+    const float4 g = gy[e];
+    float4 ra, rb, rc, rd;
+#define ROUTE(f)                                                                              \
+    {                                                                                         \
+        const float m = fmaxf(fmaxf(a.f, b.f), fmaxf(c.f, d.f));                              \
+        const float gv = m > 0.f ? g.f : 0.f;                                                 \
+        const bool ia = a.f == m, ib = !ia && b.f == m, ic = !ia && !ib && c.f == m;          \
+        ra.f = ia ? gv : 0.f; rb.f = ib ? gv : 0.f; rc.f = ic ? gv : 0.f;                     \
+        rd.f = (!ia && !ib && !ic) ? gv : 0.f;                                                \
+    }
+    ROUTE(x) ROUTE(y) ROUTE(z) ROUTE(w)
+#undef ROUTE
+    gx[o] = ra; gx[o + 2] = rb; gx[o + 2 * W] = rc; gx[o + 2 * W + 2] = rd;
+}
+
 }  // namespace
 
 extern "C" int dhz_winograd_prepack(const float* weight, float* upack, int Kout, int Cin, int transposed_rot,
@@ -368,24 +421,24 @@ extern "C" int dhz_winograd_prepack(const float* weight, float* upack, int Kout,
     return DHZ_OK;
 }
 
-extern "C" int dhz_winograd_conv3x3(const float* x, const float* act_mask, const float* upack, const float* bias,
-                                    float* y, int B, int H, int W, int C, int K, int relu, void* stream) {
+extern "C" int dhz_winograd_conv3x3(const float* x, const float* upack, const float* bias, int relu, const float* out_mask,
+                                    const float* out_addend, float* y, int B, int H, int W, int C, int K, void* stream) {
     DHZ_REQUIRE(x && upack && y, "dhz_winograd_conv3x3: null pointer");
     DHZ_REQUIRE(B > 0 && H % 16 == 0 && W % 16 == 0 && C % CC == 0 && K % KB == 0,
                 "dhz_winograd_conv3x3: unsupported shape B=%d H=%d W=%d C=%d K=%d", B, H, W, C, K);
+    const bool fwd = !(out_mask || out_addend);
+    DHZ_REQUIRE(fwd || !(bias || relu), "dhz_winograd_conv3x3: bias/relu and out_mask/out_addend are exclusive");
     const int nblk = B * (H / 16) * (W / 16);                     // 16x16-pixel output blocks, two per workgroup
     const int grid = ((nblk + 1) / 2) * (K / KB);
-    const size_t smem = WINO_SMEM;
     hipStream_t s = (hipStream_t)stream;
-#define GO(R, M)                                                                                                   \
+#define GO(F)                                                                                                      \
     do {                                                                                                           \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&winograd_conv3x3_kernel<R, M>),                   \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);                          \
-        hipLaunchKernelGGL((winograd_conv3x3_kernel<R, M>), dim3(grid), dim3(512), smem, s, x, act_mask, upack, bias, \
-                           y, H, W, C, K, nblk);                                                                         \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&winograd_conv3x3_kernel<F>),                      \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)WINO_SMEM);                     \
+        hipLaunchKernelGGL((winograd_conv3x3_kernel<F>), dim3(grid), dim3(512), WINO_SMEM, s, x, upack, bias, relu,  \
+                           out_mask, out_addend, y, H, W, C, K, nblk);                                             \
     } while (0)
-    if (relu) { if (act_mask) GO(true, true); else GO(true, false); }
-    else { if (act_mask) GO(false, true); else GO(false, false); }
+    if (fwd) GO(true); else GO(false);
 #undef GO
     DHZ_CHECK_LAUNCH("dhz_winograd_conv3x3");
     return DHZ_OK;
@@ -397,5 +450,24 @@ extern "C" int dhz_layout_blocked8(const float* src, float* dst, int B, int C, i
     hipLaunchKernelGGL(nchw_to_blocked_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src,
                        dst, B, C, HW, to_blocked);
     DHZ_CHECK_LAUNCH("dhz_layout_blocked8");
+    return DHZ_OK;
+}
+
+extern "C" int dhz_maxpool2x2_blocked_fwd(const float* x, float* y, int N, int H, int W, void* stream) {
+    DHZ_REQUIRE(x && y && N > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0, "dhz_maxpool2x2_blocked_fwd: bad arguments");
+    const size_t total = (size_t)N * (H / 2) * (W / 2) * 2;
+    hipLaunchKernelGGL(maxpool2x2_blocked_fwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const float4*>(x), reinterpret_cast<float4*>(y), total, H / 2, W / 2);
+    DHZ_CHECK_LAUNCH("dhz_maxpool2x2_blocked_fwd");
+    return DHZ_OK;
+}
+
+extern "C" int dhz_maxpool2x2_blocked_bwd(const float* gy, const float* act, float* gx, int N, int H, int W, void* stream) {
+    DHZ_REQUIRE(gy && act && gx && N > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0, "dhz_maxpool2x2_blocked_bwd: bad arguments");
+    const size_t total = (size_t)N * (H / 2) * (W / 2) * 2;
+    hipLaunchKernelGGL(maxpool2x2_blocked_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const float4*>(gy), reinterpret_cast<const float4*>(act), reinterpret_cast<float4*>(gx),
+                       total, H / 2, W / 2);
+    DHZ_CHECK_LAUNCH("dhz_maxpool2x2_blocked_bwd");
     return DHZ_OK;
 }

@@ -36,28 +36,19 @@ def to_plain(xb):
     return out
 
 
-def _pool_view(xb):
-    """blocked [B,CG,H,W,8] viewed as an [N = B*CG, 8, H, W] channels_last tensor (no copy)."""
+def pool_fwd(xb):
     B, CG, H, W, _ = xb.shape
-    return xb.view(B * CG, H, W, 8).permute(0, 3, 1, 2)
+    yb = torch.empty((B, CG, H // 2, W // 2, 8), device=xb.device, dtype=torch.float32)
+    _lib.call("dhz_maxpool2x2_blocked_fwd", _p(xb), _p(yb), B * CG, H, W, _stream())
+    return yb
 
 
-def pool_fwd(xb, want_indices):
-    B, CG, H, W, _ = xb.shape
-    v = _pool_view(xb)
-    if want_indices:
-        y, ind = F.max_pool2d(v, 2, 2, return_indices=True)
-    else:
-        y, ind = F.max_pool2d(v, 2, 2), None
-    yb = y.permute(0, 2, 3, 1).contiguous().view(B, CG, H // 2, W // 2, 8)
-    return yb, ind
-
-
-def pool_bwd(gb, xb, ind):
-    B, CG, H, W, _ = xb.shape
-    g = gb.view(B * CG, H // 2, W // 2, 8).permute(0, 3, 1, 2)
-    gx = torch.ops.aten.max_pool2d_with_indices_backward(g, _pool_view(xb), [2, 2], [2, 2], [0, 0], [1, 1], False, ind)
-    return gx.permute(0, 2, 3, 1).contiguous().view(B, CG, H, W, 8)
+def pool_bwd_relu(gb, actb):
+    """gradient w.r.t. the pre-activation below the post-ReLU map `actb` whose 2x2 max pooling received gradient gb."""
+    B, CG, H, W, _ = actb.shape
+    gx = torch.empty_like(actb)
+    _lib.call("dhz_maxpool2x2_blocked_bwd", _p(gb.contiguous()), _p(actb), _p(gx), B * CG, H, W, _stream())
+    return gx
 
 
 class VggEngine:
@@ -86,16 +77,19 @@ class VggEngine:
         C, K = CONVS[i]
         uf, _ = self.packed(i, xb.device)
         yb = torch.empty((B, K // 8, H, W, 8), device=xb.device, dtype=torch.float32)
-        _lib.call("dhz_winograd_conv3x3", _p(xb), None, _p(uf), _p(self.convs[i].bias), _p(yb), B, H, W, C, K, 1, _stream())
+        _lib.call("dhz_winograd_conv3x3", _p(xb), _p(uf), _p(self.convs[i].bias), 1, None, None, _p(yb), B, H, W, C, K, _stream())
         return yb
 
-    def conv_dgrad(self, i, gb, actb):
-        """gradient w.r.t. the input of conv i from the gradient w.r.t. its post-ReLU output (ReLU mask fused)."""
+    def conv_dgrad(self, i, gb, below_act=None, addend=None):
+        """gb: gradient w.r.t. the pre-activation of conv i.  Returns the gradient w.r.t. conv i's input; with
+        `below_act` (the saved post-ReLU map that IS that input) the tap gradient `addend` is added and the ReLU below
+        applied in the kernel's store, i.e. the result is the gradient w.r.t. the pre-activation of conv i-1."""
         B, KG, H, W, _ = gb.shape
         C, K = CONVS[i]
         _, ub = self.packed(i, gb.device)
         dxb = torch.empty((B, C // 8, H, W, 8), device=gb.device, dtype=torch.float32)
-        _lib.call("dhz_winograd_conv3x3", _p(gb), _p(actb), _p(ub), None, _p(dxb), B, H, W, K, C, 0, _stream())
+        _lib.call("dhz_winograd_conv3x3", _p(gb), _p(ub), None, 0, _p(below_act) if below_act is not None else None,
+                  _p(addend.contiguous()) if addend is not None else None, _p(dxb), B, H, W, K, C, _stream())
         return dxb
 
     # ---- full stack, forward only
@@ -107,21 +101,18 @@ class VggEngine:
         cur = to_blocked(a0)
         acts = {0: cur}
         taps = [cur]
-        pools = {}
         for i in range(1, 12):
             cur = self.conv(i, cur)
             acts[i] = cur
             if i in TAPS:
                 taps.append(cur)
             if i in POOL_AFTER:
-                pooled, ind = pool_fwd(cur, save is not None)
-                pools[i] = (pooled, ind)
-                cur = pooled
+                cur = pool_fwd(cur)
         x12 = to_plain(cur)
         a12 = F.relu(F.conv2d(x12, c12.weight, c12.bias, padding=1))
         taps.append(a12)
         if save is not None:
-            save.update(x=x, a0=a0, acts=acts, pools=pools, x12=x12, a12=a12)
+            save.update(x=x, a0=a0, acts=acts, x12=x12, a12=a12)
         return taps
 
 
@@ -139,29 +130,31 @@ class _VggTaps(Function):
     @staticmethod
     def backward(ctx, g1, g2, g3, g4, g5):
         eng, sv = ctx.engine, ctx.saved
-        acts, pools = sv["acts"], sv["pools"]
+        acts = sv["acts"]
         tap_grad = {0: g1, 2: g2, 4: g3, 8: g4}
         c0, c12 = eng.convs[0], eng.convs[12]
         with torch.no_grad():
-            # conv 12 (library) : gradient to its (pooled) input
+            # G = gradient w.r.t. the PRE-activation of conv i (None while nothing has arrived from above)
             G = None
-            if g5 is not None:
+            if g5 is not None:                                               # conv 12 (library) -> pooled a11 -> a11, ReLU 11
                 g12 = g5 * (sv["a12"] > 0)
                 gx12 = torch.ops.aten.convolution_backward(g12, sv["x12"], c12.weight, None, [1, 1], [1, 1], [1, 1], False,
                                                            [0, 0], 1, [True, False, False])[0]
-                G = pool_bwd(to_blocked(gx12), acts[11], pools[11][1])       # gradient at a11 (post-ReLU)
+                G = pool_bwd_relu(to_blocked(gx12), acts[11])
             for i in range(11, 0, -1):
-                if i in tap_grad and tap_grad[i] is not None:
-                    G = tap_grad[i].contiguous() if G is None else G + tap_grad[i]
+                below = i - 1                                                # conv i's input is a_{i-1} (pooled if i-1 in POOL_AFTER)
+                tg = tap_grad.get(below)
                 if G is None:
+                    if tg is not None:                                       # the first gradient enters at this tap
+                        G = tg * (acts[below] > 0)
                     continue
-                G = eng.conv_dgrad(i, G.contiguous(), acts[i])               # -> gradient at conv i's input
-                if (i - 1) in POOL_AFTER:                                    # that input was a pooled map
-                    G = pool_bwd(G, acts[i - 1], pools[i - 1][1])
-            if g1 is not None:
-                G = g1.contiguous() if G is None else G + g1
-            g0 = to_plain(G) * (sv["a0"] > 0)
-            gx = torch.ops.aten.convolution_backward(g0, sv["x"], c0.weight, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
+                if below in POOL_AFTER:
+                    G = pool_bwd_relu(eng.conv_dgrad(i, G), acts[below])
+                else:
+                    G = eng.conv_dgrad(i, G, below_act=acts[below], addend=tg)
+            if G is None:
+                return None, None
+            gx = torch.ops.aten.convolution_backward(to_plain(G), sv["x"], c0.weight, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
                                                      [True, False, False])[0]
         ctx.saved = None
         return None, gx

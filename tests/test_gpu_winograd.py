@@ -36,21 +36,43 @@ def test_winograd_forward_and_dgrad(B, C, K, H):
     _lib.call("dhz_winograd_prepack", w.data_ptr(), up.data_ptr(), K, C, 0, s)
     xb = _blocked(x)
     yb = torch.empty(B, K // 8, H, H, 8, device=dev)
-    _lib.call("dhz_winograd_conv3x3", xb.data_ptr(), None, up.data_ptr(), b.data_ptr(), yb.data_ptr(), B, H, H, C, K, 1, s)
+    _lib.call("dhz_winograd_conv3x3", xb.data_ptr(), up.data_ptr(), b.data_ptr(), 1, None, None, yb.data_ptr(), B, H, H, C, K, s)
     y = _plain(yb, K)
     ref = F.relu(F.conv2d(x.double(), w.double(), b.double(), padding=1)).float()
     assert torch.allclose(y, ref, atol=2e-5, rtol=1e-4), (y - ref).abs().max()
     assert torch.equal(_plain(xb, C), x)
-    # backward-data: dx = conv_transpose(dy * (y > 0), w) == winograd with transposed_rot filters and the ReLU mask
+    # backward-data with the fused store: dx = (x > 0) ? conv_transpose(dy, w) + addend : 0  (x plays the saved post-ReLU
+    # map below the layer, addend a tap gradient) == winograd with the transposed_rot filters
     dy = torch.randn(B, K, H, H, generator=g).to(dev)
+    add = torch.randn(B, C, H, H, generator=g).to(dev)
     if C % 32 == 0:
         upt = torch.empty(16 * K * C, device=dev)
         _lib.call("dhz_winograd_prepack", w.data_ptr(), upt.data_ptr(), C, K, 1, s)      # Kout = C (of fwd), Cin = K
         dxb = torch.empty(B, C // 8, H, H, 8, device=dev)
-        _lib.call("dhz_winograd_conv3x3", _blocked(dy).data_ptr(), yb.data_ptr(), upt.data_ptr(), None, dxb.data_ptr(), B, H, H, K, C, 0, s)
-        dx = _plain(dxb, C)
-        refdx = F.conv_transpose2d((dy * (ref > 0)).double(), w.double(), padding=1).float()
-        assert torch.allclose(dx, refdx, atol=5e-5, rtol=1e-4), (dx - refdx).abs().max()
+        refdx = F.conv_transpose2d(dy.double(), w.double(), padding=1).float()
+        dyb, addb = _blocked(dy), _blocked(add)
+        _lib.call("dhz_winograd_conv3x3", dyb.data_ptr(), upt.data_ptr(), None, 0, xb.data_ptr(), addb.data_ptr(),
+                  dxb.data_ptr(), B, H, H, K, C, s)
+        want = (refdx + add) * (x > 0)
+        assert torch.allclose(_plain(dxb, C), want, atol=5e-5, rtol=1e-4), (_plain(dxb, C) - want).abs().max()
+        _lib.call("dhz_winograd_conv3x3", dyb.data_ptr(), upt.data_ptr(), None, 0, None, addb.data_ptr(),
+                  dxb.data_ptr(), B, H, H, K, C, s)
+        assert torch.allclose(_plain(dxb, C), refdx + add, atol=5e-5, rtol=1e-4)
+
+
+@pytest.mark.parametrize("B,C,H", [(2, 64, 32), (1, 16, 8)])
+def test_maxpool_blocked(B, C, H):
+    from dehaze_hip import vgg as V
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(H)
+    a = torch.relu(torch.randn(B, C, H, H, generator=g)).to(dev).requires_grad_()     # post-ReLU map: many exact-zero windows
+    yb = V.pool_fwd(_blocked(a.detach()))
+    ref = F.max_pool2d(a, 2, 2)
+    assert torch.equal(_plain(yb, C), ref.detach())
+    gy = torch.randn(B, C, H // 2, H // 2, generator=g).to(dev)
+    ref.backward(gy)
+    gx = _plain(V.pool_bwd_relu(_blocked(gy), _blocked(a.detach())), C)
+    assert torch.equal(gx, a.grad * (a.detach() > 0))
 
 
 @pytest.mark.parametrize("ablation", [False, True])

@@ -19,7 +19,7 @@ for C, K, H in [(64, 64, 128), (64, 128, 64), (128, 128, 64), (128, 256, 32), (2
     xb = torch.empty(B, C // 8, H, H, 8, device=dev); yb = torch.empty(B, K // 8, H, H, 8, device=dev)
     up = torch.empty(16 * K * C, device=dev)
     _lib.call("dhz_winograd_prepack", w.data_ptr(), up.data_ptr(), K, C, 0, s)
-    t_m = timeit(lambda: _lib.call("dhz_winograd_conv3x3", xb.data_ptr(), None, up.data_ptr(), b.data_ptr(), yb.data_ptr(), B, H, H, C, K, 1, s))
+    t_m = timeit(lambda: _lib.call("dhz_winograd_conv3x3", xb.data_ptr(), up.data_ptr(), b.data_ptr(), 1, None, None, yb.data_ptr(), B, H, H, C, K, s))
     t_l = timeit(lambda: F.relu(F.conv2d(x, w, b, padding=1))) if not os.environ.get("NO_LIB") else float("nan")
     fl = 2.0 * B * H * H * C * K * 9
     print(f"C {C:4d} K {K:4d} H {H:4d}: wino-mfma {t_m:8.1f} us ({fl/t_m/1e6:6.1f} TF-equiv)   miopen+relu {t_l:8.1f} us ({fl/t_l/1e6:6.1f} TF-equiv)   x{t_l/t_m:.2f}")
