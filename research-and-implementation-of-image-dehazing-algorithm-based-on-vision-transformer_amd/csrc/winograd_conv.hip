@@ -29,6 +29,7 @@
 // The backward-data convolution is the same kernel with rotated / transposed filters (prepacked once: the VGG
 // weights are frozen, My_CR.py:75-77) and the ReLU mask of the saved activation applied to the patch.
 #include <stdlib.h>
+#include <type_traits>
 #include "common.h"
 
 namespace {
@@ -90,7 +91,8 @@ __global__ __launch_bounds__(512) void winograd_conv3x3_kernel(const float* __re
     // Out-of-image pixels are zero padding: their LDS slots are zeroed once below and never written again; the
     // global loads stay unconditional (such slots read offset 0) so that no load is waited for at its issue point.
     unsigned poff[NP4];       // offset inside a plane (floats)
-    int pdst[NP4];            // LDS destination, -1 = not written (unused slot or zero padding)
+    int pdst[NP4];            // LDS destination; unused slots and zero padding go to the pad words behind each plane
+    static_assert(PPL - 6 * RS >= 32, "dump words");
 #pragma unroll
     for (int i = 0; i < NP4; ++i) {
         const int e = lane + 64 * i;
@@ -99,7 +101,7 @@ __global__ __launch_bounds__(512) void winograd_conv3x3_kernel(const float* __re
         const int iy = wy0 - 1 + py, ix = ox0 - 1 + px;
         const bool in = e < 6 * 18 * 2 && iy >= 0 && iy < H && ix >= 0 && ix < W;
         poff[i] = in ? (unsigned)((iy * W + ix) * 8 + hf * 4) : 0u;
-        pdst[i] = in ? (2 * hf) * PPL + py * RS + px * 2 : -1;
+        pdst[i] = (2 * hf) * PPL + (in ? py * RS + px * 2 : 6 * RS + (lane & 15) * 2);
     }
     {
         float4* z = reinterpret_cast<float4*>(pw);
@@ -120,7 +122,6 @@ __global__ __launch_bounds__(512) void winograd_conv3x3_kernel(const float* __re
         ru0 = up[0]; ru1 = up[512];
     };
     auto write_patch_slot = [&](int i) {
-        if (pdst[i] < 0) return;
         const float4 val = rp[i];
         float* dst = pw + pdst[i];
         *reinterpret_cast<float2*>(dst) = make_float2(val.x, val.y);
@@ -167,7 +168,7 @@ __global__ __launch_bounds__(512) void winograd_conv3x3_kernel(const float* __re
 #pragma unroll
     for (int i = 0; i < NP4; ++i) write_patch_slot(i);
     write_u(0);
-    if (CBn > 1) { gload_patch(1); gload_u(1); }
+    { const int c1 = CBn > 1 ? 1 : 0; gload_patch(c1); gload_u(c1); }
     wave_sync();
 #pragma unroll
     for (int a = 0; a < 4; ++a) read_row(a);
@@ -180,21 +181,22 @@ __global__ __launch_bounds__(512) void winograd_conv3x3_kernel(const float* __re
 
     const float* ufrag = us + (g * 16 + i16) * 4;
     const float* vfrag = vw + g * 32 + i16 * 2;
-    for (int cb = 0; cb < CBn; ++cb) {
-        const bool next = cb + 1 < CBn, next2 = cb + 2 < CBn;
+    // one channel group: 64 MFMAs with (WITH_NEXT) the 32 work slots of group cb+1 in the gaps between MFMA pairs
+    auto group = [&](int cb, auto with_next) {
+        constexpr bool WITH_NEXT = decltype(with_next)::value;
         const float* up = ufrag + (cb % NUBUF) * UF;
         const int nbuf = (cb + 1) % NUBUF;
-        // the work of group cb+1, in 32 slots (4 per pair-step) that go between the MFMA pairs of group cb
+        const int cb2 = cb + 2 < CBn ? cb + 2 : CBn - 1;      // loads past the last group re-read it (never stored to LDS)
         auto slot = [&](int sidx) {
-            if (!next) return;
+            if (!WITH_NEXT) return;
             switch (sidx) {
                 case 0: write_u(nbuf); break;                                  // loaded during the previous group
-                case 1: if (next2) gload_u(cb + 2); break;
+                case 1: gload_u(cb2); break;
                 case 2: write_patch_slot(0); break;
                 case 3: write_patch_slot(1); break;
                 case 4: write_patch_slot(2); break;
                 case 5: write_patch_slot(3); break;
-                case 6: wave_sync(); if (next2) gload_patch(cb + 2); break;
+                case 6: wave_sync(); gload_patch(cb2); break;
                 case 8: read_row(0); break;
                 case 9: read_row(1); break;
                 case 10: read_row(2); break;
@@ -250,15 +252,18 @@ __global__ __launch_bounds__(512) void winograd_conv3x3_kernel(const float* __re
             a0 = a0n; a1 = a1n; b0 = b0n; b1 = b1n;
         }
         wave_sync();                                     // every MFMA of this group has read V
-        if (next) write_v();
+        if (WITH_NEXT) write_v();
         wave_sync();
-    }
+    };
+    for (int cb = 0; cb + 1 < CBn; ++cb) group(cb, std::true_type{});
+    group(CBn - 1, std::false_type{});
 
     // ---- epilogue, wave-local: Y = A^T M A (lane-local), + bias, ReLU -> staging [32 k][4 x 16 px] over the wave's own
     //      V/patch region; then 32-byte-group stores, 512 contiguous bytes per (channel group, row)
     float* ys = vw;
     {
         const int ty = i16 >> 3, tx = i16 & 7;
+        const float lo = relu ? 0.f : -__builtin_inff();     // ReLU as a lower clamp: no branch per output
 #pragma unroll
         for (int tr = 0; tr < 2; ++tr)
 #pragma unroll
@@ -276,7 +281,7 @@ __global__ __launch_bounds__(512) void winograd_conv3x3_kernel(const float* __re
                 const float bv = FWD ? bias_s[k] : 0.f;
                 float y00 = t0[0] + t0[1] + t0[2] + bv, y01 = t0[1] - t0[2] - t0[3] + bv;
                 float y10 = t1[0] + t1[1] + t1[2] + bv, y11 = t1[1] - t1[2] - t1[3] + bv;
-                if (FWD && relu) { y00 = fmaxf(y00, 0.f); y01 = fmaxf(y01, 0.f); y10 = fmaxf(y10, 0.f); y11 = fmaxf(y11, 0.f); }
+                if (FWD) { y00 = fmaxf(y00, lo); y01 = fmaxf(y01, lo); y10 = fmaxf(y10, lo); y11 = fmaxf(y11, lo); }
                 float* o = ys + k * YS + (2 * ty) * 16 + 2 * tx;
                 *reinterpret_cast<float2*>(o) = make_float2(y00, y01);
                 *reinterpret_cast<float2*>(o + 16) = make_float2(y10, y11);
