@@ -137,6 +137,12 @@ int dhz_maxpool2x2_blocked_fwd(const float* x, float* y, int N, int H, int W, vo
 int dhz_maxpool2x2_blocked_bwd(const float* gy, const float* act, float* gx, int N, int H, int W, void* stream);
 int dhz_layout_blocked8(const float* src, float* dst, int B, int C, int HW, int to_blocked, void* stream);
 
+/* F2  training feed (dataset.py:17-77): batch item t = table[t] = (patch id, r, c, k) -> ps x ps crop at (r, c) of the
+ *     uint8 [N,Hs,Ws,3] RGB patch pair in HBM, augmentation k of utils/dataset_utils.py:6-40 (0 id, 1-3 rot90 k with
+ *     dims=[-1,-2], 4-7 the same followed by flip(-2)), float32 [n,3,ps,ps] = value / 255. */
+int dhz_crop_augment_pair(const uint8_t* gt, const uint8_t* hazy, const int* table, float* out_gt, float* out_hazy,
+                          int n, int Hs, int Ws, int ps, void* stream);
+
 /* K6  shift mask builder: mask[nW,64,64] in {0,-100}  (M1:803-836), Hres x Wres map, win 8. */
 int dhz_shift_mask(float* mask, int Hres, int Wres, int shift, void* stream);
 

@@ -11,9 +11,11 @@ What is different by design:
     with the 'module.' key prefix so that they stay loadable by the reference scripts;
   * fp32 (the reference wraps the forward in CUDA fp16 autocast + GradScaler, TR:224,249 - BASELINE configs
     2/3 ask for fp32);
-  * `--synthetic N` trains on N synthetic haze pairs per epoch held in HBM (the PNG data pipeline of
-    dataset.py is outside the accelerated path); without it, `--train_dir/--val_dir` must
-    point at `.pt` files holding {'target': [N,3,H,W], 'input': [N,3,H,W]} float tensors in [0,1].
+  * data lives in HBM: `--train_dir/--val_dir` directories of PNG pairs (<dir>/gt, <dir>/hazy; dataset.py) are decoded
+    once into uint8 tensors on the device and every batch (random crop, 8 rotate/flip augmentations, /255) is one kernel
+    launch (dataset.PatchStoreHBM, dhz_crop_augment_pair) instead of DataLoader workers + PCIe per step; a `.pt` file
+    holding {'target': [N,3,H,W], 'input': [N,3,H,W]} float tensors in [0,1] is accepted too; `--synthetic N` trains
+    on N synthetic haze pairs per epoch.
 """
 import argparse
 import datetime
@@ -111,14 +113,23 @@ def main():
     cr = ContrastLoss(ablation=opt.is_ab).to(dev) if opt.w_loss_vgg7 > 0 else None
 
     # ---- data (HBM resident)
+    store = None
     if opt.synthetic > 0:
         tgt_all, inp_all = synthetic_batch(opt.synthetic, opt.train_ps, seed=1234 + rank, device=dev)
         vt, vi = synthetic_batch(opt.val_synthetic, opt.train_ps, seed=4321, device=dev)
+    elif os.path.isdir(opt.train_dir):
+        from dataset import PatchStoreHBM, DataLoaderVal
+        store = PatchStoreHBM.from_dir(opt.train_dir, dev, rank, world)       # this rank's share of the patch pairs
+        val_set = DataLoaderVal(opt.val_dir)
+        val_items = [val_set[i] for i in range(len(val_set))]
+        vt = torch.stack([v[0] for v in val_items]).to(dev)
+        vi = torch.stack([v[1] for v in val_items]).to(dev)
+        tgt_all = inp_all = None
     else:
         tgt_all, inp_all = load_pairs(opt.train_dir, dev)
         vt, vi = load_pairs(opt.val_dir, dev)
         tgt_all, inp_all = tgt_all[rank::world], inp_all[rank::world]
-    n_train = tgt_all.shape[0]
+    n_train = len(store) if store is not None else tgt_all.shape[0]
     steps_per_epoch = max(1, n_train // opt.batch_size)
     eval_now = max(1, steps_per_epoch // 4)
     mixup = utils.MixUp_AUG()
@@ -140,8 +151,11 @@ def main():
         perm = torch.randperm(n_train)
         epoch_loss = torch.zeros((), device=dev)
         for i in range(steps_per_epoch):
-            sel = perm[i * opt.batch_size:(i + 1) * opt.batch_size].to(dev)
-            target, input_ = tgt_all[sel], inp_all[sel]
+            sel = perm[i * opt.batch_size:(i + 1) * opt.batch_size]
+            if store is not None:
+                target, input_ = store.batch(sel.tolist(), opt.train_ps)
+            else:
+                target, input_ = tgt_all[sel.to(dev)], inp_all[sel.to(dev)]
             if epoch > 5:
                 target, input_ = mixup.aug(target, input_)
             loss, loss_rec, loss_cr = train_step(model, char, cr, optimizer, reducer, input_, target,

@@ -207,7 +207,8 @@ def synthetic_batch(batch, ps=128, seed=1234, device="cpu"):
     """Synthetic haze pairs: gt ~ U[0,1); hazy = clamp(t*gt + (1-t)*A, 0, 1) with
     per-sample transmission t ~ U(0.3,0.9) and airlight A ~ U(0.6,1.0).  Returns (target, input_)."""
     g = torch.Generator().manual_seed(seed)
-    gt = torch.rand(batch, 3, ps, ps, generator=g)
+    h, w = (ps, ps) if isinstance(ps, int) else ps
+    gt = torch.rand(batch, 3, h, w, generator=g)
     t = 0.3 + 0.6 * torch.rand(batch, 1, 1, 1, generator=g)
     A = 0.6 + 0.4 * torch.rand(batch, 1, 1, 1, generator=g)
     hazy = (t * gt + (1 - t) * A).clamp(0, 1)

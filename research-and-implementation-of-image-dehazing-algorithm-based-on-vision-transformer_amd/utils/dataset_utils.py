@@ -1,5 +1,35 @@
-"""MixUp (utils/dataset_utils.py:43-63): host randperm + Beta(1.2,1.2) draws, device-agnostic."""
+"""Drop-in for Uformer_ProbSparse/utils/dataset_utils.py: the 8 rotate/flip augmentations (:6-40) and MixUp (:43-63;
+host randperm + Beta(1.2,1.2) draws, device-agnostic - the reference hard-codes .cuda())."""
 import torch
+
+
+class Augment_RGB_torch:
+    def __init__(self):
+        pass
+
+    def transform0(self, t):
+        return t
+
+    def transform1(self, t):
+        return torch.rot90(t, k=1, dims=[-1, -2])
+
+    def transform2(self, t):
+        return torch.rot90(t, k=2, dims=[-1, -2])
+
+    def transform3(self, t):
+        return torch.rot90(t, k=3, dims=[-1, -2])
+
+    def transform4(self, t):
+        return t.flip(-2)
+
+    def transform5(self, t):
+        return torch.rot90(t, k=1, dims=[-1, -2]).flip(-2)
+
+    def transform6(self, t):
+        return torch.rot90(t, k=2, dims=[-1, -2]).flip(-2)
+
+    def transform7(self, t):
+        return torch.rot90(t, k=3, dims=[-1, -2]).flip(-2)
 
 
 class MixUp_AUG:

@@ -375,7 +375,37 @@ def gen_misc():
     npz("misc", mix_gt=gt, mix_nz=nz, mix_out_gt=a, mix_out_nz=b, lrs=np.array(lrs))
 
 
+def gen_data():
+    """utils/dataset_utils.py of the reference (imported by file path: the package __init__ pulls cv2): the 8 rotate/flip
+    augmentations on a seeded tensor and one MixUp draw (torch global RNG seeded; lam.cuda() shimmed to a no-op)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_dataset_utils", os.path.join(REF, "utils", "dataset_utils.py"))
+    du = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(du)
+    g = torch.Generator().manual_seed(11)
+    x = torch.rand(3, 6, 6, generator=g)
+    aug = du.Augment_RGB_torch()
+    names = [m for m in dir(aug) if callable(getattr(aug, m)) if not m.startswith('_')]
+    out = {"x": x, "names": np.array(names)}
+    for k, nme in enumerate(names):
+        out[f"t{k}"] = getattr(aug, nme)(x).contiguous()
+    had = hasattr(torch.Tensor, "_orig_cuda")
+    torch.Tensor._orig_cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        gt, nz = torch.rand(5, 3, 4, 4, generator=g), torch.rand(5, 3, 4, 4, generator=g)
+        torch.manual_seed(2024)
+        mg, mn = du.MixUp_AUG().aug(gt, nz)
+    finally:
+        torch.Tensor.cuda = torch.Tensor._orig_cuda
+    out.update(mix_gt_in=gt, mix_noisy_in=nz, mix_gt=mg, mix_noisy=mn)
+    npz("data_aug", **out)
+
+
 def main():
+    if len(sys.argv) > 2 and sys.argv[1] == "--only" and sys.argv[2] == "data":
+        gen_data()
+        return
     install_shims()
     import warnings
     warnings.filterwarnings("ignore")
@@ -395,6 +425,7 @@ def main():
     gen_misc()
     gen_full(M1, M0, losses)
     gen_trajectory(M1, losses)
+    gen_data()
 
 
 if __name__ == "__main__":

@@ -55,7 +55,8 @@ def _worker(rank, world, port, q):
         ops.GRAD_READY(p)
     red.wait()
     ok_inplace = bool(torch.allclose(red.flat, torch.full_like(red.flat, 3.0)))
-    q.put((rank, grads, ok_inplace))
+    q.put((rank, [g.numpy().copy() for g in grads], ok_inplace))     # by value: torch tensors would travel as shm handles
+                                                                     # that die with this process
     dist.barrier()
     dist.destroy_process_group()
 
@@ -80,7 +81,7 @@ def test_grad_reducer_world2_gloo():
     for (r, grads, ok_inplace) in res:
         assert ok_inplace
         for gp, p in zip(grads, net.parameters()):
-            assert torch.allclose(gp, p.grad, atol=1e-5, rtol=1e-5)
+            assert torch.allclose(torch.from_numpy(gp), p.grad, atol=1e-5, rtol=1e-5)
 
 
 def test_flat_adamw_layout_and_state_dict_cpu():
