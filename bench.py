@@ -82,10 +82,15 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback for the product path)")
+    # DHZ_DIST_BACKEND=gloo + DHZ_SHARE_GPU=1: test-only way to run N ranks on a box with ONE device (tests/test_gpu_ddp.py
+    # does the same for the step itself); the driver's multi-GPU runs use RCCL ("nccl"), one rank per GPU
+    backend = os.environ.get("DHZ_DIST_BACKEND", "nccl")
+    if os.environ.get("DHZ_SHARE_GPU"):
+        local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        dist.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else {}))
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     import My_model_1 as M1

@@ -167,6 +167,8 @@ class GradReducer:
         self._pending = [0] * len(self.buckets)
         self._handles = []
         self._hooks = []
+        self._seen = set()            # parameters already announced in this backward pass
+        self.calls = None             # diagnostics: set to {} to count announcements per parameter id
         if self.world > 1:
             for p, _, _ in slices:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
@@ -177,6 +179,14 @@ class GradReducer:
             self._on_grad(p)
 
     def _on_grad(self, p):
+        # A parameter can be announced twice in one backward: by the in-place wgrad path (ops.GRAD_READY, right after
+        # its kernel is enqueued) and again by autograd's post-accumulate hook, which recent PyTorch also fires for the
+        # None gradient the fused autograd nodes return for such parameters.  Only the first one counts.
+        if self.calls is not None:
+            self.calls[id(p)] = self.calls.get(id(p), 0) + 1
+        if id(p) in self._seen:
+            return
+        self._seen.add(id(p))
         b = self.bucket_of[id(p)]
         self._pending[b] += 1
         if self._pending[b] == self.buckets[b][2]:
@@ -195,6 +205,7 @@ class GradReducer:
                 h.wait()
         self._handles = []
         self._pending = [0] * len(self.buckets)
+        self._seen = set()
 
     def average_(self):
         """Stand-alone use (no FlatAdamW): turn the summed gradients into the mean."""

@@ -55,6 +55,35 @@ def _worker(rank, world, port, q):
         ops.GRAD_READY(p)
     red.wait()
     ok_inplace = bool(torch.allclose(red.flat, torch.full_like(red.flat, 3.0)))
+    # the product's shape of that path: an autograd node that accumulates a leaf's gradient in place, announces it and
+    # returns None for it - PyTorch still runs the leaf's post-accumulate hook, so the parameter is announced twice and
+    # must be counted once (a double count fires the bucket before its other parameters are done)
+    class InPlace(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x, w, b):
+            ctx.save_for_backward(x)
+            ctx.w = w
+            return x @ w.t() + b
+
+        @staticmethod
+        def backward(ctx, g):
+            (x,) = ctx.saved_tensors
+            ctx.w.grad.add_(g.t() @ x)
+            ops.GRAD_READY(ctx.w)
+            return g @ ctx.w, None, g.sum(0)
+    red.wait()
+    red.flat.zero_()
+    red.calls = {}
+    h = InPlace.apply(xs, params[0], params[1])                     # params[0]: first Linear's weight, announced in place + by hook
+    for layer in list(net)[1:]:
+        h = layer(h)
+    ((h - ys) ** 2).sum().backward()
+    red.wait()
+    red.average_()
+    ok_inplace = ok_inplace and red.calls[id(params[0])] >= 1 and all(
+        bool(torch.allclose(p.grad, g_, atol=1e-5, rtol=1e-5)) for p, g_ in zip(params[1:], grads[1:]))
+    w_grad_inplace = params[0].grad.clone()
+    grads = grads + [w_grad_inplace]
     q.put((rank, [g.numpy().copy() for g in grads], ok_inplace))     # by value: torch tensors would travel as shm handles
                                                                      # that die with this process
     dist.barrier()
@@ -82,6 +111,7 @@ def test_grad_reducer_world2_gloo():
         assert ok_inplace
         for gp, p in zip(grads, net.parameters()):
             assert torch.allclose(torch.from_numpy(gp), p.grad, atol=1e-5, rtol=1e-5)
+        assert torch.allclose(torch.from_numpy(grads[-1]), list(net.parameters())[0].grad, atol=1e-5, rtol=1e-5)
 
 
 def test_flat_adamw_layout_and_state_dict_cpu():

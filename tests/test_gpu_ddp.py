@@ -1,0 +1,104 @@
+"""-m gpu: the data-parallel step of the REAL model with two processes (one GPU box has one device, so both ranks share
+cuda:0 and talk through gloo - the collective library differs from the RCCL run, everything above it is the code the
+8-GPU bench runs: in-place weight-gradient kernels announcing finished parameters, hook-driven bucket all-reduces
+overlapped with backward, the 1/world factor folded into AdamW).  The averaged 2 x half-batch gradients and the updated
+parameters must equal the single-process full-batch step."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _model_and_data():
+    import random
+    import numpy as np
+    import My_model_1 as M1
+    random.seed(1234); np.random.seed(1234); torch.manual_seed(1234)
+    model = M1.Uformer(img_size=128, embed_dim=32, win_size=8, token_projection='linear', token_mlp='leff',
+                       drop_path_rate=0.).cuda()
+    g = torch.Generator().manual_seed(21)
+    gt = torch.rand(4, 3, 128, 128, generator=g)
+    hazy = (0.55 * gt + 0.45 * torch.rand(4, 1, 1, 1, generator=g)).clamp(0, 1)
+    return model, gt.cuda(), hazy.cuda()
+
+
+def _one_step(model, opt, reducer, hazy, gt):
+    from dehaze_hip.train import train_step
+    from losses import CharbonnierLoss
+    model.train()
+    torch.manual_seed(77)                                  # same sampled-key tables everywhere
+    loss, _, _ = train_step(model, CharbonnierLoss(), None, opt, reducer, hazy, gt, 1.0, 0.0)
+    return loss
+
+
+def _worker(rank, world, port, ref_path, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from dehaze_hip.train import FlatAdamW, GradReducer
+    model, gt, hazy = _model_and_data()
+    opt = FlatAdamW(model, lr=2e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.02)
+    opt.zero_grad()
+    red = GradReducer(opt, bucket_mb=4.0)                  # ~20 buckets: several collectives in flight during backward
+    n = gt.shape[0] // world
+    counts = red.calls = {}
+    loss = _one_step(model, opt, red, hazy[rank * n:(rank + 1) * n], gt[rank * n:(rank + 1) * n])
+    torch.cuda.synchronize()
+    ref = torch.load(ref_path, map_location="cuda")
+    grad = opt.flat_grad / world                           # the step applied grad_scale = 1/world inside AdamW
+    gerr = (grad - ref["grad"]).abs().max().item() / ref["grad"].abs().max().item()
+    perr = (opt._flat["p"] - ref["param"]).abs().max().item()
+    worst = []
+    names = {id(p): n for n, p in model.named_parameters()}
+    for p, off, k in opt.param_slices():
+        e = (grad[off:off + k] - ref["grad"][off:off + k]).abs().max().item()
+        s_ = ref["grad"][off:off + k].abs().max().item() + 1e-12
+        worst.append((e / s_, names[id(p)], red.bucket_of[id(p)]))
+    worst.sort(reverse=True)
+    missing = [names[id(p)] for p, _, _ in opt.param_slices() if id(p) not in counts]
+    assert not missing, missing[:5]                        # every live parameter announced itself at least once
+    q.put((rank, float(loss), gerr, perr, len(red.buckets), [(round(a, 4), b, c) for a, b, c in worst[:12]]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_rank_step_equals_full_batch_step(tmp_path):
+    from dehaze_hip.train import FlatAdamW
+    model, gt, hazy = _model_and_data()
+    opt = FlatAdamW(model, lr=2e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.02)
+    opt.zero_grad()
+    loss_full = float(_one_step(model, opt, None, hazy, gt))
+    ref_path = str(tmp_path / "ref.pt")
+    torch.save({"grad": opt.flat_grad.cpu(), "param": opt._flat["p"].cpu()}, ref_path)
+    del model, opt
+    torch.cuda.empty_cache()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, ref_path, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=500) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert abs(0.5 * (res[0][1] + res[1][1]) - loss_full) < 1e-5        # mean of the half-batch losses
+    for rank, _, gerr, perr, nb, worst in res:
+        assert nb >= 10
+        assert worst[0][0] < 2e-3, worst[:3]
+        assert gerr < 2e-4, (rank, gerr)                                   # fp32 atomics order + summation split
+        assert perr < 2e-6, (rank, perr)                                   # AdamW's first step moves every weight by ~lr
