@@ -137,6 +137,12 @@ int dhz_maxpool2x2_blocked_fwd(const float* x, float* y, int N, int H, int W, vo
 int dhz_maxpool2x2_blocked_bwd(const float* gy, const float* act, float* gx, int N, int H, int W, void* stream);
 int dhz_layout_blocked8(const float* src, float* dst, int B, int C, int HW, int to_blocked, void* stream);
 
+/* K11b the two L1 distances of one ContrastLoss feature tap (My_CR.py:108-112): sums[0] += sum|a-p|, sums[1] += sum|a-n|
+ *      (n may be NULL: ablation, My_CR.py:114-119); backward da = (g[0] sign(a-p) + g[1] sign(a-n)) / count with g the
+ *      device-resident gradients of the two MEANS.  count % 4 == 0; any (common) element order. */
+int dhz_l1_pair_fwd(const float* a, const float* p, const float* n, float* sums, int64_t count, void* stream);
+int dhz_l1_pair_bwd(const float* a, const float* p, const float* n, const float* g, float* da, int64_t count, void* stream);
+
 /* F2  training feed (dataset.py:17-77): batch item t = table[t] = (patch id, r, c, k) -> ps x ps crop at (r, c) of the
  *     uint8 [N,Hs,Ws,3] RGB patch pair in HBM, augmentation k of utils/dataset_utils.py:6-40 (0 id, 1-3 rot90 k with
  *     dims=[-1,-2], 4-7 the same followed by flip(-2)), float32 [n,3,ps,ps] = value / 255. */

@@ -131,6 +131,18 @@ class ContrastLoss(nn.Module):
         B = a.shape[0]
         loss, all_ap, all_an = 0, 0, 0
         for i in range(len(a_vgg)):
+            if eng is not None and a_vgg[i].numel() % 4 == 0:
+                # both distances of this tap in one pass over (a, p, n), joint backward in another
+                from dehaze_hip.vgg import l1_pair
+                d = l1_pair(a_vgg[i], pn[i][:B], None if self.ab else pn[i][B:])
+                d_ap = d[0]
+                all_ap = all_ap + d_ap
+                if not self.ab:
+                    all_an = all_an + d[1]
+                    loss = loss + self.weights[i] * (d_ap / (d[1] + 1e-7))
+                else:
+                    loss = loss + self.weights[i] * d_ap
+                continue
             d_ap = self.l1(a_vgg[i], pn[i][:B])
             all_ap = all_ap + d_ap
             if not self.ab:

@@ -429,6 +429,49 @@ __global__ __launch_bounds__(256) void charbonnier_bwd_kernel(const float* __res
     }
 }
 
+// ------------------------------------------------------------------------------------------------ K11b
+// The two L1 distances of one ContrastLoss feature tap (My_CR.py:108-112) in one pass over (a, p, n), and their joint
+// backward  da = c_p sign(a - p) + c_n sign(a - n)  (c_* = upstream gradient / N, read from device memory) in another -
+// instead of sub / abs / mean / sign / mul chains over feature maps of up to 134 MB each.
+__global__ __launch_bounds__(256) void l1_pair_fwd_kernel(const float* __restrict__ a, const float* __restrict__ p,
+                                                          const float* __restrict__ n, float* __restrict__ sums, int64_t n4) {
+    __shared__ float part[2][4];
+    float sp = 0.f, sn = 0.f;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n4; e += (int64_t)gridDim.x * blockDim.x) {
+        const float4 av = reinterpret_cast<const float4*>(a)[e];
+        const float4 pv = reinterpret_cast<const float4*>(p)[e];
+        sp += fabsf(av.x - pv.x) + fabsf(av.y - pv.y) + fabsf(av.z - pv.z) + fabsf(av.w - pv.w);
+        if (n) {
+            const float4 nv = reinterpret_cast<const float4*>(n)[e];
+            sn += fabsf(av.x - nv.x) + fabsf(av.y - nv.y) + fabsf(av.z - nv.z) + fabsf(av.w - nv.w);
+        }
+    }
+    sp = wave_sum(sp); sn = wave_sum(sn);
+    if ((threadIdx.x & 63) == 0) { part[0][threadIdx.x >> 6] = sp; part[1][threadIdx.x >> 6] = sn; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(sums, part[0][0] + part[0][1] + part[0][2] + part[0][3]);
+        if (n) atomicAdd(sums + 1, part[1][0] + part[1][1] + part[1][2] + part[1][3]);
+    }
+}
+
+__global__ __launch_bounds__(256) void l1_pair_bwd_kernel(const float* __restrict__ a, const float* __restrict__ p,
+                                                          const float* __restrict__ n, const float* __restrict__ g,
+                                                          float inv_n, float* __restrict__ da, int64_t n4) {
+    const float cp = g[0] * inv_n, cn = n ? g[1] * inv_n : 0.f;
+    auto sgn = [](float d) { return d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f); };
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n4; e += (int64_t)gridDim.x * blockDim.x) {
+        const float4 av = reinterpret_cast<const float4*>(a)[e];
+        const float4 pv = reinterpret_cast<const float4*>(p)[e];
+        float4 r = make_float4(cp * sgn(av.x - pv.x), cp * sgn(av.y - pv.y), cp * sgn(av.z - pv.z), cp * sgn(av.w - pv.w));
+        if (n) {
+            const float4 nv = reinterpret_cast<const float4*>(n)[e];
+            r.x += cn * sgn(av.x - nv.x); r.y += cn * sgn(av.y - nv.y); r.z += cn * sgn(av.z - nv.z); r.w += cn * sgn(av.w - nv.w);
+        }
+        reinterpret_cast<float4*>(da)[e] = r;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ K12
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                     float* __restrict__ m, float* __restrict__ v, int64_t n, float lr,
@@ -589,5 +632,22 @@ extern "C" int dhz_adamw_step(float* p, const float* g, float* m, float* v, int6
     hipLaunchKernelGGL(adamw_kernel, dim3(grid_for((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr,
                        beta1, beta2, eps, wd, step_size, bc2_sqrt, grad_scale);
     DHZ_CHECK_LAUNCH("dhz_adamw_step");
+    return DHZ_OK;
+}
+
+extern "C" int dhz_l1_pair_fwd(const float* a, const float* p, const float* n, float* sums, int64_t count, void* stream) {
+    DHZ_REQUIRE(a && p && sums && count > 0 && count % 4 == 0, "dhz_l1_pair_fwd: bad arguments (count must be a multiple of 4)");
+    hipLaunchKernelGGL(l1_pair_fwd_kernel, dim3(grid_for(count / 4, 256, 2048)), dim3(256), 0, (hipStream_t)stream, a, p, n, sums,
+                       count / 4);
+    DHZ_CHECK_LAUNCH("dhz_l1_pair_fwd");
+    return DHZ_OK;
+}
+
+extern "C" int dhz_l1_pair_bwd(const float* a, const float* p, const float* n, const float* g, float* da, int64_t count,
+                               void* stream) {
+    DHZ_REQUIRE(a && p && g && da && count > 0 && count % 4 == 0, "dhz_l1_pair_bwd: bad arguments (count must be a multiple of 4)");
+    hipLaunchKernelGGL(l1_pair_bwd_kernel, dim3(grid_for(count / 4)), dim3(256), 0, (hipStream_t)stream, a, p, n, g,
+                       1.0f / (float)count, da, count / 4);
+    DHZ_CHECK_LAUNCH("dhz_l1_pair_bwd");
     return DHZ_OK;
 }

@@ -180,3 +180,30 @@ class _ToPlain(Function):
 def to_plain_tap(t):
     """tap feature -> NCHW (differentiable); tap 5 already is."""
     return _ToPlain.apply(t) if t.dim() == 5 else t
+
+
+class _L1Pair(Function):
+    """(mean|a - p|, mean|a - n|) of one feature tap in one pass; gradient w.r.t. a only (p, n carry none, My_CR.py:102)."""
+
+    @staticmethod
+    def forward(ctx, a, p, n):
+        a, p = a.contiguous(), p.contiguous()
+        n = n.contiguous() if n is not None else None
+        sums = torch.zeros(2, device=a.device, dtype=torch.float32)
+        _lib.call("dhz_l1_pair_fwd", _p(a), _p(p), _p(n) if n is not None else None, _p(sums), a.numel(), _stream())
+        ctx.save_for_backward(a, p, n) if n is not None else ctx.save_for_backward(a, p)
+        ctx.has_n = n is not None
+        return sums / a.numel()
+
+    @staticmethod
+    def backward(ctx, g):
+        saved = ctx.saved_tensors
+        a, p = saved[0], saved[1]
+        n = saved[2] if ctx.has_n else None
+        da = torch.empty_like(a)
+        _lib.call("dhz_l1_pair_bwd", _p(a), _p(p), _p(n) if n is not None else None, _p(g.contiguous()), _p(da), a.numel(), _stream())
+        return da, None, None
+
+
+def l1_pair(a, p, n=None):
+    return _L1Pair.apply(a, p, n)
