@@ -94,21 +94,27 @@ __global__ __launch_bounds__(256) void ln_partition_bwd_kernel(const float* __re
     for (int base = wave_global * tpw; base < ntok; base += nwaves * tpw) {
         const int tok = base + sub;
         const bool ok = tok < ntok;
-        float4 xh[VPL], dy[VPL];
+        float4 xh[VPL], dy[VPL], rs[VPL];
         float mean = 0.f, rstd = 0.f;
         size_t src = 0;
         if (ok) {
-            const float2 st = *reinterpret_cast<const float2*>(stats + 2 * (size_t)tok);
-            mean = st.x; rstd = st.y;
             const int bimg = tok / HW, p = tok % HW;
             src = partition ? (size_t)bimg * HW + window_slot(p / Wres, p % Wres, Hres, Wres, shift) : (size_t)tok;
+            // every load of this token group is issued before the first use (the shortcut gradient included)
+#pragma unroll
+            for (int v = 0; v < VPL; ++v) {
+                xh[v] = reinterpret_cast<const float4*>(x + (size_t)tok * C)[li + v * lpt];
+                dy[v] = reinterpret_cast<const float4*>(dxw + src * C)[li + v * lpt];
+                if (dres) rs[v] = reinterpret_cast<const float4*>(dres + (size_t)tok * C)[li + v * lpt];
+            }
+            const float2 st = *reinterpret_cast<const float2*>(stats + 2 * (size_t)tok);
+            mean = st.x; rstd = st.y;
         }
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int v = 0; v < VPL; ++v) {
             if (ok) {
-                const float4 xv = reinterpret_cast<const float4*>(x + (size_t)tok * C)[li + v * lpt];
-                dy[v] = reinterpret_cast<const float4*>(dxw + src * C)[li + v * lpt];
+                const float4 xv = xh[v];
                 xh[v] = make_float4((xv.x - mean) * rstd, (xv.y - mean) * rstd, (xv.z - mean) * rstd, (xv.w - mean) * rstd);
             } else {
                 dy[v] = make_float4(0, 0, 0, 0);
@@ -132,10 +138,7 @@ __global__ __launch_bounds__(256) void ln_partition_bwd_kernel(const float* __re
                 r.z = rstd * (dy[v].z - s1 - xh[v].z * s2);
                 r.w = rstd * (dy[v].w - s1 - xh[v].w * s2);
                 float4* dst = reinterpret_cast<float4*>(dx + (size_t)tok * C) + li + v * lpt;
-                if (dres) {
-                    const float4 o4 = reinterpret_cast<const float4*>(dres + (size_t)tok * C)[li + v * lpt];
-                    r.x += o4.x; r.y += o4.y; r.z += o4.z; r.w += o4.w;
-                }
+                if (dres) { r.x += rs[v].x; r.y += rs[v].y; r.z += rs[v].z; r.w += rs[v].w; }
                 *dst = r;
             }
         }
