@@ -547,7 +547,10 @@ extern "C" int dhz_ln_partition_bwd(const float* dxw, const float* x, const floa
     int lpt, vpl;
     DHZ_REQUIRE(ln_geometry(C, &lpt, &vpl) == 0, "dhz_ln_partition_bwd: unsupported C=%d", C);
     const int ntok = B * Hres * Wres;
-    const int grid = grid_for((int64_t)ntok * lpt, 256, 1024);
+    // every workgroup ends with 2C same-address atomics (dgamma, dbeta): give each wave >= 8 token groups so that small
+    // maps do not pay 1024 workgroups' worth of them
+    int grid = (int)(((int64_t)ntok * lpt + 256 * 8 - 1) / (256 * 8));
+    grid = grid < 64 ? 64 : (grid > 512 ? 512 : grid);
     hipStream_t s = (hipStream_t)stream;
 #define LAUNCH(V) hipLaunchKernelGGL(ln_partition_bwd_kernel<V>, dim3(grid), dim3(256), 0, s, dxw, x, gamma, stats, dres, dx, dgamma, dbeta, ntok, Hres, Wres, C, shift, lpt, partition)
     switch (vpl) { case 1: LAUNCH(1); break; case 2: LAUNCH(2); break; case 3: LAUNCH(3); break; default: LAUNCH(4); }
