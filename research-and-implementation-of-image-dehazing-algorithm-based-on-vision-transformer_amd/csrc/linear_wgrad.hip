@@ -49,7 +49,11 @@ __global__ __launch_bounds__(128 * NWM) void linear_wgrad_kernel(const float* __
     for (int a = 0; a < WM; ++a)
 #pragma unroll
         for (int b = 0; b < WN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float4 ra[NA], rb[NB];
+    // Staged rows are native vectors (f32x4), NOT HIP's float4 struct: rb[] is only ever copied (global -> register -> LDS),
+    // and for a struct the front end emits that as memcpy, which left the whole array in scratch memory (private segment
+    // 48-80 B for NB >= 2): every prefetched row was waited for at once and bounced through scratch, exposing the HBM
+    // latency of each stage - the WN >= 2 variants ran at 2.4-3.5 TB/s / 60-80 TFLOP/s while the NB = 1 ones reached 5.3 TB/s.
+    f32x4 ra[NA], rb[NB];
     float4 dbacc[NA];
 #pragma unroll
     for (int i = 0; i < NA; ++i) dbacc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -61,13 +65,13 @@ __global__ __launch_bounds__(128 * NWM) void linear_wgrad_kernel(const float* __
         for (int i = 0; i < NA; ++i) {
             const int e = t + NTHR * i;
             if (TK * A4 % NTHR == 0 || e < TK * A4)
-                ra[i] = *reinterpret_cast<const float4*>(dy + (tok0 + e / A4) * ldy + n0 + (e % A4) * 4);
+                ra[i] = *reinterpret_cast<const f32x4*>(dy + (tok0 + e / A4) * ldy + n0 + (e % A4) * 4);
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             const int e = t + NTHR * i;
             if (TK * B4 % NTHR == 0 || e < TK * B4)
-                rb[i] = *reinterpret_cast<const float4*>(x + (tok0 + e / B4) * ldx + k0 + (e % B4) * 4);
+                rb[i] = *reinterpret_cast<const f32x4*>(x + (tok0 + e / B4) * ldx + k0 + (e % B4) * 4);
         }
     };
     auto swrite = [&](int buf) {
@@ -75,15 +79,15 @@ __global__ __launch_bounds__(128 * NWM) void linear_wgrad_kernel(const float* __
         for (int i = 0; i < NA; ++i) {
             const int e = t + NTHR * i;
             if (TK * A4 % NTHR == 0 || e < TK * A4) {
-                *reinterpret_cast<float4*>(&As(buf)[(e / A4) * SA + (e % A4) * 4]) = ra[i];
-                dbacc[i].x += ra[i].x; dbacc[i].y += ra[i].y; dbacc[i].z += ra[i].z; dbacc[i].w += ra[i].w;
+                *reinterpret_cast<f32x4*>(&As(buf)[(e / A4) * SA + (e % A4) * 4]) = ra[i];
+                dbacc[i].x += ra[i][0]; dbacc[i].y += ra[i][1]; dbacc[i].z += ra[i][2]; dbacc[i].w += ra[i][3];
             }
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             const int e = t + NTHR * i;
             if (TK * B4 % NTHR == 0 || e < TK * B4)
-                *reinterpret_cast<float4*>(&Bs(buf)[(e / B4) * SB + (e % B4) * 4]) = rb[i];
+                *reinterpret_cast<f32x4*>(&Bs(buf)[(e / B4) * SB + (e % B4) * 4]) = rb[i];
         }
     };
 
