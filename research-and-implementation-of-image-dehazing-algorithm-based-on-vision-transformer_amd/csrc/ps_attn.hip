@@ -263,12 +263,33 @@ __global__ __launch_bounds__(256) void ps_attn_bwd_kernel(
         for (int e = t; e < NT * NT / 4; e += 256) reinterpret_cast<float4*>(sm.acc)[e] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
 
+    // The window-heads of this workgroup are processed one after the other, ~9 barrier-separated phases each.  Their
+    // inputs (K, V, Q, dO rows and the ranks) are prefetched into registers one window-head ahead - native vectors, so
+    // that they stay in registers - otherwise every iteration opens with ~2 us of exposed global-load latency.
+    constexpr int NR = NT / RPP;                       // staged rows per thread and tensor
+    f32x4 pk[NR], pv[NR], pq[NR], pg[NR];
+    uint8_t prank = 255;
+    auto prefetch = [&](int b) {
+        const size_t tok0 = (size_t)b * NT;
+        const int c4 = t % F;
+#pragma unroll
+        for (int p = 0; p < NR; ++p) {
+            const int row = p * RPP + t / F;
+            const size_t gi = (tok0 + row) * ld + h * D + c4 * 4;
+            pk[p] = *reinterpret_cast<const f32x4*>(k + gi);
+            pv[p] = *reinterpret_cast<const f32x4*>(v + gi);
+            pq[p] = *reinterpret_cast<const f32x4*>(q + gi);
+            pg[p] = *reinterpret_cast<const f32x4*>(dout + (tok0 + row) * ldo + h * D + c4 * 4);
+        }
+        if (t < NT) prank = rank_in[((size_t)b * H + h) * NT + t];
+    };
+    if ((int)(blockIdx.x / H) < B_) prefetch(blockIdx.x / H);
+
     for (int b = blockIdx.x / H; b < B_; b += bstep) {
         const size_t tok0 = (size_t)b * NT;
-        const size_t wh = (size_t)b * H + h;
         __syncthreads();   // previous iteration's staging reads are done
         if (t < NT) {
-            const uint8_t r = rank_in[wh * NT + t];
+            const uint8_t r = prank;
             sm.rank[t] = r;
             if (r < NU) sm.top[r] = t;
         } else if (t < NT + 32 - NU) {
@@ -281,28 +302,27 @@ __global__ __launch_bounds__(256) void ps_attn_bwd_kernel(
         // ---- stage K, V, Q[top], dO[top]; reduce dO over the unselected queries (mean(V) path)
         {
             const int c4 = t % F;
-            float4 dm = make_float4(0.f, 0.f, 0.f, 0.f);
+            f32x4 dm = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int p = 0; p < NT / RPP; ++p) {
+            for (int p = 0; p < NR; ++p) {
                 const int row = p * RPP + t / F;
-                const size_t gi = (tok0 + row) * ld + h * D + c4 * 4;
-                *reinterpret_cast<float4*>(&sm.k[row * DS + c4 * 4]) = *reinterpret_cast<const float4*>(k + gi);
-                *reinterpret_cast<float4*>(&sm.v[row * DS + c4 * 4]) = *reinterpret_cast<const float4*>(v + gi);
-                const float4 go = *reinterpret_cast<const float4*>(dout + (tok0 + row) * ldo + h * D + c4 * 4);
+                *reinterpret_cast<f32x4*>(&sm.k[row * DS + c4 * 4]) = pk[p];
+                *reinterpret_cast<f32x4*>(&sm.v[row * DS + c4 * 4]) = pv[p];
                 const int r = sm.rank[row];
                 if (r < NU) {
-                    *reinterpret_cast<float4*>(&sm.qr[r * DS + c4 * 4]) = *reinterpret_cast<const float4*>(q + gi);
-                    *reinterpret_cast<float4*>(&sm.dor[r * DS + c4 * 4]) = go;
+                    *reinterpret_cast<f32x4*>(&sm.qr[r * DS + c4 * 4]) = pq[p];
+                    *reinterpret_cast<f32x4*>(&sm.dor[r * DS + c4 * 4]) = pg[p];
                 } else {
-                    dm.x += go.x; dm.y += go.y; dm.z += go.z; dm.w += go.w;
+                    dm += pg[p];
                 }
             }
+            if (b + bstep < B_) prefetch(b + bstep);          // in flight during the rest of this window-head
 #pragma unroll
             for (int o = F; o < 64; o <<= 1) {
-                dm.x += __shfl_xor(dm.x, o); dm.y += __shfl_xor(dm.y, o);
-                dm.z += __shfl_xor(dm.z, o); dm.w += __shfl_xor(dm.w, o);
+                dm[0] += __shfl_xor(dm[0], o); dm[1] += __shfl_xor(dm[1], o);
+                dm[2] += __shfl_xor(dm[2], o); dm[3] += __shfl_xor(dm[3], o);
             }
-            if (lane < F) *reinterpret_cast<float4*>(&sm.dmp[w * D + lane * 4]) = dm;
+            if (lane < F) *reinterpret_cast<f32x4*>(&sm.dmp[w * D + lane * 4]) = dm;
         }
         __syncthreads();
         if (t < D) sm.dor[NU * DS + t] = sm.dmp[t] + sm.dmp[D + t] + sm.dmp[2 * D + t] + sm.dmp[3 * D + t];
