@@ -338,21 +338,17 @@ __global__ __launch_bounds__(256) void leff_dwconv_bwd_kernel(const float* __res
                 }
             }
         }
-        // centre values of u (for gelu'(u)): issued before the barrier, consumed after the tap loop (L2 hits)
-        float4 uc[TH * TW / 32];
-#pragma unroll
-        for (int i = 0; i < TH * TW / 32; ++i) {
-            const int pos = (t >> 3) + 32 * i;
-            const int yc = min(ty * TH + pos / TW, Hres - 1), xc = min(tx * TW + pos % TW, Wres - 1);
-            uc[i] = *reinterpret_cast<const float4*>(u + (ib + (size_t)yc * Wres + xc) * Ch + ch0);
-        }
         __syncthreads();
-#pragma unroll
+#pragma unroll 1
         for (int it = 0; it < TH * TW / 32; ++it) {
             const int pos = (t >> 3) + 32 * it;
             const int py = pos / TW, px = pos % TW;
             const int yy = ty * TH + py, xx = tx * TW + px;
             if (yy >= Hres || xx >= Wres) continue;
+            const size_t o = (ib + (size_t)yy * Wres + xx) * Ch + ch0;
+            // centre value of u (for gelu'(u)): an L2 hit issued now, consumed after the tap loop.  The position loop is
+            // NOT unrolled: unrolled, the kernel needed 250 VGPRs = 2 workgroups per CU; this way 3 fit (LDS-limited).
+            const float4 uv = *reinterpret_cast<const float4*>(u + o);
             // dg[p] = sum_k w[k] * dt[p - off(k)]   (transpose of the forward correlation)
             float4 dg = make_float4(0, 0, 0, 0);
             const float4 dtc = *reinterpret_cast<const float4*>(&ds[((py + 1) * HWID + px + 1) * CT + c4 * 4]);
@@ -368,8 +364,6 @@ __global__ __launch_bounds__(256) void leff_dwconv_bwd_kernel(const float* __res
                     dwk[2][ky * 3 + kx] += dtc.z * gn.z; dwk[3][ky * 3 + kx] += dtc.w * gn.w;
                 }
             dbk[0] += dtc.x; dbk[1] += dtc.y; dbk[2] += dtc.z; dbk[3] += dtc.w;
-            const size_t o = (ib + (size_t)yy * Wres + xx) * Ch + ch0;
-            const float4 uv = uc[it];
             *reinterpret_cast<float4*>(du + o) = make_float4(dg.x * gelu_grad_f(uv.x), dg.y * gelu_grad_f(uv.y),
                                                              dg.z * gelu_grad_f(uv.z), dg.w * gelu_grad_f(uv.w));
         }
