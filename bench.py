@@ -164,7 +164,9 @@ def main():
             ms = sum(a.elapsed_time(b) for a, b, _, _ in ev)
             flops = sum(n * 2 * 64 * (4 * c * c + 75 * c) for _, _, n, c in ev)
             tf = flops / (ms * 1e-3) / 1e12
-            traffic = pmc.get("fused_window_attn_fwd_kernel", {}).get("hbm_bytes_per_launch")
+            # launch-weighted mean over the template instances (C = 32 / 64 / 128) of the committed PMC passes
+            inst = [v for k, v in pmc.items() if k.startswith("fused_window_attn_fwd_kernel")]
+            traffic = (sum(v["hbm_bytes_per_launch"] * v["launches"] for v in inst) / sum(v["launches"] for v in inst)) if inst else None
             out["roofline"] = {"kernel": "fused_window_attn_fwd_kernel<C,SAVE> (dhz_fused_window_attn_fwd), C in {32,64,128}",
                                "bound": "mfma", "achieved": round(tf, 2), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
                                "frac": round(tf / MFMA_F32_PEAK_TF, 4),
