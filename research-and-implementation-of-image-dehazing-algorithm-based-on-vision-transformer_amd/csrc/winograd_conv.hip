@@ -155,12 +155,14 @@ __global__ __launch_bounds__(512) void winograd_conv3x3_kernel(const float* __re
         d[a][0] = t0 - t2; d[a][1] = t1 + t2; d[a][2] = t2 - t1; d[a][3] = t1 - t3;
     };
     float* vdst = vw + g * 32 + i16 * 2;
+    auto write_v2 = [&](int xi) {                        // two transform positions xi, xi+1 (one row a, columns b, b+1)
+        const int a = xi >> 2, b = xi & 3;
+        *reinterpret_cast<float2*>(vdst + xi * 128) = make_float2(d[a][b].x, d[a][b].y);
+        *reinterpret_cast<float2*>(vdst + (xi + 1) * 128) = make_float2(d[a][b + 1].x, d[a][b + 1].y);
+    };
     auto write_v = [&]() {
 #pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-            for (int b = 0; b < 4; ++b)
-                *reinterpret_cast<float2*>(vdst + (4 * a + b) * 128) = make_float2(d[a][b].x, d[a][b].y);
+        for (int xi = 0; xi < 16; xi += 2) write_v2(xi);
     };
 
     float* bias_s = smem + NUBUF * UF + 8 * WAVE_LDS;    // the 32 biases of this output-channel block
@@ -214,6 +216,15 @@ __global__ __launch_bounds__(512) void winograd_conv3x3_kernel(const float* __re
                 case 19: row_transform(1); break;
                 case 20: row_transform(2); break;
                 case 21: row_transform(3); break;
+                // V rows of positions the MFMA stream is done with are overwritten early (LDS executes a wave's operations in
+                // order and the reads of pair-steps <= 3 / <= 5 were issued before slot 16 / 24): only 4 of the 16 V stores
+                // are left for the burst between two groups
+                case 22: write_v2(0); break;
+                case 23: write_v2(2); break;
+                case 24: write_v2(4); break;
+                case 25: write_v2(6); break;
+                case 26: write_v2(8); break;
+                case 27: write_v2(10); break;
                 default: break;
             }
         };
@@ -257,7 +268,7 @@ __global__ __launch_bounds__(512) void winograd_conv3x3_kernel(const float* __re
             a0 = a0n; a1 = a1n; b0 = b0n; b1 = b1n;
         }
         wave_sync();                                     // every MFMA of this group has read V
-        if (WITH_NEXT) write_v();
+        if (WITH_NEXT) { write_v2(12); write_v2(14); }
         wave_sync();
     };
     for (int cb = 0; cb + 1 < CBn; ++cb) group(cb, std::true_type{});
