@@ -174,3 +174,34 @@ def test_dense_full_model_vs_reference_golden(golden, dev):
     crop = y[0, :, 40:72, 40:72].cpu()
     assert torch.allclose(crop, T(g["y_eval_crop"]), atol=2e-4, rtol=1e-3), (crop - T(g["y_eval_crop"])).abs().max()
     assert abs(float(y.double().sum()) - float(g["y_eval_sum"])) < 1e-3 * float(g["y_eval_abs"])
+
+
+def test_embed_dim_64_vs_oracle(dev):
+    """embed_dim = 64 (BASELINE config 4's width, here in fp32): head dimension 64, channels 64..1024 - the fused
+    attention kernel (32-wide heads) does not apply and every block runs the unfused kernel chain.  One training-mode
+    forward/backward vs the CPU oracle: loss and per-parameter gradient norms."""
+    import My_model_1 as M1
+    from losses import CharbonnierLoss
+    seed_all(1234)
+    model = M1.Uformer(img_size=128, embed_dim=64, win_size=8, token_projection='linear', token_mlp='leff',
+                       drop_path_rate=0.).to(dev)
+    P = {k: v.detach().cpu().clone().requires_grad_(v.dtype.is_floating_point) for k, v in model.state_dict().items()}
+    g = torch.Generator().manual_seed(7)
+    gt = torch.rand(1, 3, 128, 128, generator=g)
+    hazy = (0.6 * gt + 0.3).clamp(0, 1)
+    model.train()
+    torch.manual_seed(5)
+    loss, _ = CharbonnierLoss().forward_clamped(model(hazy.to(dev)), gt.to(dev))
+    loss.backward()
+    torch.manual_seed(5)
+    loss_ref, _ = O.train_step_loss(P, hazy, gt, training=True, drop_path_rate=0.)
+    loss_ref.backward()
+    assert abs(loss.item() - loss_ref.item()) < 5e-5, (loss.item(), loss_ref.item())
+    worst = 0.0
+    for n, p in model.named_parameters():
+        if p.grad is None:
+            assert P[n].grad is None or float(P[n].grad.abs().max()) == 0.0, n
+            continue
+        a, b = float(p.grad.double().norm()), float(P[n].grad.double().norm())
+        worst = max(worst, abs(a - b) / (b + 1e-8))
+    assert worst < 5e-3, worst
