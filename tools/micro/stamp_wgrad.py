@@ -1,3 +1,7 @@
+"""Reader for in-kernel s_memtime stamps (phase timeline of one workgroup).  The stamped library is an ad-hoc build: a
+copy of csrc/linear_wgrad.hip with `STAMP(slot)` stores of __builtin_amdgcn_s_memtime() at the phase boundaries into a device
+buffer installed through an extra `dhz_debug_stamp(ptr)` export, compiled next to this script (hipcc -shared, with
+csrc/api.hip).  Product builds carry no stamps.  Findings are recorded in DESIGN.md section 4."""
 import ctypes, os, sys, torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 lib = ctypes.CDLL(os.path.join(HERE, "liblw_stamp.so"))
