@@ -120,7 +120,7 @@ def main():
     for _ in range(args.warmup):
         step()
     if not args.no_kernel_timing:
-        ops.KERNEL_TIMING = {"dhz_ps_attn_fwd": [], "dhz_fused_window_attn_fwd": []}
+        ops.KERNEL_TIMING = {"dhz_ps_attn_fwd": [], "dhz_fused_window_attn_fwd": [], "dhz_winograd_conv3x3": []}
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -186,6 +186,22 @@ def main():
                      "traffic": round(traffic) if traffic else None, "launches": len(ev),
                      "avg_launch_us": round(1e3 * ms / len(ev), 2), "alg_bytes_per_launch": bytes_alg // len(ev)}
             out["roofline" if "roofline" not in out else "roofline_core_unfused"] = entry
+        if timing and timing.get("dhz_winograd_conv3x3"):
+            # the kernel with the largest share of the step (VGG19 convolutions of the contrastive loss): Winograd F(2x2,3x3),
+            # so the matrix pipe executes direct-conv FLOPs / 2.25; frac is the ISSUED MFMA rate against the fp32 peak
+            ev = timing["dhz_winograd_conv3x3"]
+            ms = sum(a.elapsed_time(b) for a, b, _ in ev)
+            direct = sum(f for _, _, f in ev)
+            tf_direct = direct / (ms * 1e-3) / 1e12
+            inst = [v for k, v in pmc.items() if k.startswith("winograd_conv3x3_kernel")]
+            traffic = (sum(v["hbm_bytes_per_launch"] * v["launches"] for v in inst) / sum(v["launches"] for v in inst)) if inst else None
+            out["roofline_dominant"] = {"kernel": "winograd_conv3x3_kernel<FWD> (dhz_winograd_conv3x3): largest share of the step",
+                                        "bound": "mfma", "achieved": round(tf_direct / 2.25, 2), "peak": MFMA_F32_PEAK_TF,
+                                        "unit": "TFLOP/s", "frac": round(tf_direct / 2.25 / MFMA_F32_PEAK_TF, 4),
+                                        "direct_conv_equivalent_tflops": round(tf_direct, 1),
+                                        "traffic": round(traffic) if traffic else None, "launches": len(ev),
+                                        "avg_launch_us": round(1e3 * ms / len(ev), 2),
+                                        "alg_flops_per_launch": int(direct / 2.25 / len(ev))}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

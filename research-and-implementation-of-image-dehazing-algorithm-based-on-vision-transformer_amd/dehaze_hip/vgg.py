@@ -14,6 +14,7 @@ import torch.nn.functional as F
 from torch.autograd import Function
 
 from . import _lib
+from . import ops
 from .ops import _p, _stream
 
 CONVS = ((3, 64), (64, 64), (64, 128), (128, 128), (128, 256), (256, 256), (256, 256), (256, 256), (256, 512),
@@ -51,6 +52,23 @@ def pool_bwd_relu(gb, actb):
     return gx
 
 
+def _timing_begin():
+    """bench.py's per-kernel HIP events (ops.KERNEL_TIMING), on the launch stream, bracketing exactly this kernel."""
+    timing = ops.KERNEL_TIMING.get("dhz_winograd_conv3x3") if ops.KERNEL_TIMING is not None else None
+    if timing is None:
+        return None
+    e0 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    return timing, e0
+
+
+def _timing_end(ev, B, H, W, Cin, Kout):
+    if ev is not None:
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        ev[0].append((ev[1], e1, 2.0 * 9 * B * H * W * Cin * Kout))          # direct-convolution FLOPs of this launch
+
+
 class VggEngine:
     def __init__(self, convs):
         """convs: the 13 nn.Conv2d modules of vgg19.features[0:30]."""
@@ -77,7 +95,9 @@ class VggEngine:
         C, K = CONVS[i]
         uf, _ = self.packed(i, xb.device)
         yb = torch.empty((B, K // 8, H, W, 8), device=xb.device, dtype=torch.float32)
+        ev = _timing_begin()
         _lib.call("dhz_winograd_conv3x3", _p(xb), _p(uf), _p(self.convs[i].bias), 1, None, None, _p(yb), B, H, W, C, K, _stream())
+        _timing_end(ev, B, H, W, C, K)
         return yb
 
     def conv_dgrad(self, i, gb, below_act=None, addend=None):
@@ -88,8 +108,10 @@ class VggEngine:
         C, K = CONVS[i]
         _, ub = self.packed(i, gb.device)
         dxb = torch.empty((B, C // 8, H, W, 8), device=gb.device, dtype=torch.float32)
+        ev = _timing_begin()
         _lib.call("dhz_winograd_conv3x3", _p(gb), _p(ub), None, 0, _p(below_act) if below_act is not None else None,
                   _p(addend.contiguous()) if addend is not None else None, _p(dxb), B, H, W, K, C, _stream())
+        _timing_end(ev, B, H, W, K, C)
         return dxb
 
     # ---- full stack, forward only
