@@ -408,8 +408,26 @@ class OutputProj(nn.Module):
         self.in_channel, self.out_channel = in_channel, out_channel
 
     def forward(self, x):
-        x = self.proj(_tokens_to_map(x))
+        conv = self.proj[0]
+        if x.is_cuda and len(self.proj) == 1 and conv.bias is not None:
+            # the convolution without its bias + an explicit bias add whose backward sums in two stages: the library's
+            # bias gradient of a 3-channel map is ONE 4-block reduction over the whole gradient image (190 us per step)
+            x = _BiasAddMap.apply(F.conv2d(_tokens_to_map(x), conv.weight, None, conv.stride, conv.padding), conv.bias)
+        else:
+            x = self.proj(_tokens_to_map(x))
         return self.norm(x) if self.norm is not None else x
+
+
+class _BiasAddMap(torch.autograd.Function):
+    """y[b,c,h,w] = x[b,c,h,w] + bias[c]; d(bias) = sum over (h,w) per (b,c), then over b."""
+
+    @staticmethod
+    def forward(ctx, x, bias):
+        return x + bias.view(1, -1, 1, 1)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, g.flatten(2).sum(2).sum(0)
 
 
 # ----------------------------------------------------------------------------- the model
