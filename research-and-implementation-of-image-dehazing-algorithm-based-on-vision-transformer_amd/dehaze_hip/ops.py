@@ -218,9 +218,10 @@ class _LinearTokens(Function):
         off = 0
         for w, b in ctx.params:
             N = w.shape[0]
-            # measured on MI355X (tools/bench_wgrad.py): the split-T kernel wins 2-18x for T >= 16k tokens and
-            # for small N*K; the library's TN GEMM wins (1.2-1.7x) only on the deep stages (T <= 8k, N*K >= 256k)
-            mine = T >= 16384 or N * K < 200000
+            # measured on MI355X (tools/bench_wgrad.py): the split-T kernel wins 2-18x for T >= 16k tokens; on the deep
+            # stages (T <= 8k) it is within 0.9-1.2x of the library's TN GEMM and delivers the bias gradient for free
+            # (the library path pays a separate ~20 us column-sum kernel), so it is used everywhere
+            mine = T % 32 == 0 and N % 32 == 0 and K % 32 == 0      # (the kernel's shape contract; always true on this model)
             if mine and w.is_leaf and (b is None or b.is_leaf):
                 _accumulate_param_grads(dy, off, x, [(w, b)])
                 grads += [None, None]
