@@ -137,6 +137,13 @@ int dhz_maxpool2x2_blocked_fwd(const float* x, float* y, int N, int H, int W, vo
 int dhz_maxpool2x2_blocked_bwd(const float* gy, const float* act, float* gx, int N, int H, int W, void* stream);
 int dhz_layout_blocked8(const float* src, float* dst, int B, int C, int HW, int to_blocked, void* stream);
 
+/* K9b  output projection (My_model_1.py:696-723): Conv2d(C -> 3, 3x3, pad 1) from tokens x[B, H*W, C] to an NCHW image
+ *      y[B, 3, H, W] (+ bias[3], may be NULL); backward-data dx[B, H*W, C] from dy[B, 3, H, W]; weight / bias gradient
+ *      dw[3, C, 3, 3], db[3] (ACCUMULATED; db may be NULL).  w is the layer's own [3, C, 3, 3] tensor.  C in {64, 128}. */
+int dhz_thin_conv3x3_fwd(const float* x, const float* w, const float* bias, float* y, int B, int H, int W, int C, void* stream);
+int dhz_thin_conv3x3_dgrad(const float* dy, const float* w, float* dx, int B, int H, int W, int C, void* stream);
+int dhz_thin_conv3x3_wgrad(const float* dy, const float* x, float* dw, float* db, int B, int H, int W, int C, void* stream);
+
 /* K11b the two L1 distances of one ContrastLoss feature tap (My_CR.py:108-112): sums[0] += sum|a-p|, sums[1] += sum|a-n|
  *      (n may be NULL: ablation, My_CR.py:114-119); backward da = (g[0] sign(a-p) + g[1] sign(a-n)) / count with g the
  *      device-resident gradients of the two MEANS.  count % 4 == 0; any (common) element order. */

@@ -30,6 +30,9 @@ SIGNATURES = {
     "dhz_bias_gather": [c_f, c_f, c_i, c_p],
     "dhz_bias_table_grad": [c_f, c_i, c_f, c_i, c_i, c_p],
     "dhz_shift_mask": [c_f, c_i, c_i, c_i, c_p],
+    "dhz_thin_conv3x3_fwd": [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_p],
+    "dhz_thin_conv3x3_dgrad": [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_p],
+    "dhz_thin_conv3x3_wgrad": [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_p],
     "dhz_l1_pair_fwd": [c_f, c_f, c_f, c_f, c_l, c_p],
     "dhz_l1_pair_bwd": [c_f, c_f, c_f, c_f, c_f, c_l, c_p],
     "dhz_crop_augment_pair": [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_p],

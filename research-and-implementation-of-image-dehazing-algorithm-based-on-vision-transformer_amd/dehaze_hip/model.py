@@ -409,7 +409,13 @@ class OutputProj(nn.Module):
 
     def forward(self, x):
         conv = self.proj[0]
-        if x.is_cuda and len(self.proj) == 1 and conv.bias is not None:
+        if (x.is_cuda and len(self.proj) == 1 and self.out_channel == 3 and self.in_channel in (64, 128)
+                and conv.stride == (1, 1) and x.dtype == torch.float32):
+            # 3 output channels: nothing for the matrix pipe, the library's implicit GEMM runs at 0.6 TB/s - hand-written
+            # forward / backward-data / weight-gradient kernels on the token layout (csrc/thin_conv.hip)
+            s_ = int(math.sqrt(x.shape[1]))
+            x = ops.thin_conv3x3(x, conv.weight, conv.bias, s_, s_)
+        elif x.is_cuda and len(self.proj) == 1 and conv.bias is not None:
             # the convolution without its bias + an explicit bias add whose backward sums in two stages: the library's
             # bias gradient of a 3-channel map is ONE 4-block reduction over the whole gradient image (190 us per step)
             x = _BiasAddMap.apply(F.conv2d(_tokens_to_map(x), conv.weight, None, conv.stride, conv.padding), conv.bias)

@@ -405,3 +405,54 @@ def adamw_step_(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scal
     assert p.is_contiguous() and g.is_contiguous() and m.is_contiguous() and v.is_contiguous()
     _lib.call("dhz_adamw_step", _p(p), _p(g), _p(m), _p(v), p.numel(), float(lr), float(beta1), float(beta2),
               float(eps), float(weight_decay), int(step), float(grad_scale), _stream())
+
+
+# ----------------------------------------------------------------------------- K9b
+class _ThinConv(Function):
+    """Output projection: tokens [B, H*W, C] -> Conv2d(C, 3, 3x3, pad 1) -> [B, 3, H, W]; weight and bias gradients are
+    accumulated in place when the parameters are leaves."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, H, W):
+        _require_gpu(x, w)
+        x = x.contiguous()
+        B, L, C = x.shape
+        assert L == H * W and w.shape == (3, C, 3, 3)
+        wc = w.contiguous()
+        y = torch.empty((B, 3, H, W), device=x.device, dtype=torch.float32)
+        _lib.call("dhz_thin_conv3x3_fwd", _p(x), _p(wc), _p(b), _p(y), B, H, W, C, _stream())
+        ctx.save_for_backward(x, wc)
+        ctx.params, ctx.geom = (w, b), (B, H, W, C)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, wc = ctx.saved_tensors
+        w, b = ctx.params
+        B, H, W, C = ctx.geom
+        dy = dy.contiguous()
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            _lib.call("dhz_thin_conv3x3_dgrad", _p(dy), _p(wc), _p(dx), B, H, W, C, _stream())
+        inplace = w.is_leaf and w.requires_grad and (b is None or (b.is_leaf and b.requires_grad))
+        if inplace:
+            for p_ in (w, b):
+                if p_ is not None and p_.grad is None:
+                    p_.grad = torch.zeros_like(p_, memory_format=torch.contiguous_format)
+            inplace = w.grad.is_contiguous()
+        if inplace:
+            _lib.call("dhz_thin_conv3x3_wgrad", _p(dy), _p(x), _p(w.grad), _p(b.grad) if b is not None else None, B, H, W, C, _stream())
+            if GRAD_READY is not None:
+                GRAD_READY(w)
+                if b is not None:
+                    GRAD_READY(b)
+            return dx, None, None, None, None
+        dw = torch.zeros((3, C, 3, 3), device=x.device, dtype=torch.float32)
+        db = torch.zeros(3, device=x.device, dtype=torch.float32) if b is not None else None
+        _lib.call("dhz_thin_conv3x3_wgrad", _p(dy), _p(x), _p(dw), _p(db), B, H, W, C, _stream())
+        return dx, dw, db, None, None
+
+
+def thin_conv3x3(x, w, b, H, W):
+    return _ThinConv.apply(x, w, b, H, W)

@@ -248,3 +248,28 @@ def test_adamw(dev, ops):
         ops.adamw_step_(pd, gr.to(dev), m, v, 2e-4, 0.9, 0.999, 1e-8, 0.02, step)
     assert torch.allclose(pd.cpu(), pr.detach(), atol=1e-7, rtol=1e-6)
     assert torch.allclose(m.cpu(), opt.state[pr]["exp_avg"], atol=1e-7, rtol=1e-5)   # torch uses lerp for m
+
+
+@pytest.mark.parametrize("B,H,W,C", [(2, 24, 40, 64), (1, 16, 16, 128), (3, 9, 21, 64)])
+def test_thin_conv3x3_vs_torch(B, H, W, C):
+    """Output projection kernels (C -> 3, 3x3, pad 1; ragged tiles included) vs conv2d in float64: forward, backward-data and
+    the in-place weight / bias gradients."""
+    from dehaze_hip import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(B * 100 + H)
+    x = torch.randn(B, H * W, C, generator=g)
+    w = torch.randn(3, C, 3, 3, generator=g) * 0.05
+    b = torch.randn(3, generator=g)
+    gy = torch.randn(B, 3, H, W, generator=g)
+    x64 = x.double().requires_grad_(); w64 = w.double().requires_grad_(); b64 = b.double().requires_grad_()
+    ref = torch.nn.functional.conv2d(x64.view(B, H, W, C).permute(0, 3, 1, 2), w64, b64, padding=1)
+    ref.backward(gy.double())
+    xd = x.to(dev).requires_grad_()
+    wd = torch.nn.Parameter(w.to(dev)); bd = torch.nn.Parameter(b.to(dev))
+    y = ops.thin_conv3x3(xd, wd, bd, H, W)
+    assert y.shape == (B, 3, H, W)
+    assert torch.allclose(y.cpu(), ref.float(), atol=2e-5, rtol=1e-4), (y.cpu() - ref.float()).abs().max()
+    y.backward(gy.to(dev))
+    assert torch.allclose(xd.grad.cpu(), x64.grad.float().reshape(B, H * W, C), atol=2e-5, rtol=1e-4)
+    assert torch.allclose(wd.grad.cpu(), w64.grad.float(), atol=2e-4, rtol=1e-4), (wd.grad.cpu() - w64.grad.float()).abs().max()
+    assert torch.allclose(bd.grad.cpu(), b64.grad.float(), atol=2e-4, rtol=1e-4)
