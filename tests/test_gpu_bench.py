@@ -1,0 +1,36 @@
+"""-m gpu: the bench.py contract - one JSON line with the driver's keys, the three roofline objects timed with HIP events,
+and (here with a reduced sample) the CPU-oracle baseline."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.timeout(900)
+def test_bench_json_contract():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "2",
+                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=800, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline"):
+        assert k in d, k
+    assert d["metric"].startswith("train patches/sec") and d["unit"] == "patches/s" and d["n_gpus"] == 1
+    assert d["steps"] == 3 and d["warmup"] == 2 and d["higher_is_better"] is True and d["scaling"] == "weak"
+    assert d["vs_baseline"] is None and d["dtype"] == "f32" and d["data"] == "synthetic"
+    assert "workload" in d["config"] and "model" not in d["config"] and d["config"]["global_batch"] == 32
+    assert abs(d["value"] - 32 * 1e3 / d["ms_per_step"]) < 0.01 * d["value"] and d["value"] > 100
+    for name in ("roofline", "roofline_core_unfused", "roofline_dominant"):
+        ro = d[name]
+        assert ro["bound"] in ("hbm", "mfma") and ro["unit"] in ("GB/s", "TFLOP/s")
+        assert abs(ro["frac"] - ro["achieved"] / ro["peak"]) < 1e-3 and 0.05 < ro["frac"] < 1.0
+        assert ro["launches"] > 0 and ro["avg_launch_us"] > 0
+        assert ro["traffic"] is None or ro["traffic"] > 0
+    assert "cpu_baseline" not in d
