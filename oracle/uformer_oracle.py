@@ -198,7 +198,7 @@ def _drop_path(x, p, training):
 
 
 def lewin_block(x, P, pre, heads, win=8, shift=0, variant="probsparse", idx=None, drop_path=0.0,
-                training=False, use_bias=True, input_resolution=None):
+                training=False, use_bias=True, input_resolution=None, input_mask=None):
     """LeWinTransformerBlock.forward - M1:785-875.  x: [B,HW,C].  `pre` ends with '.' (e.g.
     'encoderlayer_0.blocks.1.').  win/shift clamp of M1:764-766 uses `input_resolution` (the
     *constructor* resolution, which differs from the runtime one in whole-image eval)."""
@@ -208,6 +208,12 @@ def lewin_block(x, P, pre, heads, win=8, shift=0, variant="probsparse", idx=None
     if res <= win:
         shift, win = 0, res
     mask = shift_attn_mask(H, W, win, shift, x.dtype) if shift > 0 else None
+    if input_mask is not None:                                          # input-mask path, M1:791-800 (+ :833-836)
+        im = F.interpolate(input_mask, size=(H, W)).permute(0, 2, 3, 1)
+        am = window_partition(im, win).view(-1, win * win)
+        am = am.unsqueeze(2) * am.unsqueeze(1)
+        am = am.masked_fill(am != 0, float(-100.0)).masked_fill(am == 0, float(0.0))
+        mask = am + mask if mask is not None else am
     shortcut = x
     y = F.layer_norm(x, (C,), P[pre + "norm1.weight"], P[pre + "norm1.bias"], 1e-5).view(B, H, W, C)
     if shift > 0:
@@ -257,7 +263,7 @@ def upsample(x, P, name):
 # ----------------------------------------------------------------------------- whole model
 
 def uformer_forward(P, img, variant="probsparse", img_size=128, win=8, drop_path_rate=0.1, training=False,
-                    idx_seq=None, use_bias=True, depths=DEPTHS, heads=HEADS):
+                    idx_seq=None, use_bias=True, depths=DEPTHS, heads=HEADS, mask=None):
     """Uformer.forward - M1:1169-1207.  `idx_seq` (optional): [18,N,u] sampled-key indices in block
     order; None => each block draws from the global CPU generator exactly where the reference does."""
     dpr = drop_path_schedule(drop_path_rate, depths)
@@ -270,7 +276,7 @@ def uformer_forward(P, img, variant="probsparse", img_size=128, win=8, drop_path
                 idx = idx_seq[blk_counter[0]]
             blk_counter[0] += 1
             x = lewin_block(x, P, f"{STAGE_NAMES[s]}.blocks.{i}.", heads[s], win, 0 if i % 2 == 0 else win // 2,
-                            variant, idx, dpr[s][i], training, use_bias, input_resolution=res)
+                            variant, idx, dpr[s][i], training, use_bias, input_resolution=res, input_mask=mask)
         return x
 
     y = input_proj(img, P)

@@ -105,3 +105,40 @@ def test_my_train_on_png_tree(tmp_path):
     assert os.path.exists(os.path.join(models, "epoch_model_1.pth"))
     sd = torch.load(os.path.join(models, "epoch_model_1.pth"), map_location="cpu")
     assert all(k.startswith("module.") for k in sd["state_dict"]) and sd["epoch"] == 1
+
+
+def test_any_resolution_mask_path_vs_oracle():
+    """test_in_any_resolution.py's path: 100 x 150 image centred in a 256 x 256 zero canvas, forward with the padding mask
+    (every block builds its -100 window masks from it, shifted blocks add the shift mask), valid region cut back out."""
+    import My_model_1 as M1
+    import test_in_any_resolution as TA
+    dev = torch.device("cuda:0")
+    torch.manual_seed(4321)
+    model = M1.Uformer(img_size=128, embed_dim=32, win_size=8, token_projection='linear', token_mlp='leff').to(dev).eval()
+    P = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    g = torch.Generator().manual_seed(8)
+    hazy = torch.rand(1, 3, 100, 150, generator=g)
+    sq, mask = TA.expand2square(hazy, factor=128)
+    assert sq.shape == (1, 3, 256, 256) and float(mask.sum()) == 100 * 150
+    assert torch.equal(sq[:, :, 78:178, 53:203], hazy) and float(sq.abs().sum() - hazy.abs().sum()) == 0.0
+    torch.manual_seed(11)
+    with torch.no_grad():
+        y = TA.restore_any(model, hazy.to(dev), factor=128).cpu()
+    torch.manual_seed(11)
+    with torch.no_grad():
+        yo_full = O.uformer_forward(P, sq, img_size=128, mask=1 - mask)
+        yo = torch.masked_select(yo_full, mask.bool()).reshape(1, 3, 100, 150)
+    assert y.shape == (1, 3, 100, 150)
+    assert torch.allclose(y, yo, atol=2e-4, rtol=1e-3), (y - yo).abs().max()
+    # the mask matters: without it the padded border leaks into the windows that straddle it
+    torch.manual_seed(11)
+    with torch.no_grad():
+        y_nomask = torch.masked_select(model(sq.to(dev)).cpu(), mask.bool()).reshape(1, 3, 100, 150)
+    assert (y_nomask - yo).abs().max() > 10 * (y - yo).abs().max()
+
+
+def test_any_resolution_driver_synthetic():
+    import test_in_any_resolution as TA
+    torch.manual_seed(6)
+    p1, s1, p2, s2 = TA.main(["--synthetic", "1", "--height", "90", "--width", "140"])
+    assert np.isfinite([p1, s1, p2, s2]).all() and abs(p1 - p2) < 1e-3       # same clamp, same MAX_I = 1
