@@ -34,6 +34,18 @@ def test_argument_validation_without_gpu():
     assert rc == -22 and b"null pointer" in lib.dhz_last_error()
     rc = lib.dhz_ps_attn_fwd(8, 8, 8, 32, 8, None, None, 8, 32, 8, 1, 1, 1, 48, None)
     assert rc == -22 and b"head_dim" in lib.dhz_last_error()
+    # the convolution / loss / feed entry points: shape contracts are checked before the launch too
+    assert lib.dhz_winograd_conv3x3(8, 8, None, 0, None, None, 8, 2, 24, 32, 64, 64, None) == -22     # H % 16 != 0
+    assert b"unsupported shape" in lib.dhz_last_error()
+    assert lib.dhz_winograd_conv3x3(8, 8, 8, 1, 8, None, 8, 2, 32, 32, 64, 64, None) == -22           # bias/relu with out_mask
+    assert b"exclusive" in lib.dhz_last_error()
+    assert lib.dhz_winograd_prepack(8, 8, 48, 64, 0, None) == -22                                     # Kout % 32 != 0
+    assert lib.dhz_maxpool2x2_blocked_fwd(8, 8, 4, 15, 16, None) == -22
+    assert lib.dhz_thin_conv3x3_fwd(8, 8, None, 8, 1, 16, 16, 32, None) == -22 and b"C=32 unsupported" in lib.dhz_last_error()
+    assert lib.dhz_thin_conv3x3_wgrad(8, 8, None, None, 1, 16, 16, 64, None) == -22
+    assert lib.dhz_l1_pair_fwd(8, 8, None, 8, 10, None) == -22 and b"multiple of 4" in lib.dhz_last_error()
+    assert lib.dhz_crop_augment_pair(8, 8, 8, 8, 8, 4, 16, 16, 32, None) == -22 and b"bad sizes" in lib.dhz_last_error()
+    assert lib.dhz_linear_wgrad(8, 32, 8, 32, 100, 32, 32, 8, None, None) == -22                      # T % 32 != 0
 
 
 @pytest.mark.parametrize("modname,gname", [("My_model_1", "full_m1_e32"), ("My_model", "full_m0_e32")])
