@@ -105,6 +105,13 @@ def test_my_train_on_png_tree(tmp_path):
     assert os.path.exists(os.path.join(models, "epoch_model_1.pth"))
     sd = torch.load(os.path.join(models, "epoch_model_1.pth"), map_location="cpu")
     assert all(k.startswith("module.") for k in sd["state_dict"]) and sd["epoch"] == 1
+    # the evaluation driver loads that checkpoint ('module.' prefix stripped) and scores the validation tree
+    cmd = [sys.executable, os.path.join(PKG, "test_long_GPU.py"), "--input_dir", str(tmp_path / "val"), "--result_dir",
+           str(tmp_path / "res"), "--weights", os.path.join(models, "epoch_model_1.pth"), "--train_ps", "128"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "Testing using weights" in r.stdout and "PSNR:" in r.stdout
+    assert sorted(os.listdir(tmp_path / "res")) == ["1_1.png", "2_1.png"]
 
 
 def test_any_resolution_mask_path_vs_oracle():
