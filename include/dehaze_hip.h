@@ -135,7 +135,8 @@ int dhz_winograd_conv3x3(const float* x, const float* upack, const float* bias, 
                          const float* out_addend, float* y, int B, int H, int W, int C, int K, void* stream);
 int dhz_maxpool2x2_blocked_fwd(const float* x, float* y, int N, int H, int W, void* stream);
 int dhz_maxpool2x2_blocked_bwd(const float* gy, const float* act, float* gx, int N, int H, int W, void* stream);
-int dhz_layout_blocked8(const float* src, float* dst, int B, int C, int HW, int to_blocked, void* stream);
+int dhz_layout_blocked8(const float* src, float* dst, int B, int C, int HW, int to_blocked, const float* bias, int relu,
+                        void* stream);   /* towards the blocked layout optionally dst = max(src + bias[c], 0) */
 
 /* K9b  output projection (My_model_1.py:696-723): Conv2d(C -> 3, 3x3, pad 1) from tokens x[B, H*W, C] to an NCHW image
  *      y[B, 3, H, W] (+ bias[3], may be NULL); backward-data dx[B, H*W, C] from dy[B, 3, H, W]; weight / bias gradient

@@ -364,9 +364,10 @@ __global__ void winograd_prepack_kernel(const float* __restrict__ wgt, float* __
     }
 }
 
-// NCHW <-> NCHW8c (blocked) layout conversion
+// NCHW <-> NCHW8c (blocked) layout conversion; towards the blocked layout optionally y = max(x + bias[c], 0) (the bias + ReLU
+// behind the library convolution that feeds the stack: two elementwise passes over the largest map saved)
 __global__ void nchw_to_blocked_kernel(const float* __restrict__ src, float* __restrict__ dst, int B, int C, int HW,
-                                       int to_blocked) {
+                                       int to_blocked, const float* __restrict__ bias, int relu) {
     const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t total = (size_t)B * C * HW;
     if (e >= total) return;
@@ -377,7 +378,14 @@ __global__ void nchw_to_blocked_kernel(const float* __restrict__ src, float* __r
     const size_t r2 = rest / HW;
     const int cg = r2 % (C / 8), b = r2 / (C / 8);
     const size_t plain = ((size_t)b * C + cg * 8 + c8) * HW + hw;
-    if (to_blocked) dst[e] = src[plain]; else dst[plain] = src[e];
+    if (to_blocked) {
+        float v = src[plain];
+        if (bias) v += bias[cg * 8 + c8];
+        if (relu) v = fmaxf(v, 0.f);
+        dst[e] = v;
+    } else {
+        dst[plain] = src[e];
+    }
 }
 
 // 2x2 / stride 2 max pooling in the blocked layout ([n = b * C/8][h][w][8]); one thread = 4 channels of one pooled pixel.
@@ -469,11 +477,13 @@ extern "C" int dhz_winograd_conv3x3(const float* x, const float* upack, const fl
     return DHZ_OK;
 }
 
-extern "C" int dhz_layout_blocked8(const float* src, float* dst, int B, int C, int HW, int to_blocked, void* stream) {
+extern "C" int dhz_layout_blocked8(const float* src, float* dst, int B, int C, int HW, int to_blocked, const float* bias,
+                                   int relu, void* stream) {
     DHZ_REQUIRE(src && dst && C % 8 == 0 && B > 0 && HW > 0, "dhz_layout_blocked8: bad arguments");
+    DHZ_REQUIRE(to_blocked || !(bias || relu), "dhz_layout_blocked8: bias / relu only towards the blocked layout");
     const size_t n = (size_t)B * C * HW;
     hipLaunchKernelGGL(nchw_to_blocked_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src,
-                       dst, B, C, HW, to_blocked);
+                       dst, B, C, HW, to_blocked, bias, relu);
     DHZ_CHECK_LAUNCH("dhz_layout_blocked8");
     return DHZ_OK;
 }

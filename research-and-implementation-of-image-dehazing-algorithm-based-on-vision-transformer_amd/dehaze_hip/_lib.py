@@ -40,7 +40,7 @@ SIGNATURES = {
     "dhz_winograd_conv3x3": [c_f, c_f, c_f, c_i, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_p],
     "dhz_maxpool2x2_blocked_fwd": [c_f, c_f, c_i, c_i, c_i, c_p],
     "dhz_maxpool2x2_blocked_bwd": [c_f, c_f, c_f, c_i, c_i, c_i, c_p],
-    "dhz_layout_blocked8": [c_f, c_f, c_i, c_i, c_i, c_i, c_p],
+    "dhz_layout_blocked8": [c_f, c_f, c_i, c_i, c_i, c_i, c_f, c_i, c_p],
     "dhz_linear_wgrad": [c_f, c_i, c_f, c_i, c_i, c_i, c_i, c_f, c_f, c_p],
     "dhz_ln_partition_fwd": [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
     "dhz_ln_partition_bwd": [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_p],

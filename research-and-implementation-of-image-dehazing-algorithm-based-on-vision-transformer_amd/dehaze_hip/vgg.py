@@ -23,17 +23,18 @@ POOL_AFTER = (1, 3, 7, 11)
 TAPS = (0, 2, 4, 8, 12)          # relu1_1, relu2_1, relu3_1, relu4_1, relu5_1
 
 
-def to_blocked(x):
+def to_blocked(x, bias=None, relu=False):
+    """NCHW -> NCHW8c; optionally max(x + bias[c], 0) on the way (the bias + ReLU behind a library convolution)."""
     B, C, H, W = x.shape
     out = torch.empty((B, C // 8, H, W, 8), device=x.device, dtype=torch.float32)
-    _lib.call("dhz_layout_blocked8", _p(x.contiguous()), _p(out), B, C, H * W, 1, _stream())
+    _lib.call("dhz_layout_blocked8", _p(x.contiguous()), _p(out), B, C, H * W, 1, _p(bias), int(relu), _stream())
     return out
 
 
 def to_plain(xb):
     B, CG, H, W, _ = xb.shape
     out = torch.empty((B, CG * 8, H, W), device=xb.device, dtype=torch.float32)
-    _lib.call("dhz_layout_blocked8", _p(xb), _p(out), B, CG * 8, H * W, 0, _stream())
+    _lib.call("dhz_layout_blocked8", _p(xb), _p(out), B, CG * 8, H * W, 0, None, 0, _stream())
     return out
 
 
@@ -119,8 +120,7 @@ class VggEngine:
         """x: [B,3,H,W] NCHW.  Returns the 5 tap features: taps 1-4 blocked [B,C/8,H,W,8], tap 5 NCHW.
         `save` (dict) receives what the backward needs."""
         c0, c12 = self.convs[0], self.convs[12]
-        a0 = F.relu(F.conv2d(x, c0.weight, c0.bias, padding=1))
-        cur = to_blocked(a0)
+        cur = to_blocked(F.conv2d(x, c0.weight, None, padding=1), c0.bias, relu=True)      # bias + ReLU ride on the layout change
         acts = {0: cur}
         taps = [cur]
         for i in range(1, 12):
@@ -134,7 +134,7 @@ class VggEngine:
         a12 = F.relu(F.conv2d(x12, c12.weight, c12.bias, padding=1))
         taps.append(a12)
         if save is not None:
-            save.update(x=x, a0=a0, acts=acts, x12=x12, a12=a12)
+            save.update(x=x, acts=acts, x12=x12, a12=a12)
         return taps
 
 

@@ -11,7 +11,7 @@ def _blocked(x):
     from dehaze_hip import _lib
     B, C, H, W = x.shape
     out = torch.empty(B, C // 8, H, W, 8, device=x.device)
-    _lib.call("dhz_layout_blocked8", x.contiguous().data_ptr(), out.data_ptr(), B, C, H * W, 1, torch.cuda.current_stream().cuda_stream)
+    _lib.call("dhz_layout_blocked8", x.contiguous().data_ptr(), out.data_ptr(), B, C, H * W, 1, None, 0, torch.cuda.current_stream().cuda_stream)
     return out
 
 
@@ -19,7 +19,7 @@ def _plain(xb, C):
     from dehaze_hip import _lib
     B, CG, H, W, _ = xb.shape
     out = torch.empty(B, C, H, W, device=xb.device)
-    _lib.call("dhz_layout_blocked8", xb.data_ptr(), out.data_ptr(), B, C, H * W, 0, torch.cuda.current_stream().cuda_stream)
+    _lib.call("dhz_layout_blocked8", xb.data_ptr(), out.data_ptr(), B, C, H * W, 0, None, 0, torch.cuda.current_stream().cuda_stream)
     return out
 
 
