@@ -29,22 +29,29 @@ struct ThinSmem {
     float part[2][3][TH * TW];                 // forward: per channel-half partial sums
 };
 
-// stage the 10 x 18 token halo tile (zero outside the image)
-template <int C>
+// stage the 10 x 18 halo tile (zero outside the image) of a token tensor [B, H*W, C] or (BLOCKED) of a channel-blocked
+// NCHW8c map [B, C/8, H, W, 8] (the layout of the VGG feature engine)
+template <int C, bool BLOCKED = false>
 __device__ __forceinline__ void stage_tokens(float* xs, const float* __restrict__ x, int bimg, int ty, int tx, int H, int W) {
     constexpr int XS = C + 4, C4 = C / 4;
     const int t = threadIdx.x;
     const size_t ib = (size_t)bimg * H * W;
     for (int e = t; e < NPOS * C4; e += 256) {
-        const int pos = e / C4, c4 = e % C4;
+        const int pos = BLOCKED ? e % NPOS : e / C4, c4 = BLOCKED ? e / NPOS : e % C4;     // consecutive lanes walk the contiguous axis
         const int yy = ty * TH - 1 + pos / HW_, xx = tx * TW - 1 + pos % HW_;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (yy >= 0 && yy < H && xx >= 0 && xx < W) v = *reinterpret_cast<const f32x4*>(x + (ib + (size_t)yy * W + xx) * C + c4 * 4);
+        if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
+            const size_t o = BLOCKED ? (((size_t)bimg * (C / 8) + c4 / 2) * H * W + (size_t)yy * W + xx) * 8 + (c4 & 1) * 4
+                                     : (ib + (size_t)yy * W + xx) * C + c4 * 4;
+            v = *reinterpret_cast<const f32x4*>(x + o);
+        }
         *reinterpret_cast<f32x4*>(&xs[pos * XS + c4 * 4]) = v;
     }
 }
 
-template <int C>
+// TRANSPOSED: w is a [C, 3, 3, 3] tensor (a 3 -> C convolution's weight) and the kernel computes that layer's
+// backward-data: y[b, o, p] = sum_{c, ky, kx} w[c][o][2 - ky][2 - kx] x[b, c, p + (ky - 1, kx - 1)]
+template <int C, bool BLOCKED, bool TRANSPOSED>
 __global__ __launch_bounds__(256) void thin_conv_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                             const float* __restrict__ bias, float* __restrict__ y, int H,
                                                             int W, int tiles_x, int tiles_y) {
@@ -55,10 +62,12 @@ __global__ __launch_bounds__(256) void thin_conv_fwd_kernel(const float* __restr
     const int tx = blockIdx.x % tiles_x, ty = (blockIdx.x / tiles_x) % tiles_y, bimg = blockIdx.x / (tiles_x * tiles_y);
     // weights -> LDS in (channel quad, tap, output, channel % 4) order: w[o][c][tap] -> sm.w[((c/4 * 9 + tap) * 3 + o) * 4 + c%4]
     for (int e = t; e < 27 * C; e += 256) {
-        const int o = e / (9 * C), c = (e / 9) % C, tap = e % 9;
+        int o, c, tap;
+        if (TRANSPOSED) { c = e / 27; o = (e / 9) % 3; tap = 8 - e % 9; }      // w[c][o][ky][kx] acts at tap (2-ky, 2-kx)
+        else { o = e / (9 * C); c = (e / 9) % C; tap = e % 9; }
         sm.w[((c / 4 * 9 + tap) * 3 + o) * 4 + (c & 3)] = w[e];
     }
-    stage_tokens<C>(sm.x, x, bimg, ty, tx, H, W);
+    stage_tokens<C, BLOCKED>(sm.x, x, bimg, ty, tx, H, W);
     __syncthreads();
     const int half = t >> 7, pix = t & 127;
     const int py = pix / TW, px = pix % TW;
@@ -198,8 +207,8 @@ int launch_all(int which, const float* a, const float* b, const float* c, float*
     const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH, ntiles = B * tiles_x * tiles_y;
     const size_t smem = sizeof(ThinSmem<C>);
     if (which == 0) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&thin_conv_fwd_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        hipLaunchKernelGGL((thin_conv_fwd_kernel<C>), dim3(ntiles), dim3(256), smem, s, a, b, c, d, H, W, tiles_x, tiles_y);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&thin_conv_fwd_kernel<C, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        hipLaunchKernelGGL((thin_conv_fwd_kernel<C, false, false>), dim3(ntiles), dim3(256), smem, s, a, b, c, d, H, W, tiles_x, tiles_y);
     } else if (which == 1) {
         hipLaunchKernelGGL((thin_conv_dgrad_kernel<C>), dim3(ntiles), dim3(256), 0, s, a, b, d, H, W, tiles_x, tiles_y);
     } else {
@@ -241,5 +250,19 @@ extern "C" int dhz_thin_conv3x3_wgrad(const float* dy, const float* x, float* dw
     DHZ_REQUIRE(C == 64 || C == 128, "dhz_thin_conv3x3_wgrad: C=%d unsupported (64, 128)", C);
     dispatch(2, C, dy, x, nullptr, dw, db, B, H, W, (hipStream_t)stream);
     DHZ_CHECK_LAUNCH("dhz_thin_conv3x3_wgrad");
+    return DHZ_OK;
+}
+
+extern "C" int dhz_thin_conv3x3_dgrad_blocked(const float* gb, const float* w, float* dx, int B, int H, int W, int C,
+                                              void* stream) {
+    DHZ_REQUIRE(gb && w && dx && B > 0 && H > 0 && W > 0, "dhz_thin_conv3x3_dgrad_blocked: bad arguments");
+    DHZ_REQUIRE(C == 64, "dhz_thin_conv3x3_dgrad_blocked: C=%d unsupported (64)", C);
+    const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH, ntiles = B * tiles_x * tiles_y;
+    const size_t smem = sizeof(ThinSmem<64>);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&thin_conv_fwd_kernel<64, true, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipLaunchKernelGGL((thin_conv_fwd_kernel<64, true, true>), dim3(ntiles), dim3(256), smem, (hipStream_t)stream, gb, w, nullptr,
+                       dx, H, W, tiles_x, tiles_y);
+    DHZ_CHECK_LAUNCH("dhz_thin_conv3x3_dgrad_blocked");
     return DHZ_OK;
 }

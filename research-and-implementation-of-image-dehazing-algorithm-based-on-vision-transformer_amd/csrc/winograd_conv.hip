@@ -388,6 +388,47 @@ __global__ void nchw_to_blocked_kernel(const float* __restrict__ src, float* __r
     }
 }
 
+// the same conversion for HW % 4 == 0: one thread = 4 pixels x 8 channels, so that both sides move 16-byte vectors and a
+// wave touches 1 KB runs of every plane (the scalar kernel above reads 32-byte runs: 2.4 TB/s on the 268 MB first VGG map)
+__global__ __launch_bounds__(256) void nchw_to_blocked_vec_kernel(const float* __restrict__ src, float* __restrict__ dst, int C,
+                                                                  int HW, size_t total, int to_blocked,
+                                                                  const float* __restrict__ bias, int relu) {
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;          // over [b][c/8][hw/4]
+    if (e >= total) return;
+    const int HW4 = HW / 4;
+    const int q = e % HW4;
+    const size_t r2 = e / HW4;
+    const int cg = r2 % (C / 8);
+    const size_t b = r2 / (C / 8);
+    const size_t pbase = (b * C + cg * 8) * HW + 4 * q;                      // plain: channel c at pbase + c * HW
+    const size_t bbase = ((b * (C / 8) + cg) * HW + 4 * q) * 8;              // blocked: pixel p at bbase + 8 p
+    f32x4 v[8];
+    if (to_blocked) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            v[c] = *reinterpret_cast<const f32x4*>(src + pbase + (size_t)c * HW);
+            if (bias) { const float bc = bias[cg * 8 + c]; v[c][0] += bc; v[c][1] += bc; v[c][2] += bc; v[c][3] += bc; }
+            if (relu) { v[c][0] = fmaxf(v[c][0], 0.f); v[c][1] = fmaxf(v[c][1], 0.f); v[c][2] = fmaxf(v[c][2], 0.f); v[c][3] = fmaxf(v[c][3], 0.f); }
+        }
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            *reinterpret_cast<f32x4*>(dst + bbase + 8 * p) = f32x4{v[0][p], v[1][p], v[2][p], v[3][p]};
+            *reinterpret_cast<f32x4*>(dst + bbase + 8 * p + 4) = f32x4{v[4][p], v[5][p], v[6][p], v[7][p]};
+        }
+    } else {
+        f32x4 u[8];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            u[2 * p] = *reinterpret_cast<const f32x4*>(src + bbase + 8 * p);
+            u[2 * p + 1] = *reinterpret_cast<const f32x4*>(src + bbase + 8 * p + 4);
+        }
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+            *reinterpret_cast<f32x4*>(dst + pbase + (size_t)c * HW) =
+                f32x4{u[(c >> 2)][c & 3], u[2 + (c >> 2)][c & 3], u[4 + (c >> 2)][c & 3], u[6 + (c >> 2)][c & 3]};
+    }
+}
+
 // 2x2 / stride 2 max pooling in the blocked layout ([n = b * C/8][h][w][8]); one thread = 4 channels of one pooled pixel.
 __global__ void maxpool2x2_blocked_fwd_kernel(const float4* __restrict__ x, float4* __restrict__ y, size_t total, int Ho,
                                               int Wo) {
@@ -482,8 +523,14 @@ extern "C" int dhz_layout_blocked8(const float* src, float* dst, int B, int C, i
     DHZ_REQUIRE(src && dst && C % 8 == 0 && B > 0 && HW > 0, "dhz_layout_blocked8: bad arguments");
     DHZ_REQUIRE(to_blocked || !(bias || relu), "dhz_layout_blocked8: bias / relu only towards the blocked layout");
     const size_t n = (size_t)B * C * HW;
-    hipLaunchKernelGGL(nchw_to_blocked_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src,
-                       dst, B, C, HW, to_blocked, bias, relu);
+    if (HW % 4 == 0) {
+        const size_t total = n / 32;
+        hipLaunchKernelGGL(nchw_to_blocked_vec_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                           src, dst, C, HW, total, to_blocked, bias, relu);
+    } else {
+        hipLaunchKernelGGL(nchw_to_blocked_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src,
+                           dst, B, C, HW, to_blocked, bias, relu);
+    }
     DHZ_CHECK_LAUNCH("dhz_layout_blocked8");
     return DHZ_OK;
 }

@@ -176,8 +176,11 @@ class _VggTaps(Function):
                     G = eng.conv_dgrad(i, G, below_act=acts[below], addend=tg)
             if G is None:
                 return None, None
-            gx = torch.ops.aten.convolution_backward(to_plain(G), sv["x"], c0.weight, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
-                                                     [True, False, False])[0]
+            # first layer (3 -> 64): its backward-data is a thin 64 -> 3 convolution - straight from the blocked gradient
+            x0 = sv["x"]
+            gx = torch.empty_like(x0, memory_format=torch.contiguous_format)
+            _lib.call("dhz_thin_conv3x3_dgrad_blocked", _p(G.contiguous()), _p(c0.weight.contiguous()), _p(gx), x0.shape[0],
+                      x0.shape[2], x0.shape[3], 64, _stream())
         ctx.saved = None
         return None, gx
 

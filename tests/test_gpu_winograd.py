@@ -141,3 +141,18 @@ def test_vgg_engine_backward_smooth_loss():
     ref = a64.grad.float()
     err = (ad.grad.cpu() - ref).abs().max().item()
     assert err < 2e-4 * ref.abs().max().item(), (err, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("B,C,H,W", [(2, 16, 8, 8), (1, 8, 7, 7), (3, 64, 12, 20)])
+def test_layout_conversion_with_bias_relu(B, C, H, W):
+    """NCHW <-> NCHW8c (vector kernel for H*W % 4 == 0, scalar otherwise), with the optional bias + ReLU on the way in."""
+    from dehaze_hip import vgg as V
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(C + H)
+    x = torch.randn(B, C, H, W, generator=g).to(dev)
+    b = torch.randn(C, generator=g).to(dev)
+    xb = V.to_blocked(x)
+    assert torch.equal(xb, x.view(B, C // 8, 8, H, W).permute(0, 1, 3, 4, 2))
+    assert torch.equal(V.to_plain(xb), x)
+    yb = V.to_blocked(x, b, relu=True)
+    assert torch.equal(V.to_plain(yb), torch.relu(x + b.view(1, C, 1, 1)))
