@@ -90,15 +90,26 @@ def test_two_rank_step_equals_full_batch_step(tmp_path):
     del model, opt
     torch.cuda.empty_cache()
     ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, ref_path, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    res = sorted([q.get(timeout=500) for _ in range(2)], key=lambda t: t[0])
-    for p in procs:
-        p.join(120)
-        assert p.exitcode == 0
+    res = None
+    for attempt in range(2):            # one retry for rendezvous / start-up hiccups of the two-process launch on a fresh box
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=_worker, args=(r, 2, port, ref_path, q)) for r in range(2)]
+        for p in procs:
+            p.start()
+        try:
+            got = sorted([q.get(timeout=400) for _ in range(2)], key=lambda t: t[0])
+        except Exception as exc:        # queue.Empty: a worker died or hung before reporting
+            got = None
+            print("two-rank launch attempt", attempt, "failed:", repr(exc))
+        for p in procs:
+            p.join(60)
+            if p.is_alive():
+                p.kill()
+        if got is not None and all(p.exitcode == 0 for p in procs):
+            res = got
+            break
+    assert res is not None, "the two-rank run did not complete"
     assert abs(0.5 * (res[0][1] + res[1][1]) - loss_full) < 1e-5        # mean of the half-batch losses
     for rank, _, gerr, perr, nb, worst in res:
         assert nb >= 10
