@@ -99,6 +99,8 @@ def main():
     from dehaze_hip import ops
     from dehaze_hip.train import FlatAdamW, GradReducer, synthetic_batch, train_step
 
+    from dehaze_hip.tuning import enable_tuned_gemms
+    tuned = enable_tuned_gemms()                  # recorded hipBLASLt solution per GEMM shape (kernel selection only)
     torch.manual_seed(1234)                       # identical replicas on every rank
     model = M1.Uformer(img_size=args.ps, embed_dim=args.embed_dim, win_size=8, token_projection='linear',
                        token_mlp='leff').to(dev)
@@ -148,7 +150,7 @@ def main():
             "config": {"workload": f"Uformer_ProbSparse train step E={args.embed_dim} ps={args.ps} per-GPU bs={args.batch} "
                                    f"fp32 {'Charbonnier' if args.no_cr else 'Charbonnier+CR(VGG19, seeded-random weights)'} "
                                    "+ AdamW (BASELINE configs[1])",
-                       "global_batch": args.batch * world, "parallelism": f"dp{world}",
+                       "global_batch": args.batch * world, "parallelism": f"dp{world}", "tuned_gemm_selection": bool(tuned),
                        "loss_last_step": round(float(loss), 6)},
         }
         pmc = {}

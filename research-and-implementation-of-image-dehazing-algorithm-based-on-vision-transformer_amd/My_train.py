@@ -70,6 +70,8 @@ def main():
         utils.mkdir(result_dir)
         utils.mkdir(model_dir)
 
+    from dehaze_hip.tuning import enable_tuned_gemms
+    enable_tuned_gemms()                          # recorded hipBLASLt solution per GEMM shape (MI355X; ignored elsewhere)
     random.seed(1234)
     np.random.seed(1234)
     torch.manual_seed(1234)
