@@ -595,7 +595,7 @@ extern "C" int dhz_leff_dwconv_bwd(const float* dz, const float* u, const float*
     DHZ_REQUIRE(B > 0 && Hres > 0 && Wres > 0 && Ch % CT == 0, "dhz_leff_dwconv_bwd: Ch=%d must be a multiple of %d", Ch, CT);
     const int tiles_x = (Wres + TW - 1) / TW, tiles_y = (Hres + TH - 1) / TH;
     const int ntiles = B * tiles_x * tiles_y, ncg = Ch / CT;
-    int wg_per_cg = 1536 / ncg;
+    int wg_per_cg = 768 / ncg;                     // one resident round: 3 workgroups per CU (LDS), persistent over tiles
     if (wg_per_cg < 1) wg_per_cg = 1;
     if (wg_per_cg > ntiles) wg_per_cg = ntiles;
     hipLaunchKernelGGL(leff_dwconv_bwd_kernel, dim3(wg_per_cg * ncg), dim3(256), 0, (hipStream_t)stream, dz, u, t, w, du,
