@@ -637,7 +637,7 @@ extern "C" int dhz_adamw_step(float* p, const float* g, float* m, float* v, int6
 
 extern "C" int dhz_l1_pair_fwd(const float* a, const float* p, const float* n, float* sums, int64_t count, void* stream) {
     DHZ_REQUIRE(a && p && sums && count > 0 && count % 4 == 0, "dhz_l1_pair_fwd: bad arguments (count must be a multiple of 4)");
-    hipLaunchKernelGGL(l1_pair_fwd_kernel, dim3(grid_for(count / 4, 256, 2048)), dim3(256), 0, (hipStream_t)stream, a, p, n, sums,
+    hipLaunchKernelGGL(l1_pair_fwd_kernel, dim3(grid_for(count / 4, 256, 768)), dim3(256), 0, (hipStream_t)stream, a, p, n, sums,
                        count / 4);
     DHZ_CHECK_LAUNCH("dhz_l1_pair_fwd");
     return DHZ_OK;
