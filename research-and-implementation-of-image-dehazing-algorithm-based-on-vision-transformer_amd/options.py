@@ -1,10 +1,34 @@
 """Drop-in for Uformer_ProbSparse/options.py: same flags and defaults (options.py:13-73) and the module
 level ablation switch `is_relative_position_bias` (options.py:5) that the attention reads at call time
-(ATT:227).  Paths that were machine-specific in the reference default to relative locations."""
-import os  # noqa: F401
+(ATT:227).  Paths that were machine-specific in the reference default to relative locations.
 
-######## Ablation Study ########
-is_relative_position_bias = True
+The flag set is data: (name, type or 'switch', default).  tests/test_host.py checks names and defaults against the
+reference's own parser (tests/golden/options.npz)."""
+
+is_relative_position_bias = True          # ablation switch: relative position bias inside the window attention
+
+SWITCH = 'switch'                         # argparse store_true flag, default False
+
+_FLAGS = (
+    # loss mix ('is_ab' keeps the reference quirk: type=bool, so any non-empty string parses as True)
+    ('is_ab', bool, False), ('w_loss_vgg7', float, 1), ('w_loss_CharbonnierLoss', float, 1),
+    # run
+    ('batch_size', int, 32), ('nepoch', int, 250), ('train_workers', int, 12), ('eval_workers', int, 8),
+    ('dataset', str, 'Dense-HAZE'), ('pretrain_weights', str, './log/UformerResave_all_My_Infor_CR/models/model_best.pth'),
+    ('optimizer', str, 'adamw'), ('lr_initial', float, 0.0002), ('weight_decay', float, 0.02), ('gpu', str, '0,1'),
+    ('arch', str, 'Uformer'), ('mode', str, 'denoising'),
+    # output
+    ('save_dir', str, '/home/ma-user/work/deNoTr/log'), ('save_images', SWITCH, False), ('env', str, '_'), ('checkpoint', int, 50),
+    # network
+    ('norm_layer', str, 'nn.LayerNorm'), ('embed_dim', int, 32), ('win_size', int, 8), ('token_projection', str, 'linear'),
+    ('token_mlp', str, 'leff'), ('att_se', SWITCH, False),
+    # ViT bottleneck flags: unused by the Uformer path, kept so that reference command lines still parse
+    ('vit_dim', int, 256), ('vit_depth', int, 12), ('vit_nheads', int, 8), ('vit_mlp_dim', int, 512), ('vit_patch_size', int, 16),
+    ('global_skip', SWITCH, False), ('local_skip', SWITCH, False), ('vit_share', SWITCH, False),
+    # training data / schedule
+    ('train_ps', int, 128), ('resume', SWITCH, False), ('train_dir', str, '../datasets/SIDD/train'),
+    ('val_dir', str, '../datasets/SIDD/val'), ('warmup', SWITCH, False), ('warmup_epochs', int, 3),
+)
 
 
 class Options():
@@ -12,51 +36,9 @@ class Options():
         pass
 
     def init(self, parser):
-        add = parser.add_argument
-        # loss mix
-        add('--is_ab', type=bool, default=False)            # reference quirk kept: any non-empty string is True
-        add('--w_loss_vgg7', type=float, default=1)
-        add('--w_loss_CharbonnierLoss', type=float, default=1)
-        # global settings
-        add('--batch_size', type=int, default=32, help='batch size')
-        add('--nepoch', type=int, default=250, help='training epochs')
-        add('--train_workers', type=int, default=12, help='train_dataloader workers')
-        add('--eval_workers', type=int, default=8, help='eval_dataloader workers')
-        add('--dataset', type=str, default='Dense-HAZE')
-        add('--pretrain_weights', type=str, default='./log/UformerResave_all_My_Infor_CR/models/model_best.pth',
-            help='path of pretrained_weights')
-        add('--optimizer', type=str, default='adamw', help='optimizer for training')
-        add('--lr_initial', type=float, default=0.0002, help='initial learning rate')
-        add('--weight_decay', type=float, default=0.02, help='weight decay')
-        add('--gpu', type=str, default='0,1', help='GPUs')
-        add('--arch', type=str, default='Uformer', help='archtechture')
-        add('--mode', type=str, default='denoising', help='image restoration mode')
-        # saving
-        add('--save_dir', type=str, default='/home/ma-user/work/deNoTr/log', help='save dir')
-        add('--save_images', action='store_true', default=False)
-        add('--env', type=str, default='_', help='env')
-        add('--checkpoint', type=int, default=50, help='checkpoint')
-        # Uformer
-        add('--norm_layer', type=str, default='nn.LayerNorm', help='normalize layer in transformer')
-        add('--embed_dim', type=int, default=32, help='dim of emdeding features')
-        add('--win_size', type=int, default=8, help='window size of self-attention')
-        add('--token_projection', type=str, default='linear', help='linear/convoptimizer token projection')
-        add('--token_mlp', type=str, default='leff', help='ffn/leff token mlp')
-        add('--att_se', action='store_true', default=False, help='se after sa')
-        # vit (unused by the Uformer path; kept so reference command lines still parse)
-        add('--vit_dim', type=int, default=256, help='vit hidden_dim')
-        add('--vit_depth', type=int, default=12, help='vit depth')
-        add('--vit_nheads', type=int, default=8, help='vit hidden_dim')
-        add('--vit_mlp_dim', type=int, default=512, help='vit mlp_dim')
-        add('--vit_patch_size', type=int, default=16, help='vit patch_size')
-        add('--global_skip', action='store_true', default=False, help='global skip connection')
-        add('--local_skip', action='store_true', default=False, help='local skip connection')
-        add('--vit_share', action='store_true', default=False, help='share vit module')
-        # training
-        add('--train_ps', type=int, default=128, help='patch size of training sample')
-        add('--resume', action='store_true', default=False)
-        add('--train_dir', type=str, default='../datasets/SIDD/train', help='dir of train data')
-        add('--val_dir', type=str, default='../datasets/SIDD/val', help='dir of train data')
-        add('--warmup', action='store_true', default=False, help='warmup')
-        add('--warmup_epochs', type=int, default=3, help='epochs for warmup')
+        for name, kind, default in _FLAGS:
+            if kind == SWITCH:
+                parser.add_argument('--' + name, action='store_true', default=False)
+            else:
+                parser.add_argument('--' + name, type=kind, default=default)
         return parser

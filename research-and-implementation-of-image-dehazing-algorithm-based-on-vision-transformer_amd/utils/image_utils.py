@@ -9,30 +9,34 @@ import torch
 import torch.nn.functional as F
 
 
+def _has_ext(filename, *exts):
+    return str(filename).endswith(exts)
+
+
 def is_numpy_file(filename):
-    return any(filename.endswith(extension) for extension in [".npy"])
+    return _has_ext(filename, ".npy")
 
 
 def is_image_file(filename):
-    return any(filename.endswith(extension) for extension in [".jpg"])
+    return _has_ext(filename, ".jpg")
 
 
 def is_png_file(filename):
-    return any(filename.endswith(extension) for extension in [".png"])
+    return _has_ext(filename, ".png")
 
 
 def is_pkl_file(filename):
-    return any(filename.endswith(extension) for extension in [".pkl"])
+    return _has_ext(filename, ".pkl")
 
 
 def load_pkl(filename_):
-    with open(filename_, 'rb') as f:
-        return pickle.load(f)
+    with open(filename_, 'rb') as fh:
+        return pickle.load(fh)
 
 
 def save_dict(dict_, filename_):
-    with open(filename_, 'wb') as f:
-        pickle.dump(dict_, f)
+    with open(filename_, 'wb') as fh:
+        pickle.dump(dict_, fh)
 
 
 def load_npy(filepath):
@@ -69,34 +73,36 @@ def batch_PSNR(img1, img2, average=True):
     return sum(vals) / len(vals) if average else sum(vals)
 
 
-# ---- SSIM with an 11x11 Gaussian window, sigma 1.5 (image_utils.py:78-127)
+# ---- SSIM with an 11x11 Gaussian window, sigma 1.5 (image_utils.py:78-127): local moments by depthwise convolution
 def gaussian(window_size, sigma):
-    gauss = torch.tensor([exp(-(x - window_size // 2) ** 2 / float(2 * sigma ** 2)) for x in range(window_size)])
-    return gauss / gauss.sum()
+    x = torch.arange(window_size, dtype=torch.float32) - window_size // 2
+    g = torch.tensor([exp(-float(v) ** 2 / float(2 * sigma ** 2)) for v in x])
+    return g / g.sum()
 
 
 def create_window(window_size, channel):
-    w1 = gaussian(window_size, 1.5).unsqueeze(1)
-    w2 = w1.mm(w1.t()).float().unsqueeze(0).unsqueeze(0)
-    return w2.expand(channel, 1, window_size, window_size).contiguous()
+    g1 = gaussian(window_size, 1.5)
+    g2 = torch.outer(g1, g1).float()
+    return g2.expand(channel, 1, window_size, window_size).contiguous()
+
+
+def _local_mean(t, window, channel):
+    return F.conv2d(t, window, padding=window.shape[-1] // 2, groups=channel)
 
 
 def _ssim(img1, img2, window, window_size, channel, size_average=True):
-    pad = window_size // 2
-    mu1 = F.conv2d(img1, window, padding=pad, groups=channel)
-    mu2 = F.conv2d(img2, window, padding=pad, groups=channel)
-    mu1_sq, mu2_sq, mu1_mu2 = mu1.pow(2), mu2.pow(2), mu1 * mu2
-    sigma1_sq = F.conv2d(img1 * img1, window, padding=pad, groups=channel) - mu1_sq
-    sigma2_sq = F.conv2d(img2 * img2, window, padding=pad, groups=channel) - mu2_sq
-    sigma12 = F.conv2d(img1 * img2, window, padding=pad, groups=channel) - mu1_mu2
-    C1, C2 = 0.01 ** 2, 0.03 ** 2
-    ssim_map = ((2 * mu1_mu2 + C1) * (2 * sigma12 + C2)) / ((mu1_sq + mu2_sq + C1) * (sigma1_sq + sigma2_sq + C2))
-    return ssim_map.mean() if size_average else ssim_map.mean(1).mean(1).mean(1)
+    m1, m2 = _local_mean(img1, window, channel), _local_mean(img2, window, channel)
+    v1 = _local_mean(img1 * img1, window, channel) - m1 * m1
+    v2 = _local_mean(img2 * img2, window, channel) - m2 * m2
+    cov = _local_mean(img1 * img2, window, channel) - m1 * m2
+    c1, c2 = 0.01 ** 2, 0.03 ** 2
+    smap = ((2 * m1 * m2 + c1) * (2 * cov + c2)) / ((m1 * m1 + m2 * m2 + c1) * (v1 + v2 + c2))
+    return smap.mean() if size_average else smap.mean(dim=(1, 2, 3))
 
 
 def SSIM(img1, img2, window_size=11, size_average=True):
-    img1 = torch.clamp(img1, min=0, max=1)
-    img2 = torch.clamp(img2, min=0, max=1)
-    channel = img1.size(1)
-    window = create_window(window_size, channel).to(img1.device).type_as(img1)
-    return _ssim(img1, img2, window, window_size, channel, size_average)
+    """Both images are clamped to [0, 1] first, like the PSNR helpers."""
+    a, b = img1.clamp(0, 1), img2.clamp(0, 1)
+    channel = a.size(1)
+    window = create_window(window_size, channel).to(device=a.device, dtype=a.dtype)
+    return _ssim(a, b, window, window_size, channel, size_average)

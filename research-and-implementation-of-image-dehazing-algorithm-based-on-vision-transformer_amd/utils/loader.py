@@ -1,24 +1,27 @@
-"""Drop-in for Uformer_ProbSparse/utils/loader.py."""
+"""Drop-in for Uformer_ProbSparse/utils/loader.py: the four dataset factories, each guarding that its directory exists."""
 import os
 
-from dataset import DataLoaderTrain, DataLoaderVal, DataLoaderTest, DataLoaderTestSR
+import dataset as _ds
+
+
+def _checked(cls, rgb_dir, *args):
+    if not os.path.exists(rgb_dir):
+        raise AssertionError(f"data directory not found: {rgb_dir}")
+    return cls(rgb_dir, *args, None)
 
 
 def get_training_data(rgb_dir, img_options):
-    assert os.path.exists(rgb_dir)
-    return DataLoaderTrain(rgb_dir, img_options, None)
+    """(clean, noisy, clean_filename, noisy_filename) items with random crop + augmentation."""
+    return _checked(_ds.DataLoaderTrain, rgb_dir, img_options)
 
 
 def get_validation_data(rgb_dir):
-    assert os.path.exists(rgb_dir)
-    return DataLoaderVal(rgb_dir, None)
+    return _checked(_ds.DataLoaderVal, rgb_dir)
 
 
 def get_test_data(rgb_dir):
-    assert os.path.exists(rgb_dir)
-    return DataLoaderTest(rgb_dir, None)
+    return _checked(_ds.DataLoaderTest, rgb_dir)
 
 
 def get_test_data_SR(rgb_dir):
-    assert os.path.exists(rgb_dir)
-    return DataLoaderTestSR(rgb_dir, None)
+    return _checked(_ds.DataLoaderTestSR, rgb_dir)
