@@ -237,3 +237,53 @@ def test_tuned_gemm_selection_numerics(dev):
         torch.cuda.tunable.enable(False)
     assert abs(loss - base_loss) < 2e-6
     assert float(((gn - base_gn).abs() / (base_gn + 1e-6)).max()) < 2e-3
+
+
+def test_full_size_batch_independence(dev):
+    """BASELINE config 2's size (32 x 128 x 128, E = 32), where the oracle is too slow to be the checker: every patch is
+    independent of its batch neighbours (LayerNorm only, per-window attention, one sampled-key table per block shared by
+    all windows), so a patch restored inside the full batch must equal the same patch restored alone - any indexing slip
+    in the window / token / batch arithmetic of the kernels at full size breaks this."""
+    import My_model_1 as M1
+    seed_all(1234)
+    model = M1.Uformer(img_size=128, embed_dim=32, win_size=8, token_projection='linear', token_mlp='leff').to(dev).eval()
+    g = torch.Generator().manual_seed(17)
+    x = torch.rand(32, 3, 128, 128, generator=g).to(dev)
+    with torch.no_grad():
+        torch.manual_seed(5)
+        y = model(x)
+        for i in (0, 13, 31):
+            torch.manual_seed(5)                       # same 18 sampled-key tables
+            yi = model(x[i:i + 1])
+            assert torch.allclose(y[i:i + 1], yi, atol=2e-5, rtol=1e-4), (i, (y[i:i + 1] - yi).abs().max().item())
+    assert torch.isfinite(y).all() and y.shape == (32, 3, 128, 128)
+
+
+def test_full_size_gradient_linearity(dev):
+    """Same size: the Charbonnier loss is a mean over patches, so the gradient of the 32-patch batch equals the mean of the
+    gradients of its two 16-patch halves (DropPath off, same sampled-key tables) - checks the backward kernels, the in-place
+    weight-gradient accumulation and the flat gradient buffer at the benchmark's size without the CPU oracle."""
+    import My_model_1 as M1
+    from dehaze_hip.train import FlatAdamW
+    from losses import CharbonnierLoss
+    seed_all(1234)
+    model = M1.Uformer(img_size=128, embed_dim=32, win_size=8, token_projection='linear', token_mlp='leff',
+                       drop_path_rate=0.).to(dev).train()
+    opt = FlatAdamW(model, lr=2e-4)
+    g = torch.Generator().manual_seed(23)
+    gt = torch.rand(32, 3, 128, 128, generator=g).to(dev)
+    hazy = (0.5 * gt + 0.5 * torch.rand(32, 1, 1, 1, generator=g).to(dev)).clamp(0, 1)
+
+    def grad_of(sl):
+        opt.zero_grad()
+        torch.manual_seed(9)
+        loss, _ = CharbonnierLoss().forward_clamped(model(hazy[sl]), gt[sl])
+        loss.backward()
+        return opt.flat_grad.clone(), loss.item()
+
+    g_full, l_full = grad_of(slice(0, 32))
+    g_a, l_a = grad_of(slice(0, 16))
+    g_b, l_b = grad_of(slice(16, 32))
+    assert abs(l_full - 0.5 * (l_a + l_b)) < 1e-6
+    err = (g_full - 0.5 * (g_a + g_b)).abs().max().item()
+    assert err < 2e-4 * g_full.abs().max().item(), (err, g_full.abs().max().item())
