@@ -5,7 +5,7 @@ clamped and scored with PSNR / SSIM (:91-95), optionally saved as PNG (:97-98).
 
 On the reference this forward needs a 48 GB card because ProbAttention materialises K_sample = 17.7 GB in the last
 decoder stage (test_long_GPU.py:19); here the sampled scores are read out of the dense S tile in LDS, nothing of that
-size exists, and the whole forward runs in a few GB of the 288 GB HBM.
+size exists; the whole forward peaks at about 16 GB of the 288 GB HBM (the 4C-wide LeFF tensors of the full-resolution stages).
 
 Differences by design: one process / one GPU, no nn.DataParallel wrapper (checkpoints with or without the `module.`
 prefix load, utils.load_checkpoint); PNG decode through PIL instead of cv2; scikit-image's metrics restated in

@@ -149,3 +149,28 @@ def test_any_resolution_driver_synthetic():
     torch.manual_seed(6)
     p1, s1, p2, s2 = TA.main(["--synthetic", "1", "--height", "90", "--width", "140"])
     assert np.isfinite([p1, s1, p2, s2]).all() and abs(p1 - p2) < 1e-3       # same clamp, same MAX_I = 1
+
+
+def test_whole_image_full_size():
+    """BASELINE config 5's size: a 1200 x 1600 image padded to 1664 x 1664 (43,264 windows per full-resolution block) in ONE
+    forward - the reference needs a 48 GB card for its 17.7 GB K_sample tensor here.  Checks that do not need the oracle:
+    nothing non-finite, the crop has the image's size and is clamped, the peak HBM use stays below 24 GB (measured 15.6), and the result is
+    bit-reproducible given the sampled-key stream."""
+    import My_model_1 as M1
+    import test_long_GPU as TL
+    dev = torch.device("cuda:0")
+    torch.manual_seed(1234)
+    model = M1.Uformer(img_size=128, embed_dim=32, win_size=8, token_projection='linear', token_mlp='leff').to(dev).eval()
+    g = torch.Generator().manual_seed(2)
+    hazy = torch.rand(1, 3, 1200, 1600, generator=g).to(dev)
+    torch.cuda.reset_peak_memory_stats()
+    with torch.no_grad():
+        torch.manual_seed(3)
+        y = TL.restore_image(model, hazy, 128)
+    assert y.shape == (1, 3, 1200, 1600) and torch.isfinite(y).all() and float(y.min()) >= 0.0 and float(y.max()) <= 1.0
+    assert torch.cuda.max_memory_allocated() < 24e9          # measured 15.6 GB
+    # determinism given the sampled-key stream
+    with torch.no_grad():
+        torch.manual_seed(3)
+        y2 = TL.restore_image(model, hazy, 128)
+    assert torch.equal(y, y2)
