@@ -146,6 +146,10 @@ int dhz_thin_conv3x3_dgrad(const float* dy, const float* w, float* dx, int B, in
 int dhz_thin_conv3x3_wgrad(const float* dy, const float* x, float* dw, float* db, int B, int H, int W, int C, void* stream);
 /*      backward-data of a 3 -> C convolution (the first VGG19 layer, My_CR.py:65) from a channel-blocked gradient
  *      gb[B, C/8, H, W, 8] and that layer's weight w[C, 3, 3, 3]: dx[B, 3, H, W].  C = 64. */
+/*      the same layer forward: y[B, K/8, H, W, 8] (channel-blocked) = max(conv(x[B, 3, H, W], w[K, 3, 3, 3]) + bias, 0 if relu).
+ *      K = 64. */
+int dhz_conv3x3_in3_blocked(const float* x, const float* w, const float* bias, float* y, int B, int H, int W, int K, int relu,
+                            void* stream);
 int dhz_thin_conv3x3_dgrad_blocked(const float* gb, const float* w, float* dx, int B, int H, int W, int C, void* stream);
 
 /* K11b the two L1 distances of one ContrastLoss feature tap (My_CR.py:108-112): sums[0] += sum|a-p|, sums[1] += sum|a-n|

@@ -202,6 +202,54 @@ __global__ __launch_bounds__(256) void thin_conv_wgrad_kernel(const float* __res
     if (db && t < 3) atomicAdd(db + t, red[4 * 27 * C + t] + red[4 * 27 * C + 4 + t] + red[4 * 27 * C + 8 + t] + red[4 * 27 * C + 12 + t]);
 }
 
+// First VGG19 layer (My_CR.py:65, features[0..1]): Conv2d(3 -> 64, 3x3, pad 1) + bias + ReLU from an NCHW image
+// [B, 3, H, W] straight into the channel-blocked layout [B, 8, H, W, 8] of the Winograd stack - the library needs a
+// convolution, a bias pass, a ReLU pass and a layout change for this.  Thin on the INPUT side: 27 MACs per output, lane <->
+// pixel, wave pair <-> 32 of the 64 output channels, weights as LDS broadcasts, 512-byte runs per (channel group, row) out.
+__global__ __launch_bounds__(256) void conv3x3_in3_blocked_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                  const float* __restrict__ bias, float* __restrict__ y,
+                                                                  int H, int W, int tiles_x, int tiles_y, int relu) {
+    __shared__ __attribute__((aligned(16))) float xs[3 * NPOS];        // [c][10 x 18]
+    __shared__ __attribute__((aligned(16))) float ws[27 * 64];         // [c * 9 + tap][k]
+    const int t = threadIdx.x;
+    const int tx = blockIdx.x % tiles_x, ty = (blockIdx.x / tiles_x) % tiles_y, bimg = blockIdx.x / (tiles_x * tiles_y);
+    for (int e = t; e < 27 * 64; e += 256) ws[(e % 27) * 64 + e / 27] = w[e];          // w[k][c][tap] -> ws[c*9+tap][k]
+    for (int e = t; e < 3 * NPOS; e += 256) {
+        const int c = e / NPOS, pos = e % NPOS;
+        const int yy = ty * TH - 1 + pos / HW_, xx = tx * TW - 1 + pos % HW_;
+        xs[e] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? x[(((size_t)bimg * 3 + c) * H + yy) * W + xx] : 0.f;
+    }
+    __syncthreads();
+    const int half = t >> 7, pix = t & 127;
+    const int py = pix / TW, px = pix % TW;
+    f32x4 acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = *reinterpret_cast<const f32x4*>(bias + half * 32 + 4 * j);
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const float xv = xs[c * NPOS + (py + tap / 3) * HW_ + px + tap % 3];
+            const float* wr = ws + (c * 9 + tap) * 64 + half * 32;                    // wave-uniform: broadcast reads
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const f32x4 wv = *reinterpret_cast<const f32x4*>(wr + 4 * j);
+                acc[j] += xv * wv;
+            }
+        }
+    const int yy = ty * TH + py, xx = tx * TW + px;
+    if (yy < H && xx < W) {
+        const float lo = relu ? 0.f : -__builtin_inff();
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            f32x4 v = acc[j];
+            v[0] = fmaxf(v[0], lo); v[1] = fmaxf(v[1], lo); v[2] = fmaxf(v[2], lo); v[3] = fmaxf(v[3], lo);
+            const int k = half * 32 + 4 * j;                                           // channel group k / 8, offset k % 8
+            *reinterpret_cast<f32x4*>(y + ((((size_t)bimg * 8 + k / 8) * H + yy) * W + xx) * 8 + (k & 7)) = v;
+        }
+    }
+}
+
 template <int C>
 int launch_all(int which, const float* a, const float* b, const float* c, float* d, float* e, int B, int H, int W, hipStream_t s) {
     const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH, ntiles = B * tiles_x * tiles_y;
@@ -264,5 +312,16 @@ extern "C" int dhz_thin_conv3x3_dgrad_blocked(const float* gb, const float* w, f
     hipLaunchKernelGGL((thin_conv_fwd_kernel<64, true, true>), dim3(ntiles), dim3(256), smem, (hipStream_t)stream, gb, w, nullptr,
                        dx, H, W, tiles_x, tiles_y);
     DHZ_CHECK_LAUNCH("dhz_thin_conv3x3_dgrad_blocked");
+    return DHZ_OK;
+}
+
+extern "C" int dhz_conv3x3_in3_blocked(const float* x, const float* w, const float* bias, float* y, int B, int H, int W,
+                                       int K, int relu, void* stream) {
+    DHZ_REQUIRE(x && w && bias && y && B > 0 && H > 0 && W > 0, "dhz_conv3x3_in3_blocked: bad arguments");
+    DHZ_REQUIRE(K == 64, "dhz_conv3x3_in3_blocked: K=%d unsupported (64)", K);
+    const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
+    hipLaunchKernelGGL(conv3x3_in3_blocked_kernel, dim3(B * tiles_x * tiles_y), dim3(256), 0, (hipStream_t)stream, x, w, bias, y,
+                       H, W, tiles_x, tiles_y, relu);
+    DHZ_CHECK_LAUNCH("dhz_conv3x3_in3_blocked");
     return DHZ_OK;
 }

@@ -32,6 +32,7 @@ SIGNATURES = {
     "dhz_shift_mask": [c_f, c_i, c_i, c_i, c_p],
     "dhz_thin_conv3x3_fwd": [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_p],
     "dhz_thin_conv3x3_dgrad": [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_p],
+    "dhz_conv3x3_in3_blocked": [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_p],
     "dhz_thin_conv3x3_dgrad_blocked": [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_p],
     "dhz_thin_conv3x3_wgrad": [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_p],
     "dhz_l1_pair_fwd": [c_f, c_f, c_f, c_f, c_l, c_p],

@@ -120,7 +120,11 @@ class VggEngine:
         """x: [B,3,H,W] NCHW.  Returns the 5 tap features: taps 1-4 blocked [B,C/8,H,W,8], tap 5 NCHW.
         `save` (dict) receives what the backward needs."""
         c0, c12 = self.convs[0], self.convs[12]
-        cur = to_blocked(F.conv2d(x, c0.weight, None, padding=1), c0.bias, relu=True)      # bias + ReLU ride on the layout change
+        # first layer (3 -> 64): thin on the input side - convolution + bias + ReLU straight into the blocked layout
+        xc = x.contiguous()
+        cur = torch.empty((xc.shape[0], 8, xc.shape[2], xc.shape[3], 8), device=x.device, dtype=torch.float32)
+        _lib.call("dhz_conv3x3_in3_blocked", _p(xc), _p(c0.weight.contiguous()), _p(c0.bias), _p(cur), xc.shape[0], xc.shape[2],
+                  xc.shape[3], 64, 1, _stream())
         acts = {0: cur}
         taps = [cur]
         for i in range(1, 12):

@@ -156,3 +156,19 @@ def test_layout_conversion_with_bias_relu(B, C, H, W):
     assert torch.equal(V.to_plain(xb), x)
     yb = V.to_blocked(x, b, relu=True)
     assert torch.equal(V.to_plain(yb), torch.relu(x + b.view(1, C, 1, 1)))
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 16, 32), (1, 13, 21)])
+def test_first_vgg_layer_kernel(B, H, W):
+    """Conv2d(3 -> 64, 3x3) + bias + ReLU from NCHW straight into the blocked layout (ragged tiles included) vs conv2d."""
+    from dehaze_hip import _lib, vgg as V
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(H)
+    x = torch.rand(B, 3, H, W, generator=g).to(dev)
+    w = (torch.randn(64, 3, 3, 3, generator=g) * 0.3).to(dev)
+    b = torch.randn(64, generator=g).to(dev)
+    yb = torch.empty(B, 8, H, W, 8, device=dev)
+    _lib.call("dhz_conv3x3_in3_blocked", x.data_ptr(), w.data_ptr(), b.data_ptr(), yb.data_ptr(), B, H, W, 64, 1,
+              torch.cuda.current_stream().cuda_stream)
+    ref = torch.relu(F.conv2d(x.double(), w.double(), b.double(), padding=1)).float()
+    assert torch.allclose(V.to_plain(yb), ref, atol=2e-5, rtol=1e-4), (V.to_plain(yb) - ref).abs().max()
