@@ -1,9 +1,10 @@
 """VGG19[:30] feature stack of the contrastive loss (My_CR.py:56-86) on the Winograd-MFMA convolution kernel.
 
-conv 0 (3 -> 64) and conv 12 (512 -> 512 on 8x8 maps) stay on the library (negligible work / a map smaller than the
-kernel's 16x16 block); convs 1..11 - 99 % of the FLOPs - run dhz_winograd_conv3x3 with bias + ReLU fused, in the
-channel-blocked NCHW8c layout end to end.  The filters are frozen (My_CR.py:75-77), so their transform-domain
-forms (forward and backward-data) are prepacked once per device.
+conv 12 (512 -> 512 on 8x8 maps, smaller than the Winograd kernel's 16x16 block) stays on the library; conv 0 (3 -> 64) runs
+thin-input kernels (dhz_conv3x3_in3_blocked forward with bias + ReLU straight into the blocked layout,
+dhz_thin_conv3x3_dgrad_blocked backward-data straight from it); convs 1..11 - 99 % of the FLOPs - run
+dhz_winograd_conv3x3 with bias + ReLU fused, in the channel-blocked NCHW8c layout end to end.  The filters are frozen
+(My_CR.py:75-77), so their transform-domain forms (forward and backward-data) are prepacked once per device.
 
 Forward-only passes (target / hazy input, My_CR.py:102) save nothing; the pass on the restored image is one autograd
 node whose backward walks the stack with the same kernel (rotated/transposed filters, ReLU mask fused into the patch
