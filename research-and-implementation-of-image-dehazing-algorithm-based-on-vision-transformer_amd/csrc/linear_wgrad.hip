@@ -17,30 +17,33 @@ constexpr int TK = 32;   // tokens per LDS stage
 
 // WM, WN: 16x16 tiles per wave along N (rows of dW) and K (cols of dW); waves are NWM x 2 (NWM = 2: 256 threads,
 // NWM = 4: 512 threads and a 256-row tile - twice the FLOP per staged byte for the compute-bound shapes)
-template <int WM, int WN, int NWM>
-__global__ __launch_bounds__(128 * NWM) void linear_wgrad_kernel(const float* __restrict__ dy, int ldy,
-                                                           const float* __restrict__ x, int ldx, int T, int N,
-                                                           int K, float* __restrict__ dw, float* __restrict__ db,
-                                                           int nsplit) {
-    constexpr int NTHR = 128 * NWM;
+template <int WM, int WN, int NWM, int TG>
+__global__ __launch_bounds__(128 * NWM * TG) void linear_wgrad_kernel(const float* __restrict__ dy, int ldy,
+                                                                const float* __restrict__ x, int ldx, int T, int N,
+                                                                int K, float* __restrict__ dw, float* __restrict__ db,
+                                                                int nsplit) {
+    constexpr int GT = 128 * NWM;                      // threads per token group
+    constexpr int NTHR = GT * TG;
     constexpr int BM = 16 * WM * NWM, BN = 32 * WN;
     constexpr int SA = BM + 16, SB = BN + 16;          // LDS row strides (floats): stride % 32 == 16
     constexpr int A4 = BM / 4, B4 = BN / 4;            // float4 per staged row
-    constexpr int NA = (TK * A4 + NTHR - 1) / NTHR, NB = (TK * B4 + NTHR - 1) / NTHR;   // float4 per thread per stage
+    constexpr int NA = (TK * A4 + GT - 1) / GT, NB = (TK * B4 + GT - 1) / GT;   // float4 per thread per stage
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int STAGE = TK * (SA + SB);              // floats per stage: [A | B]
-    auto As = [&](int buf) -> float* { return smem + buf * STAGE; };
-    auto Bs = [&](int buf) -> float* { return smem + buf * STAGE + TK * SA; };
 
-    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int t = threadIdx.x, lane = t & 63, w = (t >> 6) % (2 * NWM);
+    const int tg = t / GT, tl = t % GT;                // token group of this wave, thread index inside it
     const int i16 = lane & 15, g = lane >> 4;
     const int wm = w >> 1, wn = w & 1;
+    float* const gsm = smem + tg * 2 * STAGE;          // this group's two stages
+    auto As = [&](int buf) -> float* { return gsm + buf * STAGE; };
+    auto Bs = [&](int buf) -> float* { return gsm + buf * STAGE + TK * SA; };
     const int tiles_n = K / BN;
     int bid = blockIdx.x;
     const int split = bid % nsplit; bid /= nsplit;
     const int tn = bid % tiles_n, tm = bid / tiles_n;
     const int n0 = tm * BM, k0 = tn * BN;
-    // token slab of this workgroup (multiples of TK)
+    // token slab of this workgroup (multiples of TK); its stages are dealt round-robin to the TG token groups
     const int nst = T / TK;
     const int st0 = (int)((long long)nst * split / nsplit), st1 = (int)((long long)nst * (split + 1) / nsplit);
 
@@ -63,119 +66,136 @@ __global__ __launch_bounds__(128 * NWM) void linear_wgrad_kernel(const float* __
         const size_t tok0 = (size_t)st * TK;
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
-            const int e = t + NTHR * i;
-            if (TK * A4 % NTHR == 0 || e < TK * A4)
+            const int e = tl + GT * i;
+            if (TK * A4 % GT == 0 || e < TK * A4)
                 ra[i] = *reinterpret_cast<const f32x4*>(dy + (tok0 + e / A4) * ldy + n0 + (e % A4) * 4);
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
-            const int e = t + NTHR * i;
-            if (TK * B4 % NTHR == 0 || e < TK * B4)
+            const int e = tl + GT * i;
+            if (TK * B4 % GT == 0 || e < TK * B4)
                 rb[i] = *reinterpret_cast<const f32x4*>(x + (tok0 + e / B4) * ldx + k0 + (e % B4) * 4);
         }
     };
     auto swrite = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
-            const int e = t + NTHR * i;
-            if (TK * A4 % NTHR == 0 || e < TK * A4) {
+            const int e = tl + GT * i;
+            if (TK * A4 % GT == 0 || e < TK * A4) {
                 *reinterpret_cast<f32x4*>(&As(buf)[(e / A4) * SA + (e % A4) * 4]) = ra[i];
                 dbacc[i].x += ra[i][0]; dbacc[i].y += ra[i][1]; dbacc[i].z += ra[i][2]; dbacc[i].w += ra[i][3];
             }
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
-            const int e = t + NTHR * i;
-            if (TK * B4 % NTHR == 0 || e < TK * B4)
+            const int e = tl + GT * i;
+            if (TK * B4 % GT == 0 || e < TK * B4)
                 *reinterpret_cast<f32x4*>(&Bs(buf)[(e / B4) * SB + (e % B4) * 4]) = rb[i];
         }
     };
 
-    if (st0 < st1) {
-        gload(st0);
+    // group tg owns stages st0 + tg, st0 + tg + TG, ...; all groups run the same number of barriers
+    const int niter = (st1 - st0 + TG - 1) / TG;
+    if (st0 + tg < st1) {
+        gload(st0 + tg);
         swrite(0);
     }
     __syncthreads();
-    for (int st = st0; st < st1; ++st) {
-        const int buf = (st - st0) & 1;
-        if (st + 1 < st1) gload(st + 1);
-        const float* A = As(buf) + (wm * WM * 16 + i16);
-        const float* B = Bs(buf) + (wn * WN * 16 + i16);
+    for (int it = 0; it < niter; ++it) {
+        const int buf = it & 1;
+        const int st = st0 + it * TG + tg;
+        const bool more = st + TG < st1;
+        if (more) gload(st + TG);
+        if (st < st1) {
+            const float* A = As(buf) + (wm * WM * 16 + i16);
+            const float* B = Bs(buf) + (wn * WN * 16 + i16);
 #pragma unroll
-        for (int s = 0; s < TK / 4; ++s) {
-            float af[WM], bf[WN];
+            for (int s = 0; s < TK / 4; ++s) {
+                float af[WM], bf[WN];
 #pragma unroll
-            for (int a = 0; a < WM; ++a) af[a] = A[(4 * s + g) * SA + 16 * a];
+                for (int a = 0; a < WM; ++a) af[a] = A[(4 * s + g) * SA + 16 * a];
 #pragma unroll
-            for (int b = 0; b < WN; ++b) bf[b] = B[(4 * s + g) * SB + 16 * b];
+                for (int b = 0; b < WN; ++b) bf[b] = B[(4 * s + g) * SB + 16 * b];
 #pragma unroll
-            for (int a = 0; a < WM; ++a)
+                for (int a = 0; a < WM; ++a)
 #pragma unroll
-                for (int b = 0; b < WN; ++b) acc[a][b] = mfma16(af[a], bf[b], acc[a][b]);
+                    for (int b = 0; b < WN; ++b) acc[a][b] = mfma16(af[a], bf[b], acc[a][b]);
+            }
         }
-        if (st + 1 < st1) swrite(buf ^ 1);
+        if (more) swrite(buf ^ 1);
         __syncthreads();
     }
 
-    // ---- epilogue: partial tile -> LDS (row-major BM x BN, stride BN) -> full-line atomics into dW
+    // ---- epilogue: partial tiles of the token groups summed in LDS (row-major BM x BN, stride BN) -> full-line atomics
     float* Cs = smem;                                    // BM*BN floats <= 2 stages of LDS
+#pragma unroll 1
+    for (int r = TG - 1; r >= 0; --r) {
+        if (tg == r) {
 #pragma unroll
-    for (int a = 0; a < WM; ++a)
+            for (int a = 0; a < WM; ++a)
 #pragma unroll
-        for (int b = 0; b < WN; ++b)
+                for (int b = 0; b < WN; ++b)
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                Cs[(wm * WM * 16 + a * 16 + 4 * g + j) * BN + wn * WN * 16 + b * 16 + i16] = acc[a][b][j];
-    __syncthreads();
+                    for (int j = 0; j < 4; ++j) {
+                        float* c = &Cs[(wm * WM * 16 + a * 16 + 4 * g + j) * BN + wn * WN * 16 + b * 16 + i16];
+                        *c = (r == TG - 1) ? acc[a][b][j] : *c + acc[a][b][j];
+                    }
+        }
+        __syncthreads();
+    }
     for (int e = t; e < BM * BN; e += NTHR) {
         const int r = e / BN, c = e % BN;
         atomicAdd(dw + (size_t)(n0 + r) * K + k0 + c, Cs[e]);
     }
     if (do_db) {
-        // staged element e = t + 256 i sits at (row e / A4, float4-column e % A4) of every stage: dump the
-        // TK*A4 per-element sums and fold the TK rows of each column.
+        // staged element e = tl + GT i sits at (row e / A4, float4-column e % A4) of every stage: dump the
+        // TG*TK*A4 per-element sums and fold the TG*TK rows of each column.
         __syncthreads();
-        float* red = smem;                                // [TK*A4][4] floats = TK*BM <= one stage
+        float* red = smem + tg * TK * BM;                 // [TG][TK*A4][4] floats = TG*TK*BM <= TG stages
 #pragma unroll
         for (int i = 0; i < NA; ++i)
-            if (TK * A4 % NTHR == 0 || t + NTHR * i < TK * A4) *reinterpret_cast<float4*>(&red[(t + NTHR * i) * 4]) = dbacc[i];
+            if (TK * A4 % GT == 0 || tl + GT * i < TK * A4) *reinterpret_cast<float4*>(&red[(tl + GT * i) * 4]) = dbacc[i];
         __syncthreads();
         if (t < BM) {
             const int c4 = t / 4, comp = t % 4;
             float tot = 0.f;
-            for (int r = 0; r < TK; ++r) tot += red[(r * A4 + c4) * 4 + comp];
+            for (int r = 0; r < TG * TK; ++r) tot += smem[(r * A4 + c4) * 4 + comp];
             atomicAdd(db + n0 + t, tot);
         }
     }
 }
 
-template <int WM, int WN, int NWM = 2>
+template <int WM, int WN, int NWM = 2, int TG = 1>
 int launch(const float* dy, int ldy, const float* x, int ldx, int T, int N, int K, float* dw, float* db, hipStream_t s) {
     constexpr int BM = 16 * WM * NWM, BN = 32 * WN;
     constexpr size_t stage = (size_t)TK * (BM + 16 + BN + 16) * sizeof(float);
-    constexpr size_t smem = 2 * stage > (size_t)BM * BN * 4 ? 2 * stage : (size_t)BM * BN * 4;
+    constexpr size_t smem = 2 * TG * stage > (size_t)BM * BN * 4 ? 2 * TG * stage : (size_t)BM * BN * 4;
     const int tiles = (N / BM) * (K / BN);
     // Every workgroup ends with BM*BN fp32 atomics (chip-wide ~1.3 TB/s of added bytes): large tiles want
     // fewer, longer token slabs.  DHZ_WGRAD_TARGET overrides the workgroup target (tuning aid).
     static const int env_target = getenv("DHZ_WGRAD_TARGET") ? atoi(getenv("DHZ_WGRAD_TARGET")) : 0;
-    const int target = env_target > 0 ? env_target : (NWM == 4 ? 256 : 512);   // 2 (1 for the 512-thread tile) workgroups per CU
-    int nsplit = (target + tiles - 1) / tiles;
-    const int max_split = T / (TK * 4) > 0 ? T / (TK * 4) : 1;     // at least 4 stages per workgroup
+    // Workgroups are dealt in whole rounds over the 256 CUs: the count must not exceed the resident slots (a 257th
+    // 512-thread workgroup, or a 513th 256-thread one, runs alone after the others: measured 198 -> 130 us at
+    // T=8192, N=1536, K=512 with 12 tiles x 43 splits = 516 workgroups), so the split count is rounded DOWN.
+    int target = env_target > 0 ? env_target : (NWM * TG == 4 ? 256 : 512);   // 2 (1 for 512 threads) workgroups per CU
+    if (2 * smem > 160 * 1024 && target > 256) target = 256;
+    int nsplit = target / tiles;
+    const int max_split = T / (TK * 4 * TG) > 0 ? T / (TK * 4 * TG) : 1;     // at least 4 stages per token group
     if (nsplit > max_split) nsplit = max_split;
     if (nsplit < 1) nsplit = 1;
     // short token slabs pay the per-workgroup epilogue (BM*BN atomics) over too few stages: below 16 stages per workgroup
     // trade splits for stages down to one workgroup per CU (measured: 70 -> 62 us at T=32768, N=512, K=128; 73 -> 64 us at
     // T=131072, N=K=128; the long-slab shapes are untouched)
     if (env_target <= 0 && (T / TK) / nsplit < 16) {
-        int alt = (256 + tiles - 1) / tiles;
+        int alt = 256 / tiles;
         if (alt < (T / TK) / 16) alt = (T / TK) / 16;
         if (alt >= 1 && alt < nsplit) nsplit = alt;
     }
     if (smem > 48 * 1024)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_wgrad_kernel<WM, WN, NWM>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_wgrad_kernel<WM, WN, NWM, TG>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    hipLaunchKernelGGL((linear_wgrad_kernel<WM, WN, NWM>), dim3(tiles * nsplit), dim3(128 * NWM), smem, s, dy, ldy, x, ldx, T, N, K,
-                       dw, db, nsplit);
+    hipLaunchKernelGGL((linear_wgrad_kernel<WM, WN, NWM, TG>), dim3(tiles * nsplit), dim3(128 * NWM * TG), smem, s, dy, ldy, x,
+                       ldx, T, N, K, dw, db, nsplit);
     return 0;
 }
 
@@ -196,7 +216,18 @@ extern "C" int dhz_linear_wgrad(const float* dy, int ldy, const float* x, int ld
         DHZ_CHECK_LAUNCH("dhz_linear_wgrad");
         return DHZ_OK;
     }
-#define CASE(a, b) if (wm == a && wn == b) launch<a, b>(dy, ldy, x, ldx, T, N, K, dw, db, s);
+    // Two token groups per workgroup (512 threads, one 128 x 128 workgroup per CU) halve the atomic epilogue per staged byte:
+    // -7.5 % over the 36 shapes of the step (tools/bench_wgrad.py); slabs shorter than 8 stages stay on one group.
+    static const int tg_env = getenv("DHZ_WGRAD_TG") ? atoi(getenv("DHZ_WGRAD_TG")) : 0;
+    const int bm = 32 * wm, bn = 32 * wn;
+    const int tiles = (N / bm) * (K / bn);
+    const int splits2 = 256 / tiles > 0 ? 256 / tiles : 1;
+    const bool two = tg_env ? tg_env == 2 : (T / TK) / splits2 >= 8;
+#define CASE(a, b)                                                               \
+    if (wm == a && wn == b) {                                                    \
+        if (two) launch<a, b, 2, 2>(dy, ldy, x, ldx, T, N, K, dw, db, s);        \
+        else launch<a, b>(dy, ldy, x, ldx, T, N, K, dw, db, s);                  \
+    }
     CASE(1, 1) CASE(1, 2) CASE(1, 4) CASE(2, 1) CASE(2, 2) CASE(2, 4) CASE(3, 1) CASE(3, 2) CASE(3, 4)
     CASE(4, 1) CASE(4, 2) CASE(4, 4)
 #undef CASE
