@@ -83,8 +83,8 @@ class Vgg19(nn.Module):
         """The Winograd-MFMA feature engine (dehaze_hip/vgg.py) when it applies: frozen filters, fp32 on the GPU, maps
         that stay multiples of 16 down to relu4_4 (H, W multiples of 128); None -> library convolutions."""
         if not (self._frozen and X.is_cuda and X.dtype == torch.float32 and X.dim() == 4 and X.shape[1] == 3
-                and X.shape[2] % 128 == 0 and X.shape[3] % 128 == 0):
-            return None
+                and X.shape[2] % 128 == 0 and X.shape[3] % 128 == 0 and self.slice1[0].weight.device == X.device):
+            return None                      # (filters on another device: let the library path raise torch's own error)
         if self._engine is None:
             from dehaze_hip.vgg import VggEngine
             self._engine = VggEngine([m for m in self.modules() if isinstance(m, nn.Conv2d)])

@@ -7,7 +7,10 @@ pytestmark = pytest.mark.gpu
 
 @pytest.mark.parametrize("T,N,K", [(4096, 32, 32), (8192, 96, 32), (4096, 128, 32), (4096, 32, 128), (2048, 192, 64),
                                    (2048, 256, 64), (1024, 384, 128), (1024, 512, 128), (512, 1536, 512),
-                                   (256, 2048, 512), (512, 512, 2048), (64, 64, 64)])
+                                   (256, 2048, 512), (512, 512, 2048), (64, 64, 64),
+                                   # long token slabs: the two-token-group variant of the kernel (>= 8 stages per workgroup),
+                                   # the last two with an odd number of stages per workgroup (groups of unequal length)
+                                   (65536, 128, 128), (65536, 96, 64), (32768, 384, 128), (8192, 1536, 512), (2336 * 32, 32, 64)])
 def test_linear_tokens_grads(T, N, K):
     from dehaze_hip import ops
     dev = torch.device("cuda:0")
