@@ -287,3 +287,33 @@ def test_full_size_gradient_linearity(dev):
     assert abs(l_full - 0.5 * (l_a + l_b)) < 1e-6
     err = (g_full - 0.5 * (g_a + g_b)).abs().max().item()
     assert err < 2e-4 * g_full.abs().max().item(), (err, g_full.abs().max().item())
+
+
+def test_config4_shape_in_fp32(dev):
+    """BASELINE config 4's SHAPE (E = 64, 256 x 256 patches, 8 per GPU) in fp32 - the build has no bf16 path, so the config's
+    dtype is out of scope, but its sizes (head dimension 64, 1024 windows per patch, channels 64..1024, hidden 4096) must
+    run: batch independence of the eval forward as in the config-2 test, and one finite training step."""
+    import My_model_1 as M1
+    from dehaze_hip.train import FlatAdamW, train_step
+    from losses import CharbonnierLoss
+    seed_all(1234)
+    model = M1.Uformer(img_size=256, embed_dim=64, win_size=8, token_projection='linear', token_mlp='leff').to(dev).eval()
+    g = torch.Generator().manual_seed(23)
+    gt = torch.rand(8, 3, 256, 256, generator=g).to(dev)
+    x = (0.6 * gt + 0.3).clamp(0, 1)
+    with torch.no_grad():
+        torch.manual_seed(5)
+        y = model(x)
+        for i in (0, 7):
+            torch.manual_seed(5)
+            yi = model(x[i:i + 1])
+            assert torch.allclose(y[i:i + 1], yi, atol=5e-5, rtol=1e-4), (i, (y[i:i + 1] - yi).abs().max().item())
+    assert torch.isfinite(y).all() and y.shape == (8, 3, 256, 256)
+    model.train()
+    opt = FlatAdamW(model, lr=2e-4, weight_decay=0.02)
+    before = [p.detach().clone() for _, p in model.live_parameters()][:4]
+    loss, loss_rec, _ = train_step(model, CharbonnierLoss().to(dev), None, opt, None, x, gt, w_cr=0.0)
+    assert torch.isfinite(loss) and 0.0 < loss.item() < 1.0
+    after = [p.detach() for _, p in model.live_parameters()][:4]
+    assert any(not torch.equal(a, b) for a, b in zip(before, after))
+    assert torch.cuda.max_memory_allocated() < 80 * 2 ** 30
