@@ -115,6 +115,11 @@ int dhz_bias_table_grad(const float* dbias_part, int parts, float* dtable, int H
  *     db may be NULL.  Summation order over T is not deterministic (fp32 atomics). */
 int dhz_linear_wgrad(const float* dy, int ldy, const float* x, int ldx, int T, int N, int K,
                      float* dw, float* db, void* stream);
+/*      Same contraction for nmat (1..4) parameters that share the input x - the Q / K / V projections of
+ *      AttentionLayer.forward (ATT:385-461): columns [i*nper, (i+1)*nper) of dy belong to dw[i] / db[i] (HOST arrays of
+ *      nmat device pointers; db may be NULL, or all of its entries NULL).  One launch reads x once instead of nmat times. */
+int dhz_linear_wgrad_multi(const float* dy, int ldy, const float* x, int ldx, int T, int nmat, int nper, int K,
+                           float* const* dw, float* const* db, void* stream);
 
 /* K11  3x3 / stride 1 / pad 1 convolution of the VGG19 feature stack (My_CR.py:56-86) as Winograd F(2x2,3x3) on the
  *      fp32 matrix pipe.  Tensors are channel-blocked NCHW8c: x[b][c/8][h][w][c%8] (dhz_layout_blocked8 converts).

@@ -14,14 +14,22 @@
 namespace {
 
 constexpr int TK = 32;   // tokens per LDS stage
+constexpr int MAXMAT = 4;
+
+// Output side of one launch: the N = nmat * nper rows of dY^T X belong to up to MAXMAT separate parameters of nper rows each
+// (the Q / K / V projections share their input: one launch reads X once instead of three times).
+struct WgradOut {
+    float* dw[MAXMAT];
+    float* db[MAXMAT];
+    int nper;
+};
 
 // WM, WN: 16x16 tiles per wave along N (rows of dW) and K (cols of dW); waves are NWM x 2 (NWM = 2: 256 threads,
 // NWM = 4: 512 threads and a 256-row tile - twice the FLOP per staged byte for the compute-bound shapes)
 template <int WM, int WN, int NWM, int TG>
 __global__ __launch_bounds__(128 * NWM * TG) void linear_wgrad_kernel(const float* __restrict__ dy, int ldy,
                                                                 const float* __restrict__ x, int ldx, int T, int N,
-                                                                int K, float* __restrict__ dw, float* __restrict__ db,
-                                                                int nsplit) {
+                                                                int K, WgradOut out, int nsplit) {
     constexpr int GT = 128 * NWM;                      // threads per token group
     constexpr int NTHR = GT * TG;
     constexpr int BM = 16 * WM * NWM, BN = 32 * WN;
@@ -43,6 +51,9 @@ __global__ __launch_bounds__(128 * NWM * TG) void linear_wgrad_kernel(const floa
     const int split = bid % nsplit; bid /= nsplit;
     const int tn = bid % tiles_n, tm = bid / tiles_n;
     const int n0 = tm * BM, k0 = tn * BN;
+    const int mat = n0 / out.nper, nloc = n0 - mat * out.nper;       // BM divides nper: a tile never straddles two parameters
+    float* __restrict__ const dw = out.dw[mat];
+    float* __restrict__ const db = out.db[mat];
     // token slab of this workgroup (multiples of TK); its stages are dealt round-robin to the TG token groups
     const int nst = T / TK;
     const int st0 = (int)((long long)nst * split / nsplit), st1 = (int)((long long)nst * (split + 1) / nsplit);
@@ -145,7 +156,7 @@ __global__ __launch_bounds__(128 * NWM * TG) void linear_wgrad_kernel(const floa
     }
     for (int e = t; e < BM * BN; e += NTHR) {
         const int r = e / BN, c = e % BN;
-        atomicAdd(dw + (size_t)(n0 + r) * K + k0 + c, Cs[e]);
+        atomicAdd(dw + (size_t)(nloc + r) * K + k0 + c, Cs[e]);
     }
     if (do_db) {
         // staged element e = tl + GT i sits at (row e / A4, float4-column e % A4) of every stage: dump the
@@ -160,13 +171,13 @@ __global__ __launch_bounds__(128 * NWM * TG) void linear_wgrad_kernel(const floa
             const int c4 = t / 4, comp = t % 4;
             float tot = 0.f;
             for (int r = 0; r < TG * TK; ++r) tot += smem[(r * A4 + c4) * 4 + comp];
-            atomicAdd(db + n0 + t, tot);
+            atomicAdd(db + nloc + t, tot);
         }
     }
 }
 
 template <int WM, int WN, int NWM = 2, int TG = 1>
-int launch(const float* dy, int ldy, const float* x, int ldx, int T, int N, int K, float* dw, float* db, hipStream_t s) {
+int launch(const float* dy, int ldy, const float* x, int ldx, int T, int N, int K, const WgradOut& out, hipStream_t s) {
     constexpr int BM = 16 * WM * NWM, BN = 32 * WN;
     constexpr size_t stage = (size_t)TK * (BM + 16 + BN + 16) * sizeof(float);
     constexpr size_t smem = 2 * TG * stage > (size_t)BM * BN * 4 ? 2 * TG * stage : (size_t)BM * BN * 4;
@@ -195,27 +206,22 @@ int launch(const float* dy, int ldy, const float* x, int ldx, int T, int N, int 
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_wgrad_kernel<WM, WN, NWM, TG>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     hipLaunchKernelGGL((linear_wgrad_kernel<WM, WN, NWM, TG>), dim3(tiles * nsplit), dim3(128 * NWM * TG), smem, s, dy, ldy, x,
-                       ldx, T, N, K, dw, db, nsplit);
+                       ldx, T, N, K, out, nsplit);
     return 0;
 }
 
 }  // namespace
 
-extern "C" int dhz_linear_wgrad(const float* dy, int ldy, const float* x, int ldx, int T, int N, int K, float* dw,
-                                float* db, void* stream) {
-    DHZ_REQUIRE(dy && x && dw, "dhz_linear_wgrad: null pointer");
-    DHZ_REQUIRE(T > 0 && T % TK == 0, "dhz_linear_wgrad: T=%d must be a multiple of %d", T, TK);
-    DHZ_REQUIRE(N % 32 == 0 && K % 32 == 0 && N > 0 && K > 0, "dhz_linear_wgrad: N=%d K=%d must be multiples of 32", N, K);
-    DHZ_REQUIRE(ldy % 4 == 0 && ldx % 4 == 0 && ldy >= N && ldx >= K, "dhz_linear_wgrad: bad leading dims");
-    hipStream_t s = (hipStream_t)stream;
-    const int wm = (N % 128 == 0) ? 4 : (N % 96 == 0) ? 3 : (N % 64 == 0) ? 2 : 1;
+// nmat parameters of nper rows each (N = nmat * nper columns of dy, consecutive)
+static int wgrad_dispatch(const char* who, const float* dy, int ldy, const float* x, int ldx, int T, int nmat, int nper, int K,
+                          const WgradOut& out, hipStream_t s) {
+    const int N = nmat * nper;
+    DHZ_REQUIRE(T > 0 && T % TK == 0, "%s: T=%d must be a multiple of %d", who, T, TK);
+    DHZ_REQUIRE(nper % 32 == 0 && K % 32 == 0 && nper > 0 && K > 0, "%s: N=%d K=%d must be multiples of 32", who, nper, K);
+    DHZ_REQUIRE(ldy % 4 == 0 && ldx % 4 == 0 && ldy >= N && ldx >= K, "%s: bad leading dims", who);
+    // tile rows divide nper, so that a tile never straddles two parameters
+    const int wm = (nper % 128 == 0) ? 4 : (nper % 96 == 0) ? 3 : (nper % 64 == 0) ? 2 : 1;
     const int wn = (K % 128 == 0) ? 4 : (K % 64 == 0) ? 2 : 1;
-    static const int big_env = getenv("DHZ_WGRAD_BIG") ? atoi(getenv("DHZ_WGRAD_BIG")) : 0;   // measured: +-5 %, not worth it by default
-    if (big_env && N % 256 == 0 && K % 128 == 0) {          // compute-bound shapes: 256 x 128 tile on 8 waves
-        launch<4, 4, 4>(dy, ldy, x, ldx, T, N, K, dw, db, s);
-        DHZ_CHECK_LAUNCH("dhz_linear_wgrad");
-        return DHZ_OK;
-    }
     // Two token groups per workgroup (512 threads, one 128 x 128 workgroup per CU) halve the atomic epilogue per staged byte:
     // -7.5 % over the 36 shapes of the step (tools/bench_wgrad.py); slabs shorter than 8 stages stay on one group.
     static const int tg_env = getenv("DHZ_WGRAD_TG") ? atoi(getenv("DHZ_WGRAD_TG")) : 0;
@@ -225,12 +231,35 @@ extern "C" int dhz_linear_wgrad(const float* dy, int ldy, const float* x, int ld
     const bool two = tg_env ? tg_env == 2 : (T / TK) / splits2 >= 8;
 #define CASE(a, b)                                                               \
     if (wm == a && wn == b) {                                                    \
-        if (two) launch<a, b, 2, 2>(dy, ldy, x, ldx, T, N, K, dw, db, s);        \
-        else launch<a, b>(dy, ldy, x, ldx, T, N, K, dw, db, s);                  \
+        if (two) launch<a, b, 2, 2>(dy, ldy, x, ldx, T, N, K, out, s);           \
+        else launch<a, b>(dy, ldy, x, ldx, T, N, K, out, s);                     \
     }
     CASE(1, 1) CASE(1, 2) CASE(1, 4) CASE(2, 1) CASE(2, 2) CASE(2, 4) CASE(3, 1) CASE(3, 2) CASE(3, 4)
     CASE(4, 1) CASE(4, 2) CASE(4, 4)
 #undef CASE
-    DHZ_CHECK_LAUNCH("dhz_linear_wgrad");
+    DHZ_CHECK_LAUNCH(who);
     return DHZ_OK;
+}
+
+extern "C" int dhz_linear_wgrad(const float* dy, int ldy, const float* x, int ldx, int T, int N, int K, float* dw,
+                                float* db, void* stream) {
+    DHZ_REQUIRE(dy && x && dw, "dhz_linear_wgrad: null pointer");
+    WgradOut out = {};
+    out.dw[0] = dw; out.db[0] = db; out.nper = N;
+    return wgrad_dispatch("dhz_linear_wgrad", dy, ldy, x, ldx, T, 1, N, K, out, (hipStream_t)stream);
+}
+
+extern "C" int dhz_linear_wgrad_multi(const float* dy, int ldy, const float* x, int ldx, int T, int nmat, int nper, int K,
+                                      float* const* dw, float* const* db, void* stream) {
+    DHZ_REQUIRE(dy && x && dw, "dhz_linear_wgrad_multi: null pointer");
+    DHZ_REQUIRE(nmat >= 1 && nmat <= MAXMAT, "dhz_linear_wgrad_multi: nmat=%d must be 1..%d", nmat, MAXMAT);
+    WgradOut out = {};
+    for (int i = 0; i < nmat; ++i) {
+        DHZ_REQUIRE(dw[i], "dhz_linear_wgrad_multi: null dw[%d]", i);
+        DHZ_REQUIRE(!db || (db[i] != nullptr) == (db[0] != nullptr), "dhz_linear_wgrad_multi: bias gradients must be all set or all null");
+        out.dw[i] = dw[i];
+        out.db[i] = db ? db[i] : nullptr;
+    }
+    out.nper = nper;
+    return wgrad_dispatch("dhz_linear_wgrad_multi", dy, ldy, x, ldx, T, nmat, nper, K, out, (hipStream_t)stream);
 }

@@ -35,6 +35,19 @@ def _wgrad(dy, off, x, w, b):
     return dys.t() @ x, (dys.sum(0) if b is not None else None)
 
 
+def _wgrad_qkv(dqkv, xn, C, pairs):
+    """The three projections' gradients from the packed dqkv [T,3C]: one launch (x read once) when all of them can be
+    accumulated in place, else one _wgrad each.  Returns the six autograd slots (g_wq, g_bq, g_wk, g_bk, g_wv, g_bv)."""
+    T, K = xn.shape
+    if T % 32 == 0 and C % 32 == 0 and K % 32 == 0 and all(w.is_leaf and (b is None or b.is_leaf) for w, b in pairs):
+        ops._accumulate_param_grads(dqkv, 0, xn, pairs)
+        return (None,) * 6
+    out = ()
+    for i, (w, b) in enumerate(pairs):
+        out += _wgrad(dqkv, i * C, xn, w, b)
+    return out
+
+
 def _grad_buf(p):
     """Zero-initialised, contiguous .grad of a leaf parameter (the optimizer's flat-buffer view when FlatAdamW is in
     use), or None when in-place accumulation is not possible."""
@@ -148,9 +161,7 @@ class _FusedAttnBranch(Function):
         dtable = _table_backward(dpart, parts, table_p, H, dev) if bias is not None else None
         # (4) QKV projection
         dxn = dqkv @ torch.cat([wq_, wk_, wv_], 0)
-        g_wq, g_bq = _wgrad(dqkv, 0, xn, wq, bq)
-        g_wk, g_bk = _wgrad(dqkv, C, xn, wk, bk)
-        g_wv, g_bv = _wgrad(dqkv, 2 * C, xn, wv, bv)
+        g_wq, g_bq, g_wk, g_bk, g_wv, g_bv = _wgrad_qkv(dqkv, xn, C, [(wq, bq), (wk, bk), (wv, bv)])
         # (5) LayerNorm backward + shortcut gradient in one pass
         dx, dgamma, dbeta = _ln_backward(dxn, x, gamma_p, beta_p, gamma, stats, dout, B, Hres, Wres, C, shift, 1)
         return (dx, dgamma, dbeta, g_wq, g_bq, g_wk, g_bk, g_wv, g_bv, g_wo, g_bo, dtable,
@@ -236,9 +247,7 @@ class _AttnBranchChain(Function):
                   gb, gb + 4 * C, gb + 8 * C, 3 * C, _p(dpart), B_, H, nW, d, _stream())
         dtable = _table_backward(dpart, parts, table_p, H, dev) if bias is not None else None
         dxn = dqkv @ torch.cat([wq_, wk_, wv_], 0)
-        g_wq, g_bq = _wgrad(dqkv, 0, xn, wq, bq)
-        g_wk, g_bk = _wgrad(dqkv, C, xn, wk, bk)
-        g_wv, g_bv = _wgrad(dqkv, 2 * C, xn, wv, bv)
+        g_wq, g_bq, g_wk, g_bk, g_wv, g_bv = _wgrad_qkv(dqkv, xn, C, [(wq, bq), (wk, bk), (wv, bv)])
         dx, dgamma, dbeta = _ln_backward(dxn, x, gamma_p, beta_p, gamma, stats, dout, B, Hres, Wres, C, shift, 1)
         return (dx, dgamma, dbeta, g_wq, g_bq, g_wk, g_bk, g_wv, g_bv, g_wo, g_bo, dtable,
                 None, None, None, None, None, None, None)

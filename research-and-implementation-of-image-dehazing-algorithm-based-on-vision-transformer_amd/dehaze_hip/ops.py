@@ -4,6 +4,8 @@ PyTorch is plumbing here: it owns device memory (caching allocator), the current
 autograd tape; every op below runs a hand-written gfx950 kernel through ctypes.  CPU tensors are
 rejected - there is no fallback path.
 """
+import ctypes
+
 import torch
 from torch.autograd import Function
 
@@ -170,22 +172,34 @@ GRAD_READY = None
 
 
 def _accumulate_param_grads(dy, ldy_off, x, params):
-    """dW += dy[:, off:off+N]^T x, db += colsum for every (W, b) pair, straight into .grad (zero-init)."""
+    """dW += dy[:, off:off+N]^T x, db += colsum for every (W, b) pair, straight into .grad (zero-init).  Pairs of equal
+    shape (the Q / K / V projections) go through ONE launch that reads x once (dhz_linear_wgrad_multi)."""
     T, K = x.shape
-    off = ldy_off
     for W, b in params:
-        N = W.shape[0]
         for p in (W, b):
             if p is not None and p.grad is None:
                 p.grad = torch.zeros_like(p, memory_format=torch.contiguous_format)
         assert W.grad.is_contiguous()
-        _lib.call("dhz_linear_wgrad", dy.data_ptr() + 4 * off, dy.stride(0), _p(x), x.stride(0), T, N, K, _p(W.grad),
-                  _p(b.grad) if b is not None else None, _stream())
-        if GRAD_READY is not None:
+    N = params[0][0].shape[0]
+    same = 1 < len(params) <= 4 and all(W.shape[0] == N for W, _ in params) and \
+        len({b is None for _, b in params}) == 1
+    if same:
+        n = len(params)
+        dws = (ctypes.c_void_p * n)(*[W.grad.data_ptr() for W, _ in params])
+        dbs = (ctypes.c_void_p * n)(*[(b.grad.data_ptr() if b is not None else None) for _, b in params])
+        _lib.call("dhz_linear_wgrad_multi", dy.data_ptr() + 4 * ldy_off, dy.stride(0), _p(x), x.stride(0), T, n, N, K,
+                  ctypes.cast(dws, ctypes.c_void_p), ctypes.cast(dbs, ctypes.c_void_p), _stream())
+    else:
+        off = ldy_off
+        for W, b in params:
+            _lib.call("dhz_linear_wgrad", dy.data_ptr() + 4 * off, dy.stride(0), _p(x), x.stride(0), T, W.shape[0], K,
+                      _p(W.grad), _p(b.grad) if b is not None else None, _stream())
+            off += W.shape[0]
+    if GRAD_READY is not None:
+        for W, b in params:
             GRAD_READY(W)
             if b is not None:
                 GRAD_READY(b)
-        off += N
 
 
 class _LinearTokens(Function):
@@ -216,6 +230,10 @@ class _LinearTokens(Function):
         T, K = x.shape
         grads = []
         off = 0
+        if T % 32 == 0 and K % 32 == 0 and all(w.shape[0] % 32 == 0 and w.is_leaf and (b is None or b.is_leaf)
+                                               for w, b in ctx.params):
+            _accumulate_param_grads(dy, 0, x, ctx.params)           # one launch for equal-shaped parameters (Q / K / V)
+            return (dx,) + (None, None) * len(ctx.params)
         for w, b in ctx.params:
             N = w.shape[0]
             # measured on MI355X (tools/bench_wgrad.py): the split-T kernel wins 2-18x for T >= 16k tokens; on the deep

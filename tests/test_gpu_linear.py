@@ -37,11 +37,12 @@ def test_linear_tokens_grads(T, N, K):
     assert (Wd.grad.cpu().double() - 2 * Wr.grad).abs().max() < 4e-5 * scale
 
 
-def test_packed_qkv_grads():
+@pytest.mark.parametrize("T,C", [(2048, 64), (65536, 32), (32768, 128), (4096, 512)])
+def test_packed_qkv_grads(T, C):
+    """Q / K / V share their input: one dhz_linear_wgrad_multi launch fills the three separate .grad buffers."""
     from dehaze_hip import ops
     dev = torch.device("cuda:0")
     g = torch.Generator().manual_seed(3)
-    T, C = 2048, 64
     x = torch.randn(T, C, generator=g)
     Ws = [torch.randn(C, C, generator=g) * 0.1 for _ in range(3)]
     bs = [torch.randn(C, generator=g) * 0.1 for _ in range(3)]
@@ -55,7 +56,31 @@ def test_packed_qkv_grads():
     xd = x.to(dev).requires_grad_()
     y = ops.linear_tokens(xd, Wd[0], bd[0], Wd[1], bd[1], Wd[2], bd[2])
     (y * go.to(dev)).sum().backward()
+    tol = 2e-5 * T ** 0.5 + 1e-4
     for i in range(3):
-        assert (Wd[i].grad.cpu().double() - Wr[i].grad).abs().max() < 1e-3
-        assert (bd[i].grad.cpu().double() - br[i].grad).abs().max() < 1e-3
+        assert (Wd[i].grad.cpu().double() - Wr[i].grad).abs().max() < tol
+        assert (bd[i].grad.cpu().double() - br[i].grad).abs().max() < tol
     assert torch.allclose(xd.grad.cpu().double(), xr.grad, atol=1e-4, rtol=1e-4)
+
+
+def test_wgrad_multi_c_abi():
+    """dhz_linear_wgrad_multi through the C-ABI: 4 parameters, no bias gradients, strided dy; and its argument checks."""
+    import ctypes
+    from dehaze_hip import _lib
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(9)
+    T, n, N, K = 8192, 4, 96, 64
+    dy = torch.randn(T, n * N + 32, generator=g).to(dev)          # 32 unused trailing columns: ldy > n*N
+    x = torch.randn(T, K, generator=g).to(dev)
+    dws = [torch.zeros(N, K, device=dev) for _ in range(n)]
+    arr = (ctypes.c_void_p * n)(*[w.data_ptr() for w in dws])
+    s = torch.cuda.current_stream().cuda_stream
+    _lib.call("dhz_linear_wgrad_multi", dy.data_ptr(), dy.stride(0), x.data_ptr(), K, T, n, N, K,
+              ctypes.cast(arr, ctypes.c_void_p), None, s)
+    ref = dy[:, :n * N].double().t() @ x.double()
+    for i in range(n):
+        assert (dws[i].double() - ref[i * N:(i + 1) * N]).abs().max() < 2e-5 * T ** 0.5
+    lib = _lib.load()
+    assert lib.dhz_linear_wgrad_multi(dy.data_ptr(), dy.stride(0), x.data_ptr(), K, T, 5, N, K,
+                                      ctypes.cast(arr, ctypes.c_void_p), None, s) == -22
+    assert b"nmat" in lib.dhz_last_error()
