@@ -8,14 +8,17 @@ HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -I$ROOT/include -I$HERE -Wno-unused-result"
 mkdir -p "$HERE/build"
 objs=()
+pids=()
 for f in "$HERE"/*.hip; do
   o="$HERE/build/$(basename "${f%.hip}").o"
   if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ "$HERE/common.h" -nt "$o" ] || [ "$ROOT/include/dehaze_hip.h" -nt "$o" ]; then
     echo "hipcc -c $(basename "$f")"
+    rm -f "$o"                                   # a failed compile must not leave the previous object behind
     "$HIPCC" $FLAGS -c "$f" -o "$o" &
+    pids+=($!)
   fi
   objs+=("$o")
 done
-wait
+for p in "${pids[@]}"; do wait "$p" || { echo "build.sh: compile failed" >&2; exit 1; }; done
 "$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$OUT" "${objs[@]}"
 echo "built $OUT"

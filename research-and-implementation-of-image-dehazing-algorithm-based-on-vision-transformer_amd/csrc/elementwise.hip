@@ -91,57 +91,73 @@ __global__ __launch_bounds__(256) void ln_partition_bwd_kernel(const float* __re
         dg[v] = make_float4(0, 0, 0, 0);
         db[v] = make_float4(0, 0, 0, 0);
     }
-    for (int base = wave_global * tpw; base < ntok; base += nwaves * tpw) {
-        const int tok = base + sub;
-        const bool ok = tok < ntok;
+    // Two token groups per trip, all loads of both issued before the first use: with the grid capped for the dgamma/dbeta
+    // atomics (<= 2 workgroups per CU) a single group left only ~24 KB per CU in flight.
+    struct Group {
         float4 xh[VPL], dy[VPL], rs[VPL];
-        float mean = 0.f, rstd = 0.f;
-        size_t src = 0;
-        if (ok) {
-            const int bimg = tok / HW, p = tok % HW;
-            src = partition ? (size_t)bimg * HW + window_slot(p / Wres, p % Wres, Hres, Wres, shift) : (size_t)tok;
-            // every load of this token group is issued before the first use (the shortcut gradient included)
+        float mean, rstd;
+        int tok;
+        bool ok;
+    };
+    auto load = [&](int base, Group& G) {
+        G.tok = base + sub;
+        G.ok = G.tok < ntok;
+        G.mean = 0.f; G.rstd = 0.f;
+        if (G.ok) {
+            const int bimg = G.tok / HW, p = G.tok % HW;
+            const size_t src = partition ? (size_t)bimg * HW + window_slot(p / Wres, p % Wres, Hres, Wres, shift) : (size_t)G.tok;
 #pragma unroll
             for (int v = 0; v < VPL; ++v) {
-                xh[v] = reinterpret_cast<const float4*>(x + (size_t)tok * C)[li + v * lpt];
-                dy[v] = reinterpret_cast<const float4*>(dxw + src * C)[li + v * lpt];
-                if (dres) rs[v] = reinterpret_cast<const float4*>(dres + (size_t)tok * C)[li + v * lpt];
+                G.xh[v] = reinterpret_cast<const float4*>(x + (size_t)G.tok * C)[li + v * lpt];
+                G.dy[v] = reinterpret_cast<const float4*>(dxw + src * C)[li + v * lpt];
+                if (dres) G.rs[v] = reinterpret_cast<const float4*>(dres + (size_t)G.tok * C)[li + v * lpt];
             }
-            const float2 st = *reinterpret_cast<const float2*>(stats + 2 * (size_t)tok);
-            mean = st.x; rstd = st.y;
+            const float2 st = *reinterpret_cast<const float2*>(stats + 2 * (size_t)G.tok);
+            G.mean = st.x; G.rstd = st.y;
         }
+    };
+    auto compute = [&](Group& G) {
         float s1 = 0.f, s2 = 0.f;
+        const float mean = G.mean, rstd = G.rstd;
 #pragma unroll
         for (int v = 0; v < VPL; ++v) {
-            if (ok) {
-                const float4 xv = xh[v];
-                xh[v] = make_float4((xv.x - mean) * rstd, (xv.y - mean) * rstd, (xv.z - mean) * rstd, (xv.w - mean) * rstd);
-            } else {
-                dy[v] = make_float4(0, 0, 0, 0);
-                xh[v] = make_float4(0, 0, 0, 0);
+            float4 xn = make_float4(0, 0, 0, 0), d = make_float4(0, 0, 0, 0);
+            if (G.ok) {
+                const float4 xv = G.xh[v];
+                xn = make_float4((xv.x - mean) * rstd, (xv.y - mean) * rstd, (xv.z - mean) * rstd, (xv.w - mean) * rstd);
+                d = G.dy[v];
             }
-            dg[v].x += dy[v].x * xh[v].x; dg[v].y += dy[v].y * xh[v].y; dg[v].z += dy[v].z * xh[v].z; dg[v].w += dy[v].w * xh[v].w;
-            db[v].x += dy[v].x; db[v].y += dy[v].y; db[v].z += dy[v].z; db[v].w += dy[v].w;
+            dg[v].x += d.x * xn.x; dg[v].y += d.y * xn.y; dg[v].z += d.z * xn.z; dg[v].w += d.w * xn.w;
+            db[v].x += d.x; db[v].y += d.y; db[v].z += d.z; db[v].w += d.w;
             // dxhat = dy * gamma
-            dy[v].x *= gm[v].x; dy[v].y *= gm[v].y; dy[v].z *= gm[v].z; dy[v].w *= gm[v].w;
-            s1 += dy[v].x + dy[v].y + dy[v].z + dy[v].w;
-            s2 += dy[v].x * xh[v].x + dy[v].y * xh[v].y + dy[v].z * xh[v].z + dy[v].w * xh[v].w;
+            d.x *= gm[v].x; d.y *= gm[v].y; d.z *= gm[v].z; d.w *= gm[v].w;
+            s1 += d.x + d.y + d.z + d.w;
+            s2 += d.x * xn.x + d.y * xn.y + d.z * xn.z + d.w * xn.w;
+            G.xh[v] = xn; G.dy[v] = d;
         }
         for (int o = 1; o < lpt; o <<= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
         s1 *= invC; s2 *= invC;
-        if (ok) {
+        if (G.ok) {
 #pragma unroll
             for (int v = 0; v < VPL; ++v) {
                 float4 r;
-                r.x = rstd * (dy[v].x - s1 - xh[v].x * s2);
-                r.y = rstd * (dy[v].y - s1 - xh[v].y * s2);
-                r.z = rstd * (dy[v].z - s1 - xh[v].z * s2);
-                r.w = rstd * (dy[v].w - s1 - xh[v].w * s2);
-                float4* dst = reinterpret_cast<float4*>(dx + (size_t)tok * C) + li + v * lpt;
-                if (dres) { r.x += rs[v].x; r.y += rs[v].y; r.z += rs[v].z; r.w += rs[v].w; }
+                r.x = rstd * (G.dy[v].x - s1 - G.xh[v].x * s2);
+                r.y = rstd * (G.dy[v].y - s1 - G.xh[v].y * s2);
+                r.z = rstd * (G.dy[v].z - s1 - G.xh[v].z * s2);
+                r.w = rstd * (G.dy[v].w - s1 - G.xh[v].w * s2);
+                float4* dst = reinterpret_cast<float4*>(dx + (size_t)G.tok * C) + li + v * lpt;
+                if (dres) { r.x += G.rs[v].x; r.y += G.rs[v].y; r.z += G.rs[v].z; r.w += G.rs[v].w; }
                 *dst = r;
             }
         }
+    };
+    const int stride = nwaves * tpw;
+    for (int base = wave_global * tpw; base < ntok; base += 2 * stride) {
+        Group A, Bg;
+        load(base, A);
+        load(base + stride, Bg);          // past the end: ok = false, nothing loaded or stored
+        compute(A);
+        compute(Bg);
     }
     // reduce dgamma/dbeta: lanes with equal li inside the wave, then waves through LDS, then one atomic per channel
 #pragma unroll

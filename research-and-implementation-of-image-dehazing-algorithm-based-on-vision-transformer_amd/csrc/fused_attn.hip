@@ -43,6 +43,15 @@ __device__ __forceinline__ float r4sum(float v) { v += dpp<0xB1>(v); return v + 
 __device__ __forceinline__ float r8max(float v) { v = r4max(v); return fmaxf(v, dpp<0x141>(v)); }
 __device__ __forceinline__ float r8sum(float v) { v = r4sum(v); return v + dpp<0x141>(v); }
 
+// v_writelane_b32: lane LANE of `old` := the wave-uniform value (this compiler has no builtin for it).  The lane select is an
+// inline constant - a second SGPR would exceed the one-scalar-operand (constant bus) limit of a VALU instruction; the value is a
+// SALU result, which the hardware interlocks (no manual wait states).
+template <int LANE>
+__device__ __forceinline__ int writelane(int old, int val_uniform) {
+    asm("v_writelane_b32 %0, %1, %2" : "+v"(old) : "s"(val_uniform), "n"(LANE));
+    return old;
+}
+
 __device__ __forceinline__ void ld4(const float* p, float* dst) {
     const float4 v = *reinterpret_cast<const float4*>(p);
     dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
@@ -264,20 +273,47 @@ __global__ __launch_bounds__(256, C == 128 ? 1 : 2) void fused_window_attn_fwd_k
                 if (j == 0) sm.m[qi] = mx - su * (1.0f / NT);
             }
             __syncthreads();                       // S and M complete
-            // ---- 2c. every wave ranks all 64 queries itself (lane q <-> query q): no partial-count exchange
+            // ---- 2c. every wave ranks all 64 queries itself: no partial-count exchange.  Lane j holds M[j]; for every query q
+            //      the number of larger measures is ONE vector compare against the broadcast M[q] + a scalar population
+            //      count of the lane mask, handed to lane q with v_writelane: 2 VALU + 3 SALU per query instead of ~4.5 VALU
+            //      for the per-lane count with the index tie rule.  The window has two EQUAL measures iff the counts do not add
+            //      up to 64*63/2 ordered pairs - only then (practically never) the exact tie rule is evaluated per lane.
             int myrank = lane;
             if (!(abl & 8)) {
                 const float mq = sm.m[lane];
-                int cnt = 0;
+                int total = 0, rk = 0;
+// four compares first (four different scalar-pair destinations), then the four population counts, then the four lane
+// writes: one query at a time the chain v_cmp -> s_bcnt1 -> v_writelane is pure latency (~44 cycles per query measured)
+#define RANK4(Q4)                                                                                                        \
+    {                                                                                                                    \
+        float mv[4];                                                                                                     \
+        ld4(&sm.m[(Q4)], mv);                                                                                            \
+        const unsigned long long b0 = __builtin_amdgcn_ballot_w64(mq > mv[0]);   /* {j : M[j] > M[Q4]} */                \
+        const unsigned long long b1 = __builtin_amdgcn_ballot_w64(mq > mv[1]);                                           \
+        const unsigned long long b2 = __builtin_amdgcn_ballot_w64(mq > mv[2]);                                           \
+        const unsigned long long b3 = __builtin_amdgcn_ballot_w64(mq > mv[3]);                                           \
+        const int c0 = __builtin_popcountll(b0), c1 = __builtin_popcountll(b1);                                          \
+        const int c2 = __builtin_popcountll(b2), c3 = __builtin_popcountll(b3);                                          \
+        total += (c0 + c1) + (c2 + c3);                                                                                  \
+        rk = writelane<(Q4) + 0>(rk, c0); rk = writelane<(Q4) + 1>(rk, c1);                                              \
+        rk = writelane<(Q4) + 2>(rk, c2); rk = writelane<(Q4) + 3>(rk, c3);                                              \
+    }
+                RANK4(0) RANK4(4) RANK4(8) RANK4(12) RANK4(16) RANK4(20) RANK4(24) RANK4(28)
+                RANK4(32) RANK4(36) RANK4(40) RANK4(44) RANK4(48) RANK4(52) RANK4(56) RANK4(60)
+#undef RANK4
+                if (total != NT * (NT - 1) / 2) {
+                    int cnt = 0;
 #pragma unroll 2
-                for (int jj = 0; jj < NT; jj += 4) {
-                    float mv[4];
-                    ld4(&sm.m[jj], mv);
+                    for (int jj = 0; jj < NT; jj += 4) {
+                        float mv[4];
+                        ld4(&sm.m[jj], mv);
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) cnt += (mv[u] > mq) || (mv[u] == mq && (jj + u) < lane);
+                        for (int u = 0; u < 4; ++u) cnt += (mv[u] > mq) || (mv[u] == mq && (jj + u) < lane);
+                    }
+                    rk = cnt;
                 }
-                myrank = cnt;
-                if (cnt < NU) sm.top[w][cnt] = lane;
+                myrank = rk;
+                if (rk < NU) sm.top[w][rk] = lane;
                 if (lane >= NU && lane < 32) sm.top[w][lane] = 0;
             }
             // ---- 2d. P = softmax(softmax(scale S[top]) + bias + mask): wave w -> rows 8w..8w+7

@@ -7,7 +7,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdehaze_hip.so")
+LIB_PATH = os.environ.get("DHZ_LIB_PATH") or os.path.join(_HERE, "libdehaze_hip.so")   # override: A/B of two builds
 
 c_f = ctypes.c_void_p      # device float*
 c_p = ctypes.c_void_p

@@ -69,6 +69,37 @@ def test_fused_equals_unfused_chain(dev, C, heads, res, shift, B):
     assert torch.allclose(ye, yu, atol=2e-5, rtol=1e-4)
 
 
+@pytest.mark.parametrize("C,heads,mode", [(32, 1, "pairs"), (32, 1, "all"), (64, 2, "pairs"), (128, 4, "all")])
+def test_fused_rank_ties(dev, C, heads, mode):
+    """Windows with bit-equal sparsity measures: duplicated token rows + one shared sample row make M[i] == M[i'] exactly
+    (pairs of horizontally adjacent tokens, or all 64 tokens of every window), so the top-25 set is decided by the index
+    tie rule (lower index first, ATT:122 / the oracle).  The fused kernel counts larger measures with lane masks and only
+    falls back to the per-lane tie rule when the counts reveal a tie - this is the case that takes the fallback."""
+    import My_model_1 as M1
+    torch.manual_seed(C)
+    res, B = 16, 2
+    blk = M1.LeWinTransformerBlock(dim=C, input_resolution=(res, res), num_heads=heads, win_size=8, shift_size=0,
+                                   token_mlp='leff', drop_path=0.).to(dev).eval()
+    if mode == "pairs":
+        base = torch.randn(B, res, res // 2, C, device=dev)
+        x = base.repeat_interleave(2, dim=2).reshape(B, res * res, C)
+    else:
+        x = torch.randn(B, 1, C, device=dev).expand(B, res * res, C).contiguous()
+    idx = torch.randint(64, (1, 25)).expand(64, 25).contiguous().to(torch.uint8).to(dev)
+    from dehaze_hip import fused
+    with torch.no_grad():
+        blk._staged_idx = idx
+        yf = blk(x)
+        fused.ENABLED = False
+        try:
+            blk._staged_idx = idx
+            yu = blk(x)
+        finally:
+            fused.ENABLED = True
+    assert torch.isfinite(yf).all()
+    assert torch.allclose(yf, yu, atol=2e-5, rtol=1e-4), (yf - yu).abs().max()
+
+
 @pytest.mark.parametrize("name,heads,shift,C", [("block_m1_c32_shift0", 1, 0, 32), ("block_m1_c32_shift4", 1, 4, 32),
                                                 ("block_m1_c64_shift4", 2, 4, 64)])
 def test_fused_block_vs_reference_golden(golden, dev, name, heads, shift, C):
