@@ -19,7 +19,7 @@ st = torch.zeros(4 * 8 * 16, dtype=torch.int64, device=dev)
 lib.dhz_debug_stamp(V(st.data_ptr()))
 for _ in range(3):
     rc = lib.dhz_fused_window_attn_fwd(V(x.data_ptr()), V(gamma.data_ptr()), V(beta.data_ptr()), V(wqkv_p.data_ptr()), V(bq.data_ptr()), V(wo_p.data_ptr()), V(bo.data_ptr()),
-        V(idx.data_ptr()), V(bias.data_ptr()), None, None, V(out.data_ptr()), V(xn.data_ptr()), V(qkv.data_ptr()), V(ctx.data_ptr()), V(stats.data_ptr()), V(rank.data_ptr()), B, res, res, C, 0, V(s))
+        V(idx.data_ptr()), (None if os.environ.get("NOBIAS") else V(bias.data_ptr())), None, None, V(out.data_ptr()), V(xn.data_ptr()), V(qkv.data_ptr()), V(ctx.data_ptr()), V(stats.data_ptr()), V(rank.data_ptr()), B, res, res, C, 0, V(s))
 torch.cuda.synchronize()
 a = st.cpu().view(4, 8, 16)
 names = ["LN", "QKV", "bar", "save", "S", "M", "bar", "rank", "smax", "bar", "PV", "bar", "proj", "bar", "epi"]
