@@ -23,6 +23,8 @@ def enable_tuned_gemms(path=None):
     tun = torch.cuda.tunable
     tun.enable(True)
     tun.tuning_enable(False)           # never tune inside a run: unknown shapes fall back to the default heuristic
+    if hasattr(tun, "write_file_on_exit"):
+        tun.write_file_on_exit(False)  # nothing new to record; N ranks must not race on a results file in the cwd
     try:
         return bool(tun.read_file(path))
     except Exception:                  # a stale / foreign file must never break a run
