@@ -70,6 +70,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (weak scaling)")
+    ap.add_argument("--strong", action="store_true", help="strong scaling (SURVEY 8d): GLOBAL batch = --batch, split over the ranks")
     ap.add_argument("--embed_dim", type=int, default=32)
     ap.add_argument("--ps", type=int, default=128)
     ap.add_argument("--no-cr", action="store_true", help="Charbonnier only (NOT the headline config)")
@@ -92,6 +93,9 @@ def main():
     if world > 1:
         dist.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else {}))
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if args.strong:
+        assert args.batch % world == 0, f"--strong: global batch {args.batch} not divisible by {world} ranks"
+        args.batch //= world
 
     import My_model_1 as M1
     import My_CR
@@ -145,7 +149,7 @@ def main():
         out = {
             "metric": "train patches/sec (128x128, embed_dim=32)", "value": round(total / elapsed, 3),
             "unit": "patches/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "strong" if args.strong else "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"Uformer_ProbSparse train step E={args.embed_dim} ps={args.ps} per-GPU bs={args.batch} "
                                    f"fp32 {'Charbonnier' if args.no_cr else 'Charbonnier+CR(VGG19, seeded-random weights)'} "

@@ -34,3 +34,21 @@ def test_bench_json_contract():
         assert ro["launches"] > 0 and ro["avg_launch_us"] > 0
         assert ro["traffic"] is None or ro["traffic"] > 0
     assert "cpu_baseline" not in d
+
+
+def test_bench_two_ranks_strong_scaling():
+    """The driver's multi-GPU launch line on a ONE-GPU box: two ranks share the device and reduce over gloo (test-only
+    switches DHZ_DIST_BACKEND / DHZ_SHARE_GPU; the real runs use RCCL, one rank per GPU).  --strong splits the global
+    batch of 32 over the ranks (SURVEY 8d asks for both scalings); rank 0 alone prints the line."""
+    env = dict(os.environ, DHZ_DIST_BACKEND="gloo", DHZ_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2", "--strong",
+           "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["global_batch"] == 32
+    assert d["config"]["parallelism"] == "dp2" and d["value"] > 50
+    assert abs(d["value"] - 32 * 1e3 / d["ms_per_step"]) < 0.01 * d["value"]
