@@ -507,9 +507,22 @@ void launch_fused(hipStream_t s, int nwin, const float* x, const float* gamma, c
     if (smem > 48 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_window_attn_fwd_kernel<C, SAVE>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    // persistent workgroups: as many as fit the chip at this LDS footprint (3 per CU at C = 32, 2 above)
-    const int per_cu = (int)(160 * 1024 / smem) > 0 ? (int)(160 * 1024 / smem) : 1;
-    int grid = (C == 32 && FUSED_PERSIST_C32) ? 256 * (per_cu > 3 ? 3 : per_cu) : nwin;   // persistent only with register-resident weights
+    // persistent workgroups (only with register-resident weights): exactly as many as are RESIDENT at once - the occupancy
+    // the runtime reports for this code object (registers and LDS together: 2 per CU at 222 VGPRs, although 3 would fit the
+    // LDS) - a third workgroup per CU would run alone after the first two have finished.  DHZ_FUSED_WG_PER_CU overrides.
+    static const int env_wg = getenv("DHZ_FUSED_WG_PER_CU") ? atoi(getenv("DHZ_FUSED_WG_PER_CU")) : 0;
+    static int per_cu = 0, ncu = 0;          // queried once per code object (all devices of a node are the same part)
+    if (per_cu == 0) {
+        int q = 0, dev = 0;
+        hipDeviceProp_t prop;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, reinterpret_cast<const void*>(&fused_window_attn_fwd_kernel<C, SAVE>),
+                                                         256, smem) != hipSuccess || q < 1)
+            q = 2;
+        ncu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
+               prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+        per_cu = env_wg > 0 ? env_wg : q;
+    }
+    int grid = (C == 32 && FUSED_PERSIST_C32) ? ncu * per_cu : nwin;
     if (grid > nwin) grid = nwin;
     hipLaunchKernelGGL((fused_window_attn_fwd_kernel<C, SAVE>), dim3(grid), dim3(256), smem, s, x, gamma, beta,
                        reinterpret_cast<const float4*>(wqkv_p), bqkv, reinterpret_cast<const float4*>(wo_p), bo, idx,
