@@ -250,6 +250,7 @@ class LeWinTransformerBlock(nn.Module):
         self.mlp = LeFF(dim, int(dim * mlp_ratio), act_layer=act_layer, drop=drop)
         self._mask_cache = {}
         self._staged_idx = None      # set by Uformer.forward (one batched host draw per model forward)
+        self._staged_scales = None   # set by Uformer.forward on the GPU: the two DropPath vectors of this block
 
     def extra_repr(self):
         return (f"dim={self.dim}, input_resolution={self.input_resolution}, num_heads={self.num_heads}, "
@@ -264,6 +265,8 @@ class LeWinTransformerBlock(nn.Module):
         return m
 
     def _scale(self, x):
+        if self._staged_scales:                      # drawn for the whole model in one call (Uformer._stage_drop_path)
+            return self._staged_scales.pop(0)
         return self.drop_path.sample_scale(x) if isinstance(self.drop_path, DropPath) else None
 
     def forward(self, x, mask=None):
@@ -522,8 +525,34 @@ class Uformer(nn.Module):
         for i, b in enumerate(blocks):
             b._staged_idx = idx[i]
 
+    def _stage_drop_path(self, x):
+        """All DropPath keep/keep_prob vectors of one training forward (two per block with drop_prob > 0) from ONE
+        bernoulli launch + one division instead of two tiny launches per residual (~70 launches of ~4 us per step).  GPU
+        only: on the CPU every residual keeps its own draw, in the order the reference consumes the CPU generator (the
+        golden training trajectory pins that order); the GPU's Philox stream has no reference counterpart to match."""
+        blocks = [b for st in self.stages() for b in st.blocks]
+        for b in blocks:
+            b._staged_scales = None
+        if not (self.training and x.is_cuda):
+            return
+        live = [b for b in blocks if isinstance(b.drop_path, DropPath) and b.drop_path.drop_prob > 0.]
+        if not live:
+            return
+        B = x.shape[0]
+        key = (B, str(x.device), tuple(b.drop_path.drop_prob for b in live))
+        if getattr(self, "_keep_key", None) != key:
+            keep = torch.tensor([1.0 - b.drop_path.drop_prob for b in live for _ in range(2)], dtype=torch.float32)
+            self._keep_mat = keep.view(-1, 1).expand(-1, B).contiguous().to(x.device)
+            self._keep_inv = (1.0 / keep).view(-1, 1).to(x.device)
+            self._keep_key = key
+        r = torch.bernoulli(self._keep_mat)
+        r.mul_(self._keep_inv)                       # scale_by_keep (timm default)
+        for i, b in enumerate(live):
+            b._staged_scales = [r[2 * i], r[2 * i + 1]]
+
     def forward(self, x, mask=None):
         self._stage_sample_indices(x.device)
+        self._stage_drop_path(x)
         y = self.pos_drop(self.input_proj(x))
         skips = []
         for s in range(4):

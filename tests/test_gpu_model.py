@@ -317,3 +317,39 @@ def test_config4_shape_in_fp32(dev):
     after = [p.detach() for _, p in model.live_parameters()][:4]
     assert any(not torch.equal(a, b) for a, b in zip(before, after))
     assert torch.cuda.max_memory_allocated() < 80 * 2 ** 30
+
+
+def test_drop_path_staged_once_per_forward(dev):
+    """Training forward on the GPU: the 34 DropPath vectors (two per block with drop_prob > 0) come from one bernoulli launch;
+    every block consumes exactly its two, values are 0 or 1/keep_prob, eval mode stages nothing."""
+    import My_model_1 as M1
+    seed_all(3)
+    model = M1.Uformer(img_size=128, embed_dim=32, win_size=8, token_projection='linear', token_mlp='leff').to(dev).train()
+    x = torch.rand(4, 3, 128, 128, device=dev)
+    seen = []
+    blocks = [b for st in model.stages() for b in st.blocks]
+    orig = type(blocks[0])._scale
+
+    def spy(self, t):
+        s = orig(self, t)
+        seen.append((self, s))
+        return s
+
+    type(blocks[0])._scale = spy
+    try:
+        y = model(x)
+    finally:
+        type(blocks[0])._scale = orig
+    assert torch.isfinite(y).all() and len(seen) == 2 * len(blocks)
+    for b, s in seen:
+        p = b.drop_path.drop_prob if hasattr(b.drop_path, "drop_prob") else 0.
+        if p == 0.:
+            assert s is None
+        else:
+            assert s.shape == (4,) and s.is_contiguous()
+            assert all(abs(v) < 1e-7 or abs(v - 1 / (1 - p)) < 1e-6 for v in s.tolist())
+    assert all(not b._staged_scales for b in blocks)                     # all consumed
+    model.eval()
+    with torch.no_grad():
+        model(x)
+    assert all(b._staged_scales is None for b in blocks)
