@@ -237,3 +237,74 @@ class _L1Pair(Function):
 
 def l1_pair(a, p, n=None):
     return _L1Pair.apply(a, p, n)
+
+
+_TAP_CONST = {}
+
+
+class _ContrastTaps(Function):
+    """The scalar side of ContrastLoss.forward (My_CR.py:104-123) for ALL taps as one autograd node:
+        loss = sum_i w_i * ap_i / (an_i + 1e-7)   (ablation: sum_i w_i * ap_i),  all_ap = sum_i ap_i,  all_an = sum_i an_i
+    with ap_i / an_i the L1 means of tap i (dhz_l1_pair_fwd, one pass over a, p, n per tap).  As separate autograd scalars the
+    five taps cost ~100 launches of 4-8 us per step (0-dim add / div / mul / neg, select_backward, zero fills); here the
+    combination and the ten backward coefficients are a handful of [5]-vector ops."""
+
+    @staticmethod
+    def forward(ctx, weights, ablation, B, *feats):
+        k = len(feats) // 2
+        a = [f.contiguous() for f in feats[:k]]
+        dev = a[0].device
+        key = (str(dev), tuple(f.numel() for f in a), tuple(weights))
+        if key not in _TAP_CONST:
+            _TAP_CONST[key] = (torch.tensor([1.0 / f.numel() for f in a], dtype=torch.float32).view(k, 1).to(dev),
+                               torch.tensor(list(weights), dtype=torch.float32).to(dev))
+        inv_cnt, w = _TAP_CONST[key]
+        sums = torch.zeros((k, 2), device=dev, dtype=torch.float32)
+        ps, ns = [], []
+        for i in range(k):
+            p = feats[k + i][:B].contiguous()
+            n = None if ablation else feats[k + i][B:].contiguous()
+            _lib.call("dhz_l1_pair_fwd", _p(a[i]), _p(p), _p(n) if n is not None else None, sums.data_ptr() + 8 * i,
+                      a[i].numel(), _stream())
+            ps.append(p)
+            ns.append(n)
+        d = sums * inv_cnt                                            # [k, 2] means
+        ratio = d[:, 0] if ablation else d[:, 0] / (d[:, 1] + 1e-7)
+        tot = d.sum(0)
+        ctx.set_materialize_grads(False)
+        ctx.k, ctx.ablation = k, ablation
+        ctx.save_for_backward(d, w, *a, *ps, *([] if ablation else ns))
+        return (w * ratio).sum(), tot[0], tot[1]
+
+    @staticmethod
+    def backward(ctx, g_loss, g_ap, g_an):
+        k, ablation = ctx.k, ctx.ablation
+        saved = ctx.saved_tensors
+        d, w = saved[0], saved[1]
+        a, ps = saved[2:2 + k], saved[2 + k:2 + 2 * k]
+        ns = [None] * k if ablation else saved[2 + 2 * k:2 + 3 * k]
+        g = torch.zeros((k, 2), device=d.device, dtype=torch.float32)          # d loss / d (ap_i, an_i)
+        if g_loss is not None:
+            if ablation:
+                g[:, 0] = g_loss * w
+            else:
+                den = d[:, 1] + 1e-7
+                c0 = g_loss * w / den
+                g[:, 0] = c0
+                g[:, 1] = -c0 * d[:, 0] / den
+        if g_ap is not None:
+            g[:, 0] += g_ap
+        if g_an is not None:
+            g[:, 1] += g_an
+        das = []
+        for i in range(k):
+            da = torch.empty_like(a[i])
+            _lib.call("dhz_l1_pair_bwd", _p(a[i]), _p(ps[i]), _p(ns[i]) if ns[i] is not None else None, g.data_ptr() + 8 * i,
+                      _p(da), a[i].numel(), _stream())
+            das.append(da)
+        return (None, None, None) + tuple(das) + (None,) * k
+
+
+def contrast_taps(a_taps, pn_taps, B, weights, ablation):
+    """(loss, all_ap, all_an) of ContrastLoss from the feature taps of a (grad) and of cat([p, n]) / p (no grad)."""
+    return _ContrastTaps.apply(tuple(weights), bool(ablation), int(B), *a_taps, *pn_taps)

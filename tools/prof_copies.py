@@ -27,6 +27,18 @@ for e in prof.events():
     if e.name in want and e.device_time_total > 4:
         stack = [s for s in (e.stack or []) if "dehaze" in s or "My_" in s or "losses" in s]
         rows.append((e.device_time_total, e.name, str(e.input_shapes)[:60], stack[0][-70:] if stack else ""))
+import collections, sys
+if len(sys.argv) > 1 and sys.argv[1] == "--small":       # group the small launches: (op, shapes, first model-side frame) -> count, total us
+    agg = collections.defaultdict(lambda: [0, 0.0])
+    for e in prof.events():
+        if e.device_time_total > 0 and e.device_time_total < 14 and e.name.startswith("aten::") and e.name not in ("aten::clone", "aten::contiguous", "aten::zero_", "aten::zeros", "aten::zeros_like", "aten::to", "aten::_to_copy", "aten::reshape", "aten::ones", "aten::ones_like", "aten::full", "aten::sub", "aten::rsub"):
+            stack = [s for s in (e.stack or []) if "dehaze" in s or "My_" in s or "losses" in s or "train.py" in s]
+            k = (e.name, str(e.input_shapes)[:50], stack[0][-60:] if stack else "")
+            agg[k][0] += 1; agg[k][1] += e.device_time_total
+    for k, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:60]:
+        print(f"{t:7.1f} us {c:4d}x  {k[0]:16s} {k[1]:50s} {k[2]}")
+    print("total", sum(v[1] for v in agg.values()), "us in", sum(v[0] for v in agg.values()), "launches")
+    sys.exit(0)
 rows.sort(reverse=True)
 tot = sum(r[0] for r in rows)
 print(f"{len(rows)} ops, {tot/1e3:.2f} ms")
