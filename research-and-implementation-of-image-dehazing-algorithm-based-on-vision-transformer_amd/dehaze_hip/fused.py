@@ -104,7 +104,7 @@ class _FusedAttnBranch(Function):
         wqkv_p = torch.empty(3 * C * C, **f32)
         wo_p = torch.empty(C * C, **f32)
         _lib.call("dhz_fused_attn_prepack", _p(wq), _p(wk), _p(wv), _p(wo), _p(wqkv_p), _p(wo_p), C, _stream())
-        bqkv = torch.cat([bq, bk, bv])
+        bqkv = ops.cat_rows([bq.detach(), bk.detach(), bv.detach()])
         bias = None
         if table is not None:
             bias = torch.empty((H, NTOK, NTOK), **f32)
@@ -160,7 +160,7 @@ class _FusedAttnBranch(Function):
                   gb, gb + 4 * C, gb + 8 * C, 3 * C, _p(dpart), B_, H, nW, 32, _stream())
         dtable = _table_backward(dpart, parts, table_p, H, dev) if bias is not None else None
         # (4) QKV projection
-        dxn = dqkv @ torch.cat([wq_, wk_, wv_], 0)
+        dxn = dqkv @ ops.cat_rows([wq_.detach(), wk_.detach(), wv_.detach()])
         g_wq, g_bq, g_wk, g_bk, g_wv, g_bv = _wgrad_qkv(dqkv, xn, C, [(wq, bq), (wk, bk), (wv, bv)])
         # (5) LayerNorm backward + shortcut gradient in one pass
         dx, dgamma, dbeta = _ln_backward(dxn, x, gamma_p, beta_p, gamma, stats, dout, B, Hres, Wres, C, shift, 1)
@@ -195,8 +195,8 @@ class _AttnBranchChain(Function):
         stats = torch.empty((T, 2), **f32)
         _lib.call("dhz_ln_partition_fwd", _p(x), _p(gamma), _p(beta), _p(xn), _p(stats), B, Hres, Wres, C, shift, 1,
                   _stream())
-        wcat = torch.cat([wq, wk, wv], 0)
-        qkv = torch.addmm(torch.cat([bq, bk, bv]), xn, wcat.t())
+        wcat = ops.cat_rows([wq.detach(), wk.detach(), wv.detach()])
+        qkv = torch.addmm(ops.cat_rows([bq.detach(), bk.detach(), bv.detach()]), xn, wcat.t())
         bias = None
         if table is not None:
             bias = torch.empty((H, NTOK, NTOK), **f32)
@@ -246,7 +246,7 @@ class _AttnBranchChain(Function):
         _lib.call("dhz_ps_attn_bwd", base, base + 4 * C, base + 8 * C, 3 * C, _p(bias), _p(mask), _p(rank), _p(dctx), C,
                   gb, gb + 4 * C, gb + 8 * C, 3 * C, _p(dpart), B_, H, nW, d, _stream())
         dtable = _table_backward(dpart, parts, table_p, H, dev) if bias is not None else None
-        dxn = dqkv @ torch.cat([wq_, wk_, wv_], 0)
+        dxn = dqkv @ ops.cat_rows([wq_.detach(), wk_.detach(), wv_.detach()])
         g_wq, g_bq, g_wk, g_bk, g_wv, g_bv = _wgrad_qkv(dqkv, xn, C, [(wq, bq), (wk, bk), (wv, bv)])
         dx, dgamma, dbeta = _ln_backward(dxn, x, gamma_p, beta_p, gamma, stats, dout, B, Hres, Wres, C, shift, 1)
         return (dx, dgamma, dbeta, g_wq, g_bq, g_wk, g_bk, g_wv, g_bv, g_wo, g_bo, dtable,

@@ -202,6 +202,30 @@ def _accumulate_param_grads(dy, ldy_off, x, params):
                 GRAD_READY(b)
 
 
+_NO_CAT_VIEW = bool(__import__("os").environ.get("DHZ_NO_CAT_VIEW"))     # A/B switch: always copy
+
+
+def cat_rows(ts):
+    """torch.cat(ts, 0) for detached row blocks - WITHOUT a copy when they already sit back to back in memory, which is how
+    FlatAdamW lays out the Q / K / V weights (and biases) of an attention layer in its flat parameter buffer.  Only for use
+    where autograd does not track the result (inside Function.forward / backward)."""
+    t0 = ts[0]
+    end = t0.data_ptr() + t0.numel() * t0.element_size()
+    base = t0.untyped_storage().data_ptr()          # same allocation, not merely neighbouring ones
+    ok = t0.is_contiguous() and not t0.requires_grad and not _NO_CAT_VIEW
+    for t in ts[1:]:
+        ok = ok and t.is_contiguous() and not t.requires_grad and t.dtype == t0.dtype and t.device == t0.device \
+            and t.shape[1:] == t0.shape[1:] and t.data_ptr() == end and t.untyped_storage().data_ptr() == base
+        if not ok:
+            break
+        end += t.numel() * t.element_size()
+    if not ok:
+        return torch.cat(list(ts), 0)
+    rows = sum(t.shape[0] for t in ts)
+    shape = (rows,) + tuple(t0.shape[1:])
+    return t0.as_strided(shape, t0.stride())
+
+
 class _LinearTokens(Function):
     """y = x [W_1;..;W_n]^T + [b_1;..;b_n] for token-major x [T,K].  Forward and dgrad are plain library
     GEMMs (rocBLAS/hipBLASLt run them near the fp32 MFMA peak); the weight/bias gradients - skinny TN
@@ -215,8 +239,8 @@ class _LinearTokens(Function):
         if len(params) == 1:
             W, b = params[0]
         else:
-            W = torch.cat([w for w, _ in params], 0)
-            b = torch.cat([b_ for _, b_ in params], 0)
+            W = cat_rows([w.detach() for w, _ in params])
+            b = cat_rows([b_.detach() for _, b_ in params])
         y = torch.addmm(b, x, W.t()) if b is not None else x @ W.t()
         ctx.save_for_backward(x, W)
         ctx.params = params

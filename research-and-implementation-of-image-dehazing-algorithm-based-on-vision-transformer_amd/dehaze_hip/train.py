@@ -27,8 +27,10 @@ class FlatAdamW(torch.optim.Optimizer):
     """
 
     def __init__(self, model_or_params, lr=2e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.02, live=None):
+        names = {}
         if isinstance(model_or_params, torch.nn.Module):
             params = list(model_or_params.parameters())
+            names = {id(p): n for n, p in model_or_params.named_parameters()}
             if live is None and hasattr(model_or_params, "live_parameters"):
                 live = [p for _, p in model_or_params.live_parameters()]
         else:
@@ -36,6 +38,7 @@ class FlatAdamW(torch.optim.Optimizer):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self._all = params
         self._live = live if live is not None else [p for p in params if p.requires_grad]
+        self._names = names
         self._flat = None
         self._step = 0
         self.grad_scale = 1.0          # set to 1/world_size by the gradient reducer (SUM all-reduce)
@@ -44,7 +47,7 @@ class FlatAdamW(torch.optim.Optimizer):
     def _ensure_flat(self):
         if self._flat is not None:
             return
-        order = list(reversed(self._live))
+        order = self._qkv_adjacent(list(reversed(self._live)))
         dev = order[0].device
         n = sum(p.numel() for p in order)
         npad = (n + 3) // 4 * 4
@@ -63,15 +66,35 @@ class FlatAdamW(torch.optim.Optimizer):
             off += k
         self._flat = dict(p=fp, g=fg, m=torch.zeros_like(fp), v=torch.zeros_like(fp), n=n)
 
+    def _qkv_adjacent(self, order):
+        """Within every attention layer put the three projection weights back to back (Wq, Wk, Wv) and the three biases
+        likewise: the packed [3C, C] operand of the QKV GEMMs is then a VIEW of the flat buffer (ops.cat_rows) instead of a
+        torch.cat per block and pass.  The six tensors occupy the same six consecutive slots as before (registration order
+        q.w q.b k.w k.b v.w v.b), so bucket boundaries in backward order are unchanged."""
+        pos = {self._names.get(id(p), ""): i for i, p in enumerate(order)}
+        for name, i in list(pos.items()):
+            if not name.endswith("query_projection.weight"):
+                continue
+            pre = name[:-len("query_projection.weight")]
+            six = [pre + f"{m}_projection.{t}" for t in ("weight", "bias") for m in ("query", "key", "value")]
+            if not all(n in pos for n in six):
+                continue
+            slots = sorted(pos[n] for n in six)
+            if slots != list(range(slots[0], slots[0] + 6)):
+                continue
+            for slot, n in zip(slots, six):
+                order[slot] = next(p for p in self._live if self._names.get(id(p)) == n)
+        return order
+
     @property
     def flat_grad(self):
         self._ensure_flat()
         return self._flat["g"]
 
     def param_slices(self):
-        """[(param, offset, numel)] in flat (= reverse registration) order."""
+        """[(param, offset, numel)] in flat-buffer order (reverse registration, Q/K/V grouped - _qkv_adjacent)."""
         self._ensure_flat()
-        return [(p,) + self._offsets[id(p)] for p in reversed(self._live)]
+        return sorted(((p,) + self._offsets[id(p)] for p in self._live), key=lambda t: t[1])
 
     def zero_grad(self, set_to_none=False):
         self._ensure_flat()

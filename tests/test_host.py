@@ -126,3 +126,45 @@ def test_get_arch_and_checkpoint_roundtrip(tmp_path):
     utils.load_checkpoint(m2, path)
     assert utils.load_start_epoch(path) == 7
     assert all(torch.equal(a, b) for a, b in zip(m.state_dict().values(), m2.state_dict().values()))
+
+
+def test_flat_buffer_layout_packs_qkv():
+    """FlatAdamW's flat parameter buffer: values preserved, slices sorted and gap-free, and in every attention layer the three
+    projection weights (and biases) sit back to back, so that ops.cat_rows returns a VIEW of the buffer instead of a copy."""
+    import My_model_1 as M1
+    from dehaze_hip import ops
+    from dehaze_hip.train import FlatAdamW
+    torch.manual_seed(0)
+    model = M1.Uformer(img_size=128, embed_dim=32, win_size=8, token_projection='linear', token_mlp='leff')
+    before = {n: p.detach().clone() for n, p in model.named_parameters()}
+    opt = FlatAdamW(model)
+    opt._ensure_flat()
+    for n, p in model.named_parameters():
+        assert torch.equal(p.detach(), before[n]), n
+    sl = opt.param_slices()
+    live = [p for _, p in model.live_parameters()]
+    assert len(sl) == len(live) and {id(p) for p, _, _ in sl} == {id(p) for p in live}
+    off = 0
+    for p, o, k in sl:
+        assert o == off and k == p.numel()
+        off += k
+    layers = [m for m in model.modules() if hasattr(m, "query_projection")]
+    assert len(layers) == 18
+    for m in layers:
+        ws = [m.query_projection.weight.detach(), m.key_projection.weight.detach(), m.value_projection.weight.detach()]
+        bs = [m.query_projection.bias.detach(), m.key_projection.bias.detach(), m.value_projection.bias.detach()]
+        W, b = ops.cat_rows(ws), ops.cat_rows(bs)
+        assert W.data_ptr() == ws[0].data_ptr() and b.data_ptr() == bs[0].data_ptr()          # views, not copies
+        assert torch.equal(W, torch.cat(ws, 0)) and torch.equal(b, torch.cat(bs, 0))
+    # not adjacent (or tracked by autograd): falls back to a copy with the same values
+    a, c = torch.randn(4, 3), torch.randn(2, 3)
+    assert torch.equal(ops.cat_rows([a, c]), torch.cat([a, c], 0))
+    # neighbouring addresses in DIFFERENT allocations must not be taken for one buffer
+    import ctypes
+    raw = torch.zeros(64)
+    u, v = raw[:12].view(4, 3).clone(), None
+    blob = torch.empty(24)
+    u2, v2 = blob[:12].view(4, 3), blob[12:].view(4, 3)
+    assert ops.cat_rows([u2, v2]).data_ptr() == u2.data_ptr()
+    assert ops.cat_rows([u, u2]).data_ptr() not in (u.data_ptr(), u2.data_ptr())
+    assert ops.cat_rows([m.query_projection.weight, m.key_projection.weight]).data_ptr() != m.query_projection.weight.data_ptr()
