@@ -359,6 +359,28 @@ class Downsample(nn.Module):
         return _map_to_tokens(self.conv(_tokens_to_map(x)))
 
 
+class _ShuffleConcat(torch.autograd.Function):
+    """cat([pixel_shuffle(y), skip], -1) for the decoder (M1:1192-1204): y [B*s*s, (a, b, o)] is the token-Linear form of
+    the 2x2/stride-2 transposed convolution, skip [B, 4*s*s, Co].  Two strided copies straight into the concatenated
+    buffer instead of a shuffle copy followed by a cat (and one strided copy instead of two on the way back)."""
+
+    @staticmethod
+    def forward(ctx, y, skip, B, s, Co):
+        Cs = skip.shape[-1]
+        out = torch.empty((B, 4 * s * s, Co + Cs), device=y.device, dtype=y.dtype)
+        out.view(B, s, 2, s, 2, Co + Cs)[..., :Co].copy_(y.view(B, s, s, 2, 2, Co).permute(0, 1, 3, 2, 4, 5))
+        out[..., Co:].copy_(skip)
+        ctx.dims = (B, s, Co, Cs)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        B, s, Co, Cs = ctx.dims
+        gy = torch.empty((B * s * s, 4 * Co), device=g.device, dtype=g.dtype)
+        gy.view(B, s, s, 2, 2, Co).copy_(g.view(B, s, 2, s, 2, Co + Cs)[..., :Co].permute(0, 1, 3, 2, 4, 5))
+        return gy, g[..., Co:], None, None, None
+
+
 class Upsample(nn.Module):
     """ConvTranspose k2 s2 (M1:633-648)."""
 
@@ -367,9 +389,11 @@ class Upsample(nn.Module):
         self.deconv = nn.Sequential(nn.ConvTranspose2d(in_channel, out_channel, kernel_size=2, stride=2))
         self.in_channel, self.out_channel = in_channel, out_channel
 
-    def forward(self, x):
+    def forward(self, x, skip=None):
+        """skip: optional [B, 4L, Cs] tensor to concatenate behind the up-sampled tokens (the decoder's skip connection)."""
         if not x.is_cuda:
-            return _map_to_tokens(self.deconv(_tokens_to_map(x)))
+            y = _map_to_tokens(self.deconv(_tokens_to_map(x)))
+            return y if skip is None else torch.cat([y, skip], -1)
         # kernel 2 / stride 2: every input token produces its own 2x2 output pixels and nothing overlaps, so the layer IS
         # a token Linear K = Cin -> N = 4*Cout followed by a pixel shuffle: one library GEMM (forward / dgrad) + the
         # split-T weight-gradient kernel instead of MIOpen's implicit-GEMM transposed convolution (~2.3x slower here).
@@ -380,8 +404,11 @@ class Upsample(nn.Module):
         w4 = dc.weight.permute(2, 3, 1, 0).reshape(4 * Co, Cin)            # rows (a, b, o): y[(2i+a, 2j+b), o]
         b4 = dc.bias.repeat(4)
         y = ops.linear_tokens(x.reshape(B * L, Cin), w4, b4)                # [B*s*s, (a, b, o)]
+        if skip is not None and (y.requires_grad or skip.requires_grad or not torch.is_grad_enabled()):
+            return _ShuffleConcat.apply(y, skip.contiguous(), B, s, Co)
         y = y.view(B, s, s, 2, 2, Co).permute(0, 1, 3, 2, 4, 5)             # [B, i, a, j, b, o]
-        return y.reshape(B, 4 * L, Co)
+        y = y.reshape(B, 4 * L, Co)
+        return y if skip is None else torch.cat([y, skip], -1)
 
 
 class InputProj(nn.Module):
@@ -561,8 +588,7 @@ class Uformer(nn.Module):
             y = getattr(self, f"dowsample_{s}")(y)
         y = self.conv(y, mask=mask)
         for s in range(4):
-            y = getattr(self, f"upsample_{s}")(y)
-            y = torch.cat([y, skips[3 - s]], -1)
+            y = getattr(self, f"upsample_{s}")(y, skips[3 - s])
             y = getattr(self, f"decoderlayer_{s}")(y, mask=mask)
         return x + self.output_proj(y)
 
