@@ -105,6 +105,9 @@ def main():
 
     from dehaze_hip.tuning import enable_tuned_gemms
     tuned = enable_tuned_gemms()                  # recorded hipBLASLt solution per GEMM shape (kernel selection only)
+    # MIOpen picks the convolution algorithms of the projection / resampling layers by measurement during the warm-up steps,
+    # as the reference's driver does (My_train.py:35, cudnn.benchmark = True); DHZ_CONV_FIND=0 keeps the heuristic pick
+    torch.backends.cudnn.benchmark = bool(int(os.environ.get("DHZ_CONV_FIND", "1")))
     torch.manual_seed(1234)                       # identical replicas on every rank
     model = M1.Uformer(img_size=args.ps, embed_dim=args.embed_dim, win_size=8, token_projection='linear',
                        token_mlp='leff').to(dev)
@@ -154,7 +157,7 @@ def main():
             "config": {"workload": f"Uformer_ProbSparse train step E={args.embed_dim} ps={args.ps} per-GPU bs={args.batch} "
                                    f"fp32 {'Charbonnier' if args.no_cr else 'Charbonnier+CR(VGG19, seeded-random weights)'} "
                                    "+ AdamW (BASELINE configs[1])",
-                       "global_batch": args.batch * world, "parallelism": f"dp{world}", "tuned_gemm_selection": bool(tuned),
+                       "global_batch": args.batch * world, "parallelism": f"dp{world}", "tuned_gemm_selection": bool(tuned), "miopen_find": bool(torch.backends.cudnn.benchmark),
                        "loss_last_step": round(float(loss), 6)},
         }
         pmc = {}

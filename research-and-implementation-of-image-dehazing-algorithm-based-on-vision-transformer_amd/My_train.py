@@ -40,6 +40,9 @@ from My_CR import ContrastLoss  # noqa: E402
 from warmup_scheduler import GradualWarmupScheduler  # noqa: E402
 
 
+torch.backends.cudnn.benchmark = True      # TR:35 - on ROCm: MIOpen measures its convolution algorithms at first use
+
+
 def load_pairs(path, device):
     blob = torch.load(path, map_location="cpu")
     return blob["target"].float().to(device), blob["input"].float().to(device)
