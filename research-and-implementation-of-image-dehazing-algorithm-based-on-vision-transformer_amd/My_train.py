@@ -40,9 +40,6 @@ from My_CR import ContrastLoss  # noqa: E402
 from warmup_scheduler import GradualWarmupScheduler  # noqa: E402
 
 
-torch.backends.cudnn.benchmark = True      # TR:35 - on ROCm: MIOpen measures its convolution algorithms at first use
-
-
 def load_pairs(path, device):
     blob = torch.load(path, map_location="cpu")
     return blob["target"].float().to(device), blob["input"].float().to(device)
@@ -54,6 +51,7 @@ def main():
     parser.add_argument('--val_synthetic', type=int, default=8)
     parser.add_argument('--log_every', type=int, default=10, help='host sync cadence for the progress line')
     opt = parser.parse_args()
+    torch.backends.cudnn.benchmark = True      # TR:35 - on ROCm: MIOpen measures its convolution algorithms at first use
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

@@ -60,7 +60,13 @@ def _worker(rank, world, port, ref_path, q):
     ref = torch.load(ref_path, map_location="cuda")
     grad = opt.flat_grad / world                           # the step applied grad_scale = 1/world inside AdamW
     gerr = (grad - ref["grad"]).abs().max().item() / ref["grad"].abs().max().item()
-    perr = (opt._flat["p"] - ref["param"]).abs().max().item()
+    # AdamW's first step moves a weight by lr * g / (|g| + 1e-8): where the gradient itself is rounding noise (key-projection
+    # biases, weights nobody uses) any 1e-9 difference - split summation order, MIOpen serving a 2-patch and a 4-patch batch
+    # with different algorithms - is a different step, so the parameter check looks at elements with a real gradient
+    real = ref["grad"].abs() > 1e-4 * ref["grad"].abs().max()
+    dp = (opt._flat["p"] - ref["param"]).abs()
+    perr = (dp * real).max().item()
+    assert dp.max().item() < 2.5 * 2e-4                    # nobody moved by more than ~lr either way
     worst = []
     gmax = ref["grad"].abs().max().item()
     names = {id(p): n for n, p in model.named_parameters()}
