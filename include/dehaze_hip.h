@@ -107,6 +107,42 @@ int dhz_bias_gather(const float* table, float* bias, int H, void* stream);
 int dhz_bias_table_grad(const float* dbias_part, int parts, float* dtable, int H, int accumulate,
                         void* stream);
 
+/* K5 fused  The whole LeFF branch of a LeWin block for C = 32, 64, 128 (hidden width 4C), forward, in one kernel:
+ *     out = x + drop_scale[b] * linear2(gelu(dwconv3x3(gelu(linear1(norm2(x))))))          replaces M1:873 + M1:496-534
+ *     (LayerNorm, both Linears on the fp32 matrix pipe around an LDS-resident 8x16-pixel tile + halo, both GELUs, the
+ *     depthwise 3x3 convolution, bias adds, DropPath scale and the residual - the 4C-wide hidden tensors never travel
+ *     to HBM except as the saves below).
+ * x, out: [B, Hres*Wres, C] tokens; gamma, beta [C]; w1 [4C, C], b1 [4C]; wd [4C, 3, 3] (Conv2d groups = 4C), bd [4C];
+ * w2 [C, 4C], b2 [C]; drop_scale [B] or NULL.  Hres % 8 == 0, Wres % 16 == 0.
+ * Training mode - the five save pointers all non-NULL (else all NULL): xn_save [T, C] (norm2 output), stats_save [T, 2]
+ * (mean, rstd), u_save [T, 4C] (linear1 output before GELU), tp_save [T, 4C] (gelu'(t), t = dwconv output + bd),
+ * z_save [T, 4C] (gelu(t), the input of linear2) - what dhz_leff_fused_bwd and dhz_linear_wgrad consume. */
+int dhz_leff_fused_fwd(const float* x, const float* gamma, const float* beta, const float* w1, const float* b1,
+                       const float* wd, const float* bd, const float* w2, const float* b2, const float* drop_scale,
+                       float* out, float* xn_save, float* stats_save, float* u_save, float* tp_save, float* z_save,
+                       int B, int Hres, int Wres, int C, void* stream);
+
+/* Backward-data of the fused LeFF branch (autograd of M1:496-534 from the out-projection side down to norm2's output):
+ *     dz = (drop_scale[b] dout) w2;  dt = dz * tp;  du = dwconv3x3^T(dt) * gelu'(u);  dxn = du w1
+ * dout [B, HW, C]; u, tp as saved by dhz_leff_fused_fwd.  Written: du [T, 4C] (input of linear1's weight gradient),
+ * dxn [T, C] (gradient of norm2's output -> dhz_ln_partition_bwd), dy_save [T, C] = drop_scale[b] dout (input of linear2's
+ * weight gradient; may be NULL - pass dout itself to dhz_linear_wgrad when drop_scale is NULL).  ACCUMULATED (fp32 atomics,
+ * caller zeroes): dwd [4C, 3, 3], dbd [4C] - the depthwise convolution's weight / bias gradients. */
+int dhz_leff_fused_bwd(const float* dout, const float* drop_scale, const float* u, const float* tp, const float* w1,
+                       const float* wd, const float* w2, float* du, float* dxn, float* dy_save, float* dwd, float* dbd,
+                       int B, int Hres, int Wres, int C, void* stream);
+
+/* K2/K4/K5  forward and backward-data GEMMs of every token-major nn.Linear on the path (query/key/value/out
+ *     projections ATT:420-422,454-458; LeFF linear1/linear2 M1:487-492,508,529; the 2x2/stride-2 transposed convolution
+ *     of Upsample M1:633-648 in its token-Linear form), on the fp32 matrix pipe (v_mfma_f32_16x16x4_f32):
+ *     dhz_linear_fwd  : y[T,N]  = x[T,K] . w[N,K]^T + bias[N]       replaces aten::addmm / F.linear   (bias may be NULL)
+ *     dhz_linear_dgrad: dx[T,K] = dy[T,N] . w[N,K]                   replaces the aten::mm of Linear's backward
+ *     x / y / dy / dx are token-major with row strides ldx / ldy (floats, multiples of 4; packed QKV buffers pass 3C);
+ *     w is contiguous [N,K].  N % 32 == 0, K % 32 == 0, any T >= 1; all pointers 16-byte aligned. */
+int dhz_linear_fwd(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy, int T, int N, int K,
+                   void* stream);
+int dhz_linear_dgrad(const float* dy, int ldy, const float* w, float* dx, int ldx, int T, int N, int K, void* stream);
+
 /* K2/K4/K5 (backward)  weight + bias gradient of every token-major nn.Linear on the path
  *     (query/key/value/out projections ATT:420-422,454-458; LeFF linear1/linear2 M1:487-492):
  *     dw[N,K] += dy^T[N,T] . x[T,K]        db[N] += sum_t dy[t,:]        (ACCUMULATED: caller zeroes,

@@ -208,23 +208,6 @@ __global__ __launch_bounds__(256) void reverse_residual_kernel(const float* __re
 }
 
 // ------------------------------------------------------------------------------------------------ K5 middle
-// GELU (exact-erf form, nn.GELU default) and its derivative from ONE exponential:
-//   erf(|x|/sqrt2) = 1 - (a1 t + ... + a5 t^5) exp(-x^2/2),  t = 1/(1 + p|x|/sqrt2)   (Abramowitz-Stegun 7.1.26,
-//   |error| <= 1.5e-7 - at the fp32 rounding level of the cdf), and the same exponential is the Gaussian pdf
-//   needed by the derivative.  ~15 VALU instructions for both values instead of ~45 with erff()+expf().
-__device__ __forceinline__ void gelu_both(float x, float& g, float& gp) {
-    const float ax = fabsf(x) * 0.70710678118654752440f;
-    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * ax);       // v_rcp_f32 (1 ulp), no IEEE division sequence
-    const float e = __expf(-ax * ax);                                    // = exp(-x^2/2)
-    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
-    const float erf_abs = 1.0f - poly * e;
-    const float cdf = 0.5f * (1.0f + copysignf(erf_abs, x));
-    g = x * cdf;
-    gp = cdf + x * (0.39894228040143267794f * e);
-}
-__device__ __forceinline__ float gelu_f(float x) { float g, gp; gelu_both(x, g, gp); return g; }
-__device__ __forceinline__ float gelu_grad_f(float x) { float g, gp; gelu_both(x, g, gp); return gp; }
-
 constexpr int TW = 16, TH = 8;                 // spatial tile (positions)
 constexpr int HWID = TW + 2, HHGT = TH + 2;    // with halo
 constexpr int CT = 32;                         // channels per workgroup (128 B per position)

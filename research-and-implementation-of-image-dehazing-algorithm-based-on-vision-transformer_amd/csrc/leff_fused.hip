@@ -1,0 +1,643 @@
+// K5 fused: the whole LeFF branch of a LeWin block (M1:873 + M1:496-534) for C = 32 / 64 / 128 in ONE forward kernel
+// and ONE backward-data kernel, so that the 4C-wide hidden tensors cross HBM only as saves for the backward:
+//
+//   forward   out = x + s[b] * ( gelu(dwconv3x3(gelu(LN(x) W1^T + b1)) + bd) W2^T + b2 )
+//   backward  dxn = ( dwconv3x3^T( (s[b] dout W2) * gelu'(t) ) * gelu'(u) ) W1          (+ du, dwd, dbd)
+//
+// One workgroup owns an 8 x 16 pixel tile of one image.  The LayerNorm-ed tile with its 1-pixel halo (180 tokens, padded
+// to 12 MFMA row tiles) stays in LDS for the whole kernel; the hidden dimension is walked in chunks of HC channels:
+//   P1  u[192 x HC]  = xn[192 x C] . W1[chunk]^T          v_mfma_f32_16x16x4_f32, operands by conflict-free ds_read_b128
+//   P2  u + b1 -> (saved) -> GELU -> G[180 x HC] in LDS   (zero outside the image = Conv2d padding)
+//   P3  t = dwconv3x3(G) + bd ; z = gelu(t) -> Z[128 x HC] in LDS (+ saved z, gelu'(t))
+//   P4  y[128 x C] += Z . W2[:, chunk]^T                  accumulators live across the chunks
+// with two barriers per chunk; the next chunk's weight slices are fetched into registers at the top of a chunk and
+// written to the other LDS buffer behind the first barrier.  The halo makes P1 compute 192 rows for 128 outputs (1.5x
+// on one of the two GEMMs) - the price of never writing u or z for the consumer to read back.
+// LDS images of MFMA operands are [row][k] with the 16-byte k-quads XOR-swizzled (swz below) so that a lane's four
+// consecutive k come from one ds_read_b128; MFMA j of a 16-deep step contracts over k = 16 s + 4 (lane >> 4) + j.
+#include "common.h"
+
+namespace {
+
+constexpr int TH = 8, TW = 16, HWID = TW + 2, HHGT = TH + 2;
+constexpr int NPOS = HWID * HHGT;      // 180 tokens with halo
+constexpr int NINT = TH * TW;          // 128 interior tokens
+
+// float index of element (r, k) in a swizzled [rows][R] image (R = 16, 32, 64 or 128 floats per row)
+template <int R>
+__device__ __forceinline__ int swz(int r, int k) {
+    if (R == 16) {
+        const int f = (0x6C >> (2 * ((r >> 2) & 3))) & 3;          // [0, 3, 2, 1][(r >> 2) & 3]
+        return r * 16 + 4 * (((k >> 2) & 3) ^ f) + (k & 3);
+    }
+    int kb = k >> 5;
+    if (R >= 64) kb ^= (r & 1);
+    return r * R + 32 * kb + 4 * (((k >> 2) & 7) ^ ((r >> 1) & 7)) + (k & 3);
+}
+
+template <int C, int HC, int NW>
+struct FwdCfg {
+    static constexpr int NTHR = 64 * NW;
+    static constexpr int Ch = 4 * C;
+    static constexpr int NCHUNK = Ch / HC;
+    static constexpr int XN_F = NPOS * C;                  // rows 180..191 read by the MFMAs fall into the next region
+    static constexpr int W1_F = HC * C, W2_F = C * HC;
+    static constexpr int G_F = NPOS * HC, Z_F = NINT * HC;
+    static constexpr int OFF_W1 = XN_F, OFF_W2 = OFF_W1 + 2 * W1_F, OFF_G = OFF_W2 + 2 * W2_F, OFF_Z = OFF_G + G_F;
+    static constexpr int TOTAL_F = OFF_Z + Z_F;
+    static constexpr size_t SMEM = (size_t)TOTAL_F * sizeof(float);
+    static_assert(NINT * (C + 4) <= XN_F, "epilogue staging must fit in the xn image");
+    static_assert(12 * 16 * C <= TOTAL_F, "padded rows of the xn image must stay inside the allocation");
+};
+
+template <int C, int HC, int NW>
+__global__ __launch_bounds__(64 * NW) void leff_fused_fwd_kernel(
+    const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+    const float* __restrict__ W1, const float* __restrict__ b1, const float* __restrict__ wd, const float* __restrict__ bd,
+    const float* __restrict__ W2, const float* __restrict__ b2, const float* __restrict__ scale, float* __restrict__ out,
+    float* __restrict__ xn_save, float* __restrict__ stats_save, float* __restrict__ u_save, float* __restrict__ tp_save,
+    float* __restrict__ z_save, int Hres, int Wres, int tiles_x, int tiles_y) {
+    using Cfg = FwdCfg<C, HC, NW>;
+    constexpr int NTHR = Cfg::NTHR, Ch = Cfg::Ch, NCHUNK = Cfg::NCHUNK;
+    constexpr int NCT1 = HC / 16;                 // column tiles of P1
+    static_assert(NW / NCT1 == 4, "P1: four wave groups of three row tiles");
+    constexpr int RT2 = 8 / NW, CT2 = C / 16;     // P4: row tiles per wave, column tiles (all of them)
+    constexpr int Q = HC / 4;                     // channel quads per chunk
+    constexpr int NPS = NTHR / Q;                 // pixel slots of P3
+    static_assert(NINT % NPS == 0, "P3 pixel loop");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* const XN = smem;
+    float* const GS = smem + Cfg::OFF_G;
+    float* const ZS = smem + Cfg::OFF_Z;
+
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int i16 = lane & 15, g = lane >> 4;
+    int bid = blockIdx.x;
+    const int tx = bid % tiles_x; bid /= tiles_x;
+    const int ty = bid % tiles_y;
+    const int bimg = bid / tiles_y;
+    const int x0 = tx * TW - 1, y0 = ty * TH - 1;
+    const size_t tokbase = (size_t)bimg * Hres * Wres;
+    const bool train = u_save != nullptr;
+
+    // ---- weight slices of chunk 0 -> LDS buffer 0 (register staging shared with the per-chunk prefetch below)
+    constexpr int NWV = (HC * C / 4 + NTHR - 1) / NTHR;     // float4 per thread per weight slice
+    f32x4 rw1[NWV], rw2[NWV];
+    auto wload = [&](int hc0) {
+#pragma unroll
+        for (int i = 0; i < NWV; ++i) {
+            const int e = t + NTHR * i;
+            if ((HC * C / 4) % NTHR == 0 || e < HC * C / 4) {
+                const int n = e / (C / 4), kq = e % (C / 4);
+                rw1[i] = *reinterpret_cast<const f32x4*>(W1 + (size_t)(hc0 + n) * C + 4 * kq);
+                const int c = e / Q, hq = e % Q;
+                rw2[i] = *reinterpret_cast<const f32x4*>(W2 + (size_t)c * Ch + hc0 + 4 * hq);
+            }
+        }
+    };
+    auto wwrite = [&](int buf) {
+        float* W1S = smem + Cfg::OFF_W1 + buf * Cfg::W1_F;
+        float* W2S = smem + Cfg::OFF_W2 + buf * Cfg::W2_F;
+#pragma unroll
+        for (int i = 0; i < NWV; ++i) {
+            const int e = t + NTHR * i;
+            if ((HC * C / 4) % NTHR == 0 || e < HC * C / 4) {
+                const int n = e / (C / 4), kq = e % (C / 4);
+                *reinterpret_cast<f32x4*>(&W1S[swz<C>(n, 4 * kq)]) = rw1[i];
+                const int c = e / Q, hq = e % Q;
+                *reinterpret_cast<f32x4*>(&W2S[swz<HC>(c, 4 * hq)]) = rw2[i];
+            }
+        }
+    };
+    wload(0);
+
+    // ---- LayerNorm (norm2) of the 180 tokens of tile + halo -> XN (swizzled); out-of-image tokens are clamped copies whose
+    //      hidden activations are zeroed in P2
+    {
+        constexpr int LPT = C / 4;                 // lanes per token, one float4 each
+        constexpr int TPP = NTHR / LPT;            // tokens per pass
+        const int li = t % LPT, sub = t / LPT;
+        const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + 4 * li);
+        const f32x4 bt = *reinterpret_cast<const f32x4*>(beta + 4 * li);
+        constexpr float invC = 1.0f / (float)C;
+#pragma unroll 2
+        for (int r0 = 0; r0 < NPOS; r0 += TPP) {
+            const int r = r0 + sub;
+            const int rc = r < NPOS ? r : NPOS - 1;
+            const int hy = rc / HWID, hx = rc % HWID;
+            const int yy = y0 + hy, xx = x0 + hx;
+            const int yc = min(max(yy, 0), Hres - 1), xc = min(max(xx, 0), Wres - 1);
+            const size_t tok = tokbase + (size_t)yc * Wres + xc;
+            const f32x4 xv = *reinterpret_cast<const f32x4*>(x + tok * C + 4 * li);
+            float s = xv[0] + xv[1] + xv[2] + xv[3];
+#pragma unroll
+            for (int o = 1; o < LPT; o <<= 1) s += __shfl_xor(s, o);
+            const float mean = s * invC;
+            const f32x4 dv = xv - mean;
+            float var = dv[0] * dv[0] + dv[1] * dv[1] + dv[2] * dv[2] + dv[3] * dv[3];
+#pragma unroll
+            for (int o = 1; o < LPT; o <<= 1) var += __shfl_xor(var, o);
+            const float rstd = rsqrtf(var * invC + 1e-5f);
+            f32x4 y;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) y[c] = dv[c] * rstd * gm[c] + bt[c];
+            if (r < NPOS) {
+                *reinterpret_cast<f32x4*>(&XN[swz<C>(r, 4 * li)]) = y;
+                const bool interior = hy >= 1 && hy <= TH && hx >= 1 && hx <= TW;
+                if (train && interior) {
+                    *reinterpret_cast<f32x4*>(xn_save + tok * C + 4 * li) = y;
+                    if (li == 0) *reinterpret_cast<float2*>(stats_save + 2 * tok) = make_float2(mean, rstd);
+                }
+            }
+        }
+    }
+    wwrite(0);
+
+    // ---- per-lane bookkeeping of the P1 rows this lane owns in the accumulator layout: row = 16 (rt0 + a) + 4 g + j
+    const int rt0 = 3 * (w & 3), ct1 = w >> 2;
+    int tokoff[3][4];          // token offset inside the image for interior rows, -1 otherwise
+    unsigned inmask = 0;       // bit (4 a + j): row is inside the image (and < 180)
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int r = 16 * (rt0 + a) + 4 * g + j;
+            const int hy = r / HWID, hx = r % HWID;
+            const int yy = y0 + hy, xx = x0 + hx;
+            const bool in = r < NPOS && yy >= 0 && yy < Hres && xx >= 0 && xx < Wres;
+            const bool interior = hy >= 1 && hy <= TH && hx >= 1 && hx <= TW;
+            if (in) inmask |= 1u << (4 * a + j);
+            tokoff[a][j] = (in && interior) ? yy * Wres + xx : -1;
+        }
+
+    f32x4 yacc[RT2][CT2];
+#pragma unroll
+    for (int a = 0; a < RT2; ++a)
+#pragma unroll
+        for (int b = 0; b < CT2; ++b) yacc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    __syncthreads();
+
+    const int c4 = t % Q, ps = t / Q;       // P3: channel quad and pixel slot of this thread
+#pragma unroll 1
+    for (int ck = 0; ck < NCHUNK; ++ck) {
+        const int hc0 = ck * HC, buf = ck & 1;
+        const float* W1S = smem + Cfg::OFF_W1 + buf * Cfg::W1_F;
+        const float* W2S = smem + Cfg::OFF_W2 + buf * Cfg::W2_F;
+        const bool more = ck + 1 < NCHUNK;
+        if (more) wload(hc0 + HC);
+        // depthwise weights / bias of this thread's 4 channels (L2-resident, consumed in P3)
+        f32x4 wkv[9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) wkv[i] = *reinterpret_cast<const f32x4*>(wd + (size_t)(hc0 + 4 * c4) * 9 + 4 * i);
+        const f32x4 bdv = *reinterpret_cast<const f32x4*>(bd + hc0 + 4 * c4);
+        const float b1v = b1[hc0 + 16 * ct1 + i16];
+
+        // ---- P1: u = xn . W1[chunk]^T for row tiles rt0..rt0+2, column tile ct1
+        f32x4 acc[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) acc[a] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < C / 16; ++s) {
+            const f32x4 bf = *reinterpret_cast<const f32x4*>(&W1S[swz<C>(16 * ct1 + i16, 16 * s + 4 * g)]);
+            f32x4 af[3];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) af[a] = *reinterpret_cast<const f32x4*>(&XN[swz<C>(16 * (rt0 + a) + i16, 16 * s + 4 * g)]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int a = 0; a < 3; ++a) acc[a] = mfma16(af[a][j], bf[j], acc[a]);
+        }
+        // ---- P2: + b1, save u, GELU -> G
+        {
+            const int hcol = 16 * ct1 + i16;
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int r = 16 * (rt0 + a) + 4 * g + j;
+                    const float u = acc[a][j] + b1v;
+                    if (train && tokoff[a][j] >= 0) u_save[(tokbase + tokoff[a][j]) * Ch + hc0 + hcol] = u;
+                    const float gv = ((inmask >> (4 * a + j)) & 1) ? gelu_f(u) : 0.f;
+                    if (r < NPOS) GS[r * HC + hcol] = gv;
+                }
+        }
+        __syncthreads();
+        if (more) wwrite(buf ^ 1);
+        // ---- P3: t = dwconv3x3(G) + bd, z = gelu(t) -> Z (+ saves)
+#pragma unroll
+        for (int it = 0; it < NINT / NPS; ++it) {
+            const int p = ps + NPS * it;
+            const int py = p / TW, px = p % TW;
+            f32x4 tacc = bdv;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const f32x4 gv = *reinterpret_cast<const f32x4*>(&GS[((py + ky) * HWID + px + kx) * HC + 4 * c4]);
+                    const int k = ky * 3 + kx;
+                    // wkv holds the 4 channels' 9 taps back to back: channel c, tap k = element 9 c + k
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) tacc[c] += wkv[(9 * c + k) >> 2][(9 * c + k) & 3] * gv[c];
+                }
+            f32x4 zz, zp;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { float a_, b_; gelu_both(tacc[c], a_, b_); zz[c] = a_; zp[c] = b_; }
+            *reinterpret_cast<f32x4*>(&ZS[swz<HC>(p, 4 * c4)]) = zz;
+            if (train) {
+                const size_t o = (tokbase + (size_t)(y0 + 1 + py) * Wres + (x0 + 1 + px)) * Ch + hc0 + 4 * c4;
+                *reinterpret_cast<f32x4*>(z_save + o) = zz;
+                *reinterpret_cast<f32x4*>(tp_save + o) = zp;
+            }
+        }
+        __syncthreads();
+        // ---- P4: y += Z . W2[:, chunk]^T
+#pragma unroll
+        for (int s = 0; s < HC / 16; ++s) {
+            f32x4 af[RT2], bf[CT2];
+#pragma unroll
+            for (int a = 0; a < RT2; ++a) af[a] = *reinterpret_cast<const f32x4*>(&ZS[swz<HC>(16 * (RT2 * w + a) + i16, 16 * s + 4 * g)]);
+#pragma unroll
+            for (int b = 0; b < CT2; ++b) bf[b] = *reinterpret_cast<const f32x4*>(&W2S[swz<HC>(16 * b + i16, 16 * s + 4 * g)]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int a = 0; a < RT2; ++a)
+#pragma unroll
+                    for (int b = 0; b < CT2; ++b) yacc[a][b] = mfma16(af[a][j], bf[b][j], yacc[a][b]);
+        }
+    }
+
+    // ---- epilogue: y -> LDS (the xn image is dead) -> out = x + s[b] (y + b2), full-line stores
+    constexpr int SO = C + 4;
+    float* OS = smem;
+#pragma unroll
+    for (int a = 0; a < RT2; ++a)
+#pragma unroll
+        for (int b = 0; b < CT2; ++b)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) OS[(16 * (RT2 * w + a) + 4 * g + j) * SO + 16 * b + i16] = yacc[a][b][j];
+    __syncthreads();
+    const float sc = scale ? scale[bimg] : 1.0f;
+    for (int e = t; e < NINT * (C / 4); e += NTHR) {
+        const int p = e / (C / 4), cq = e % (C / 4);
+        const int py = p / TW, px = p % TW;
+        const size_t o = (tokbase + (size_t)(y0 + 1 + py) * Wres + (x0 + 1 + px)) * C + 4 * cq;
+        const f32x4 yv = *reinterpret_cast<const f32x4*>(&OS[p * SO + 4 * cq]);
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(b2 + 4 * cq);
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(x + o);
+        *reinterpret_cast<f32x4*>(out + o) = xv + sc * (yv + bv);
+    }
+}
+
+template <int C, int HC, int NW>
+int launch_fwd(const float* x, const float* gamma, const float* beta, const float* W1, const float* b1, const float* wd,
+               const float* bd, const float* W2, const float* b2, const float* scale, float* out, float* xn_save,
+               float* stats_save, float* u_save, float* tp_save, float* z_save, int B, int Hres, int Wres, hipStream_t s) {
+    using Cfg = FwdCfg<C, HC, NW>;
+    const int tiles_x = Wres / TW, tiles_y = Hres / TH;
+    auto kern = &leff_fused_fwd_kernel<C, HC, NW>;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::SMEM);
+    hipLaunchKernelGGL(kern, dim3(B * tiles_x * tiles_y), dim3(Cfg::NTHR), Cfg::SMEM, s, x, gamma, beta, W1, b1, wd, bd, W2, b2,
+                       scale, out, xn_save, stats_save, u_save, tp_save, z_save, Hres, Wres, tiles_x, tiles_y);
+    return 0;
+}
+
+
+// ------------------------------------------------------------------------------------------------ backward-data
+// Persistent workgroups (one per CU) walk the tiles; per tile and hidden chunk:
+//   P1  dz[192 x HC] = dy[192 x C] . W2[:, chunk]          dy = s[b] dout on tile + halo, LDS-resident
+//   P2  dt = dz * gelu'(t) (saved), g = gelu(u)  -> DS, GS in LDS (zero outside the image)
+//   P3  du = dwconv3x3^T(dt) * gelu'(u) -> DU in LDS + global (input of the linear1 weight gradient);
+//       dwd[k] += dt[p] g[p + off(k)], dbd += dt[p]: per-thread partials, folded over the lanes that share a channel quad
+//       and added to a per-workgroup LDS accumulator that is flushed with one atomic per value at the end of the kernel
+//   P4  dxn[128 x C] += DU . W1[chunk, :]
+// Both weight slices are needed K-major for their B fragments (contraction over c in P1, over h in P4), i.e. transposed
+// with respect to their storage: the staging writes scatter the float4 rows into the swizzled images.
+template <int C, int HC, int NW>
+struct BwdCfg {
+    static constexpr int NTHR = 64 * NW;
+    static constexpr int Ch = 4 * C;
+    static constexpr int NCHUNK = Ch / HC;
+    static constexpr int DY_F = NPOS * C;
+    static constexpr int W_F = HC * C;                      // W2T [HC][C] and W1T [C][HC]
+    static constexpr int DS_F = NPOS * HC, DU_F = NINT * HC;
+    static constexpr int ACC_F = Ch * 10;                   // dwd (9) + dbd (1) per hidden channel
+    static constexpr int OFF_W2T = DY_F, OFF_W1T = OFF_W2T + W_F, OFF_DS = OFF_W1T + W_F, OFF_GS = OFF_DS + DS_F,
+                         OFF_DU = OFF_GS + DS_F, OFF_ACC = OFF_DU + DU_F;
+    static constexpr int TOTAL_F = OFF_ACC + ACC_F;
+    static constexpr size_t SMEM = (size_t)TOTAL_F * sizeof(float);
+    static_assert(NINT * (C + 4) <= DY_F, "epilogue staging must fit in the dy image");
+    static_assert(SMEM <= 160 * 1024, "LDS budget");
+};
+
+template <int C, int HC, int NW>
+__global__ __launch_bounds__(64 * NW) void leff_fused_bwd_kernel(
+    const float* __restrict__ dout, const float* __restrict__ scale, const float* __restrict__ u, const float* __restrict__ tp,
+    const float* __restrict__ W1, const float* __restrict__ wd, const float* __restrict__ W2, float* __restrict__ du,
+    float* __restrict__ dxn, float* __restrict__ dy_save, float* __restrict__ dwd, float* __restrict__ dbd, int Hres, int Wres,
+    int tiles_x, int tiles_y, int ntiles) {
+    using Cfg = BwdCfg<C, HC, NW>;
+    constexpr int NTHR = Cfg::NTHR, Ch = Cfg::Ch, NCHUNK = Cfg::NCHUNK;
+    constexpr int NCT1 = HC / 16;
+    static_assert(NW / NCT1 == 4, "P1: four wave groups of three row tiles");
+    constexpr int RT2 = 8 / NW, CT2 = C / 16;
+    constexpr int Q = HC / 4;
+    constexpr int NPS = NTHR / Q;
+    static_assert(NINT % NPS == 0, "P3 pixel loop");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* const DY = smem;
+    float* const W2T = smem + Cfg::OFF_W2T;
+    float* const W1T = smem + Cfg::OFF_W1T;
+    float* const DS = smem + Cfg::OFF_DS;
+    float* const GS = smem + Cfg::OFF_GS;
+    float* const DU = smem + Cfg::OFF_DU;
+    float* const ACC = smem + Cfg::OFF_ACC;
+
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int i16 = lane & 15, g = lane >> 4;
+    const int rt0 = 3 * (w & 3), ct1 = w >> 2;
+    const int c4 = t % Q, ps = t / Q;
+    for (int e = t; e < Cfg::ACC_F; e += NTHR) ACC[e] = 0.f;
+
+    constexpr int NWV = (HC * C / 4 + NTHR - 1) / NTHR;
+    f32x4 rw1[NWV], rw2[NWV];
+    auto wload2 = [&](int hc0) {           // W2[:, chunk]: rows c, HC contiguous floats
+#pragma unroll
+        for (int i = 0; i < NWV; ++i) {
+            const int e = t + NTHR * i;
+            if ((HC * C / 4) % NTHR == 0 || e < HC * C / 4)
+                rw2[i] = *reinterpret_cast<const f32x4*>(W2 + (size_t)(e / Q) * Ch + hc0 + 4 * (e % Q));
+        }
+    };
+    auto wwrite2 = [&]() {                 // -> W2T[h][c]
+#pragma unroll
+        for (int i = 0; i < NWV; ++i) {
+            const int e = t + NTHR * i;
+            if ((HC * C / 4) % NTHR == 0 || e < HC * C / 4) {
+                const int c = e / Q, hq = e % Q;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) W2T[swz<C>(4 * hq + k, c)] = rw2[i][k];
+            }
+        }
+    };
+    auto wload1 = [&](int hc0) {           // W1[chunk, :]: rows h, C contiguous floats
+#pragma unroll
+        for (int i = 0; i < NWV; ++i) {
+            const int e = t + NTHR * i;
+            if ((HC * C / 4) % NTHR == 0 || e < HC * C / 4)
+                rw1[i] = *reinterpret_cast<const f32x4*>(W1 + (size_t)(hc0 + e / (C / 4)) * C + 4 * (e % (C / 4)));
+        }
+    };
+    auto wwrite1 = [&]() {                 // -> W1T[c][h]
+#pragma unroll
+        for (int i = 0; i < NWV; ++i) {
+            const int e = t + NTHR * i;
+            if ((HC * C / 4) % NTHR == 0 || e < HC * C / 4) {
+                const int h = e / (C / 4), cq = e % (C / 4);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) W1T[swz<HC>(4 * cq + k, h)] = rw1[i][k];
+            }
+        }
+    };
+
+#pragma unroll 1
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, bimg = tile / (tiles_x * tiles_y);
+        const int x0 = tx * TW - 1, y0 = ty * TH - 1;
+        const size_t tokbase = (size_t)bimg * Hres * Wres;
+        const float sc = scale ? scale[bimg] : 1.0f;
+        __syncthreads();                    // previous tile's epilogue reads of the staging area / first-tile ACC zeroing
+        wload2(0);
+        // ---- dy = s[b] dout on tile + halo -> DY (zero outside the image)
+        for (int e = t; e < NPOS * (C / 4); e += NTHR) {
+            const int r = e / (C / 4), cq = e % (C / 4);
+            const int hy = r / HWID, hx = r % HWID;
+            const int yy = y0 + hy, xx = x0 + hx;
+            f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (yy >= 0 && yy < Hres && xx >= 0 && xx < Wres) {
+                const size_t tok = tokbase + (size_t)yy * Wres + xx;
+                v = sc * *reinterpret_cast<const f32x4*>(dout + tok * C + 4 * cq);
+                if (dy_save && hy >= 1 && hy <= TH && hx >= 1 && hx <= TW) *reinterpret_cast<f32x4*>(dy_save + tok * C + 4 * cq) = v;
+            }
+            *reinterpret_cast<f32x4*>(&DY[swz<C>(r, 4 * cq)]) = v;
+        }
+        wwrite2();
+        // rows of P1 owned by this lane in the accumulator layout
+        int tokh[3][4];            // clamped in-image token offset of the row
+        unsigned inmask = 0;
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int r = 16 * (rt0 + a) + 4 * g + j;
+                const int hy = r / HWID, hx = r % HWID;
+                const int yy = y0 + hy, xx = x0 + hx;
+                const bool in = r < NPOS && yy >= 0 && yy < Hres && xx >= 0 && xx < Wres;
+                if (in) inmask |= 1u << (4 * a + j);
+                tokh[a][j] = min(max(yy, 0), Hres - 1) * Wres + min(max(xx, 0), Wres - 1);
+            }
+        f32x4 xacc[RT2][CT2];
+#pragma unroll
+        for (int a = 0; a < RT2; ++a)
+#pragma unroll
+            for (int b = 0; b < CT2; ++b) xacc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+        __syncthreads();
+
+#pragma unroll 1
+        for (int ck = 0; ck < NCHUNK; ++ck) {
+            const int hc0 = ck * HC;
+            const bool more = ck + 1 < NCHUNK;
+            wload1(hc0);
+            if (more) wload2(hc0 + HC);
+            // saved gelu'(t) and u of this lane's P1 rows (accumulator layout), consumed in P2
+            float tpv[3][4], uv[3][4];
+            {
+                const int hcol = hc0 + 16 * ct1 + i16;
+#pragma unroll
+                for (int a = 0; a < 3; ++a)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const size_t o = (tokbase + tokh[a][j]) * Ch + hcol;
+                        tpv[a][j] = tp[o];
+                        uv[a][j] = u[o];
+                    }
+            }
+            // ---- P1: dz = dy . W2[:, chunk]
+            f32x4 acc[3];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) acc[a] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < C / 16; ++s) {
+                const f32x4 bf = *reinterpret_cast<const f32x4*>(&W2T[swz<C>(16 * ct1 + i16, 16 * s + 4 * g)]);
+                f32x4 af[3];
+#pragma unroll
+                for (int a = 0; a < 3; ++a) af[a] = *reinterpret_cast<const f32x4*>(&DY[swz<C>(16 * (rt0 + a) + i16, 16 * s + 4 * g)]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int a = 0; a < 3; ++a) acc[a] = mfma16(af[a][j], bf[j], acc[a]);
+            }
+            // ---- P2: dt = dz gelu'(t), g = gelu(u)
+            {
+                const int hcol = 16 * ct1 + i16;
+#pragma unroll
+                for (int a = 0; a < 3; ++a)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int r = 16 * (rt0 + a) + 4 * g + j;
+                        const bool in = (inmask >> (4 * a + j)) & 1;
+                        if (r < NPOS) {
+                            DS[r * HC + hcol] = in ? acc[a][j] * tpv[a][j] : 0.f;
+                            GS[r * HC + hcol] = in ? gelu_f(uv[a][j]) : 0.f;
+                        }
+                    }
+            }
+            // depthwise taps of this thread's 4 channels (L1/L2-resident): issued here so that the barrier covers their latency
+            f32x4 wkv[9];
+#pragma unroll
+            for (int i = 0; i < 9; ++i) wkv[i] = *reinterpret_cast<const f32x4*>(wd + (size_t)(hc0 + 4 * c4) * 9 + 4 * i);
+            __syncthreads();
+            wwrite1();
+            if (more) wwrite2();
+            // ---- P3: depthwise backward on the interior
+            float dwk[4][9], dbk[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                dbk[c] = 0.f;
+#pragma unroll
+                for (int k = 0; k < 9; ++k) dwk[c][k] = 0.f;
+            }
+#pragma unroll 1
+            for (int it = 0; it < NINT / NPS; ++it) {
+                const int p = ps + NPS * it;
+                const int py = p / TW, px = p % TW;
+                const size_t o = (tokbase + (size_t)(y0 + 1 + py) * Wres + (x0 + 1 + px)) * Ch + hc0 + 4 * c4;
+                const f32x4 uc = *reinterpret_cast<const f32x4*>(u + o);          // centre u (L2 hit), used after the taps
+                const f32x4 dtc = *reinterpret_cast<const f32x4*>(&DS[((py + 1) * HWID + px + 1) * HC + 4 * c4]);
+                f32x4 dg = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const int k = ky * 3 + kx;
+                        const f32x4 dn = *reinterpret_cast<const f32x4*>(&DS[((py + 2 - ky) * HWID + px + 2 - kx) * HC + 4 * c4]);
+                        const f32x4 gn = *reinterpret_cast<const f32x4*>(&GS[((py + ky) * HWID + px + kx) * HC + 4 * c4]);
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            dg[c] += wkv[(9 * c + k) >> 2][(9 * c + k) & 3] * dn[c];
+                            dwk[c][k] += dtc[c] * gn[c];
+                        }
+                        if (kx == 2) __builtin_amdgcn_sched_barrier(0);     // keep the 18 LDS reads from being hoisted at once
+                    }
+                f32x4 duv;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) { dbk[c] += dtc[c]; duv[c] = dg[c] * gelu_grad_f(uc[c]); }
+                *reinterpret_cast<f32x4*>(&DU[swz<HC>(p, 4 * c4)]) = duv;
+                *reinterpret_cast<f32x4*>(du + o) = duv;
+            }
+            // fold the partials of the lanes that share this channel quad (lane % Q), one LDS atomic per value and wave
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+#pragma unroll
+                for (int k = 0; k < 10; ++k) {
+                    float v = k < 9 ? dwk[c][k] : dbk[c];
+#pragma unroll
+                    for (int o = Q; o < 64; o <<= 1) v += __shfl_xor(v, o);
+                    if (lane < Q) atomicAdd(&ACC[(hc0 + 4 * c4 + c) * 10 + k], v);
+                }
+            }
+            __syncthreads();
+            // ---- P4: dxn += DU . W1[chunk, :]
+#pragma unroll
+            for (int s = 0; s < HC / 16; ++s) {
+                f32x4 af[RT2], bf[CT2];
+#pragma unroll
+                for (int a = 0; a < RT2; ++a) af[a] = *reinterpret_cast<const f32x4*>(&DU[swz<HC>(16 * (RT2 * w + a) + i16, 16 * s + 4 * g)]);
+#pragma unroll
+                for (int b = 0; b < CT2; ++b) bf[b] = *reinterpret_cast<const f32x4*>(&W1T[swz<HC>(16 * b + i16, 16 * s + 4 * g)]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int a = 0; a < RT2; ++a)
+#pragma unroll
+                        for (int b = 0; b < CT2; ++b) xacc[a][b] = mfma16(af[a][j], bf[b][j], xacc[a][b]);
+            }
+        }
+        // ---- tile epilogue: dxn -> LDS (dy image is dead) -> global
+        constexpr int SO = C + 4;
+        float* OS = smem;
+#pragma unroll
+        for (int a = 0; a < RT2; ++a)
+#pragma unroll
+            for (int b = 0; b < CT2; ++b)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) OS[(16 * (RT2 * w + a) + 4 * g + j) * SO + 16 * b + i16] = xacc[a][b][j];
+        __syncthreads();
+        for (int e = t; e < NINT * (C / 4); e += NTHR) {
+            const int p = e / (C / 4), cq = e % (C / 4);
+            const int py = p / TW, px = p % TW;
+            const size_t o = (tokbase + (size_t)(y0 + 1 + py) * Wres + (x0 + 1 + px)) * C + 4 * cq;
+            *reinterpret_cast<f32x4*>(dxn + o) = *reinterpret_cast<const f32x4*>(&OS[p * SO + 4 * cq]);
+        }
+    }
+    // ---- flush the depthwise weight / bias gradients of this workgroup
+    __syncthreads();
+    for (int e = t; e < Cfg::ACC_F; e += NTHR) {
+        const int ch = e / 10, k = e % 10;
+        const float v = ACC[e];
+        if (k < 9) atomicAdd(dwd + ch * 9 + k, v);
+        else atomicAdd(dbd + ch, v);
+    }
+}
+
+template <int C, int HC, int NW>
+int launch_bwd(const float* dout, const float* scale, const float* u, const float* tp, const float* W1, const float* wd,
+               const float* W2, float* du, float* dxn, float* dy_save, float* dwd, float* dbd, int B, int Hres, int Wres,
+               hipStream_t s) {
+    using Cfg = BwdCfg<C, HC, NW>;
+    const int tiles_x = Wres / TW, tiles_y = Hres / TH;
+    const int ntiles = B * tiles_x * tiles_y;
+    auto kern = &leff_fused_bwd_kernel<C, HC, NW>;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::SMEM);
+    const int grid = ntiles < 256 ? ntiles : 256;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(Cfg::NTHR), Cfg::SMEM, s, dout, scale, u, tp, W1, wd, W2, du, dxn, dy_save, dwd, dbd,
+                       Hres, Wres, tiles_x, tiles_y, ntiles);
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int dhz_leff_fused_fwd(const float* x, const float* gamma, const float* beta, const float* w1, const float* b1,
+                                  const float* wd, const float* bd, const float* w2, const float* b2, const float* drop_scale,
+                                  float* out, float* xn_save, float* stats_save, float* u_save, float* tp_save, float* z_save,
+                                  int B, int Hres, int Wres, int C, void* stream) {
+    DHZ_REQUIRE(x && gamma && beta && w1 && b1 && wd && bd && w2 && b2 && out, "dhz_leff_fused_fwd: null pointer");
+    DHZ_REQUIRE(C == 32 || C == 64 || C == 128, "dhz_leff_fused_fwd: C=%d (supported: 32, 64, 128)", C);
+    DHZ_REQUIRE(B > 0 && Hres > 0 && Wres > 0 && Hres % TH == 0 && Wres % TW == 0,
+                "dhz_leff_fused_fwd: map %dx%d must be a multiple of the %dx%d tile", Hres, Wres, TH, TW);
+    const bool all = xn_save && stats_save && u_save && tp_save && z_save;
+    const bool none = !xn_save && !stats_save && !u_save && !tp_save && !z_save;
+    DHZ_REQUIRE(all || none, "dhz_leff_fused_fwd: the five save pointers must be all set (training) or all NULL (inference)");
+    hipStream_t s = (hipStream_t)stream;
+    if (C == 32) launch_fwd<32, 32, 8>(x, gamma, beta, w1, b1, wd, bd, w2, b2, drop_scale, out, xn_save, stats_save, u_save, tp_save, z_save, B, Hres, Wres, s);
+    else if (C == 64) launch_fwd<64, 32, 8>(x, gamma, beta, w1, b1, wd, bd, w2, b2, drop_scale, out, xn_save, stats_save, u_save, tp_save, z_save, B, Hres, Wres, s);
+    else launch_fwd<128, 16, 4>(x, gamma, beta, w1, b1, wd, bd, w2, b2, drop_scale, out, xn_save, stats_save, u_save, tp_save, z_save, B, Hres, Wres, s);
+    DHZ_CHECK_LAUNCH("dhz_leff_fused_fwd");
+    return DHZ_OK;
+}
+
+extern "C" int dhz_leff_fused_bwd(const float* dout, const float* drop_scale, const float* u, const float* tp, const float* w1,
+                                  const float* wd, const float* w2, float* du, float* dxn, float* dy_save, float* dwd, float* dbd,
+                                  int B, int Hres, int Wres, int C, void* stream) {
+    DHZ_REQUIRE(dout && u && tp && w1 && wd && w2 && du && dxn && dwd && dbd, "dhz_leff_fused_bwd: null pointer");
+    DHZ_REQUIRE(C == 32 || C == 64 || C == 128, "dhz_leff_fused_bwd: C=%d (supported: 32, 64, 128)", C);
+    DHZ_REQUIRE(B > 0 && Hres > 0 && Wres > 0 && Hres % TH == 0 && Wres % TW == 0,
+                "dhz_leff_fused_bwd: map %dx%d must be a multiple of the %dx%d tile", Hres, Wres, TH, TW);
+    hipStream_t s = (hipStream_t)stream;
+    if (C == 32) launch_bwd<32, 32, 8>(dout, drop_scale, u, tp, w1, wd, w2, du, dxn, dy_save, dwd, dbd, B, Hres, Wres, s);
+    else if (C == 64) launch_bwd<64, 32, 8>(dout, drop_scale, u, tp, w1, wd, w2, du, dxn, dy_save, dwd, dbd, B, Hres, Wres, s);
+    else launch_bwd<128, 16, 4>(dout, drop_scale, u, tp, w1, wd, w2, du, dxn, dy_save, dwd, dbd, B, Hres, Wres, s);
+    DHZ_CHECK_LAUNCH("dhz_leff_fused_bwd");
+    return DHZ_OK;
+}

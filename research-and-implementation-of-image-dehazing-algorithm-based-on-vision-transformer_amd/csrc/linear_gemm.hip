@@ -1,0 +1,219 @@
+// Forward and backward-data GEMMs of every token-major nn.Linear on the path, on the fp32 matrix pipe:
+//     forward        y[T,N]  = x[T,K]  . W[N,K]^T + b        (WT = true : W rows are output features, K contiguous)
+//     backward-data  dx[T,K] = dy[T,N] . W[N,K]              (WT = false: W rows are the CONTRACTION index)
+// Both are "tall" GEMMs: T = B*H*W tokens (2k .. 524k) against 32..2048 features, so the block tile is 32*WM tokens x
+// 32*WN features with four waves as 2 x 2, the contraction streamed in 32-deep stages through double-buffered LDS
+// (coalesced float4 global loads -> registers -> LDS while the previous stage feeds v_mfma_f32_16x16x4_f32; one barrier
+// per stage).  LDS images:
+//   * token operand (and W when WT): [row][32 k] with the 16-byte k-quads of a row XOR-swizzled by (row >> 1) & 7, so
+//     that a lane's four consecutive k are ONE conflict-free ds_read_b128; MFMA j of a 16-deep step then contracts over
+//     k = 16 s + 4 g + j (g = lane >> 4) - any order of k is valid as long as both operands use the same one.
+//   * W when !WT: [32 k][BN + 4] (row stride = 4 mod 8 floats -> the g = 0 / 1 halves of a ds_read_b32 hit disjoint banks).
+// Epilogue: accumulators -> LDS -> (+ bias) -> full-line float4 stores.
+#include "common.h"
+
+namespace {
+
+constexpr int BK = 32;
+
+template <int WM, int WN, bool WT>
+__global__ __launch_bounds__(256) void linear_gemm_kernel(const float* __restrict__ A, int lda,
+                                                          const float* __restrict__ W, int ldw,
+                                                          const float* __restrict__ bias, float* __restrict__ Y, int ldy,
+                                                          int M, int N, int K, int tiles_n, int nblocks) {
+    constexpr int BM = 32 * WM, BN = 32 * WN;
+    constexpr int SBN = BN + 4;                                   // !WT image row stride
+    constexpr int A_FLOATS = BM * BK;
+    constexpr int B_FLOATS = WT ? BN * BK : BK * SBN;
+    constexpr int STAGE = A_FLOATS + B_FLOATS;
+    constexpr int NA = BM * 8 / 256;                              // float4 per thread per stage (= WM)
+    constexpr int NB = WT ? BN * 8 / 256 : (BK * BN / 4 + 255) / 256;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int i16 = lane & 15, g = lane >> 4;
+    const int wm = w >> 1, wn = w & 1;
+    // XCD-aware numbering: blocks b and b + 8 share an XCD (round-robin dispatch); make consecutive LOGICAL tiles - which
+    // share their token rows across the tn sweep - land on one XCD so that the re-read of A comes from that XCD's L2.
+    int bid = blockIdx.x;
+    if ((nblocks & 7) == 0) bid = (bid & 7) * (nblocks >> 3) + (bid >> 3);
+    const int tn = bid % tiles_n, tm = bid / tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    f32x4 acc[WM][WN];
+#pragma unroll
+    for (int a = 0; a < WM; ++a)
+#pragma unroll
+        for (int b = 0; b < WN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    f32x4 ra[NA], rb[NB];
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int e = t + 256 * i, row = e >> 3, q = e & 7;
+            const int m = min(m0 + row, M - 1);
+            ra[i] = *reinterpret_cast<const f32x4*>(A + (size_t)m * lda + k0 + 4 * q);
+        }
+        if (WT) {
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                const int e = t + 256 * i, row = e >> 3, q = e & 7;
+                rb[i] = *reinterpret_cast<const f32x4*>(W + (size_t)(n0 + row) * ldw + k0 + 4 * q);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                const int e = t + 256 * i;
+                if ((BK * BN / 4) % 256 == 0 || e < BK * BN / 4) {
+                    const int row = e / (BN / 4), c4 = e % (BN / 4);
+                    rb[i] = *reinterpret_cast<const f32x4*>(W + (size_t)(k0 + row) * ldw + n0 + 4 * c4);
+                }
+            }
+        }
+    };
+    auto swrite = [&](int buf) {
+        float* As = smem + buf * STAGE;
+        float* Bs = As + A_FLOATS;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int e = t + 256 * i, row = e >> 3, q = e & 7;
+            *reinterpret_cast<f32x4*>(&As[row * BK + 4 * (q ^ ((row >> 1) & 7))]) = ra[i];
+        }
+        if (WT) {
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                const int e = t + 256 * i, row = e >> 3, q = e & 7;
+                *reinterpret_cast<f32x4*>(&Bs[row * BK + 4 * (q ^ ((row >> 1) & 7))]) = rb[i];
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                const int e = t + 256 * i;
+                if ((BK * BN / 4) % 256 == 0 || e < BK * BN / 4) {
+                    const int row = e / (BN / 4), c4 = e % (BN / 4);
+                    *reinterpret_cast<f32x4*>(&Bs[row * SBN + 4 * c4]) = rb[i];
+                }
+            }
+        }
+    };
+
+    const int nst = K / BK;
+    gload(0);
+    swrite(0);
+    __syncthreads();
+    const int sw = (i16 >> 1) & 7;
+    for (int st = 0; st < nst; ++st) {
+        const int buf = st & 1;
+        const bool more = st + 1 < nst;
+        if (more) gload((st + 1) * BK);
+        const float* As = smem + buf * STAGE + (wm * WM * 16 + i16) * BK;
+        const float* Bs = smem + buf * STAGE + A_FLOATS;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            f32x4 af[WM], bf[WN];
+#pragma unroll
+            for (int a = 0; a < WM; ++a)
+                af[a] = *reinterpret_cast<const f32x4*>(&As[a * 16 * BK + 4 * ((4 * s + g) ^ sw)]);
+            if (WT) {
+#pragma unroll
+                for (int b = 0; b < WN; ++b)
+                    bf[b] = *reinterpret_cast<const f32x4*>(&Bs[((wn * WN + b) * 16 + i16) * BK + 4 * ((4 * s + g) ^ sw)]);
+            } else {
+#pragma unroll
+                for (int b = 0; b < WN; ++b)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) bf[b][j] = Bs[(16 * s + 4 * g + j) * SBN + (wn * WN + b) * 16 + i16];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int a = 0; a < WM; ++a)
+#pragma unroll
+                    for (int b = 0; b < WN; ++b) acc[a][b] = mfma16(af[a][j], bf[b][j], acc[a][b]);
+        }
+        if (more) swrite(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue through LDS: Cs[BM][BN + 4]
+    constexpr int SC = BN + 4;
+    float* Cs = smem;
+#pragma unroll
+    for (int a = 0; a < WM; ++a)
+#pragma unroll
+        for (int b = 0; b < WN; ++b)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                Cs[(wm * WM * 16 + a * 16 + 4 * g + j) * SC + (wn * WN + b) * 16 + i16] = acc[a][b][j];
+    __syncthreads();
+    constexpr int C4 = BN / 4;
+    for (int e = t; e < BM * C4; e += 256) {
+        const int r = e / C4, c4 = e % C4;
+        if (m0 + r < M) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(&Cs[r * SC + 4 * c4]);
+            if (bias) {
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + n0 + 4 * c4);
+                v += bv;
+            }
+            *reinterpret_cast<f32x4*>(Y + (size_t)(m0 + r) * ldy + n0 + 4 * c4) = v;
+        }
+    }
+}
+
+template <int WM, int WN, bool WT>
+void launch(const float* A, int lda, const float* W, int ldw, const float* bias, float* Y, int ldy, int M, int N, int K,
+            hipStream_t s) {
+    constexpr int BM = 32 * WM, BN = 32 * WN;
+    constexpr size_t stage = (size_t)(BM * BK + (WT ? BN * BK : BK * (BN + 4))) * sizeof(float);
+    constexpr size_t epi = (size_t)BM * (BN + 4) * sizeof(float);
+    constexpr size_t smem = 2 * stage > epi ? 2 * stage : epi;
+    const int tiles_n = N / BN, tiles_m = (M + BM - 1) / BM;
+    const int nblocks = tiles_n * tiles_m;
+    if (smem > 48 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_gemm_kernel<WM, WN, WT>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipLaunchKernelGGL((linear_gemm_kernel<WM, WN, WT>), dim3(nblocks), dim3(256), smem, s, A, lda, W, ldw, bias, Y, ldy, M, N,
+                       K, tiles_n, nblocks);
+}
+
+template <bool WT>
+int dispatch(const char* who, const float* A, int lda, const float* W, int ldw, const float* bias, float* Y, int ldy, int M,
+             int N, int K, hipStream_t s) {
+    DHZ_REQUIRE(A && W && Y, "%s: null pointer", who);
+    DHZ_REQUIRE(M > 0 && N > 0 && K > 0 && N % 32 == 0 && K % 32 == 0, "%s: T=%d N=%d K=%d (N, K must be multiples of 32)", who,
+                M, N, K);
+    DHZ_REQUIRE(lda % 4 == 0 && ldy % 4 == 0 && ldw % 4 == 0 && lda >= K && ldy >= N, "%s: bad leading dimensions", who);
+    DHZ_REQUIRE((((uintptr_t)A | (uintptr_t)W | (uintptr_t)Y | (uintptr_t)bias) & 15) == 0, "%s: pointers must be 16-byte aligned", who);
+    // largest tile that still gives every CU a block: 128 x 128 down to 64 x 32 (tile width must divide N)
+    int wm = 2, wn = 1;
+    {
+        static const int cand[8][2] = {{4, 4}, {4, 3}, {4, 2}, {2, 4}, {2, 3}, {2, 2}, {4, 1}, {2, 1}};
+        long best_blocks = -1;
+        for (int i = 0; i < 8; ++i) {
+            const int a = cand[i][0], b = cand[i][1];
+            if (N % (32 * b)) continue;
+            const long blocks = (long)((M + 32 * a - 1) / (32 * a)) * (N / (32 * b));
+            if (blocks >= 256) { wm = a; wn = b; break; }
+            if (blocks > best_blocks) { best_blocks = blocks; wm = a; wn = b; }
+        }
+    }
+#define CASE(a, b) \
+    if (wm == a && wn == b) launch<a, b, WT>(A, lda, W, ldw, bias, Y, ldy, M, N, K, s);
+    CASE(4, 1) CASE(4, 2) CASE(4, 3) CASE(4, 4) CASE(2, 1) CASE(2, 2) CASE(2, 3) CASE(2, 4)
+#undef CASE
+    DHZ_CHECK_LAUNCH(who);
+    return DHZ_OK;
+}
+
+}  // namespace
+
+extern "C" int dhz_linear_fwd(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy, int T, int N, int K,
+                              void* stream) {
+    return dispatch<true>("dhz_linear_fwd", x, ldx, w, K, bias, y, ldy, T, N, K, (hipStream_t)stream);
+}
+
+extern "C" int dhz_linear_dgrad(const float* dy, int ldy, const float* w, float* dx, int ldx, int T, int N, int K,
+                                void* stream) {
+    // dx[T,K] = dy[T,N] w[N,K]: the contraction runs over the N rows of w, the output features are its K columns
+    return dispatch<false>("dhz_linear_dgrad", dy, ldy, w, K, nullptr, dx, ldx, T, K, N, (hipStream_t)stream);
+}

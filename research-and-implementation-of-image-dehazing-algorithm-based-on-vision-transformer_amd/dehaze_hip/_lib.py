@@ -43,6 +43,10 @@ SIGNATURES = {
     "dhz_maxpool2x2_blocked_fwd": [c_f, c_f, c_i, c_i, c_i, c_p],
     "dhz_maxpool2x2_blocked_bwd": [c_f, c_f, c_f, c_i, c_i, c_i, c_p],
     "dhz_layout_blocked8": [c_f, c_f, c_i, c_i, c_i, c_i, c_f, c_i, c_p],
+    "dhz_leff_fused_fwd": [c_f] * 16 + [c_i, c_i, c_i, c_i, c_p],
+    "dhz_leff_fused_bwd": [c_f] * 12 + [c_i, c_i, c_i, c_i, c_p],
+    "dhz_linear_fwd": [c_f, c_i, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_p],
+    "dhz_linear_dgrad": [c_f, c_i, c_f, c_f, c_i, c_i, c_i, c_i, c_p],
     "dhz_linear_wgrad": [c_f, c_i, c_f, c_i, c_i, c_i, c_i, c_f, c_f, c_p],
     "dhz_linear_wgrad_multi": [c_f, c_i, c_f, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p],
     "dhz_ln_partition_fwd": [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_p],

@@ -14,6 +14,8 @@ from .ops import NTOK, _p, _require_gpu, _stream
 
 SUPPORTED_C = (32, 64, 128)
 ENABLED = True      # set False to force the unfused chain (tests compare the two)
+LEFF_FUSED = True   # fused LeFF kernels (csrc/leff_fused.hip) for the widths below; False forces the kernel chain
+LEFF_FUSED_C = (32, 64, 128)
 
 
 def _wgrad(dy, off, x, w, b):
@@ -93,7 +95,7 @@ def _table_backward(dpart, parts, table_p, H, dev):
 
 class _FusedAttnBranch(Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, wq, bq, wk, bk, wv, bv, wo, bo, table, idx, mask, dscale, Hres, Wres, shift, H):
+    def forward(ctx, x, gamma, beta, wq, bq, wk, bk, wv, bv, wo, bo, table, idx, mask, dscale, Hres, Wres, shift, H, grad_mode):
         _require_gpu(x, gamma, beta, wq, wo, table, idx, mask, dscale)
         x = x.contiguous()
         B, L, C = x.shape
@@ -110,7 +112,7 @@ class _FusedAttnBranch(Function):
             bias = torch.empty((H, NTOK, NTOK), **f32)
             _lib.call("dhz_bias_gather", _p(table.contiguous()), _p(bias), H, _stream())
         out = torch.empty_like(x)
-        train = any(ctx.needs_input_grad)
+        train = grad_mode and any(ctx.needs_input_grad)
         xn = qkv = cx = stats = rank = None
         if train:
             xn = torch.empty((T, C), **f32)
@@ -148,7 +150,7 @@ class _FusedAttnBranch(Function):
         daw = torch.empty((T, C), **f32)
         _lib.call("dhz_reverse_residual_bwd", _p(dout), _p(dscale), _p(daw), B, Hres, Wres, C, shift, 1, _stream())
         # (2) out-projection
-        dctx = daw @ wo_
+        dctx = ops.gemm_dgrad(daw, wo_)
         g_wo, g_bo = _wgrad(daw, 0, cx, wo, bo)
         # (3) attention core
         dqkv = torch.empty_like(qkv)
@@ -160,19 +162,19 @@ class _FusedAttnBranch(Function):
                   gb, gb + 4 * C, gb + 8 * C, 3 * C, _p(dpart), B_, H, nW, 32, _stream())
         dtable = _table_backward(dpart, parts, table_p, H, dev) if bias is not None else None
         # (4) QKV projection
-        dxn = dqkv @ ops.cat_rows([wq_.detach(), wk_.detach(), wv_.detach()])
+        dxn = ops.gemm_dgrad(dqkv, ops.cat_rows([wq_.detach(), wk_.detach(), wv_.detach()]))
         g_wq, g_bq, g_wk, g_bk, g_wv, g_bv = _wgrad_qkv(dqkv, xn, C, [(wq, bq), (wk, bk), (wv, bv)])
         # (5) LayerNorm backward + shortcut gradient in one pass
         dx, dgamma, dbeta = _ln_backward(dxn, x, gamma_p, beta_p, gamma, stats, dout, B, Hres, Wres, C, shift, 1)
         return (dx, dgamma, dbeta, g_wq, g_bq, g_wk, g_bk, g_wv, g_bv, g_wo, g_bo, dtable,
-                None, None, None, None, None, None, None)
+                None, None, None, None, None, None, None, None)
 
 
 def fused_attn_branch(x, norm, layer, table, idx, mask, dscale, Hres, Wres, shift, heads):
     """x: [B,L,C]; norm: nn.LayerNorm; layer: AttentionLayer (query/key/value/out projections)."""
     q, k, v, o = layer.query_projection, layer.key_projection, layer.value_projection, layer.out_projection
     return _FusedAttnBranch.apply(x, norm.weight, norm.bias, q.weight, q.bias, k.weight, k.bias, v.weight, v.bias,
-                                  o.weight, o.bias, table, idx, mask, dscale, Hres, Wres, shift, heads)
+                                  o.weight, o.bias, table, idx, mask, dscale, Hres, Wres, shift, heads, torch.is_grad_enabled())
 
 
 # ----------------------------------------------------------------------------- unfused forward, same hand-sequenced backward
@@ -183,7 +185,7 @@ class _AttnBranchChain(Function):
     (shortcut gradient folded into the LayerNorm backward, weight gradients accumulated in place)."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, wq, bq, wk, bk, wv, bv, wo, bo, table, idx, mask, dscale, Hres, Wres, shift, H):
+    def forward(ctx, x, gamma, beta, wq, bq, wk, bk, wv, bv, wo, bo, table, idx, mask, dscale, Hres, Wres, shift, H, grad_mode):
         _require_gpu(x, gamma, beta, wq, wo, table, idx, mask, dscale)
         x = x.contiguous()
         B, L, C = x.shape
@@ -196,7 +198,7 @@ class _AttnBranchChain(Function):
         _lib.call("dhz_ln_partition_fwd", _p(x), _p(gamma), _p(beta), _p(xn), _p(stats), B, Hres, Wres, C, shift, 1,
                   _stream())
         wcat = ops.cat_rows([wq.detach(), wk.detach(), wv.detach()])
-        qkv = torch.addmm(ops.cat_rows([bq.detach(), bk.detach(), bv.detach()]), xn, wcat.t())
+        qkv = ops.gemm_fwd(xn, wcat, ops.cat_rows([bq.detach(), bk.detach(), bv.detach()]))
         bias = None
         if table is not None:
             bias = torch.empty((H, NTOK, NTOK), **f32)
@@ -214,10 +216,10 @@ class _AttnBranchChain(Function):
         if timing is not None:
             e1.record()
             timing.append((e0, e1, (T // NTOK) * H))
-        aw = torch.addmm(bo, cx, wo.t())
+        aw = ops.gemm_fwd(cx, wo, bo)
         out = torch.empty_like(x)
         _lib.call("dhz_reverse_residual_fwd", _p(aw), _p(x), _p(dscale), _p(out), B, Hres, Wres, C, shift, 1, _stream())
-        if any(ctx.needs_input_grad):
+        if grad_mode and any(ctx.needs_input_grad):
             ctx.save_for_backward(x, gamma, stats, xn, qkv, cx, rank, bias, mask, dscale, wq, wk, wv, wo)
             ctx.params = (wq, bq, wk, bk, wv, bv, wo, bo, gamma, beta, table)
             ctx.geom = (B, Hres, Wres, C, shift, H)
@@ -236,7 +238,7 @@ class _AttnBranchChain(Function):
         f32 = dict(device=dev, dtype=torch.float32)
         daw = torch.empty((T, C), **f32)
         _lib.call("dhz_reverse_residual_bwd", _p(dout), _p(dscale), _p(daw), B, Hres, Wres, C, shift, 1, _stream())
-        dctx = daw @ wo_
+        dctx = ops.gemm_dgrad(daw, wo_)
         g_wo, g_bo = _wgrad(daw, 0, cx, wo, bo)
         dqkv = torch.empty_like(qkv)
         parts = _lib.load().dhz_ps_attn_bwd_parts(B_, H)
@@ -246,11 +248,11 @@ class _AttnBranchChain(Function):
         _lib.call("dhz_ps_attn_bwd", base, base + 4 * C, base + 8 * C, 3 * C, _p(bias), _p(mask), _p(rank), _p(dctx), C,
                   gb, gb + 4 * C, gb + 8 * C, 3 * C, _p(dpart), B_, H, nW, d, _stream())
         dtable = _table_backward(dpart, parts, table_p, H, dev) if bias is not None else None
-        dxn = dqkv @ ops.cat_rows([wq_.detach(), wk_.detach(), wv_.detach()])
+        dxn = ops.gemm_dgrad(dqkv, ops.cat_rows([wq_.detach(), wk_.detach(), wv_.detach()]))
         g_wq, g_bq, g_wk, g_bk, g_wv, g_bv = _wgrad_qkv(dqkv, xn, C, [(wq, bq), (wk, bk), (wv, bv)])
         dx, dgamma, dbeta = _ln_backward(dxn, x, gamma_p, beta_p, gamma, stats, dout, B, Hres, Wres, C, shift, 1)
         return (dx, dgamma, dbeta, g_wq, g_bq, g_wk, g_bk, g_wv, g_bv, g_wo, g_bo, dtable,
-                None, None, None, None, None, None, None)
+                None, None, None, None, None, None, None, None)
 
 
 def attn_branch(x, norm, layer, table, idx, mask, dscale, Hres, Wres, shift, heads):
@@ -258,7 +260,7 @@ def attn_branch(x, norm, layer, table, idx, mask, dscale, Hres, Wres, shift, hea
     C = x.shape[-1]
     q, k, v, o = layer.query_projection, layer.key_projection, layer.value_projection, layer.out_projection
     args = (x, norm.weight, norm.bias, q.weight, q.bias, k.weight, k.bias, v.weight, v.bias, o.weight, o.bias, table, idx,
-            mask, dscale, Hres, Wres, shift, heads)
+            mask, dscale, Hres, Wres, shift, heads, torch.is_grad_enabled())
     use_fused = ENABLED and C == 32 * heads and (C in (32, 64) or (C == 128 and Hres * Wres <= 1024))
     return (_FusedAttnBranch if use_fused else _AttnBranchChain).apply(*args)
 
@@ -272,7 +274,7 @@ class _LeffBranch(Function):
               LayerNorm backward (no autograd accumulation kernels)."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, w1, b1, wd, bd, w2, b2, dscale, Hres, Wres):
+    def forward(ctx, x, gamma, beta, w1, b1, wd, bd, w2, b2, dscale, Hres, Wres, grad_mode):
         _require_gpu(x, gamma, beta, w1, wd, w2, dscale)
         x = x.contiguous()
         B, L, C = x.shape
@@ -280,18 +282,31 @@ class _LeffBranch(Function):
         T = B * L
         dev = x.device
         f32 = dict(device=dev, dtype=torch.float32)
-        train = any(ctx.needs_input_grad)
-        xn = torch.empty((T, C), **f32)
-        stats = torch.empty((T, 2), **f32)
-        _lib.call("dhz_ln_partition_fwd", _p(x), _p(gamma), _p(beta), _p(xn), _p(stats), B, L, 1, C, 0, 0, _stream())
-        u = torch.addmm(b1, xn, w1.t())
-        z = torch.empty_like(u)
-        tg = torch.empty_like(u) if train else None
+        train = grad_mode and any(ctx.needs_input_grad)      # grad mode reads False inside Function.forward: passed in
         wdc = wd.contiguous()
-        _lib.call("dhz_leff_dwconv_fwd", _p(u), _p(wdc), _p(bd), _p(tg), _p(z), B, Hres, Wres, Ch, _stream())
-        y = torch.addmm(b2, z, w2.t())
         out = torch.empty_like(x)
-        _lib.call("dhz_reverse_residual_fwd", _p(y), _p(x), _p(dscale), _p(out), B, L, 1, C, 0, 0, _stream())
+        ctx.fused = LEFF_FUSED and C in LEFF_FUSED_C and Hres % 8 == 0 and Wres % 16 == 0
+        if ctx.fused:
+            # one kernel: norm2, linear1, GELU, depthwise 3x3, GELU, linear2, DropPath scale, residual (csrc/leff_fused.hip)
+            xn = stats = u = tg = z = None
+            if train:
+                xn = torch.empty((T, C), **f32)
+                stats = torch.empty((T, 2), **f32)
+                u = torch.empty((B, L, Ch), **f32)
+                tg = torch.empty((B, L, Ch), **f32)
+                z = torch.empty((T, Ch), **f32)
+            _lib.call("dhz_leff_fused_fwd", _p(x), _p(gamma), _p(beta), _p(w1), _p(b1), _p(wdc), _p(bd), _p(w2), _p(b2),
+                      _p(dscale), _p(out), _p(xn), _p(stats), _p(u), _p(tg), _p(z), B, Hres, Wres, C, _stream())
+        else:
+            xn = torch.empty((T, C), **f32)
+            stats = torch.empty((T, 2), **f32)
+            _lib.call("dhz_ln_partition_fwd", _p(x), _p(gamma), _p(beta), _p(xn), _p(stats), B, L, 1, C, 0, 0, _stream())
+            u = ops.gemm_fwd(xn, w1, b1)
+            z = torch.empty_like(u)
+            tg = torch.empty_like(u) if train else None
+            _lib.call("dhz_leff_dwconv_fwd", _p(u), _p(wdc), _p(bd), _p(tg), _p(z), B, Hres, Wres, Ch, _stream())
+            y = ops.gemm_fwd(z, w2, b2)
+            _lib.call("dhz_reverse_residual_fwd", _p(y), _p(x), _p(dscale), _p(out), B, L, 1, C, 0, 0, _stream())
         if train:
             ctx.save_for_backward(x, gamma, stats, xn, u, tg, z, dscale, w1, wdc, w2)
             ctx.params = (w1, b1, wd, bd, w2, b2, gamma, beta)
@@ -307,15 +322,35 @@ class _LeffBranch(Function):
         dout = dout.contiguous()
         dev = x.device
         f32 = dict(device=dev, dtype=torch.float32)
+        gwd, gbd = _grad_buf(wd), _grad_buf(bd)
+        if ctx.fused:
+            # one kernel from dout down to d(norm2 output): linear2 dgrad, both GELU derivatives, depthwise backward (+ its
+            # weight / bias gradients), linear1 dgrad; the two Linear weight gradients read its du / dy outputs
+            dy = torch.empty((T, C), **f32) if dscale is not None else None
+            du = torch.empty((T, Ch), **f32)
+            dxn = torch.empty((T, C), **f32)
+            inplace = gwd is not None and gbd is not None
+            dwb = None if inplace else torch.zeros((Ch * 10,), **f32)
+            _lib.call("dhz_leff_fused_bwd", _p(dout), _p(dscale), _p(u), _p(tg), _p(w1_), _p(wdc), _p(w2_), _p(du), _p(dxn),
+                      _p(dy), _p(gwd) if inplace else dwb.data_ptr(), _p(gbd) if inplace else dwb.data_ptr() + 4 * Ch * 9,
+                      B, Hres, Wres, C, _stream())
+            if inplace:
+                _ready(wd, bd)
+                g_wd = g_bd = None
+            else:
+                g_wd, g_bd = dwb[:Ch * 9].view(Ch, 1, 3, 3), dwb[Ch * 9:]
+            g_w2, g_b2 = _wgrad(dy if dy is not None else dout.view(T, C), 0, z, w2, b2)
+            g_w1, g_b1 = _wgrad(du, 0, xn, w1, b1)
+            dx, dgamma, dbeta = _ln_backward(dxn, x, gamma_p, beta_p, gamma, stats, dout, B, L, 1, C, 0, 0)
+            return (dx, dgamma, dbeta, g_w1, g_b1, g_wd, g_bd, g_w2, g_b2, None, None, None, None)
         if dscale is not None:
             dy = torch.empty((T, C), **f32)
             _lib.call("dhz_reverse_residual_bwd", _p(dout), _p(dscale), _p(dy), B, L, 1, C, 0, 0, _stream())
         else:
             dy = dout.view(T, C)
-        dz = dy @ w2_
+        dz = ops.gemm_dgrad(dy, w2_)
         g_w2, g_b2 = _wgrad(dy, 0, z, w2, b2)
         du = torch.empty_like(u)
-        gwd, gbd = _grad_buf(wd), _grad_buf(bd)
         if gwd is not None and gbd is not None:          # depthwise weight / bias gradients straight into .grad
             _lib.call("dhz_leff_dwconv_bwd", _p(dz), _p(u), _p(tg), _p(wdc), _p(du), _p(gwd), _p(gbd), B, Hres, Wres, Ch,
                       _stream())
@@ -326,13 +361,13 @@ class _LeffBranch(Function):
             _lib.call("dhz_leff_dwconv_bwd", _p(dz), _p(u), _p(tg), _p(wdc), _p(du), dwb.data_ptr(),
                       dwb.data_ptr() + 4 * Ch * 9, B, Hres, Wres, Ch, _stream())
             g_wd, g_bd = dwb[:Ch * 9].view(Ch, 1, 3, 3), dwb[Ch * 9:]
-        dxn = du @ w1_
+        dxn = ops.gemm_dgrad(du, w1_)
         g_w1, g_b1 = _wgrad(du, 0, xn, w1, b1)
         dx, dgamma, dbeta = _ln_backward(dxn, x, gamma_p, beta_p, gamma, stats, dout, B, L, 1, C, 0, 0)
-        return (dx, dgamma, dbeta, g_w1, g_b1, g_wd, g_bd, g_w2, g_b2, None, None, None)
+        return (dx, dgamma, dbeta, g_w1, g_b1, g_wd, g_bd, g_w2, g_b2, None, None, None, None)
 
 
 def leff_branch(x, norm, mlp, dscale, Hres, Wres):
     return _LeffBranch.apply(x, norm.weight, norm.bias, mlp.linear1[0].weight, mlp.linear1[0].bias,
                              mlp.dwconv[0].weight, mlp.dwconv[0].bias, mlp.linear2[0].weight, mlp.linear2[0].bias,
-                             dscale, Hres, Wres)
+                             dscale, Hres, Wres, torch.is_grad_enabled())

@@ -1,8 +1,10 @@
 """torch.autograd.Function wrappers over the C-ABI (include/dehaze_hip.h).
 
 PyTorch is plumbing here: it owns device memory (caching allocator), the current HIP stream and the
-autograd tape; every op below runs a hand-written gfx950 kernel through ctypes.  CPU tensors are
-rejected - there is no fallback path.
+autograd tape; the ops below run hand-written gfx950 kernels through ctypes (the token-Linear GEMMs included:
+dhz_linear_fwd / dhz_linear_dgrad / dhz_linear_wgrad).  What still runs on vendor libraries is listed in DESIGN.md §4
+(the 4x4/stride-2 down-sampling and 3->E input convolutions on MIOpen).  CPU tensors are rejected - there is no
+fallback path.
 """
 import ctypes
 
@@ -33,6 +35,31 @@ def _require_gpu(*tensors):
                                "there is deliberately no CPU/PyTorch fallback")
         if t is not None and t.dtype not in (torch.float32, torch.uint8):
             raise RuntimeError(f"dehaze_hip: fp32 tensors expected, got {t.dtype}")
+
+
+def gemm_fwd(x, W, b=None):
+    """y[T,N] = x[T,K] W[N,K]^T + b on the fp32 matrix pipe (dhz_linear_fwd).  x: rows of K contiguous floats (any row
+    stride), W contiguous."""
+    _require_gpu(x, W, b)
+    T, K = x.shape
+    N = W.shape[0]
+    assert x.stride(1) == 1 and W.shape[1] == K
+    W = W if W.is_contiguous() else W.contiguous()
+    y = torch.empty((T, N), device=x.device, dtype=torch.float32)
+    _lib.call("dhz_linear_fwd", _p(x), x.stride(0), _p(W), _p(b), _p(y), N, T, N, K, _stream())
+    return y
+
+
+def gemm_dgrad(dy, W):
+    """dx[T,K] = dy[T,N] W[N,K] (dhz_linear_dgrad)."""
+    _require_gpu(dy, W)
+    T, N = dy.shape
+    K = W.shape[1]
+    assert dy.stride(1) == 1 and W.shape[0] == N
+    W = W if W.is_contiguous() else W.contiguous()
+    dx = torch.empty((T, K), device=dy.device, dtype=torch.float32)
+    _lib.call("dhz_linear_dgrad", _p(dy), dy.stride(0), _p(W), _p(dx), K, T, N, K, _stream())
+    return dx
 
 
 # ----------------------------------------------------------------------------- K3 / K7
@@ -227,10 +254,9 @@ def cat_rows(ts):
 
 
 class _LinearTokens(Function):
-    """y = x [W_1;..;W_n]^T + [b_1;..;b_n] for token-major x [T,K].  Forward and dgrad are plain library
-    GEMMs (rocBLAS/hipBLASLt run them near the fp32 MFMA peak); the weight/bias gradients - skinny TN
-    GEMMs over T tokens that the library runs at 5-20 TFLOP/s - use dhz_linear_wgrad and are accumulated
-    in place into the parameters' .grad (the optimizer's flat gradient buffer)."""
+    """y = x [W_1;..;W_n]^T + [b_1;..;b_n] for token-major x [T,K]: dhz_linear_fwd forward, dhz_linear_dgrad for the
+    input gradient, dhz_linear_wgrad for the weight/bias gradients, which are accumulated in place into the parameters'
+    .grad (the optimizer's flat gradient buffer)."""
 
     @staticmethod
     def forward(ctx, x, *wb):
@@ -241,7 +267,7 @@ class _LinearTokens(Function):
         else:
             W = cat_rows([w.detach() for w, _ in params])
             b = cat_rows([b_.detach() for _, b_ in params])
-        y = torch.addmm(b, x, W.t()) if b is not None else x @ W.t()
+        y = gemm_fwd(x, W, b)
         ctx.save_for_backward(x, W)
         ctx.params = params
         return y
@@ -250,7 +276,7 @@ class _LinearTokens(Function):
     def backward(ctx, dy):
         x, W = ctx.saved_tensors
         dy = dy.contiguous()
-        dx = dy @ W if ctx.needs_input_grad[0] else None
+        dx = gemm_dgrad(dy, W) if ctx.needs_input_grad[0] else None
         T, K = x.shape
         grads = []
         off = 0
@@ -286,7 +312,7 @@ def linear_tokens(x, *wb):
         params = [(wb[i], wb[i + 1]) for i in range(0, len(wb), 2)]
         W = params[0][0] if len(params) == 1 else torch.cat([w for w, _ in params], 0)
         b = params[0][1] if len(params) == 1 else torch.cat([b_ for _, b_ in params], 0)
-        return torch.addmm(b, x, W.t())
+        return gemm_fwd(x.contiguous(), W, b)
     return _LinearTokens.apply(x.contiguous(), *wb)
 
 

@@ -84,3 +84,37 @@ def test_wgrad_multi_c_abi():
     assert lib.dhz_linear_wgrad_multi(dy.data_ptr(), dy.stride(0), x.data_ptr(), K, T, 5, N, K,
                                       ctypes.cast(arr, ctypes.c_void_p), None, s) == -22
     assert b"nmat" in lib.dhz_last_error()
+
+
+@pytest.mark.parametrize("T,N,K", [(4096, 96, 32), (4096, 32, 32), (8192, 128, 32), (8192, 32, 128), (2048, 192, 64),
+                                   (2048, 256, 64), (1000, 384, 128), (1024, 512, 128), (512, 1536, 512), (64, 2048, 512),
+                                   (300, 512, 2048), (64, 64, 64), (1, 32, 32), (131072, 64, 256), (70000, 256, 64)])
+def test_linear_gemm_c_abi(T, N, K):
+    """dhz_linear_fwd / dhz_linear_dgrad through the raw C-ABI vs an fp64 matmul: every tile shape of the dispatch
+    (32*WN features, 64 / 128 tokens), ragged token counts, a packed input with row stride > K and an output written into
+    the middle of a wider buffer."""
+    from dehaze_hip import _lib
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(T * 7 + N + K)
+    xw = torch.randn(T, K + 32, generator=g).to(dev)               # x = the first K columns of a wider buffer
+    W = (torch.randn(N, K, generator=g) * 0.1).to(dev)
+    b = (torch.randn(N, generator=g) * 0.1).to(dev)
+    s = torch.cuda.current_stream().cuda_stream
+    yw = torch.full((T, N + 64), 7.0, device=dev)                  # y = columns 32 .. 32+N
+    _lib.call("dhz_linear_fwd", xw.data_ptr(), xw.stride(0), W.data_ptr(), b.data_ptr(), yw.data_ptr() + 4 * 32, yw.stride(0),
+              T, N, K, s)
+    ref = xw[:, :K].double() @ W.double().t() + b.double()
+    tol = 2e-6 * K ** 0.5 + 1e-5
+    assert (yw[:, 32:32 + N].double() - ref).abs().max() < tol * max(1.0, ref.abs().max().item())
+    assert (yw[:, :32] == 7.0).all() and (yw[:, 32 + N:] == 7.0).all()          # nothing outside the output columns
+    y0 = torch.empty(T, N, device=dev)
+    _lib.call("dhz_linear_fwd", xw.data_ptr(), xw.stride(0), W.data_ptr(), None, y0.data_ptr(), N, T, N, K, s)
+    assert (y0.double() - (ref - b.double())).abs().max() < tol * max(1.0, ref.abs().max().item())
+    dy = torch.randn(T, N, generator=g).to(dev)
+    dx = torch.empty(T, K, device=dev)
+    _lib.call("dhz_linear_dgrad", dy.data_ptr(), N, W.data_ptr(), dx.data_ptr(), K, T, N, K, s)
+    refd = dy.double() @ W.double()
+    assert (dx.double() - refd).abs().max() < (2e-6 * N ** 0.5 + 1e-5) * max(1.0, refd.abs().max().item())
+    lib = _lib.load()
+    assert lib.dhz_linear_fwd(xw.data_ptr(), xw.stride(0), W.data_ptr(), None, y0.data_ptr(), N, T, N + 1, K, s) == -22
+    assert b"multiples of 32" in lib.dhz_last_error()
