@@ -183,7 +183,8 @@ int dispatch(const char* who, const float* A, int lda, const float* W, int ldw, 
     DHZ_REQUIRE(M > 0 && N > 0 && K > 0 && N % 32 == 0 && K % 32 == 0, "%s: T=%d N=%d K=%d (N, K must be multiples of 32)", who,
                 M, N, K);
     DHZ_REQUIRE(lda % 4 == 0 && ldy % 4 == 0 && ldw % 4 == 0 && lda >= K && ldy >= N, "%s: bad leading dimensions", who);
-    DHZ_REQUIRE((((uintptr_t)A | (uintptr_t)W | (uintptr_t)Y | (uintptr_t)bias) & 15) == 0, "%s: pointers must be 16-byte aligned", who);
+    DHZ_REQUIRE((((uintptr_t)A | (uintptr_t)Y) & 15) == 0 && (((uintptr_t)W | (uintptr_t)bias) & 3) == 0,
+                "%s: activations must be 16-byte aligned (weights: 4-byte)", who);
     // largest tile that still gives every CU a block: 128 x 128 down to 64 x 32 (tile width must divide N)
     int wm = 2, wn = 1;
     {

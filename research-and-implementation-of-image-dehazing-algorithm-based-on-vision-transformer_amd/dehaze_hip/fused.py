@@ -14,8 +14,14 @@ from .ops import NTOK, _p, _require_gpu, _stream
 
 SUPPORTED_C = (32, 64, 128)
 ENABLED = True      # set False to force the unfused chain (tests compare the two)
-LEFF_FUSED = True   # fused LeFF kernels (csrc/leff_fused.hip) for the widths below; False forces the kernel chain
-LEFF_FUSED_C = (32, 64, 128)
+# Fused LeFF kernels (csrc/leff_fused.hip).  Measured on MI355X (tools/bench_leff.py, bs 32): the fused forward wins at C = 32 / 64
+# (inference 0.76-0.85x of the chain, training 0.87-0.95x) and loses at C = 128; the fused backward-data kernel is correct
+# (tests/test_gpu_leff.py) but 1.5-2x slower than the kernel chain in fp32 - fp32-input MFMA and fp32 VALU instructions share the
+# SIMD's issue (profiles/r02_coexec_micro.txt), so fusing the GELU / depthwise VALU work into the GEMM kernels ADDS its time to the
+# matrix time instead of hiding it behind HBM traffic as the stand-alone streaming kernels do.
+LEFF_FUSED = True           # False forces the kernel chain everywhere
+LEFF_FUSED_C = (32, 64)     # widths that take the fused forward
+LEFF_FUSED_BWD = False      # True: dhz_leff_fused_bwd instead of the backward kernel chain (any C in 32 / 64 / 128)
 
 
 def _wgrad(dy, off, x, w, b):
@@ -285,15 +291,16 @@ class _LeffBranch(Function):
         train = grad_mode and any(ctx.needs_input_grad)      # grad mode reads False inside Function.forward: passed in
         wdc = wd.contiguous()
         out = torch.empty_like(x)
-        ctx.fused = LEFF_FUSED and C in LEFF_FUSED_C and Hres % 8 == 0 and Wres % 16 == 0
-        if ctx.fused:
+        tiled = Hres % 8 == 0 and Wres % 16 == 0
+        ctx.fused_bwd = LEFF_FUSED and LEFF_FUSED_BWD and C in (32, 64, 128) and tiled
+        if LEFF_FUSED and C in LEFF_FUSED_C and tiled:
             # one kernel: norm2, linear1, GELU, depthwise 3x3, GELU, linear2, DropPath scale, residual (csrc/leff_fused.hip)
             xn = stats = u = tg = z = None
             if train:
                 xn = torch.empty((T, C), **f32)
                 stats = torch.empty((T, 2), **f32)
-                u = torch.empty((B, L, Ch), **f32)
-                tg = torch.empty((B, L, Ch), **f32)
+                u = torch.empty((T, Ch), **f32)
+                tg = torch.empty((T, Ch), **f32)
                 z = torch.empty((T, Ch), **f32)
             _lib.call("dhz_leff_fused_fwd", _p(x), _p(gamma), _p(beta), _p(w1), _p(b1), _p(wdc), _p(bd), _p(w2), _p(b2),
                       _p(dscale), _p(out), _p(xn), _p(stats), _p(u), _p(tg), _p(z), B, Hres, Wres, C, _stream())
@@ -323,7 +330,7 @@ class _LeffBranch(Function):
         dev = x.device
         f32 = dict(device=dev, dtype=torch.float32)
         gwd, gbd = _grad_buf(wd), _grad_buf(bd)
-        if ctx.fused:
+        if ctx.fused_bwd:
             # one kernel from dout down to d(norm2 output): linear2 dgrad, both GELU derivatives, depthwise backward (+ its
             # weight / bias gradients), linear1 dgrad; the two Linear weight gradients read its du / dy outputs
             dy = torch.empty((T, C), **f32) if dscale is not None else None

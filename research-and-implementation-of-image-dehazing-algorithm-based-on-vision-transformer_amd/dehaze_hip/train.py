@@ -49,13 +49,17 @@ class FlatAdamW(torch.optim.Optimizer):
             return
         order = self._qkv_adjacent(list(reversed(self._live)))
         dev = order[0].device
-        n = sum(p.numel() for p in order)
-        npad = (n + 3) // 4 * 4
+        # every parameter starts on a 16-byte boundary (the kernels read weights with 16-byte loads; the only sizes that are
+        # not multiples of 4 floats are the 225 x H bias tables of the 1- and 2-head stages): the pad floats stay zero in all
+        # four buffers (zero gradient -> zero moments -> zero update)
+        n = sum((p.numel() + 3) // 4 * 4 for p in order)
+        npad = n
         fp = torch.zeros(npad, device=dev, dtype=torch.float32)
         fg = torch.zeros(npad, device=dev, dtype=torch.float32)
         self._offsets = {}
         off = 0
         for p in order:
+            off = (off + 3) // 4 * 4
             k = p.numel()
             fp[off:off + k].copy_(p.data.reshape(-1))
             if p.grad is not None:

@@ -48,8 +48,9 @@ def test_leff_fused_vs_fp64_and_chain(C, H, W, B, drop):
     for n_, p in list(n64.named_parameters(prefix="norm")) + list(m64.named_parameters(prefix="mlp")):
         ref[n_] = p.grad
 
-    def run(fused_on):
-        fused.LEFF_FUSED = fused_on
+    def run(fused_on, fused_bwd=True):
+        saved = (fused.LEFF_FUSED, fused.LEFF_FUSED_C, fused.LEFF_FUSED_BWD)
+        fused.LEFF_FUSED, fused.LEFF_FUSED_C, fused.LEFF_FUSED_BWD = fused_on, (32, 64, 128), fused_bwd
         try:
             nd, md = copy.deepcopy(norm).to(dev), copy.deepcopy(mlp).to(dev)
             xd = x.to(dev).requires_grad_()
@@ -62,15 +63,16 @@ def test_leff_fused_vs_fp64_and_chain(C, H, W, B, drop):
                 out["y_eval"] = fused.leff_branch(x.to(dev), nd, md, None, H, W).cpu().double()
             return out
         finally:
-            fused.LEFF_FUSED = True
+            fused.LEFF_FUSED, fused.LEFF_FUSED_C, fused.LEFF_FUSED_BWD = saved
 
-    got, chain = run(True), run(False)
+    got, chain, mixed = run(True), run(False), run(True, False)     # mixed = the shipped default: fused forward, chain backward
     for k, r in ref.items():
         tol = 3e-5 + 3e-5 * r.abs().max().item()
         if k not in ("y", "dx"):
             tol *= (B * H * W) ** 0.5                   # sums over all tokens
         assert (got[k] - r).abs().max().item() < tol, (k, (got[k] - r).abs().max().item(), tol)
         assert (chain[k] - r).abs().max().item() < tol, ("chain", k)
+        assert (mixed[k] - r).abs().max().item() < tol, ("mixed", k)
     assert (got["y_eval"] - chain["y_eval"]).abs().max().item() < 3e-5
 
 

@@ -1,28 +1,48 @@
-"""Micro-benchmark of the LeFF depthwise stage kernels at the model's shapes (bs=32)."""
+"""Fused LeFF kernels against the kernel chain on the config-2 stage shapes (bs = 32): forward, forward+backward (us)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, os.path.join(ROOT, "research-and-implementation-of-image-dehazing-algorithm-based-on-vision-transformer_amd"))
+sys.path[:0] = [os.path.join(ROOT, "research-and-implementation-of-image-dehazing-algorithm-based-on-vision-transformer_amd"), ROOT]
 import torch
-from dehaze_hip import ops
+import My_model_1 as M1
+from dehaze_hip import fused
 dev = torch.device("cuda:0")
-tot_f = tot_b = 0
-for res, C in [(128, 32), (64, 64), (32, 128), (16, 256), (8, 512), (16, 512), (32, 256), (64, 128), (128, 64)]:
-    Ch = 4 * C
-    u = torch.randn(32, res * res, Ch, device=dev, requires_grad=True)
-    w = torch.randn(Ch, 1, 3, 3, device=dev, requires_grad=True); b = torch.randn(Ch, device=dev, requires_grad=True)
-    z = ops.leff_dwconv(u, w, b, res, res); go = torch.randn_like(z)
-    def fwd(): return ops.leff_dwconv(u, w, b, res, res)
-    def bwd(): z.backward(go, retain_graph=True)
-    out = []
-    for f in (fwd, bwd):
-        for _ in range(2): f()
-        torch.cuda.synchronize()
+
+
+def bench(f, reps=5):
+    f(); torch.cuda.synchronize()
+    best = 1e9
+    for _ in range(4):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        for _ in range(5): f()
+        for _ in range(reps):
+            f()
         e1.record(); torch.cuda.synchronize()
-        out.append(e0.elapsed_time(e1) / 5 * 1e3)
-    mb = u.numel() * 4 / 1e6
-    tot_f += out[0]; tot_b += out[1]
-    print(f"res {res:4d} Ch {Ch:5d} ({mb:6.1f} MB/tensor)  fwd {out[0]:7.1f} us ({3*mb/out[0]*1e3:5.0f} GB/s)   bwd {out[1]:7.1f} us ({4*mb/out[1]*1e3:5.0f} GB/s)")
-print(f"sum fwd {tot_f:.0f} us  bwd {tot_b:.0f} us  (x2 blocks per stage per step)")
+        best = min(best, e0.elapsed_time(e1) / reps * 1e3)
+    return best
+
+
+print(f"{'C':>4} {'res':>4} | fwd chain  fused | fwd+bwd chain  fused   (us; MFMA floor fwd at 157 TF)")
+for C, res in [(32, 128), (64, 64), (128, 32), (128, 64), (64, 128)]:
+    B = 32
+    norm = torch.nn.LayerNorm(C).to(dev)
+    mlp = M1.LeFF(C, 4 * C).to(dev)
+    x = torch.randn(B, res * res, C, device=dev, requires_grad=True)
+    g = torch.randn(B, res * res, C, device=dev)
+    sc = torch.ones(B, device=dev)
+    r = []
+    fused.LEFF_FUSED_C, fused.LEFF_FUSED_BWD = (32, 64, 128), bool(os.environ.get('LEFF_BWD'))
+    for on in (False, True):
+        fused.LEFF_FUSED = on
+        def fwd():
+            with torch.no_grad():
+                fused.leff_branch(x, norm, mlp, sc, res, res)
+        def fb():
+            y = fused.leff_branch(x, norm, mlp, sc, res, res)
+            y.backward(g)
+            x.grad = None
+        def ftrain():
+            fused.leff_branch(x, norm, mlp, sc, res, res)
+        r += [bench(fwd), bench(fb), bench(ftrain)]
+    fused.LEFF_FUSED = True
+    floor = 2 * B * res * res * 8 * C * C / 157.3e12 * 1e6
+    print(f"{C:4d} {res:4d} | {r[0]:9.1f} {r[3]:6.1f} | {r[1]:13.1f} {r[4]:6.1f}   ({floor:.0f}) | fwd with saves: chain {r[2]:.1f} fused {r[5]:.1f}")
