@@ -9,7 +9,8 @@
 //     that a lane's four consecutive k are ONE conflict-free ds_read_b128; MFMA j of a 16-deep step then contracts over
 //     k = 16 s + 4 g + j (g = lane >> 4) - any order of k is valid as long as both operands use the same one.
 //   * W when !WT: [32 k][BN + 4] (row stride = 4 mod 8 floats -> the g = 0 / 1 halves of a ds_read_b32 hit disjoint banks).
-// Epilogue: accumulators -> LDS -> (+ bias) -> full-line float4 stores.
+// Workgroups are persistent (two per CU) and pipeline across their tiles; the epilogue (+ bias) stores straight from the
+// accumulators.
 #include "common.h"
 
 namespace {
@@ -20,25 +21,33 @@ template <int WM, int WN, bool WT>
 __global__ __launch_bounds__(256) void linear_gemm_kernel(const float* __restrict__ A, int lda,
                                                           const float* __restrict__ W, int ldw,
                                                           const float* __restrict__ bias, float* __restrict__ Y, int ldy,
-                                                          int M, int N, int K, int tiles_n, int nblocks) {
+                                                          int M, int N, int K, int tiles_n, int ntiles) {
     constexpr int BM = 32 * WM, BN = 32 * WN;
     constexpr int SBN = BN + 4;                                   // !WT image row stride
     constexpr int A_FLOATS = BM * BK;
     constexpr int B_FLOATS = WT ? BN * BK : BK * SBN;
     constexpr int STAGE = A_FLOATS + B_FLOATS;
     constexpr int NA = BM * 8 / 256;                              // float4 per thread per stage (= WM)
-    constexpr int NB = WT ? BN * 8 / 256 : (BK * BN / 4 + 255) / 256;
+    constexpr int NB = WN;
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int i16 = lane & 15, g = lane >> 4;
     const int wm = w >> 1, wn = w & 1;
-    // XCD-aware numbering: blocks b and b + 8 share an XCD (round-robin dispatch); make consecutive LOGICAL tiles - which
-    // share their token rows across the tn sweep - land on one XCD so that the re-read of A comes from that XCD's L2.
-    int bid = blockIdx.x;
-    if ((nblocks & 7) == 0) bid = (bid & 7) * (nblocks >> 3) + (bid >> 3);
-    const int tn = bid % tiles_n, tm = bid / tiles_n;
-    const int m0 = tm * BM, n0 = tn * BN;
+    const int nst = K / BK;
+
+    // Persistent workgroups: a workgroup walks the tiles bid, bid + grid, ... and treats their (tile, stage) pairs as ONE
+    // stream of stages, so the loads of the next tile's first stage are in flight while the current tile finishes and its
+    // epilogue stores drain behind the next tile's matrix work.  XCD-aware numbering: workgroups b and b + 8 share an XCD
+    // (round-robin dispatch), and consecutive LOGICAL tiles share their token rows across the tn sweep: map the tiles so that
+    // an XCD owns a contiguous range of them (the re-read of A then comes from that XCD's L2).
+    const int grid = gridDim.x;
+    auto tile_of = [&](int i) -> int {                            // i-th tile of this workgroup, or -1
+        const int lin = blockIdx.x + i * grid;
+        if (lin >= ntiles) return -1;
+        if ((grid & 7) == 0 && (ntiles & 7) == 0) return (lin & 7) * (ntiles >> 3) + (lin >> 3);
+        return lin;
+    };
 
     f32x4 acc[WM][WN];
 #pragma unroll
@@ -47,29 +56,29 @@ __global__ __launch_bounds__(256) void linear_gemm_kernel(const float* __restric
         for (int b = 0; b < WN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     f32x4 ra[NA], rb[NB];
-    auto gload = [&](int k0) {
+    // per-tile operand row pointers (recomputed only when the stream moves on to another tile): a stage adds its k offset
+    const float* pa[NA];
+    const float* pb[NB];
+    auto set_tile = [&](int tile) {
+        const int tn = tile % tiles_n, tm = tile / tiles_n;
+        const int m0 = tm * BM, n0 = tn * BN;
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             const int e = t + 256 * i, row = e >> 3, q = e & 7;
-            const int m = min(m0 + row, M - 1);
-            ra[i] = *reinterpret_cast<const f32x4*>(A + (size_t)m * lda + k0 + 4 * q);
+            pa[i] = A + (size_t)min(m0 + row, M - 1) * lda + 4 * q;
         }
-        if (WT) {
 #pragma unroll
-            for (int i = 0; i < NB; ++i) {
-                const int e = t + 256 * i, row = e >> 3, q = e & 7;
-                rb[i] = *reinterpret_cast<const f32x4*>(W + (size_t)(n0 + row) * ldw + k0 + 4 * q);
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < NB; ++i) {
-                const int e = t + 256 * i;
-                if ((BK * BN / 4) % 256 == 0 || e < BK * BN / 4) {
-                    const int row = e / (BN / 4), c4 = e % (BN / 4);
-                    rb[i] = *reinterpret_cast<const f32x4*>(W + (size_t)(k0 + row) * ldw + n0 + 4 * c4);
-                }
-            }
+        for (int i = 0; i < NB; ++i) {
+            const int e = t + 256 * i;
+            if (WT) pb[i] = W + (size_t)(n0 + (e >> 3)) * ldw + 4 * (e & 7);
+            else pb[i] = W + (size_t)(e / (BN / 4)) * ldw + n0 + 4 * (e % (BN / 4));
         }
+    };
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) ra[i] = *reinterpret_cast<const f32x4*>(pa[i] + k0);
+#pragma unroll
+        for (int i = 0; i < NB; ++i) rb[i] = *reinterpret_cast<const f32x4*>(pb[i] + (WT ? (size_t)k0 : (size_t)k0 * ldw));
     };
     auto swrite = [&](int buf) {
         float* As = smem + buf * STAGE;
@@ -89,74 +98,87 @@ __global__ __launch_bounds__(256) void linear_gemm_kernel(const float* __restric
 #pragma unroll
             for (int i = 0; i < NB; ++i) {
                 const int e = t + 256 * i;
-                if ((BK * BN / 4) % 256 == 0 || e < BK * BN / 4) {
-                    const int row = e / (BN / 4), c4 = e % (BN / 4);
-                    *reinterpret_cast<f32x4*>(&Bs[row * SBN + 4 * c4]) = rb[i];
-                }
+                const int row = e / (BN / 4), c4 = e % (BN / 4);
+                *reinterpret_cast<f32x4*>(&Bs[row * SBN + 4 * c4]) = rb[i];
             }
         }
     };
 
-    const int nst = K / BK;
+    int ti = 0, tile = tile_of(0);
+    if (tile < 0) return;
+    set_tile(tile);
     gload(0);
     swrite(0);
     __syncthreads();
     const int sw = (i16 >> 1) & 7;
-    for (int st = 0; st < nst; ++st) {
-        const int buf = st & 1;
-        const bool more = st + 1 < nst;
-        if (more) gload((st + 1) * BK);
-        const float* As = smem + buf * STAGE + (wm * WM * 16 + i16) * BK;
-        const float* Bs = smem + buf * STAGE + A_FLOATS;
+    int buf = 0;
+    while (true) {
+        const int ntile = tile_of(ti + 1);
+        const int tn = tile % tiles_n, tm = tile / tiles_n;
+        for (int st = 0; st < nst; ++st) {
+            // next stage of the stream: the same tile, or the first stage of this workgroup's next tile
+            const bool last = st + 1 == nst;
+            const bool more = !last || ntile >= 0;
+            if (!last) gload((st + 1) * BK);
+            else if (ntile >= 0) { set_tile(ntile); gload(0); }
+            const float* As = smem + buf * STAGE + (wm * WM * 16 + i16) * BK;
+            const float* Bs = smem + buf * STAGE + A_FLOATS;
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            f32x4 af[WM], bf[WN];
-#pragma unroll
-            for (int a = 0; a < WM; ++a)
-                af[a] = *reinterpret_cast<const f32x4*>(&As[a * 16 * BK + 4 * ((4 * s + g) ^ sw)]);
-            if (WT) {
-#pragma unroll
-                for (int b = 0; b < WN; ++b)
-                    bf[b] = *reinterpret_cast<const f32x4*>(&Bs[((wn * WN + b) * 16 + i16) * BK + 4 * ((4 * s + g) ^ sw)]);
-            } else {
-#pragma unroll
-                for (int b = 0; b < WN; ++b)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) bf[b][j] = Bs[(16 * s + 4 * g + j) * SBN + (wn * WN + b) * 16 + i16];
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int s = 0; s < 2; ++s) {
+                f32x4 af[WM], bf[WN];
 #pragma unroll
                 for (int a = 0; a < WM; ++a)
+                    af[a] = *reinterpret_cast<const f32x4*>(&As[a * 16 * BK + 4 * ((4 * s + g) ^ sw)]);
+                if (WT) {
 #pragma unroll
-                    for (int b = 0; b < WN; ++b) acc[a][b] = mfma16(af[a][j], bf[b][j], acc[a][b]);
-        }
-        if (more) swrite(buf ^ 1);
-        __syncthreads();
-    }
-
-    // ---- epilogue through LDS: Cs[BM][BN + 4]
-    constexpr int SC = BN + 4;
-    float* Cs = smem;
+                    for (int b = 0; b < WN; ++b)
+                        bf[b] = *reinterpret_cast<const f32x4*>(&Bs[((wn * WN + b) * 16 + i16) * BK + 4 * ((4 * s + g) ^ sw)]);
+                } else {
 #pragma unroll
-    for (int a = 0; a < WM; ++a)
+                    for (int b = 0; b < WN; ++b)
 #pragma unroll
-        for (int b = 0; b < WN; ++b)
+                        for (int j = 0; j < 4; ++j) bf[b][j] = Bs[(16 * s + 4 * g + j) * SBN + (wn * WN + b) * 16 + i16];
+                }
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                Cs[(wm * WM * 16 + a * 16 + 4 * g + j) * SC + (wn * WN + b) * 16 + i16] = acc[a][b][j];
-    __syncthreads();
-    constexpr int C4 = BN / 4;
-    for (int e = t; e < BM * C4; e += 256) {
-        const int r = e / C4, c4 = e % C4;
-        if (m0 + r < M) {
-            f32x4 v = *reinterpret_cast<const f32x4*>(&Cs[r * SC + 4 * c4]);
-            if (bias) {
-                const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + n0 + 4 * c4);
-                v += bv;
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int a = 0; a < WM; ++a)
+#pragma unroll
+                        for (int b = 0; b < WN; ++b) acc[a][b] = mfma16(af[a][j], bf[b][j], acc[a][b]);
             }
-            *reinterpret_cast<f32x4*>(Y + (size_t)(m0 + r) * ldy + n0 + 4 * c4) = v;
+            if (more) {
+                swrite(buf ^ 1);
+                __syncthreads();
+                buf ^= 1;
+            }
         }
+        // ---- tile epilogue straight from the accumulators: acc[a][b][j] = C[16 a + 4 g + j][16 b + i16]; the 16 lanes of a row
+        //      write 64 contiguous bytes and the b sweep completes the lines, which the L2 merges before they leave.  The stores
+        //      drain behind the next tile's matrix work (its first stage is already in LDS).
+        {
+            const int m0 = tm * BM + wm * WM * 16 + 4 * g, n0 = tn * BN + wn * WN * 16 + i16;
+            float bv[WN];
+#pragma unroll
+            for (int b = 0; b < WN; ++b) bv[b] = bias ? bias[n0 + 16 * b] : 0.f;
+#pragma unroll
+            for (int a = 0; a < WM; ++a)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int m = m0 + 16 * a + j;
+                    if (m < M) {
+                        float* yr = Y + (size_t)m * ldy + n0;
+#pragma unroll
+                        for (int b = 0; b < WN; ++b) yr[16 * b] = acc[a][b][j] + bv[b];
+                    }
+                }
+#pragma unroll
+            for (int a = 0; a < WM; ++a)
+#pragma unroll
+                for (int b = 0; b < WN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        if (ntile < 0) break;
+        tile = ntile;
+        ++ti;
     }
 }
 
@@ -165,15 +187,17 @@ void launch(const float* A, int lda, const float* W, int ldw, const float* bias,
             hipStream_t s) {
     constexpr int BM = 32 * WM, BN = 32 * WN;
     constexpr size_t stage = (size_t)(BM * BK + (WT ? BN * BK : BK * (BN + 4))) * sizeof(float);
-    constexpr size_t epi = (size_t)BM * (BN + 4) * sizeof(float);
-    constexpr size_t smem = 2 * stage > epi ? 2 * stage : epi;
+    constexpr size_t smem = 2 * stage;
     const int tiles_n = N / BN, tiles_m = (M + BM - 1) / BM;
-    const int nblocks = tiles_n * tiles_m;
+    const int ntiles = tiles_n * tiles_m;
+    // two workgroups per CU when the LDS allows (it does for every tile shape: <= 66.5 KiB per workgroup)
+    const int slots = 512;
+    const int grid = ntiles < slots ? ntiles : slots;
     if (smem > 48 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_gemm_kernel<WM, WN, WT>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    hipLaunchKernelGGL((linear_gemm_kernel<WM, WN, WT>), dim3(nblocks), dim3(256), smem, s, A, lda, W, ldw, bias, Y, ldy, M, N,
-                       K, tiles_n, nblocks);
+    hipLaunchKernelGGL((linear_gemm_kernel<WM, WN, WT>), dim3(grid), dim3(256), smem, s, A, lda, W, ldw, bias, Y, ldy, M, N,
+                       K, tiles_n, ntiles);
 }
 
 template <bool WT>
