@@ -71,8 +71,6 @@ def main():
         utils.mkdir(result_dir)
         utils.mkdir(model_dir)
 
-    from dehaze_hip.tuning import enable_tuned_gemms
-    enable_tuned_gemms()                          # recorded hipBLASLt solution per GEMM shape (MI355X; ignored elsewhere)
     random.seed(1234)
     np.random.seed(1234)
     torch.manual_seed(1234)
@@ -94,6 +92,7 @@ def main():
 
     start_epoch = 1
     scheduler = None
+    resumed_rng = None
     if opt.resume:
         utils.load_checkpoint(model, opt.pretrain_weights, map_location=dev)
         start_epoch = utils.load_start_epoch(opt.pretrain_weights) + 1
@@ -101,6 +100,7 @@ def main():
         for p in optimizer.param_groups:
             p['lr'] = lr
         scheduler = torch.optim.lr_scheduler.CosineAnnealingLR(optimizer, opt.nepoch - start_epoch + 1, eta_min=1e-6)
+        resumed_rng = opt.pretrain_weights
     elif opt.warmup:
         cosine = torch.optim.lr_scheduler.CosineAnnealingLR(optimizer, opt.nepoch - opt.warmup_epochs, eta_min=1e-6)
         scheduler = GradualWarmupScheduler(optimizer, multiplier=1, total_epoch=opt.warmup_epochs, after_scheduler=cosine)
@@ -108,12 +108,30 @@ def main():
         scheduler = torch.optim.lr_scheduler.StepLR(optimizer, step_size=50, gamma=0.5)
 
     reducer = None
-    if world > 1 and isinstance(optimizer, FlatAdamW):
-        optimizer.zero_grad()
-        reducer = GradReducer(optimizer)
+    if world > 1:
+        if isinstance(optimizer, FlatAdamW):
+            optimizer.zero_grad()
+            reducer = GradReducer(optimizer)
+        else:
+            # `--optimizer adam`: the stand-alone reducer owns a flat gradient buffer, averages it after the all-reduce
+            # (train_step) and leaves the update to torch.optim.Adam - the replicas stay identical like under DataParallel
+            reducer = GradReducer(params=[p for _, p in model.live_parameters()] if hasattr(model, "live_parameters")
+                                  else model.parameters())
 
     char = CharbonnierLoss()
+    if opt.w_loss_vgg7 > 0 and not os.environ.get("DEHAZE_VGG19_WEIGHTS") and not opt.synthetic \
+            and not os.environ.get("DEHAZE_ALLOW_RANDOM_VGG"):
+        raise SystemExit("My_train: the contrastive loss (w_loss_vgg7 > 0) needs the ImageNet VGG19 checkpoint the reference "
+                         "downloads (My_CR.py:59): set DEHAZE_VGG19_WEIGHTS=/path/to/vgg19-dcbb9e9d.pth (no network here), "
+                         "or DEHAZE_ALLOW_RANDOM_VGG=1 to train against SEEDED RANDOM VGG features (not the reference's loss)")
     cr = ContrastLoss(ablation=opt.is_ab).to(dev) if opt.w_loss_vgg7 > 0 else None
+    if world > 1:
+        # identical replicas above (same seed -> same initial weights); from here on every rank draws its own permutations,
+        # crops, augmentations, MixUp lambdas, DropPath masks and sampled keys
+        random.seed(1234 + rank)
+        np.random.seed(1234 + rank)
+        torch.manual_seed(1234 + rank)
+        torch.cuda.manual_seed_all(1234 + rank)
 
     # ---- data (HBM resident)
     store = None
@@ -133,7 +151,14 @@ def main():
         vt, vi = load_pairs(opt.val_dir, dev)
         tgt_all, inp_all = tgt_all[rank::world], inp_all[rank::world]
     n_train = len(store) if store is not None else tgt_all.shape[0]
-    steps_per_epoch = max(1, n_train // opt.batch_size)
+    n_epoch = n_train
+    if world > 1:
+        # rank::world shards differ by one item when N % world != 0: every rank must run the SAME number of steps (a rank
+        # with an extra step would wait in its bucket all-reduce for ever), so an epoch uses the smallest shard's item count
+        nmin = torch.tensor([n_train], device=dev)
+        dist.all_reduce(nmin, op=dist.ReduceOp.MIN)
+        n_epoch = int(nmin.item())
+    steps_per_epoch = max(1, -(-n_epoch // opt.batch_size))      # drop_last=False (TR:160): the last batch may be partial
     eval_now = max(1, steps_per_epoch // 4)
     mixup = utils.MixUp_AUG()
 
@@ -147,6 +172,8 @@ def main():
         model.train()
         return sum(vals) / len(vals)
 
+    if resumed_rng is not None and utils.load_rng_state(resumed_rng) and is_main:
+        print("==> generator states restored from the checkpoint (continues the interrupted run's random streams)")
     best_psnr, best_epoch, best_iter = 0, 0, 0
     model.train()
     for epoch in range(start_epoch, opt.nepoch + 1):
@@ -154,7 +181,7 @@ def main():
         perm = torch.randperm(n_train)
         epoch_loss = torch.zeros((), device=dev)
         for i in range(steps_per_epoch):
-            sel = perm[i * opt.batch_size:(i + 1) * opt.batch_size]
+            sel = perm[:n_epoch][i * opt.batch_size:(i + 1) * opt.batch_size]
             if store is not None:
                 target, input_ = store.batch(sel.tolist(), opt.train_ps)
             else:
@@ -174,7 +201,8 @@ def main():
                     if val > best_psnr:
                         best_psnr, best_epoch, best_iter = val, epoch, i
                         torch.save({'epoch': epoch, 'state_dict': {'module.' + k: v for k, v in model.state_dict().items()},
-                                    'optimizer': optimizer.state_dict()}, os.path.join(model_dir, "model_best.pth"))
+                                    'optimizer': optimizer.state_dict(), 'rng_state': utils.rng_state_dict()},
+                                   os.path.join(model_dir, "model_best.pth"))
                     line = "[Ep %d it %d/%d\t PSNR: %.4f\t] ----  [best_Ep: %d, best_it: %d, Best_PSNR: %.4f]" % (
                         epoch, i, steps_per_epoch, val, best_epoch, best_iter, best_psnr)
                     print("\n" + line)
@@ -188,7 +216,8 @@ def main():
             with open(logname, 'a') as f:
                 f.write(line + '\n')
             torch.save({'epoch': epoch, 'state_dict': {'module.' + k: v for k, v in model.state_dict().items()},
-                        'optimizer': optimizer.state_dict()}, os.path.join(model_dir, "epoch_model_{}.pth".format(epoch)))
+                        'optimizer': optimizer.state_dict(), 'rng_state': utils.rng_state_dict()},
+                       os.path.join(model_dir, "epoch_model_{}.pth".format(epoch)))
     if world > 1:
         dist.destroy_process_group()
 

@@ -502,7 +502,13 @@ void launch_fused(hipStream_t s, int nwin, const float* x, const float* gamma, c
                   const float* bqkv, const float* wo_p, const float* bo, const uint8_t* idx, const float* bias,
                   const float* mask, const float* dscale, float* out, float* xn_save, float* qkv_save, float* ctx_save,
                   float* stats_save, uint8_t* rank_save, int Hres, int Wres, int shift) {
-    static const int abl = getenv("DHZ_FUSED_ABLATE") ? atoi(getenv("DHZ_FUSED_ABLATE")) : 0;   // timing diagnostics only
+    // Phase skipping for timing diagnostics exists only in a build with -DDHZ_DIAG (tools/abl_fused.sh compiles its own copy of
+    // the library); the product library has no run-time switch that can change results.
+#ifdef DHZ_DIAG
+    static const int abl = getenv("DHZ_FUSED_ABLATE") ? atoi(getenv("DHZ_FUSED_ABLATE")) : 0;
+#else
+    constexpr int abl = 0;
+#endif
     const size_t smem = sizeof(FusedSmem<C>);
     if (smem > 48 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_window_attn_fwd_kernel<C, SAVE>),
@@ -510,7 +516,11 @@ void launch_fused(hipStream_t s, int nwin, const float* x, const float* gamma, c
     // persistent workgroups (only with register-resident weights): exactly as many as are RESIDENT at once - the occupancy
     // the runtime reports for this code object (registers and LDS together: 2 per CU at 222 VGPRs, although 3 would fit the
     // LDS) - a third workgroup per CU would run alone after the first two have finished.  DHZ_FUSED_WG_PER_CU overrides.
+#ifdef DHZ_DIAG
     static const int env_wg = getenv("DHZ_FUSED_WG_PER_CU") ? atoi(getenv("DHZ_FUSED_WG_PER_CU")) : 0;
+#else
+    constexpr int env_wg = 0;
+#endif
     static int per_cu = 0, ncu = 0;          // queried once per code object (all devices of a node are the same part)
     if (per_cu == 0) {
         int q = 0, dev = 0;

@@ -184,7 +184,11 @@ int launch(const float* dy, int ldy, const float* x, int ldx, int T, int N, int 
     const int tiles = (N / BM) * (K / BN);
     // Every workgroup ends with BM*BN fp32 atomics (chip-wide ~1.3 TB/s of added bytes): large tiles want
     // fewer, longer token slabs.  DHZ_WGRAD_TARGET overrides the workgroup target (tuning aid).
+#ifdef DHZ_DIAG
     static const int env_target = getenv("DHZ_WGRAD_TARGET") ? atoi(getenv("DHZ_WGRAD_TARGET")) : 0;
+#else
+    constexpr int env_target = 0;
+#endif
     // Workgroups are dealt in whole rounds over the 256 CUs: the count must not exceed the resident slots (a 257th
     // 512-thread workgroup, or a 513th 256-thread one, runs alone after the others: measured 198 -> 130 us at
     // T=8192, N=1536, K=512 with 12 tiles x 43 splits = 516 workgroups), so the split count is rounded DOWN.
@@ -224,7 +228,11 @@ static int wgrad_dispatch(const char* who, const float* dy, int ldy, const float
     const int wn = (K % 128 == 0) ? 4 : (K % 64 == 0) ? 2 : 1;
     // Two token groups per workgroup (512 threads, one 128 x 128 workgroup per CU) halve the atomic epilogue per staged byte:
     // -7.5 % over the 36 shapes of the step (tools/bench_wgrad.py); slabs shorter than 8 stages stay on one group.
+#ifdef DHZ_DIAG
     static const int tg_env = getenv("DHZ_WGRAD_TG") ? atoi(getenv("DHZ_WGRAD_TG")) : 0;
+#else
+    constexpr int tg_env = 0;
+#endif
     const int bm = 32 * wm, bn = 32 * wn;
     const int tiles = (N / bm) * (K / bn);
     const int splits2 = 256 / tiles > 0 ? 256 / tiles : 1;

@@ -501,7 +501,12 @@ extern "C" int dhz_winograd_conv3x3(const float* x, const float* upack, const fl
     const int nblk = B * (H / 16) * (W / 16);                     // 16x16-pixel output blocks, two per workgroup
     const int grid = ((nblk + 1) / 2) * (K / KB);
     hipStream_t s = (hipStream_t)stream;
-    static const int xcd_env = getenv("DHZ_WINO_XCD") ? atoi(getenv("DHZ_WINO_XCD")) : -1;        // tuning aid: 0 / 1 forces
+#ifdef DHZ_DIAG
+    static const int xcd_env = getenv("DHZ_WINO_XCD") ? atoi(getenv("DHZ_WINO_XCD")) : -1;
+#else
+    constexpr int xcd_env = -1;
+#endif
+           // tuning aid: 0 / 1 forces
     // measured (FETCH_SIZE, batch 64): 2-4x fewer HBM reads on the K <= 256 layers (reads ~= the input once), no change
     // at K = 512, never slower
     const int xcd_group = (grid % 8 == 0) && (xcd_env >= 0 ? xcd_env : 1);

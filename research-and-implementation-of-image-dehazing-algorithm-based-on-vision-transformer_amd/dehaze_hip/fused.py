@@ -29,8 +29,10 @@ def _wgrad(dy, off, x, w, b):
     the split-T kernel is the better choice; returns (dw, db) to hand to autograd, or (None, None)."""
     T, K = x.shape
     N = w.shape[0]
+    if not w.requires_grad and (b is None or not b.requires_grad):
+        return None, None                                   # frozen Linear: nothing to compute
     mine = T % 32 == 0 and N % 32 == 0 and K % 32 == 0      # (the kernel's shape contract; always true on this model)
-    if mine and w.is_leaf and (b is None or b.is_leaf):
+    if mine and w.is_leaf and w.requires_grad and (b is None or (b.is_leaf and b.requires_grad)):
         ops._accumulate_param_grads(dy, off, x, [(w, b)])
         return None, None
     if mine:
@@ -39,15 +41,16 @@ def _wgrad(dy, off, x, w, b):
         _lib.call("dhz_linear_wgrad", dy.data_ptr() + 4 * off, dy.stride(0), _p(x), x.stride(0), T, N, K, _p(dw), _p(db),
                   _stream())
         return dw, db
-    dys = dy[:, off:off + N]
-    return dys.t() @ x, (dys.sum(0) if b is not None else None)
+    raise RuntimeError(f"dehaze_hip: Linear weight gradient for T={T}, N={N}, K={K}: the HIP kernel needs multiples of 32 "
+                       "(there is deliberately no library fallback)")
 
 
 def _wgrad_qkv(dqkv, xn, C, pairs):
     """The three projections' gradients from the packed dqkv [T,3C]: one launch (x read once) when all of them can be
     accumulated in place, else one _wgrad each.  Returns the six autograd slots (g_wq, g_bq, g_wk, g_bk, g_wv, g_bv)."""
     T, K = xn.shape
-    if T % 32 == 0 and C % 32 == 0 and K % 32 == 0 and all(w.is_leaf and (b is None or b.is_leaf) for w, b in pairs):
+    if T % 32 == 0 and C % 32 == 0 and K % 32 == 0 and all(w.is_leaf and w.requires_grad and (b is None or (b.is_leaf and b.requires_grad))
+                                                           for w, b in pairs):
         ops._accumulate_param_grads(dqkv, 0, xn, pairs)
         return (None,) * 6
     out = ()

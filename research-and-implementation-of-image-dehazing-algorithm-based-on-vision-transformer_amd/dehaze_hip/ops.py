@@ -280,8 +280,8 @@ class _LinearTokens(Function):
         T, K = x.shape
         grads = []
         off = 0
-        if T % 32 == 0 and K % 32 == 0 and all(w.shape[0] % 32 == 0 and w.is_leaf and (b is None or b.is_leaf)
-                                               for w, b in ctx.params):
+        if T % 32 == 0 and K % 32 == 0 and all(w.shape[0] % 32 == 0 and w.is_leaf and w.requires_grad
+                                               and (b is None or (b.is_leaf and b.requires_grad)) for w, b in ctx.params):
             _accumulate_param_grads(dy, 0, x, ctx.params)           # one launch for equal-shaped parameters (Q / K / V)
             return (dx,) + (None, None) * len(ctx.params)
         for w, b in ctx.params:
@@ -290,7 +290,9 @@ class _LinearTokens(Function):
             # stages (T <= 8k) it is within 0.9-1.2x of the library's TN GEMM and delivers the bias gradient for free
             # (the library path pays a separate ~20 us column-sum kernel), so it is used everywhere
             mine = T % 32 == 0 and N % 32 == 0 and K % 32 == 0      # (the kernel's shape contract; always true on this model)
-            if mine and w.is_leaf and (b is None or b.is_leaf):
+            if not w.requires_grad and (b is None or not b.requires_grad):
+                grads += [None, None]                                 # frozen Linear
+            elif mine and w.is_leaf and w.requires_grad and (b is None or (b.is_leaf and b.requires_grad)):
                 _accumulate_param_grads(dy, off, x, [(w, b)])
                 grads += [None, None]
             elif mine:
@@ -300,8 +302,8 @@ class _LinearTokens(Function):
                           _stream())
                 grads += [dw, db]
             else:
-                dys = dy[:, off:off + N]
-                grads += [dys.t() @ x, dys.sum(0) if b is not None else None]
+                raise RuntimeError(f"dehaze_hip: Linear weight gradient for T={T}, N={N}, K={K}: the HIP kernel needs "
+                                   "multiples of 32 (there is deliberately no library fallback)")
             off += N
         return (dx,) + tuple(grads)
 

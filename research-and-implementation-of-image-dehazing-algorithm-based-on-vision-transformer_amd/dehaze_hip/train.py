@@ -37,7 +37,8 @@ class FlatAdamW(torch.optim.Optimizer):
             params = list(model_or_params)
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self._all = params
-        self._live = live if live is not None else [p for p in params if p.requires_grad]
+        # frozen parameters (utils.freeze / a partial fine-tune) stay out of the flat buffers: neither updated nor decayed
+        self._live = [p for p in (live if live is not None else params) if p.requires_grad]
         self._names = names
         self._flat = None
         self._step = 0
@@ -179,6 +180,7 @@ class GradReducer:
                 p.grad = self.flat[off:off + p.numel()].view_as(p)
                 slices.append((p, off, p.numel()))
                 off += p.numel()
+        self._slices = slices
         cap = int(bucket_mb * 1024 * 1024 / 4)
         self.buckets = []            # [lo, hi, n_params]
         self.bucket_of = {}
@@ -200,6 +202,19 @@ class GradReducer:
             for p, _, _ in slices:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
             ops.GRAD_READY = self._on_grad_inplace      # wgrad kernels accumulate in place, bypassing autograd hooks
+
+    def plan(self, world=None, link_gbs=153.0):
+        """The exchange this reducer performs per step, without performing it: bucket byte ranges in launch (= backward)
+        order and the ring all-reduce time they imply on xGMI.  A ring over N GPUs moves 2 (N - 1) / N of the payload over
+        every GPU's slowest used link (one ~153 GB/s xGMI link per ring neighbour: MI355X_MICROARCH / the task's numbers);
+        RCCL can stripe several rings over the 7 links, so this is the conservative single-ring figure."""
+        world = world or self.world
+        total = sum(hi - lo for lo, hi, _ in self.buckets) * 4
+        factor = 2.0 * (world - 1) / world if world > 1 else 0.0
+        return {"world": world, "payload_bytes": total,
+                "buckets": [{"lo": lo, "hi": hi, "bytes": (hi - lo) * 4, "params": n} for lo, hi, n in self.buckets],
+                "ring_time_ms": 1e3 * factor * total / (link_gbs * 1e9),
+                "ring_time_ms_per_bucket": [1e3 * factor * (hi - lo) * 4 / (link_gbs * 1e9) for lo, hi, _ in self.buckets]}
 
     def _on_grad_inplace(self, p):
         if id(p) in self.bucket_of:
@@ -239,6 +254,13 @@ class GradReducer:
         if self.world > 1:
             self.flat.div_(self.world)
 
+    def zero_grad(self):
+        """Stand-alone use: zero the flat gradient and re-bind every parameter's .grad to its slice (torch optimizers'
+        zero_grad(set_to_none=True) would detach them from the buffer the buckets are cut from)."""
+        self.flat.zero_()
+        for p, off, k in self._slices:
+            p.grad = self.flat[off:off + k].view_as(p)
+
 
 # ----------------------------------------------------------------------------- data + step
 def synthetic_batch(batch, ps=128, seed=1234, device="cpu"):
@@ -258,7 +280,11 @@ def train_step(model, char_loss, cr_loss, optimizer, reducer, input_, target, w_
     clamp(0,1) -> w_char*Charbonnier + w_cr*Contrast -> backward (bucketed all-reduce overlapped) ->
     AdamW.  Returns (loss, loss_rec, loss_cr) as device scalars (no host sync here; the reference's
     per-step .item() calls, TR:250-254, are left to the caller's logging cadence)."""
-    optimizer.zero_grad()
+    standalone = reducer is not None and reducer.opt is None          # torch optimizer + stand-alone reducer (--optimizer adam)
+    if standalone:
+        reducer.zero_grad()
+    else:
+        optimizer.zero_grad()
     restored = model(input_)
     loss_rec, clamped = char_loss.forward_clamped(restored, target)
     loss = w_char * loss_rec if w_char > 0 else 0
@@ -269,6 +295,8 @@ def train_step(model, char_loss, cr_loss, optimizer, reducer, input_, target, w_
     loss.backward()
     if reducer is not None:
         reducer.wait()
+        if standalone:
+            reducer.average_()
     optimizer.step()
     return loss.detach(), loss_rec.detach(), (loss_cr.detach() if loss_cr is not None else None)
 

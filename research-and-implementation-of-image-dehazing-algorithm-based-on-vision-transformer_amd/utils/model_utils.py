@@ -62,6 +62,44 @@ def load_optim(optimizer, weights):
     return lr
 
 
+def rng_state_dict():
+    """State of every generator a training step draws from (python, numpy, torch CPU - the sampled-key tables and the
+    epoch permutation - and the current HIP device - DropPath).  The reference's checkpoints hold none of this (TR:296-333:
+    epoch, state_dict, optimizer), so a resumed run there re-draws from fresh seeds; My_train.py stores it under the extra
+    key 'rng_state' (ignored by the reference's loaders) and restores it on --resume when present.  Tensors only, so that
+    the file still loads with torch.load's default weights_only=True: the python / numpy states travel as a pickled byte
+    tensor that only set_rng_state() decodes."""
+    import pickle
+    import random
+    import numpy as np
+    blob = pickle.dumps({"python": random.getstate(), "numpy": np.random.get_state()})
+    st = {"host": torch.frombuffer(bytearray(blob), dtype=torch.uint8).clone(), "torch": torch.get_rng_state()}
+    if torch.cuda.is_available():
+        st["cuda"] = torch.cuda.get_rng_state()
+    return st
+
+
+def set_rng_state(st):
+    import pickle
+    import random
+    import numpy as np
+    host = pickle.loads(st["host"].cpu().numpy().tobytes())
+    random.setstate(host["python"])
+    np.random.set_state(host["numpy"])
+    torch.set_rng_state(st["torch"].cpu())
+    if "cuda" in st and torch.cuda.is_available():
+        torch.cuda.set_rng_state(st["cuda"].cpu())
+
+
+def load_rng_state(weights):
+    """Restore the generators from a checkpoint written by this My_train.py; False for a reference checkpoint (no such key)."""
+    checkpoint = torch.load(weights, map_location="cpu")
+    if "rng_state" not in checkpoint:
+        return False
+    set_rng_state(checkpoint["rng_state"])
+    return True
+
+
 def get_arch(opt):
     from My_model_1 import UNet, Uformer          # the ProbSparse model, as model_utils.py:81
     arch = opt.arch

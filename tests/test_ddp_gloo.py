@@ -135,6 +135,20 @@ def test_flat_adamw_layout_and_state_dict_cpu():
     last = opt.param_slices()[-1]
     assert red.buckets[0][0] == 0 and red.buckets[-1][1] == last[1] + last[2]
     assert all(a[1] == b[0] for a, b in zip(red.buckets, red.buckets[1:])) and 3 <= len(red.buckets) <= 5
+    # the exchange plan of the 8-GPU run (config 3), checked without the hardware: buckets in reverse registration order - the last
+    # decoder stage (whose gradients arrive first) in bucket 0, the input projection (last to arrive) in the last one -, the
+    # 108 dead tensors in none, ~25 MB each, and a single-ring xGMI time far below the step time
+    plan = red.plan(world=8)
+    names = {id(p): n for n, p in m.named_parameters()}
+    first = [names[id(p)] for p, off, k in opt.param_slices() if off + k <= plan["buckets"][0]["hi"]]
+    lastb = [names[id(p)] for p, off, k in opt.param_slices() if off >= plan["buckets"][-1]["lo"]]
+    assert any(n.startswith("decoderlayer_3.") for n in first) and any(n.startswith("input_proj.") for n in lastb)
+    assert not any(id(p) in red.bucket_of for p in dead)
+    assert sum(b["params"] for b in plan["buckets"]) == len(live)
+    assert all(b["bytes"] >= 25 * 2 ** 20 for b in plan["buckets"][:-1]) and plan["buckets"][-1]["bytes"] > 0
+    assert abs(plan["payload_bytes"] - 4 * 20628317) < 4 * 4 * len(live)
+    assert 0.8 < plan["ring_time_ms"] < 1.1                      # 2 * 7/8 * 82.5 MB / 153 GB/s = 0.94 ms
+    assert red.plan(world=1)["ring_time_ms"] == 0.0
     sd = opt.state_dict()
     assert sd["param_groups"][0]["params"] == list(range(len(list(m.parameters()))))
     ref = torch.optim.AdamW(m.parameters(), lr=2e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.02)

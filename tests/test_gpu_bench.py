@@ -52,3 +52,21 @@ def test_bench_two_ranks_strong_scaling():
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["global_batch"] == 32
     assert d["config"]["parallelism"] == "dp2" and d["value"] > 50
     assert abs(d["value"] - 32 * 1e3 / d["ms_per_step"]) < 0.01 * d["value"]
+
+
+def test_bench_two_ranks_rccl():
+    """bench.py --gpus 2 exactly as the driver launches it - one rank per GPU, RCCL ("nccl") over xGMI - whenever the box has
+    two devices; on a one-GPU box the RCCL path cannot run and the exchange plan (bucket sizes, backward order, dead
+    parameters, predicted ring time) is what tests/test_ddp_gloo.py pins instead."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("one visible GPU: RCCL needs two devices (plan checked on the CPU in tests/test_ddp_gloo.py)")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("DHZ_DIST_BACKEND", None); env.pop("DHZ_SHARE_GPU", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29534", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2",
+           "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["global_batch"] == 64

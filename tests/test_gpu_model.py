@@ -132,11 +132,11 @@ def test_contrast_loss_vs_oracle(golden, dev):
         loss, ap, an = cl(a, T(g[tag + "/p"]).to(dev), T(g[tag + "/n"]).to(dev))
         assert abs(loss.item() - float(g[tag + "/loss"])) < 1e-4 * max(1.0, abs(float(g[tag + "/loss"])))
         loss.backward()
-        # the VGG convolutions run on MIOpen, which picks an fp32 Winograd F(2,3) kernel for 3x3 convs: its
-        # rounding differs from a direct convolution at the 1e-3 relative level (gradients here are ~1e-4)
+        # fp32 Winograd F(2x2,3x3) on the matrix pipe (csrc/winograd_conv.hip) against the oracle's direct convolutions:
+        # the transform-domain rounding shows at the 1e-3 relative level of the largest gradient entry
         ref = T(g[tag + "/da"])
         err = (a.grad.cpu() - ref).abs().max().item()
-        assert err < 2e-2 * ref.abs().max().item(), err
+        assert err < 3e-3 * ref.abs().max().item(), err
 
 
 # ----------------------------------------------------------------------------- dense twin (My_model.Uformer)
@@ -205,38 +205,6 @@ def test_embed_dim_64_vs_oracle(dev):
         a, b = float(p.grad.double().norm()), float(P[n].grad.double().norm())
         worst = max(worst, abs(a - b) / (b + 1e-8))
     assert worst < 5e-3, worst
-
-
-def test_tuned_gemm_selection_numerics(dev):
-    """dehaze_hip/tunableop_gfx950.csv only changes WHICH hipBLASLt kernel runs: one forward/backward with the recorded
-    selection must agree with the default heuristic to fp32 rounding."""
-    import My_model_1 as M1
-    from dehaze_hip import tuning
-    from losses import CharbonnierLoss
-    seed_all(1234)
-    model = M1.Uformer(img_size=128, embed_dim=32, win_size=8, token_projection='linear', token_mlp='leff',
-                       drop_path_rate=0.).to(dev).train()
-    g = torch.Generator().manual_seed(3)
-    gt = torch.rand(2, 3, 128, 128, generator=g).to(dev)
-    hazy = (0.6 * gt + 0.3).clamp(0, 1)
-
-    def run():
-        for p in model.parameters():
-            p.grad = None
-        torch.manual_seed(5)
-        loss, _ = CharbonnierLoss().forward_clamped(model(hazy), gt)
-        loss.backward()
-        gn = torch.stack([p.grad.double().norm() for p in model.parameters() if p.grad is not None])
-        return loss.item(), gn.cpu()
-
-    base_loss, base_gn = run()
-    try:
-        assert tuning.enable_tuned_gemms() and torch.cuda.tunable.is_enabled() and not torch.cuda.tunable.tuning_is_enabled()
-        loss, gn = run()
-    finally:
-        torch.cuda.tunable.enable(False)
-    assert abs(loss - base_loss) < 2e-6
-    assert float(((gn - base_gn).abs() / (base_gn + 1e-6)).max()) < 2e-3
 
 
 def test_full_size_batch_independence(dev):
