@@ -132,11 +132,13 @@ def test_contrast_loss_vs_oracle(golden, dev):
         loss, ap, an = cl(a, T(g[tag + "/p"]).to(dev), T(g[tag + "/n"]).to(dev))
         assert abs(loss.item() - float(g[tag + "/loss"])) < 1e-4 * max(1.0, abs(float(g[tag + "/loss"])))
         loss.backward()
-        # fp32 Winograd F(2x2,3x3) on the matrix pipe (csrc/winograd_conv.hip) against the oracle's direct convolutions:
-        # the transform-domain rounding shows at the 1e-3 relative level of the largest gradient entry
+        # d|fa - fp| = sign(fa - fp): the fp32 Winograd features (csrc/winograd_conv.hip) differ from the oracle's direct
+        # convolutions at rounding level, which flips a few signs / ReLU masks among the ~10^6 feature elements - the MAX error
+        # is therefore loose by nature, the MEAN error pins the chain (tests/test_gpu_winograd.py pins it tightly on a smooth loss)
         ref = T(g[tag + "/da"])
-        err = (a.grad.cpu() - ref).abs().max().item()
-        assert err < 3e-3 * ref.abs().max().item(), err
+        err = (a.grad.cpu() - ref).abs()
+        assert err.max().item() < 3e-2 * ref.abs().max().item(), err.max().item()
+        assert err.mean().item() < 3e-3 * ref.abs().mean().item(), (err.mean().item(), ref.abs().mean().item())
 
 
 # ----------------------------------------------------------------------------- dense twin (My_model.Uformer)
