@@ -29,6 +29,11 @@ extern "C" {
 #define DHZ_EINVAL (-22)  /* bad argument (shape / null pointer / unsupported head_dim) */
 #define DHZ_ELAUNCH (-5)  /* hipLaunchKernel reported an error */
 
+/* Storage type of token tensors for the dhz_*_dt entry points (BASELINE config 4: bf16 activations in HBM, fp32 arithmetic
+ * and accumulation inside every kernel, fp32 parameters / statistics / parameter gradients). */
+#define DHZ_F32 0
+#define DHZ_BF16 1
+
 #define DHZ_NTOK 64 /* tokens per 8x8 window */
 #define DHZ_NTOP 25 /* u = U_part = 5*ceil(ln 64)  (ATT:310-315) */
 
@@ -142,6 +147,39 @@ int dhz_leff_fused_bwd(const float* dout, const float* drop_scale, const float* 
 int dhz_linear_fwd(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy, int T, int N, int K,
                    void* stream);
 int dhz_linear_dgrad(const float* dy, int ldy, const float* w, float* dx, int ldx, int T, int N, int K, void* stream);
+
+/* bf16 forms of the three token-Linear GEMMs (BASELINE config 4: bf16 activations and bf16 weight copies, fp32 accumulation on
+ *     v_mfma_f32_16x16x32_bf16; biases and all parameter gradients stay fp32).  Same contracts as dhz_linear_fwd / _dgrad /
+ *     _wgrad_multi with bf16 token tensors (x, y, dy, dx) and a bf16 copy of w [N,K]; N % 64 == 0, K % 64 == 0, wgrad T % 64 == 0;
+ *     token operands 16-byte aligned, leading dimensions multiples of 8 elements.  The reference runs this path under
+ *     torch.cuda.amp.autocast (TR:224). */
+int dhz_linear_fwd_bf16(const void* x, int ldx, const void* w, const float* bias, void* y, int ldy, int T, int N, int K,
+                        void* stream);
+int dhz_linear_dgrad_bf16(const void* dy, int ldy, const void* w, void* dx, int ldx, int T, int N, int K, void* stream);
+int dhz_linear_wgrad_bf16(const void* dy, int ldy, const void* x, int ldx, int T, int nmat, int nper, int K,
+                          float* const* dw, float* const* db, void* stream);
+
+/* dtype-generic forms (dtype = DHZ_F32 / DHZ_BF16 storage of the token tensors, fp32 arithmetic inside) of the streaming
+ * kernels around the GEMMs; argument meaning as the fp32 entry points of the same name. */
+int dhz_ln_partition_fwd_dt(const void* x, const float* gamma, const float* beta, void* xw, float* stats, int B, int Hres,
+                            int Wres, int C, int shift, int partition, int dtype, void* stream);
+int dhz_ln_partition_bwd_dt(const void* dxw, const void* x, const float* gamma, const float* stats, const void* dres, void* dx,
+                            float* dgamma, float* dbeta, int B, int Hres, int Wres, int C, int shift, int partition, int dtype,
+                            void* stream);
+int dhz_reverse_residual_fwd_dt(const void* yw, const void* shortcut, const float* scale, void* out, int B, int Hres, int Wres,
+                                int C, int shift, int partition, int dtype, void* stream);
+int dhz_reverse_residual_bwd_dt(const void* dout, const float* scale, void* dyw, int B, int Hres, int Wres, int C, int shift,
+                                int partition, int dtype, void* stream);
+int dhz_leff_dwconv_fwd_dt(const void* u, const float* w, const float* b, void* t, void* z, int B, int Hres, int Wres, int Ch,
+                           int dtype, void* stream);
+int dhz_leff_dwconv_bwd_dt(const void* dz, const void* u, const void* t, const float* w, void* du, float* dw, float* db, int B,
+                           int Hres, int Wres, int Ch, int dtype, void* stream);
+int dhz_ps_attn_fwd_dt(const void* q, const void* k, const void* v, int ld, const uint8_t* idx, const float* bias,
+                       const float* mask, void* out, int ldo, uint8_t* rank, int B_, int H, int nW, int d, int dtype,
+                       void* stream);
+int dhz_ps_attn_bwd_dt(const void* q, const void* k, const void* v, int ld, const float* bias, const float* mask,
+                       const uint8_t* rank, const void* dout, int ldo, void* dq, void* dk, void* dv, int ldg,
+                       float* dbias_part, int B_, int H, int nW, int d, int dtype, void* stream);
 
 /* K2/K4/K5 (backward)  weight + bias gradient of every token-major nn.Linear on the path
  *     (query/key/value/out projections ATT:420-422,454-458; LeFF linear1/linear2 M1:487-492):

@@ -8,6 +8,36 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// ---- activation storage types: fp32, or bf16 storage with fp32 arithmetic (BASELINE config 4).  Kernels are templated on the
+//      storage type T of their token tensors and go through ld4 / st4 (4 consecutive elements, aligned to 4 elements).
+struct bf16s { uint16_t v; };
+__device__ __forceinline__ float bf16_to_f32(uint16_t h) { return __uint_as_float((uint32_t)h << 16); }
+__device__ __forceinline__ uint16_t f32_to_bf16(float f) {           // round to nearest even; hipcc emits v_cvt_pk_bf16_f32
+    const __bf16 b = (__bf16)f;
+    return __builtin_bit_cast(uint16_t, b);
+}
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ float4 ld4(const bf16s* p) {
+    const uint2 r = *reinterpret_cast<const uint2*>(p);
+    return make_float4(__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u), __uint_as_float(r.y << 16),
+                       __uint_as_float(r.y & 0xffff0000u));
+}
+__device__ __forceinline__ void st4(bf16s* p, float4 v) {
+    uint2 r;
+    r.x = (uint32_t)f32_to_bf16(v.x) | ((uint32_t)f32_to_bf16(v.y) << 16);
+    r.y = (uint32_t)f32_to_bf16(v.z) | ((uint32_t)f32_to_bf16(v.w) << 16);
+    *reinterpret_cast<uint2*>(p) = r;
+}
+__device__ __forceinline__ f32x4 ld4v(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ void st4v(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+__device__ __forceinline__ f32x4 ld4v(const bf16s* p) { const float4 r = ld4(p); return f32x4{r.x, r.y, r.z, r.w}; }
+__device__ __forceinline__ void st4v(bf16s* p, f32x4 v) { st4(p, make_float4(v[0], v[1], v[2], v[3])); }
+__device__ __forceinline__ float ld1(const float* p) { return *p; }
+__device__ __forceinline__ float ld1(const bf16s* p) { return bf16_to_f32(p->v); }
+__device__ __forceinline__ void st1(float* p, float v) { *p = v; }
+__device__ __forceinline__ void st1(bf16s* p, float v) { p->v = f32_to_bf16(v); }
+
 void dhz_set_error(const char* fmt, ...);
 
 #define DHZ_REQUIRE(cond, ...)            \

@@ -9,10 +9,10 @@ namespace {
 
 // ------------------------------------------------------------------------------------------------ K1
 // One token = C floats.  LPT lanes cooperate on a token (C/4 float4, up to 4 per lane).
-template <int VPL>   // float4 per lane
-__global__ __launch_bounds__(256) void ln_partition_fwd_kernel(const float* __restrict__ x,
+template <int VPL, typename T>   // float4 per lane; T = storage type of x / xw
+__global__ __launch_bounds__(256) void ln_partition_fwd_kernel(const T* __restrict__ x,
                                                                const float* __restrict__ gamma,
-                                                               const float* __restrict__ beta, float* __restrict__ xw,
+                                                               const float* __restrict__ beta, T* __restrict__ xw,
                                                                float* __restrict__ stats, int ntok, int Hres, int Wres,
                                                                int C, int shift, int lpt, int partition) {
     const int tpw = 64 / lpt;                                  // tokens per wave
@@ -35,7 +35,7 @@ __global__ __launch_bounds__(256) void ln_partition_fwd_kernel(const float* __re
         float s = 0.f;
 #pragma unroll
         for (int v = 0; v < VPL; ++v) {
-            xv[v] = ok ? reinterpret_cast<const float4*>(x + (size_t)tok * C)[li + v * lpt] : make_float4(0, 0, 0, 0);
+            xv[v] = ok ? ld4(x + (size_t)tok * C + 4 * (li + v * lpt)) : make_float4(0, 0, 0, 0);
             s += xv[v].x + xv[v].y + xv[v].z + xv[v].w;
         }
         for (int o = 1; o < lpt; o <<= 1) s += __shfl_xor(s, o);
@@ -58,19 +58,19 @@ __global__ __launch_bounds__(256) void ln_partition_fwd_kernel(const float* __re
                 y.y = (xv[v].y - mean) * rstd * gm[v].y + bt[v].y;
                 y.z = (xv[v].z - mean) * rstd * gm[v].z + bt[v].z;
                 y.w = (xv[v].w - mean) * rstd * gm[v].w + bt[v].w;
-                reinterpret_cast<float4*>(xw + dst * C)[li + v * lpt] = y;
+                st4(xw + dst * C + 4 * (li + v * lpt), y);
             }
             if (li == 0 && stats) *reinterpret_cast<float2*>(stats + 2 * (size_t)tok) = make_float2(mean, rstd);
         }
     }
 }
 
-template <int VPL>
-__global__ __launch_bounds__(256) void ln_partition_bwd_kernel(const float* __restrict__ dxw,
-                                                               const float* __restrict__ x,
+template <int VPL, typename T>
+__global__ __launch_bounds__(256) void ln_partition_bwd_kernel(const T* __restrict__ dxw,
+                                                               const T* __restrict__ x,
                                                                const float* __restrict__ gamma,
                                                                const float* __restrict__ stats,
-                                                               const float* dres, float* dx,
+                                                               const T* dres, T* dx,
                                                                float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                                int ntok, int Hres, int Wres, int C, int shift, int lpt,
                                                                int partition) {
@@ -108,9 +108,9 @@ __global__ __launch_bounds__(256) void ln_partition_bwd_kernel(const float* __re
             const size_t src = partition ? (size_t)bimg * HW + window_slot(p / Wres, p % Wres, Hres, Wres, shift) : (size_t)G.tok;
 #pragma unroll
             for (int v = 0; v < VPL; ++v) {
-                G.xh[v] = reinterpret_cast<const float4*>(x + (size_t)G.tok * C)[li + v * lpt];
-                G.dy[v] = reinterpret_cast<const float4*>(dxw + src * C)[li + v * lpt];
-                if (dres) G.rs[v] = reinterpret_cast<const float4*>(dres + (size_t)G.tok * C)[li + v * lpt];
+                G.xh[v] = ld4(x + (size_t)G.tok * C + 4 * (li + v * lpt));
+                G.dy[v] = ld4(dxw + src * C + 4 * (li + v * lpt));
+                if (dres) G.rs[v] = ld4(dres + (size_t)G.tok * C + 4 * (li + v * lpt));
             }
             const float2 st = *reinterpret_cast<const float2*>(stats + 2 * (size_t)G.tok);
             G.mean = st.x; G.rstd = st.y;
@@ -145,9 +145,8 @@ __global__ __launch_bounds__(256) void ln_partition_bwd_kernel(const float* __re
                 r.y = rstd * (G.dy[v].y - s1 - G.xh[v].y * s2);
                 r.z = rstd * (G.dy[v].z - s1 - G.xh[v].z * s2);
                 r.w = rstd * (G.dy[v].w - s1 - G.xh[v].w * s2);
-                float4* dst = reinterpret_cast<float4*>(dx + (size_t)G.tok * C) + li + v * lpt;
                 if (dres) { r.x += G.rs[v].x; r.y += G.rs[v].y; r.z += G.rs[v].z; r.w += G.rs[v].w; }
-                *dst = r;
+                st4(dx + (size_t)G.tok * C + 4 * (li + v * lpt), r);
             }
         }
     };
@@ -184,10 +183,10 @@ __global__ __launch_bounds__(256) void ln_partition_bwd_kernel(const float* __re
 }
 
 // ------------------------------------------------------------------------------------------------ K4 tail
-template <bool BWD>
-__global__ __launch_bounds__(256) void reverse_residual_kernel(const float* __restrict__ a,        // yw (fwd) / dout (bwd)
-                                                               const float* __restrict__ shortcut,
-                                                               const float* __restrict__ scale, float* __restrict__ o,
+template <bool BWD, typename T>
+__global__ __launch_bounds__(256) void reverse_residual_kernel(const T* __restrict__ a,        // yw (fwd) / dout (bwd)
+                                                               const T* __restrict__ shortcut,
+                                                               const float* __restrict__ scale, T* __restrict__ o,
                                                                int ntok, int Hres, int Wres, int C4, int shift, int partition) {
     const int HW = Hres * Wres;
     const size_t total = (size_t)ntok * C4;
@@ -197,12 +196,12 @@ __global__ __launch_bounds__(256) void reverse_residual_kernel(const float* __re
         const size_t slot = partition ? (size_t)bimg * HW + window_slot(p / Wres, p % Wres, Hres, Wres, shift) : (size_t)tok;
         const float sc = scale ? scale[bimg] : 1.0f;
         if (!BWD) {
-            const float4 y = reinterpret_cast<const float4*>(a)[slot * C4 + c];
-            const float4 s = reinterpret_cast<const float4*>(shortcut)[e];
-            reinterpret_cast<float4*>(o)[e] = make_float4(s.x + sc * y.x, s.y + sc * y.y, s.z + sc * y.z, s.w + sc * y.w);
+            const float4 y = ld4(a + 4 * (slot * C4 + c));
+            const float4 s = ld4(shortcut + 4 * e);
+            st4(o + 4 * e, make_float4(s.x + sc * y.x, s.y + sc * y.y, s.z + sc * y.z, s.w + sc * y.w));
         } else {
-            const float4 g = reinterpret_cast<const float4*>(a)[e];
-            reinterpret_cast<float4*>(o)[slot * C4 + c] = make_float4(sc * g.x, sc * g.y, sc * g.z, sc * g.w);
+            const float4 g = ld4(a + 4 * e);
+            st4(o + 4 * (slot * C4 + c), make_float4(sc * g.x, sc * g.y, sc * g.z, sc * g.w));
         }
     }
 }
@@ -213,9 +212,10 @@ constexpr int HWID = TW + 2, HHGT = TH + 2;    // with halo
 constexpr int CT = 32;                         // channels per workgroup (128 B per position)
 
 // LDS tile: [HHGT][HWID][CT] floats
-__global__ __launch_bounds__(256) void leff_dwconv_fwd_kernel(const float* __restrict__ u, const float* __restrict__ w,
-                                                              const float* __restrict__ bconv, float* __restrict__ tpre,
-                                                              float* __restrict__ z, int Hres, int Wres, int Ch,
+template <typename T>
+__global__ __launch_bounds__(256) void leff_dwconv_fwd_kernel(const T* __restrict__ u, const float* __restrict__ w,
+                                                              const float* __restrict__ bconv, T* __restrict__ tpre,
+                                                              T* __restrict__ z, int Hres, int Wres, int Ch,
                                                               int tiles_x, int tiles_y) {
     __shared__ __attribute__((aligned(16))) float g[HHGT * HWID * CT];
     const int t = threadIdx.x;
@@ -226,7 +226,7 @@ __global__ __launch_bounds__(256) void leff_dwconv_fwd_kernel(const float* __res
     const int bimg = rest / tiles_y;
     const int c4 = t & 7, ch0 = cg * CT + c4 * 4;
     const int x0 = tx * TW - 1, y0 = ty * TH - 1;
-    const float* ub = u + (size_t)bimg * Hres * Wres * Ch;
+    const T* ub = u + (size_t)bimg * Hres * Wres * Ch;
     // stage gelu(u) with a 1-pixel halo (zero outside the image: Conv2d padding=1)
     {
         constexpr int NPOS = HHGT * HWID, NIT = (NPOS + 31) / 32;
@@ -239,7 +239,7 @@ __global__ __launch_bounds__(256) void leff_dwconv_fwd_kernel(const float* __res
             const int yy = y0 + pc / HWID, xx = x0 + pc % HWID;
             ok[i] = pos < NPOS && yy >= 0 && yy < Hres && xx >= 0 && xx < Wres;
             const int yc = min(max(yy, 0), Hres - 1), xc = min(max(xx, 0), Wres - 1);
-            ru[i] = *reinterpret_cast<const float4*>(ub + ((size_t)yc * Wres + xc) * Ch + ch0);
+            ru[i] = ld4(ub + ((size_t)yc * Wres + xc) * Ch + ch0);
         }
 #pragma unroll
         for (int i = 0; i < NIT; ++i) {
@@ -274,16 +274,17 @@ __global__ __launch_bounds__(256) void leff_dwconv_fwd_kernel(const float* __res
         const size_t o = ((size_t)bimg * Hres * Wres + (size_t)yy * Wres + xx) * Ch + ch0;
         float4 zz, zp;
         gelu_both(acc.x, zz.x, zp.x); gelu_both(acc.y, zz.y, zp.y); gelu_both(acc.z, zz.z, zp.z); gelu_both(acc.w, zz.w, zp.w);
-        if (tpre) *reinterpret_cast<float4*>(tpre + o) = zp;      // saved for backward: gelu'(t), not t itself
-        *reinterpret_cast<float4*>(z + o) = zz;
+        if (tpre) st4(tpre + o, zp);      // saved for backward: gelu'(t), not t itself
+        st4(z + o, zz);
     }
 }
 
 // Backward: persistent over tiles of one channel group so that dw/db are accumulated in registers and
 // hit global memory with one atomic per (channel, tap) per workgroup.
-__global__ __launch_bounds__(256) void leff_dwconv_bwd_kernel(const float* __restrict__ dz, const float* __restrict__ u,
-                                                              const float* __restrict__ tpre, const float* __restrict__ w,
-                                                              float* __restrict__ du, float* __restrict__ dw,
+template <typename T>
+__global__ __launch_bounds__(256) void leff_dwconv_bwd_kernel(const T* __restrict__ dz, const T* __restrict__ u,
+                                                              const T* __restrict__ tpre, const float* __restrict__ w,
+                                                              T* __restrict__ du, float* __restrict__ dw,
                                                               float* __restrict__ db, int B, int Hres, int Wres, int Ch,
                                                               int tiles_x, int tiles_y, int wg_per_cg) {
     __shared__ __attribute__((aligned(16))) float gs[HHGT * HWID * CT];    // gelu(u) with halo
@@ -319,9 +320,9 @@ __global__ __launch_bounds__(256) void leff_dwconv_bwd_kernel(const float* __res
                 ok[i] = pos < NPOS && yy >= 0 && yy < Hres && xx >= 0 && xx < Wres;
                 const int yc = min(max(yy, 0), Hres - 1), xc = min(max(xx, 0), Wres - 1);
                 const size_t o = (ib + (size_t)yc * Wres + xc) * Ch + ch0;
-                ru[i] = *reinterpret_cast<const float4*>(u + o);
-                rt[i] = *reinterpret_cast<const float4*>(tpre + o);
-                rz[i] = *reinterpret_cast<const float4*>(dz + o);
+                ru[i] = ld4(u + o);
+                rt[i] = ld4(tpre + o);
+                rz[i] = ld4(dz + o);
             }
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
@@ -347,7 +348,7 @@ __global__ __launch_bounds__(256) void leff_dwconv_bwd_kernel(const float* __res
             const size_t o = (ib + (size_t)yy * Wres + xx) * Ch + ch0;
             // centre value of u (for gelu'(u)): an L2 hit issued now, consumed after the tap loop.  The position loop is
             // NOT unrolled: unrolled, the kernel needed 250 VGPRs = 2 workgroups per CU; this way 3 fit (LDS-limited).
-            const float4 uv = *reinterpret_cast<const float4*>(u + o);
+            const float4 uv = ld4(u + o);
             // dg[p] = sum_k w[k] * dt[p - off(k)]   (transpose of the forward correlation)
             float4 dg = make_float4(0, 0, 0, 0);
             const float4 dtc = *reinterpret_cast<const float4*>(&ds[((py + 1) * HWID + px + 1) * CT + c4 * 4]);
@@ -363,8 +364,8 @@ __global__ __launch_bounds__(256) void leff_dwconv_bwd_kernel(const float* __res
                     dwk[2][ky * 3 + kx] += dtc.z * gn.z; dwk[3][ky * 3 + kx] += dtc.w * gn.w;
                 }
             dbk[0] += dtc.x; dbk[1] += dtc.y; dbk[2] += dtc.z; dbk[3] += dtc.w;
-            *reinterpret_cast<float4*>(du + o) = make_float4(dg.x * gelu_grad_f(uv.x), dg.y * gelu_grad_f(uv.y),
-                                                             dg.z * gelu_grad_f(uv.z), dg.w * gelu_grad_f(uv.w));
+            st4(du + o, make_float4(dg.x * gelu_grad_f(uv.x), dg.y * gelu_grad_f(uv.y), dg.z * gelu_grad_f(uv.z),
+                                    dg.w * gelu_grad_f(uv.w)));
         }
     }
     // reduce the 32 position-slots (t>>3) that share a channel quad, one quantity at a time
@@ -514,8 +515,17 @@ static int ln_geometry(int C, int* lpt, int* vpl) {
     return (*vpl >= 1 && *vpl <= 4) ? 0 : -1;
 }
 
-extern "C" int dhz_ln_partition_fwd(const float* x, const float* gamma, const float* beta, float* xw, float* stats,
-                                    int B, int Hres, int Wres, int C, int shift, int partition, void* stream) {
+// Each token-tensor op exists as dhz_<op>_dt(..., dtype, stream) with dtype = DHZ_F32 / DHZ_BF16 (the storage type of the token
+// tensors; parameters, statistics and parameter gradients are always fp32) and as the fp32 entry point dhz_<op>.
+#define DT_SWITCH(dtype, who, CALL)                                                      \
+    do {                                                                                 \
+        if ((dtype) == DHZ_F32) { typedef float T; CALL; }                               \
+        else if ((dtype) == DHZ_BF16) { typedef bf16s T; CALL; }                         \
+        else { dhz_set_error("%s: unknown dtype %d", who, (int)(dtype)); return DHZ_EINVAL; } \
+    } while (0)
+
+extern "C" int dhz_ln_partition_fwd_dt(const void* x, const float* gamma, const float* beta, void* xw, float* stats,
+                                       int B, int Hres, int Wres, int C, int shift, int partition, int dtype, void* stream) {
     DHZ_REQUIRE(x && gamma && beta && xw, "dhz_ln_partition_fwd: null pointer");
     DHZ_REQUIRE(B > 0 && Hres > 0 && Wres > 0 && (!partition || (Hres % 8 == 0 && Wres % 8 == 0 && shift >= 0 && shift < 8)),
                 "dhz_ln_partition_fwd: bad shape");
@@ -524,16 +534,21 @@ extern "C" int dhz_ln_partition_fwd(const float* x, const float* gamma, const fl
     const int ntok = B * Hres * Wres;
     const int grid = grid_for((int64_t)ntok * lpt);
     hipStream_t s = (hipStream_t)stream;
-#define LAUNCH(V) hipLaunchKernelGGL(ln_partition_fwd_kernel<V>, dim3(grid), dim3(256), 0, s, x, gamma, beta, xw, stats, ntok, Hres, Wres, C, shift, lpt, partition)
-    switch (vpl) { case 1: LAUNCH(1); break; case 2: LAUNCH(2); break; case 3: LAUNCH(3); break; default: LAUNCH(4); }
+#define LAUNCH(V) hipLaunchKernelGGL((ln_partition_fwd_kernel<V, T>), dim3(grid), dim3(256), 0, s, (const T*)x, gamma, beta, (T*)xw, stats, ntok, Hres, Wres, C, shift, lpt, partition)
+    DT_SWITCH(dtype, "dhz_ln_partition_fwd",
+              switch (vpl) { case 1: LAUNCH(1); break; case 2: LAUNCH(2); break; case 3: LAUNCH(3); break; default: LAUNCH(4); });
 #undef LAUNCH
     DHZ_CHECK_LAUNCH("dhz_ln_partition_fwd");
     return DHZ_OK;
 }
+extern "C" int dhz_ln_partition_fwd(const float* x, const float* gamma, const float* beta, float* xw, float* stats,
+                                    int B, int Hres, int Wres, int C, int shift, int partition, void* stream) {
+    return dhz_ln_partition_fwd_dt(x, gamma, beta, xw, stats, B, Hres, Wres, C, shift, partition, DHZ_F32, stream);
+}
 
-extern "C" int dhz_ln_partition_bwd(const float* dxw, const float* x, const float* gamma, const float* stats,
-                                    const float* dres, float* dx, float* dgamma, float* dbeta, int B, int Hres, int Wres,
-                                    int C, int shift, int partition, void* stream) {
+extern "C" int dhz_ln_partition_bwd_dt(const void* dxw, const void* x, const float* gamma, const float* stats,
+                                       const void* dres, void* dx, float* dgamma, float* dbeta, int B, int Hres, int Wres,
+                                       int C, int shift, int partition, int dtype, void* stream) {
     DHZ_REQUIRE(dxw && x && gamma && stats && dx && dgamma && dbeta, "dhz_ln_partition_bwd: null pointer");
     DHZ_REQUIRE(B > 0 && Hres > 0 && Wres > 0 && (!partition || (Hres % 8 == 0 && Wres % 8 == 0 && shift >= 0 && shift < 8)),
                 "dhz_ln_partition_bwd: bad shape");
@@ -545,51 +560,74 @@ extern "C" int dhz_ln_partition_bwd(const float* dxw, const float* x, const floa
     int grid = (int)(((int64_t)ntok * lpt + 256 * 8 - 1) / (256 * 8));
     grid = grid < 64 ? 64 : (grid > 512 ? 512 : grid);
     hipStream_t s = (hipStream_t)stream;
-#define LAUNCH(V) hipLaunchKernelGGL(ln_partition_bwd_kernel<V>, dim3(grid), dim3(256), 0, s, dxw, x, gamma, stats, dres, dx, dgamma, dbeta, ntok, Hres, Wres, C, shift, lpt, partition)
-    switch (vpl) { case 1: LAUNCH(1); break; case 2: LAUNCH(2); break; case 3: LAUNCH(3); break; default: LAUNCH(4); }
+#define LAUNCH(V) hipLaunchKernelGGL((ln_partition_bwd_kernel<V, T>), dim3(grid), dim3(256), 0, s, (const T*)dxw, (const T*)x, gamma, stats, (const T*)dres, (T*)dx, dgamma, dbeta, ntok, Hres, Wres, C, shift, lpt, partition)
+    DT_SWITCH(dtype, "dhz_ln_partition_bwd",
+              switch (vpl) { case 1: LAUNCH(1); break; case 2: LAUNCH(2); break; case 3: LAUNCH(3); break; default: LAUNCH(4); });
 #undef LAUNCH
     DHZ_CHECK_LAUNCH("dhz_ln_partition_bwd");
     return DHZ_OK;
 }
+extern "C" int dhz_ln_partition_bwd(const float* dxw, const float* x, const float* gamma, const float* stats,
+                                    const float* dres, float* dx, float* dgamma, float* dbeta, int B, int Hres, int Wres,
+                                    int C, int shift, int partition, void* stream) {
+    return dhz_ln_partition_bwd_dt(dxw, x, gamma, stats, dres, dx, dgamma, dbeta, B, Hres, Wres, C, shift, partition, DHZ_F32, stream);
+}
 
-extern "C" int dhz_reverse_residual_fwd(const float* yw, const float* shortcut, const float* scale, float* out, int B,
-                                        int Hres, int Wres, int C, int shift, int partition, void* stream) {
+extern "C" int dhz_reverse_residual_fwd_dt(const void* yw, const void* shortcut, const float* scale, void* out, int B,
+                                           int Hres, int Wres, int C, int shift, int partition, int dtype, void* stream) {
     DHZ_REQUIRE(yw && shortcut && out, "dhz_reverse_residual_fwd: null pointer");
     DHZ_REQUIRE(B > 0 && C % 4 == 0 && (!partition || (Hres % 8 == 0 && Wres % 8 == 0 && shift >= 0 && shift < 8)),
                 "dhz_reverse_residual_fwd: bad shape");
     const int ntok = B * Hres * Wres;
-    hipLaunchKernelGGL(reverse_residual_kernel<false>, dim3(grid_for((int64_t)ntok * (C / 4))), dim3(256), 0,
-                       (hipStream_t)stream, yw, shortcut, scale, out, ntok, Hres, Wres, C / 4, shift, partition);
+    DT_SWITCH(dtype, "dhz_reverse_residual_fwd",
+              hipLaunchKernelGGL((reverse_residual_kernel<false, T>), dim3(grid_for((int64_t)ntok * (C / 4))), dim3(256), 0,
+                                 (hipStream_t)stream, (const T*)yw, (const T*)shortcut, scale, (T*)out, ntok, Hres, Wres, C / 4, shift,
+                                 partition));
     DHZ_CHECK_LAUNCH("dhz_reverse_residual_fwd");
     return DHZ_OK;
 }
+extern "C" int dhz_reverse_residual_fwd(const float* yw, const float* shortcut, const float* scale, float* out, int B,
+                                        int Hres, int Wres, int C, int shift, int partition, void* stream) {
+    return dhz_reverse_residual_fwd_dt(yw, shortcut, scale, out, B, Hres, Wres, C, shift, partition, DHZ_F32, stream);
+}
 
-extern "C" int dhz_reverse_residual_bwd(const float* dout, const float* scale, float* dyw, int B, int Hres, int Wres,
-                                        int C, int shift, int partition, void* stream) {
+extern "C" int dhz_reverse_residual_bwd_dt(const void* dout, const float* scale, void* dyw, int B, int Hres, int Wres,
+                                           int C, int shift, int partition, int dtype, void* stream) {
     DHZ_REQUIRE(dout && dyw, "dhz_reverse_residual_bwd: null pointer");
     DHZ_REQUIRE(B > 0 && C % 4 == 0 && (!partition || (Hres % 8 == 0 && Wres % 8 == 0 && shift >= 0 && shift < 8)),
                 "dhz_reverse_residual_bwd: bad shape");
     const int ntok = B * Hres * Wres;
-    hipLaunchKernelGGL(reverse_residual_kernel<true>, dim3(grid_for((int64_t)ntok * (C / 4))), dim3(256), 0,
-                       (hipStream_t)stream, dout, nullptr, scale, dyw, ntok, Hres, Wres, C / 4, shift, partition);
+    DT_SWITCH(dtype, "dhz_reverse_residual_bwd",
+              hipLaunchKernelGGL((reverse_residual_kernel<true, T>), dim3(grid_for((int64_t)ntok * (C / 4))), dim3(256), 0,
+                                 (hipStream_t)stream, (const T*)dout, (const T*)nullptr, scale, (T*)dyw, ntok, Hres, Wres, C / 4, shift,
+                                 partition));
     DHZ_CHECK_LAUNCH("dhz_reverse_residual_bwd");
     return DHZ_OK;
 }
+extern "C" int dhz_reverse_residual_bwd(const float* dout, const float* scale, float* dyw, int B, int Hres, int Wres,
+                                        int C, int shift, int partition, void* stream) {
+    return dhz_reverse_residual_bwd_dt(dout, scale, dyw, B, Hres, Wres, C, shift, partition, DHZ_F32, stream);
+}
 
-extern "C" int dhz_leff_dwconv_fwd(const float* u, const float* w, const float* b, float* t, float* z, int B, int Hres,
-                                   int Wres, int Ch, void* stream) {
+extern "C" int dhz_leff_dwconv_fwd_dt(const void* u, const float* w, const float* b, void* t, void* z, int B, int Hres,
+                                      int Wres, int Ch, int dtype, void* stream) {
     DHZ_REQUIRE(u && w && b && z, "dhz_leff_dwconv_fwd: null pointer");
     DHZ_REQUIRE(B > 0 && Hres > 0 && Wres > 0 && Ch % CT == 0, "dhz_leff_dwconv_fwd: Ch=%d must be a multiple of %d", Ch, CT);
     const int tiles_x = (Wres + TW - 1) / TW, tiles_y = (Hres + TH - 1) / TH;
     const int grid = B * tiles_x * tiles_y * (Ch / CT);
-    hipLaunchKernelGGL(leff_dwconv_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, u, w, b, t, z, Hres, Wres,
-                       Ch, tiles_x, tiles_y);
+    DT_SWITCH(dtype, "dhz_leff_dwconv_fwd",
+              hipLaunchKernelGGL((leff_dwconv_fwd_kernel<T>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const T*)u, w, b, (T*)t,
+                                 (T*)z, Hres, Wres, Ch, tiles_x, tiles_y));
     DHZ_CHECK_LAUNCH("dhz_leff_dwconv_fwd");
     return DHZ_OK;
 }
+extern "C" int dhz_leff_dwconv_fwd(const float* u, const float* w, const float* b, float* t, float* z, int B, int Hres,
+                                   int Wres, int Ch, void* stream) {
+    return dhz_leff_dwconv_fwd_dt(u, w, b, t, z, B, Hres, Wres, Ch, DHZ_F32, stream);
+}
 
-extern "C" int dhz_leff_dwconv_bwd(const float* dz, const float* u, const float* t, const float* w, float* du, float* dw,
-                                   float* db, int B, int Hres, int Wres, int Ch, void* stream) {
+extern "C" int dhz_leff_dwconv_bwd_dt(const void* dz, const void* u, const void* t, const float* w, void* du, float* dw,
+                                      float* db, int B, int Hres, int Wres, int Ch, int dtype, void* stream) {
     DHZ_REQUIRE(dz && u && t && w && du && dw && db, "dhz_leff_dwconv_bwd: null pointer");
     DHZ_REQUIRE(B > 0 && Hres > 0 && Wres > 0 && Ch % CT == 0, "dhz_leff_dwconv_bwd: Ch=%d must be a multiple of %d", Ch, CT);
     const int tiles_x = (Wres + TW - 1) / TW, tiles_y = (Hres + TH - 1) / TH;
@@ -597,10 +635,15 @@ extern "C" int dhz_leff_dwconv_bwd(const float* dz, const float* u, const float*
     int wg_per_cg = 768 / ncg;                     // one resident round: 3 workgroups per CU (LDS), persistent over tiles
     if (wg_per_cg < 1) wg_per_cg = 1;
     if (wg_per_cg > ntiles) wg_per_cg = ntiles;
-    hipLaunchKernelGGL(leff_dwconv_bwd_kernel, dim3(wg_per_cg * ncg), dim3(256), 0, (hipStream_t)stream, dz, u, t, w, du,
-                       dw, db, B, Hres, Wres, Ch, tiles_x, tiles_y, wg_per_cg);
+    DT_SWITCH(dtype, "dhz_leff_dwconv_bwd",
+              hipLaunchKernelGGL((leff_dwconv_bwd_kernel<T>), dim3(wg_per_cg * ncg), dim3(256), 0, (hipStream_t)stream, (const T*)dz,
+                                 (const T*)u, (const T*)t, w, (T*)du, dw, db, B, Hres, Wres, Ch, tiles_x, tiles_y, wg_per_cg));
     DHZ_CHECK_LAUNCH("dhz_leff_dwconv_bwd");
     return DHZ_OK;
+}
+extern "C" int dhz_leff_dwconv_bwd(const float* dz, const float* u, const float* t, const float* w, float* du, float* dw,
+                                   float* db, int B, int Hres, int Wres, int Ch, void* stream) {
+    return dhz_leff_dwconv_bwd_dt(dz, u, t, w, du, dw, db, B, Hres, Wres, Ch, DHZ_F32, stream);
 }
 
 extern "C" int dhz_charbonnier_fwd(const float* x, const float* y, float* clampd, float* loss_sum, int64_t n, float eps,

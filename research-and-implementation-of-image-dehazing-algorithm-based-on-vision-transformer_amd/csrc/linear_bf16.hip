@@ -1,0 +1,407 @@
+// Token-Linear GEMMs for bf16 activations / bf16 weight copies with fp32 accumulation (BASELINE config 4) on
+// v_mfma_f32_16x16x32_bf16:
+//     forward        y[T,N]  = x[T,K]  . W[N,K]^T + b      both operands K-contiguous: fragments by ds_read_b128
+//     backward-data  dx[T,K] = dy[T,N] . W[N,K]            W's rows are the CONTRACTION index: B fragments by the
+//                                                          hardware transpose read ds_read_b64_tr_b16 (no transposed copy)
+//     weight grad    dW[N,K] += dy^T[N,T] . x[T,K]         the contraction runs over token ROWS of both operands: both
+//                    db[N]   += sum_t dy[t,:]              fragments by transpose reads; split over T, fp32 atomics
+// Operand fragment of the 16x16x32 MFMA: lane (i = lane & 15, g = lane >> 4) holds the 8 bf16 k = 8 g .. 8 g + 7 of row
+// (A) / column (B) i.  LDS images (64 contraction elements per stage):
+//   * K-contiguous operand: [row][64 bf16 = 128 B], the eight 16-byte chunks of a row XOR-swizzled by (row >> 1) & 7
+//     -> conflict-free ds_read_b128;
+//   * contraction-major operand: [64 contraction rows][F features] with F = 128 (256-B rows, chunk ^ (((row & 3) << 2) |
+//     ((row >> 2) & 3))) or F = 64 (128-B rows, chunk ^ ((row & 2) | ((row & 8) >> 1))) -> conflict-free transpose reads:
+//     lane 4 q + p of a 16-lane group addresses row r0 + q, columns 4 p .. 4 p + 3 of a 4 x 16 block and receives column
+//     (lane & 15), rows r0 .. r0 + 3.
+// Forward / backward-data: persistent workgroups pipelined across tiles (as csrc/linear_gemm.hip); outputs leave as bf16.
+#include "common.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int BK = 64;
+
+__device__ __forceinline__ f32x4 mfma_bf16(s16x8 a, s16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+// byte offset of 16-byte chunk ch of row `row` in a K-contiguous image (128-B rows)
+__device__ __forceinline__ int off_row(int row, int ch) { return row * 128 + 16 * (ch ^ ((row >> 1) & 7)); }
+// byte offset of 16-byte chunk ch of contraction row `row` in a contraction-major image with F features per row
+template <int F>
+__device__ __forceinline__ int off_tr(int row, int ch) {
+    if (F == 128) return row * 256 + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3)));
+    return row * 128 + 16 * (ch ^ ((row & 2) | ((row & 8) >> 1)));
+}
+// fragment (8 contraction rows r0 .. r0 + 7 of feature column 16 cb + (lane & 15)) from a contraction-major image
+template <int F>
+__device__ __forceinline__ s16x8 tr_frag(const unsigned char* img, int r0, int cb, int lane) {
+    const int m = lane & 15, q = m >> 2, p = m & 3;
+    typedef s16x4 __attribute__((address_space(3))) * lds_ptr;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(img + off_tr<F>(r0 + q, 2 * cb + (p >> 1)) + 8 * (p & 1)));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(img + off_tr<F>(r0 + 4 + q, 2 * cb + (p >> 1)) + 8 * (p & 1)));
+    return s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+
+// ------------------------------------------------------------------------------------------------ forward / backward-data
+// C[M,N] = A[M,K] . op(B) (+ bias), A K-contiguous.  BTR = false: B is [N][K] (forward); true: B is [K][N] (backward-data).
+template <int WM, int WN, bool BTR>
+__global__ __launch_bounds__(256) void gemm_bf16_kernel(const uint16_t* __restrict__ A, int lda,
+                                                        const uint16_t* __restrict__ B, int ldb,
+                                                        const float* __restrict__ bias, uint16_t* __restrict__ C, int ldc,
+                                                        int M, int N, int K, int tiles_n, int ntiles) {
+    constexpr int BM = 32 * WM, BN = 32 * WN;
+    constexpr int A_BYTES = BM * 128;
+    constexpr int B_BYTES = BTR ? BK * BN * 2 : BN * 128;
+    constexpr int STAGE = A_BYTES + B_BYTES;
+    constexpr int NA = WM, NB = WN;                              // 16-byte chunks per thread per stage
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int i16 = lane & 15, g = lane >> 4;
+    const int wm = w >> 1, wn = w & 1;
+    const int nst = K / BK;
+    const int grid = gridDim.x;
+    auto tile_of = [&](int i) -> int {
+        const int lin = blockIdx.x + i * grid;
+        if (lin >= ntiles) return -1;
+        if ((grid & 7) == 0 && (ntiles & 7) == 0) return (lin & 7) * (ntiles >> 3) + (lin >> 3);
+        return lin;
+    };
+    f32x4 acc[WM][WN];
+#pragma unroll
+    for (int a = 0; a < WM; ++a)
+#pragma unroll
+        for (int b = 0; b < WN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    u32x4 ra[NA], rb[NB];
+    const uint16_t* pa[NA];
+    const uint16_t* pb[NB];
+    auto set_tile = [&](int tile) {
+        const int tn = tile % tiles_n, tm = tile / tiles_n;
+        const int m0 = tm * BM, n0 = tn * BN;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int e = t + 256 * i;
+            pa[i] = A + (size_t)min(m0 + (e >> 3), M - 1) * lda + 8 * (e & 7);
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int e = t + 256 * i;
+            if (BTR) pb[i] = B + (size_t)(e / (BN / 8)) * ldb + n0 + 8 * (e % (BN / 8));
+            else pb[i] = B + (size_t)(n0 + (e >> 3)) * ldb + 8 * (e & 7);
+        }
+    };
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) ra[i] = *reinterpret_cast<const u32x4*>(pa[i] + k0);
+#pragma unroll
+        for (int i = 0; i < NB; ++i) rb[i] = *reinterpret_cast<const u32x4*>(pb[i] + (BTR ? (size_t)k0 * ldb : (size_t)k0));
+    };
+    auto swrite = [&](int buf) {
+        unsigned char* As = smem + buf * STAGE;
+        unsigned char* Bs = As + A_BYTES;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int e = t + 256 * i;
+            *reinterpret_cast<u32x4*>(As + off_row(e >> 3, e & 7)) = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int e = t + 256 * i;
+            if (BTR) *reinterpret_cast<u32x4*>(Bs + off_tr<BN>(e / (BN / 8), e % (BN / 8))) = rb[i];
+            else *reinterpret_cast<u32x4*>(Bs + off_row(e >> 3, e & 7)) = rb[i];
+        }
+    };
+
+    int ti = 0, tile = tile_of(0);
+    if (tile < 0) return;
+    set_tile(tile);
+    gload(0);
+    swrite(0);
+    __syncthreads();
+    const int sw = (i16 >> 1) & 7;
+    int buf = 0;
+    while (true) {
+        const int ntile = tile_of(ti + 1);
+        const int tn = tile % tiles_n, tm = tile / tiles_n;
+        for (int st = 0; st < nst; ++st) {
+            const bool last = st + 1 == nst;
+            const bool more = !last || ntile >= 0;
+            if (!last) gload((st + 1) * BK);
+            else if (ntile >= 0) { set_tile(ntile); gload(0); }
+            const unsigned char* As = smem + buf * STAGE;
+            const unsigned char* Bs = As + A_BYTES;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                s16x8 af[WM], bf[WN];
+#pragma unroll
+                for (int a = 0; a < WM; ++a)
+                    af[a] = *reinterpret_cast<const s16x8*>(As + (wm * WM * 16 + a * 16 + i16) * 128 + 16 * ((4 * s + g) ^ sw));
+#pragma unroll
+                for (int b = 0; b < WN; ++b) {
+                    if (BTR) bf[b] = tr_frag<BN>(Bs, 32 * s + 8 * g, wn * WN + b, lane);
+                    else bf[b] = *reinterpret_cast<const s16x8*>(Bs + ((wn * WN + b) * 16 + i16) * 128 + 16 * ((4 * s + g) ^ sw));
+                }
+#pragma unroll
+                for (int a = 0; a < WM; ++a)
+#pragma unroll
+                    for (int b = 0; b < WN; ++b) acc[a][b] = mfma_bf16(af[a], bf[b], acc[a][b]);
+            }
+            if (more) {
+                swrite(buf ^ 1);
+                __syncthreads();
+                buf ^= 1;
+            }
+        }
+        {   // epilogue from the accumulators: acc[a][b][j] = C[16 a + 4 g + j][16 b + i16]
+            const int m0 = tm * BM + wm * WM * 16 + 4 * g, n0 = tn * BN + wn * WN * 16 + i16;
+            float bv[WN];
+#pragma unroll
+            for (int b = 0; b < WN; ++b) bv[b] = bias ? bias[n0 + 16 * b] : 0.f;
+#pragma unroll
+            for (int a = 0; a < WM; ++a)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int m = m0 + 16 * a + j;
+                    if (m < M) {
+                        uint16_t* cr = C + (size_t)m * ldc + n0;
+#pragma unroll
+                        for (int b = 0; b < WN; ++b) cr[16 * b] = f32_to_bf16(acc[a][b][j] + bv[b]);
+                    }
+                }
+#pragma unroll
+            for (int a = 0; a < WM; ++a)
+#pragma unroll
+                for (int b = 0; b < WN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        if (ntile < 0) break;
+        tile = ntile;
+        ++ti;
+    }
+}
+
+template <int WM, int WN, bool BTR>
+void launch_gemm(const uint16_t* A, int lda, const uint16_t* B, int ldb, const float* bias, uint16_t* C, int ldc, int M, int N,
+                 int K, hipStream_t s) {
+    constexpr int BM = 32 * WM, BN = 32 * WN;
+    constexpr size_t smem = 2 * (size_t)(BM * 128 + (BTR ? BK * BN * 2 : BN * 128));
+    const int tiles_n = N / BN, tiles_m = (M + BM - 1) / BM;
+    const int ntiles = tiles_n * tiles_m;
+    const int grid = ntiles < 512 ? ntiles : 512;
+    if (smem > 48 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<WM, WN, BTR>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipLaunchKernelGGL((gemm_bf16_kernel<WM, WN, BTR>), dim3(grid), dim3(256), smem, s, A, lda, B, ldb, bias, C, ldc, M, N, K,
+                       tiles_n, ntiles);
+}
+
+template <bool BTR>
+int dispatch_gemm(const char* who, const uint16_t* A, int lda, const uint16_t* B, int ldb, const float* bias, uint16_t* C, int ldc,
+                  int M, int N, int K, hipStream_t s) {
+    DHZ_REQUIRE(A && B && C, "%s: null pointer", who);
+    DHZ_REQUIRE(M > 0 && N > 0 && K > 0 && N % 64 == 0 && K % 64 == 0, "%s: T=%d N=%d K=%d (N, K must be multiples of 64)", who, M, N,
+                K);
+    DHZ_REQUIRE(lda % 8 == 0 && ldb % 8 == 0 && ldc >= N && lda >= K, "%s: bad leading dimensions", who);
+    DHZ_REQUIRE((((uintptr_t)A | (uintptr_t)B) & 15) == 0 && ((uintptr_t)C & 1) == 0, "%s: operands must be 16-byte aligned", who);
+    const int wn = N % 128 == 0 ? 4 : 2;
+    const long blocks128 = (long)((M + 127) / 128) * (N / (32 * wn));
+    const int wm = blocks128 >= 256 ? 4 : 2;
+#define CASE(a, b) \
+    if (wm == a && wn == b) launch_gemm<a, b, BTR>(A, lda, B, ldb, bias, C, ldc, M, N, K, s);
+    CASE(4, 4) CASE(4, 2) CASE(2, 4) CASE(2, 2)
+#undef CASE
+    DHZ_CHECK_LAUNCH(who);
+    return DHZ_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ weight gradient
+constexpr int MAXMAT = 4;
+struct WgradOut {
+    float* dw[MAXMAT];
+    float* db[MAXMAT];
+    int nper;
+};
+
+// dW tile [32 WM rows of N] x [32 WN cols of K] per workgroup for one slab of tokens; FM = 32 WM, FN = 32 WN in {64, 128}
+template <int WM, int WN>
+__global__ __launch_bounds__(256) void wgrad_bf16_kernel(const uint16_t* __restrict__ dy, int ldy,
+                                                         const uint16_t* __restrict__ x, int ldx, int T, int N, int K,
+                                                         WgradOut out, int nsplit) {
+    constexpr int FM = 32 * WM, FN = 32 * WN;
+    constexpr int A_BYTES = BK * FM * 2, B_BYTES = BK * FN * 2;
+    constexpr int STAGE = A_BYTES + B_BYTES;
+    constexpr int NA = BK * (FM / 8) / 256, NB = BK * (FN / 8) / 256;       // chunks per thread per stage (2 or 4)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int i16 = lane & 15, g = lane >> 4;
+    const int wm = w >> 1, wn = w & 1;
+    const int tiles_n = K / FN;
+    int bid = blockIdx.x;
+    const int split = bid % nsplit; bid /= nsplit;
+    const int tn = bid % tiles_n, tm = bid / tiles_n;
+    const int n0 = tm * FM, k0 = tn * FN;
+    const int mat = n0 / out.nper, nloc = n0 - mat * out.nper;
+    float* __restrict__ const dw = out.dw[mat];
+    float* __restrict__ const db = out.db[mat];
+    const int nst = T / BK;
+    const int st0 = (int)((long long)nst * split / nsplit), st1 = (int)((long long)nst * (split + 1) / nsplit);
+
+    f32x4 acc[WM][WN];
+#pragma unroll
+    for (int a = 0; a < WM; ++a)
+#pragma unroll
+        for (int b = 0; b < WN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    u32x4 ra[NA], rb[NB];
+    float dbacc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};     // column sums of this thread's 8 dy columns (chunk t % (FM/8))
+    const bool do_db = (db != nullptr) && (tn == 0);
+
+    auto gload = [&](int st) {
+        const size_t tok0 = (size_t)st * BK;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int e = t + 256 * i;
+            ra[i] = *reinterpret_cast<const u32x4*>(dy + (tok0 + e / (FM / 8)) * ldy + n0 + 8 * (e % (FM / 8)));
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int e = t + 256 * i;
+            rb[i] = *reinterpret_cast<const u32x4*>(x + (tok0 + e / (FN / 8)) * ldx + k0 + 8 * (e % (FN / 8)));
+        }
+    };
+    auto swrite = [&](int buf) {
+        unsigned char* As = smem + buf * STAGE;
+        unsigned char* Bs = As + A_BYTES;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int e = t + 256 * i;
+            *reinterpret_cast<u32x4*>(As + off_tr<FM>(e / (FM / 8), e % (FM / 8))) = ra[i];
+            if (do_db) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    dbacc[2 * c] += __uint_as_float(ra[i][c] << 16);
+                    dbacc[2 * c + 1] += __uint_as_float(ra[i][c] & 0xffff0000u);
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int e = t + 256 * i;
+            *reinterpret_cast<u32x4*>(Bs + off_tr<FN>(e / (FN / 8), e % (FN / 8))) = rb[i];
+        }
+    };
+
+    if (st0 < st1) {
+        gload(st0);
+        swrite(0);
+    }
+    __syncthreads();
+    for (int st = st0; st < st1; ++st) {
+        const int buf = (st - st0) & 1;
+        const bool more = st + 1 < st1;
+        if (more) gload(st + 1);
+        const unsigned char* As = smem + buf * STAGE;
+        const unsigned char* Bs = As + A_BYTES;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            s16x8 af[WM], bf[WN];
+#pragma unroll
+            for (int a = 0; a < WM; ++a) af[a] = tr_frag<FM>(As, 32 * s + 8 * g, wm * WM + a, lane);
+#pragma unroll
+            for (int b = 0; b < WN; ++b) bf[b] = tr_frag<FN>(Bs, 32 * s + 8 * g, wn * WN + b, lane);
+#pragma unroll
+            for (int a = 0; a < WM; ++a)
+#pragma unroll
+                for (int b = 0; b < WN; ++b) acc[a][b] = mfma_bf16(af[a], bf[b], acc[a][b]);
+        }
+        if (more) swrite(buf ^ 1);
+        __syncthreads();
+    }
+    // ---- epilogue: tile -> LDS (row-major FM x FN fp32) -> full-line fp32 atomics
+    float* Cs = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int a = 0; a < WM; ++a)
+#pragma unroll
+        for (int b = 0; b < WN; ++b)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) Cs[(wm * WM * 16 + a * 16 + 4 * g + j) * FN + wn * WN * 16 + b * 16 + i16] = acc[a][b][j];
+    __syncthreads();
+    for (int e = t; e < FM * FN; e += 256) atomicAdd(dw + (size_t)(nloc + e / FN) * K + k0 + e % FN, Cs[e]);
+    if (do_db) {
+        // thread t always staged chunk (t % (FM/8)) of rows (t / (FM/8)) + k * 256 / (FM/8): fold the 256 / (FM/8) row groups
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(smem);          // [256 / (FM/8)][FM]
+        constexpr int CPR = FM / 8;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) red[(t / CPR) * FM + 8 * (t % CPR) + c] = dbacc[c];
+        __syncthreads();
+        if (t < FM) {
+            float tot = 0.f;
+            for (int r = 0; r < 256 / CPR; ++r) tot += red[r * FM + t];
+            atomicAdd(db + nloc + t, tot);
+        }
+    }
+}
+
+template <int WM, int WN>
+void launch_wgrad(const uint16_t* dy, int ldy, const uint16_t* x, int ldx, int T, int N, int K, const WgradOut& out, hipStream_t s) {
+    constexpr int FM = 32 * WM, FN = 32 * WN;
+    constexpr size_t stage = (size_t)BK * (FM + FN) * 2;
+    constexpr size_t smem = 2 * stage > (size_t)FM * FN * 4 ? 2 * stage : (size_t)FM * FN * 4;
+    const int tiles = (N / FM) * (K / FN);
+    int nsplit = 512 / tiles;
+    const int max_split = T / (BK * 4) > 0 ? T / (BK * 4) : 1;           // at least 4 stages per workgroup
+    if (nsplit > max_split) nsplit = max_split;
+    if (nsplit < 1) nsplit = 1;
+    if (smem > 48 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_bf16_kernel<WM, WN>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)smem);
+    hipLaunchKernelGGL((wgrad_bf16_kernel<WM, WN>), dim3(tiles * nsplit), dim3(256), smem, s, dy, ldy, x, ldx, T, N, K, out, nsplit);
+}
+
+int dispatch_wgrad(const char* who, const uint16_t* dy, int ldy, const uint16_t* x, int ldx, int T, int nmat, int nper, int K,
+                   const WgradOut& out, hipStream_t s) {
+    const int N = nmat * nper;
+    DHZ_REQUIRE(T > 0 && T % BK == 0, "%s: T=%d must be a multiple of %d", who, T, BK);
+    DHZ_REQUIRE(nper % 64 == 0 && K % 64 == 0 && nper > 0 && K > 0, "%s: N=%d K=%d must be multiples of 64", who, nper, K);
+    DHZ_REQUIRE(ldy % 8 == 0 && ldx % 8 == 0 && ldy >= N && ldx >= K, "%s: bad leading dims", who);
+    DHZ_REQUIRE((((uintptr_t)dy | (uintptr_t)x) & 15) == 0, "%s: operands must be 16-byte aligned", who);
+    const int wm = nper % 128 == 0 ? 4 : 2, wn = K % 128 == 0 ? 4 : 2;
+#define CASE(a, b) \
+    if (wm == a && wn == b) launch_wgrad<a, b>(dy, ldy, x, ldx, T, N, K, out, s);
+    CASE(4, 4) CASE(4, 2) CASE(2, 4) CASE(2, 2)
+#undef CASE
+    DHZ_CHECK_LAUNCH(who);
+    return DHZ_OK;
+}
+
+}  // namespace
+
+extern "C" int dhz_linear_fwd_bf16(const void* x, int ldx, const void* w, const float* bias, void* y, int ldy, int T, int N, int K,
+                                   void* stream) {
+    return dispatch_gemm<false>("dhz_linear_fwd_bf16", (const uint16_t*)x, ldx, (const uint16_t*)w, K, bias, (uint16_t*)y, ldy, T, N, K,
+                                (hipStream_t)stream);
+}
+
+extern "C" int dhz_linear_dgrad_bf16(const void* dy, int ldy, const void* w, void* dx, int ldx, int T, int N, int K, void* stream) {
+    // dx[T,K] = dy[T,N] w[N,K]: contraction over the N rows of w (transpose reads), output features = its K columns
+    return dispatch_gemm<true>("dhz_linear_dgrad_bf16", (const uint16_t*)dy, ldy, (const uint16_t*)w, K, nullptr, (uint16_t*)dx, ldx, T, K,
+                               N, (hipStream_t)stream);
+}
+
+extern "C" int dhz_linear_wgrad_bf16(const void* dy, int ldy, const void* x, int ldx, int T, int nmat, int nper, int K,
+                                     float* const* dw, float* const* db, void* stream) {
+    DHZ_REQUIRE(dy && x && dw, "dhz_linear_wgrad_bf16: null pointer");
+    DHZ_REQUIRE(nmat >= 1 && nmat <= MAXMAT, "dhz_linear_wgrad_bf16: nmat=%d must be 1..%d", nmat, MAXMAT);
+    WgradOut out = {};
+    for (int i = 0; i < nmat; ++i) {
+        DHZ_REQUIRE(dw[i], "dhz_linear_wgrad_bf16: null dw[%d]", i);
+        out.dw[i] = dw[i];
+        out.db[i] = db ? db[i] : nullptr;
+    }
+    out.nper = nper;
+    return dispatch_wgrad("dhz_linear_wgrad_bf16", (const uint16_t*)dy, ldy, (const uint16_t*)x, ldx, T, nmat, nper, K, out,
+                          (hipStream_t)stream);
+}

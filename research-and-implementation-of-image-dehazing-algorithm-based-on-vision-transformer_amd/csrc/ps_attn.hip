@@ -82,12 +82,12 @@ __device__ __forceinline__ void double_softmax8(const float* x, const float* bro
     for (int i = 0; i < 8; ++i) p2[i] = e[i] * sum2;
 }
 
-template <int D>
-__global__ __launch_bounds__(256) void ps_attn_fwd_kernel(const float* __restrict__ q, const float* __restrict__ k,
-                                                          const float* __restrict__ v, int ld,
+template <int D, typename T>
+__global__ __launch_bounds__(256) void ps_attn_fwd_kernel(const T* __restrict__ q, const T* __restrict__ k,
+                                                          const T* __restrict__ v, int ld,
                                                           const uint8_t* __restrict__ idx,
                                                           const float* __restrict__ bias,
-                                                          const float* __restrict__ mask, float* __restrict__ out,
+                                                          const float* __restrict__ mask, T* __restrict__ out,
                                                           int ldo, uint8_t* __restrict__ rank_out, int H, int nW) {
     constexpr int DS = D + 4;
     constexpr int F = D / 4;            // float4 per row
@@ -105,9 +105,9 @@ __global__ __launch_bounds__(256) void ps_attn_fwd_kernel(const float* __restric
         for (int p = 0; p < NT / RPP; ++p) {
             const int row = p * RPP + t / F;
             const size_t g = (tok0 + row) * ld + h * D + c4 * 4;
-            *reinterpret_cast<float4*>(&sm.q[row * DS + c4 * 4]) = *reinterpret_cast<const float4*>(q + g);
-            *reinterpret_cast<float4*>(&sm.k[row * DS + c4 * 4]) = *reinterpret_cast<const float4*>(k + g);
-            *reinterpret_cast<float4*>(&sm.v[row * DS + c4 * 4]) = *reinterpret_cast<const float4*>(v + g);
+            *reinterpret_cast<float4*>(&sm.q[row * DS + c4 * 4]) = ld4(q + g);
+            *reinterpret_cast<float4*>(&sm.k[row * DS + c4 * 4]) = ld4(k + g);
+            *reinterpret_cast<float4*>(&sm.v[row * DS + c4 * 4]) = ld4(v + g);
         }
         if (t < NT * NU / 16) reinterpret_cast<uint4*>(sm.idx)[t] = reinterpret_cast<const uint4*>(idx)[t];
     }
@@ -217,8 +217,7 @@ __global__ __launch_bounds__(256) void ps_attn_fwd_kernel(const float* __restric
         for (int p = 0; p < NT / RPP; ++p) {
             const int row = p * RPP + t / F;
             const int r = sm.rank[row] < NU ? sm.rank[row] : NU;
-            *reinterpret_cast<float4*>(out + (tok0 + row) * ldo + h * D + c4 * 4) =
-                *reinterpret_cast<const float4*>(&O[r * DS + c4 * 4]);
+            st4(out + (tok0 + row) * ldo + h * D + c4 * 4, *reinterpret_cast<const float4*>(&O[r * DS + c4 * 4]));
         }
         if (t < NT / 4) reinterpret_cast<uint32_t*>(rank_out + (size_t)blockIdx.x * NT)[t] =
             reinterpret_cast<const uint32_t*>(sm.rank)[t];
@@ -242,11 +241,11 @@ struct BwdSmem {
     uint8_t rank[NT];
 };
 
-template <int D, bool HAS_BIAS>
+template <int D, bool HAS_BIAS, typename T>
 __global__ __launch_bounds__(256) void ps_attn_bwd_kernel(
-    const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v, int ld,
+    const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v, int ld,
     const float* __restrict__ bias, const float* __restrict__ mask, const uint8_t* __restrict__ rank_in,
-    const float* __restrict__ dout, int ldo, float* __restrict__ dq, float* __restrict__ dk, float* __restrict__ dv,
+    const T* __restrict__ dout, int ldo, T* __restrict__ dq, T* __restrict__ dk, T* __restrict__ dv,
     int ldg, float* __restrict__ dbias_part, int B_, int H, int nW) {
     constexpr int DS = D + 4;
     constexpr int F = D / 4;
@@ -276,10 +275,10 @@ __global__ __launch_bounds__(256) void ps_attn_bwd_kernel(
         for (int p = 0; p < NR; ++p) {
             const int row = p * RPP + t / F;
             const size_t gi = (tok0 + row) * ld + h * D + c4 * 4;
-            pk[p] = *reinterpret_cast<const f32x4*>(k + gi);
-            pv[p] = *reinterpret_cast<const f32x4*>(v + gi);
-            pq[p] = *reinterpret_cast<const f32x4*>(q + gi);
-            pg[p] = *reinterpret_cast<const f32x4*>(dout + (tok0 + row) * ldo + h * D + c4 * 4);
+            pk[p] = ld4v(k + gi);
+            pv[p] = ld4v(v + gi);
+            pq[p] = ld4v(q + gi);
+            pg[p] = ld4v(dout + (tok0 + row) * ldo + h * D + c4 * 4);
         }
         if (t < NT) prank = rank_in[((size_t)b * H + h) * NT + t];
     };
@@ -427,8 +426,7 @@ __global__ __launch_bounds__(256) void ps_attn_bwd_kernel(
 #pragma unroll
             for (int p = 0; p < NT / RPP; ++p) {
                 const int row = p * RPP + t / F;
-                *reinterpret_cast<float4*>(dv + (tok0 + row) * ldg + h * D + c4 * 4) =
-                    *reinterpret_cast<const float4*>(&sm.v[row * DS + c4 * 4]);
+                st4(dv + (tok0 + row) * ldg + h * D + c4 * 4, *reinterpret_cast<const float4*>(&sm.v[row * DS + c4 * 4]));
             }
         }
         __syncthreads();
@@ -475,11 +473,11 @@ __global__ __launch_bounds__(256) void ps_attn_bwd_kernel(
             for (int p = 0; p < NT / RPP; ++p) {
                 const int row = p * RPP + t / F;
                 const size_t go = (tok0 + row) * ldg + h * D + c4 * 4;
-                *reinterpret_cast<float4*>(dk + go) = *reinterpret_cast<const float4*>(&sm.k[row * DS + c4 * 4]);
+                st4(dk + go, *reinterpret_cast<const float4*>(&sm.k[row * DS + c4 * 4]));
                 const int r = sm.rank[row];
                 float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (r < NU) val = *reinterpret_cast<const float4*>(&dqs[r * DS + c4 * 4]);
-                *reinterpret_cast<float4*>(dq + go) = val;
+                st4(dq + go, val);
             }
         }
     }
@@ -552,8 +550,9 @@ static void allow_smem(const void* fn, size_t bytes) {
     if (bytes > 48 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
-extern "C" int dhz_ps_attn_fwd(const float* q, const float* k, const float* v, int ld, const uint8_t* idx,
-                               const float* bias, const float* mask, float* out, int ldo, uint8_t* rank, int B_,
+template <typename T>
+static int ps_attn_fwd_t(const T* q, const T* k, const T* v, int ld, const uint8_t* idx,
+                               const float* bias, const float* mask, T* out, int ldo, uint8_t* rank, int B_,
                                int H, int nW, int d, void* stream) {
     DHZ_REQUIRE(q && k && v && idx && out && rank, "dhz_ps_attn_fwd: null pointer");
     DHZ_REQUIRE(B_ > 0 && H > 0, "dhz_ps_attn_fwd: B_=%d H=%d", B_, H);
@@ -562,16 +561,30 @@ extern "C" int dhz_ps_attn_fwd(const float* q, const float* k, const float* v, i
     DHZ_REQUIRE(!mask || (nW > 0 && B_ % nW == 0), "dhz_ps_attn_fwd: B_=%d not a multiple of nW=%d", B_, nW);
     hipStream_t s = (hipStream_t)stream;
     if (d == 32) {
-        allow_smem(reinterpret_cast<const void*>(&ps_attn_fwd_kernel<32>), sizeof(FwdSmem<32>));
-        hipLaunchKernelGGL(ps_attn_fwd_kernel<32>, dim3(B_ * H), dim3(256), sizeof(FwdSmem<32>), s, q, k, v, ld, idx,
+        allow_smem(reinterpret_cast<const void*>(&ps_attn_fwd_kernel<32, T>), sizeof(FwdSmem<32>));
+        hipLaunchKernelGGL((ps_attn_fwd_kernel<32, T>), dim3(B_ * H), dim3(256), sizeof(FwdSmem<32>), s, q, k, v, ld, idx,
                            bias, mask, out, ldo, rank, H, nW > 0 ? nW : 1);
     } else {
-        allow_smem(reinterpret_cast<const void*>(&ps_attn_fwd_kernel<64>), sizeof(FwdSmem<64>));
-        hipLaunchKernelGGL(ps_attn_fwd_kernel<64>, dim3(B_ * H), dim3(256), sizeof(FwdSmem<64>), s, q, k, v, ld, idx,
+        allow_smem(reinterpret_cast<const void*>(&ps_attn_fwd_kernel<64, T>), sizeof(FwdSmem<64>));
+        hipLaunchKernelGGL((ps_attn_fwd_kernel<64, T>), dim3(B_ * H), dim3(256), sizeof(FwdSmem<64>), s, q, k, v, ld, idx,
                            bias, mask, out, ldo, rank, H, nW > 0 ? nW : 1);
     }
     DHZ_CHECK_LAUNCH("dhz_ps_attn_fwd");
     return DHZ_OK;
+}
+
+extern "C" int dhz_ps_attn_fwd(const float* q, const float* k, const float* v, int ld, const uint8_t* idx,
+                               const float* bias, const float* mask, float* out, int ldo, uint8_t* rank, int B_,
+                               int H, int nW, int d, void* stream) {
+    return ps_attn_fwd_t<float>(q, k, v, ld, idx, bias, mask, out, ldo, rank, B_, H, nW, d, stream);
+}
+extern "C" int dhz_ps_attn_fwd_dt(const void* q, const void* k, const void* v, int ld, const uint8_t* idx,
+                                  const float* bias, const float* mask, void* out, int ldo, uint8_t* rank, int B_,
+                                  int H, int nW, int d, int dtype, void* stream) {
+    if (dtype == DHZ_F32) return ps_attn_fwd_t<float>((const float*)q, (const float*)k, (const float*)v, ld, idx, bias, mask, (float*)out, ldo, rank, B_, H, nW, d, stream);
+    if (dtype == DHZ_BF16) return ps_attn_fwd_t<bf16s>((const bf16s*)q, (const bf16s*)k, (const bf16s*)v, ld, idx, bias, mask, (bf16s*)out, ldo, rank, B_, H, nW, d, stream);
+    dhz_set_error("dhz_ps_attn_fwd_dt: unknown dtype %d", dtype);
+    return DHZ_EINVAL;
 }
 
 extern "C" int dhz_ps_attn_bwd_parts(int B_, int H) {
@@ -583,20 +596,21 @@ extern "C" int dhz_ps_attn_bwd_parts(int B_, int H) {
     return per_head * H;
 }
 
-template <int D, bool HB>
-static void launch_bwd(int parts, hipStream_t s, const float* q, const float* k, const float* v, int ld,
-                       const float* bias, const float* mask, const uint8_t* rank, const float* dout, int ldo,
-                       float* dq, float* dk, float* dv, int ldg, float* dbias_part, int B_, int H, int nW) {
+template <int D, bool HB, typename T>
+static void launch_bwd(int parts, hipStream_t s, const T* q, const T* k, const T* v, int ld,
+                       const float* bias, const float* mask, const uint8_t* rank, const T* dout, int ldo,
+                       T* dq, T* dk, T* dv, int ldg, float* dbias_part, int B_, int H, int nW) {
     const size_t smem = sizeof(BwdSmem<D>);
-    allow_smem(reinterpret_cast<const void*>(&ps_attn_bwd_kernel<D, HB>), smem);
-    hipLaunchKernelGGL((ps_attn_bwd_kernel<D, HB>), dim3(parts), dim3(256), smem, s, q, k, v, ld, bias, mask, rank,
+    allow_smem(reinterpret_cast<const void*>(&ps_attn_bwd_kernel<D, HB, T>), smem);
+    hipLaunchKernelGGL((ps_attn_bwd_kernel<D, HB, T>), dim3(parts), dim3(256), smem, s, q, k, v, ld, bias, mask, rank,
                        dout, ldo, dq, dk, dv, ldg, dbias_part, B_, H, nW);
 }
 
-extern "C" int dhz_ps_attn_bwd(const float* q, const float* k, const float* v, int ld, const float* bias,
-                               const float* mask, const uint8_t* rank, const float* dout, int ldo, float* dq,
-                               float* dk, float* dv, int ldg, float* dbias_part, int B_, int H, int nW, int d,
-                               void* stream) {
+template <typename T>
+static int ps_attn_bwd_t(const T* q, const T* k, const T* v, int ld, const float* bias,
+                         const float* mask, const uint8_t* rank, const T* dout, int ldo, T* dq,
+                         T* dk, T* dv, int ldg, float* dbias_part, int B_, int H, int nW, int d,
+                         void* stream) {
     DHZ_REQUIRE(q && k && v && rank && dout && dq && dk && dv, "dhz_ps_attn_bwd: null pointer");
     DHZ_REQUIRE(d == 32 || d == 64, "dhz_ps_attn_bwd: head_dim %d unsupported (32 or 64)", d);
     DHZ_REQUIRE(!bias || dbias_part, "dhz_ps_attn_bwd: bias given but dbias_part is NULL");
@@ -614,6 +628,22 @@ extern "C" int dhz_ps_attn_bwd(const float* q, const float* k, const float* v, i
     }
     DHZ_CHECK_LAUNCH("dhz_ps_attn_bwd");
     return DHZ_OK;
+}
+
+extern "C" int dhz_ps_attn_bwd(const float* q, const float* k, const float* v, int ld, const float* bias,
+                               const float* mask, const uint8_t* rank, const float* dout, int ldo, float* dq,
+                               float* dk, float* dv, int ldg, float* dbias_part, int B_, int H, int nW, int d,
+                               void* stream) {
+    return ps_attn_bwd_t<float>(q, k, v, ld, bias, mask, rank, dout, ldo, dq, dk, dv, ldg, dbias_part, B_, H, nW, d, stream);
+}
+extern "C" int dhz_ps_attn_bwd_dt(const void* q, const void* k, const void* v, int ld, const float* bias,
+                                  const float* mask, const uint8_t* rank, const void* dout, int ldo, void* dq,
+                                  void* dk, void* dv, int ldg, float* dbias_part, int B_, int H, int nW, int d,
+                                  int dtype, void* stream) {
+    if (dtype == DHZ_F32) return ps_attn_bwd_t<float>((const float*)q, (const float*)k, (const float*)v, ld, bias, mask, rank, (const float*)dout, ldo, (float*)dq, (float*)dk, (float*)dv, ldg, dbias_part, B_, H, nW, d, stream);
+    if (dtype == DHZ_BF16) return ps_attn_bwd_t<bf16s>((const bf16s*)q, (const bf16s*)k, (const bf16s*)v, ld, bias, mask, rank, (const bf16s*)dout, ldo, (bf16s*)dq, (bf16s*)dk, (bf16s*)dv, ldg, dbias_part, B_, H, nW, d, stream);
+    dhz_set_error("dhz_ps_attn_bwd_dt: unknown dtype %d", dtype);
+    return DHZ_EINVAL;
 }
 
 extern "C" int dhz_bias_gather(const float* table, float* bias, int H, void* stream) {

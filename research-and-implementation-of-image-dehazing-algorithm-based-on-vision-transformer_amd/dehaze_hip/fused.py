@@ -31,15 +31,15 @@ def _wgrad(dy, off, x, w, b):
     N = w.shape[0]
     if not w.requires_grad and (b is None or not b.requires_grad):
         return None, None                                   # frozen Linear: nothing to compute
-    mine = T % 32 == 0 and N % 32 == 0 and K % 32 == 0      # (the kernel's shape contract; always true on this model)
+    q = 64 if dy.dtype == ops.BF16 else 32
+    mine = T % q == 0 and N % q == 0 and K % q == 0         # (the kernel's shape contract; always true on this model)
     if mine and w.is_leaf and w.requires_grad and (b is None or (b.is_leaf and b.requires_grad)):
         ops._accumulate_param_grads(dy, off, x, [(w, b)])
         return None, None
     if mine:
         dw = torch.zeros_like(w, memory_format=torch.contiguous_format)
         db = torch.zeros_like(b) if b is not None else None
-        _lib.call("dhz_linear_wgrad", dy.data_ptr() + 4 * off, dy.stride(0), _p(x), x.stride(0), T, N, K, _p(dw), _p(db),
-                  _stream())
+        ops.wgrad_into(dy, off, x, N, dw, db)
         return dw, db
     raise RuntimeError(f"dehaze_hip: Linear weight gradient for T={T}, N={N}, K={K}: the HIP kernel needs multiples of 32 "
                        "(there is deliberately no library fallback)")
@@ -49,7 +49,8 @@ def _wgrad_qkv(dqkv, xn, C, pairs):
     """The three projections' gradients from the packed dqkv [T,3C]: one launch (x read once) when all of them can be
     accumulated in place, else one _wgrad each.  Returns the six autograd slots (g_wq, g_bq, g_wk, g_bk, g_wv, g_bv)."""
     T, K = xn.shape
-    if T % 32 == 0 and C % 32 == 0 and K % 32 == 0 and all(w.is_leaf and w.requires_grad and (b is None or (b.is_leaf and b.requires_grad))
+    q = 64 if dqkv.dtype == ops.BF16 else 32
+    if T % q == 0 and C % q == 0 and K % q == 0 and all(w.is_leaf and w.requires_grad and (b is None or (b.is_leaf and b.requires_grad))
                                                            for w, b in pairs):
         ops._accumulate_param_grads(dqkv, 0, xn, pairs)
         return (None,) * 6
@@ -81,13 +82,13 @@ def _ln_backward(dxn, x, gamma_p, beta_p, gamma, stats, dres, B, Hres, Wres, C, 
     dx = torch.empty_like(x)
     gg, gb = _grad_buf(gamma_p), _grad_buf(beta_p)
     if gg is not None and gb is not None:
-        _lib.call("dhz_ln_partition_bwd", _p(dxn), _p(x), _p(gamma), _p(stats), _p(dres), _p(dx), _p(gg), _p(gb),
-                  B, Hres, Wres, C, shift, partition, _stream())
+        _lib.call("dhz_ln_partition_bwd_dt", _p(dxn), _p(x), _p(gamma), _p(stats), _p(dres), _p(dx), _p(gg), _p(gb),
+                  B, Hres, Wres, C, shift, partition, ops._dt(x), _stream())
         _ready(gamma_p, beta_p)
         return dx, None, None
     dgb = torch.zeros((2, C), device=x.device, dtype=torch.float32)
-    _lib.call("dhz_ln_partition_bwd", _p(dxn), _p(x), _p(gamma), _p(stats), _p(dres), _p(dx), dgb[0].data_ptr(),
-              dgb[1].data_ptr(), B, Hres, Wres, C, shift, partition, _stream())
+    _lib.call("dhz_ln_partition_bwd_dt", _p(dxn), _p(x), _p(gamma), _p(stats), _p(dres), _p(dx), dgb[0].data_ptr(),
+              dgb[1].data_ptr(), B, Hres, Wres, C, shift, partition, ops._dt(x), _stream())
     return dx, dgb[0], dgb[1]
 
 
@@ -157,7 +158,7 @@ class _FusedAttnBranch(Function):
         f32 = dict(device=dev, dtype=torch.float32)
         # (1) gradient of the window-ordered out-projection output
         daw = torch.empty((T, C), **f32)
-        _lib.call("dhz_reverse_residual_bwd", _p(dout), _p(dscale), _p(daw), B, Hres, Wres, C, shift, 1, _stream())
+        _lib.call("dhz_reverse_residual_bwd_dt", _p(dout), _p(dscale), _p(daw), B, Hres, Wres, C, shift, 1, ops._dt(dout), _stream())
         # (2) out-projection
         dctx = ops.gemm_dgrad(daw, wo_)
         g_wo, g_bo = _wgrad(daw, 0, cx, wo, bo)
@@ -202,17 +203,17 @@ class _AttnBranchChain(Function):
         dev = x.device
         T = B * L
         f32 = dict(device=dev, dtype=torch.float32)
-        xn = torch.empty((T, C), **f32)
+        xn = torch.empty((T, C), device=dev, dtype=x.dtype)
         stats = torch.empty((T, 2), **f32)
-        _lib.call("dhz_ln_partition_fwd", _p(x), _p(gamma), _p(beta), _p(xn), _p(stats), B, Hres, Wres, C, shift, 1,
-                  _stream())
+        _lib.call("dhz_ln_partition_fwd_dt", _p(x), _p(gamma), _p(beta), _p(xn), _p(stats), B, Hres, Wres, C, shift, 1,
+                  ops._dt(x), _stream())
         wcat = ops.cat_rows([wq.detach(), wk.detach(), wv.detach()])
         qkv = ops.gemm_fwd(xn, wcat, ops.cat_rows([bq.detach(), bk.detach(), bv.detach()]))
         bias = None
         if table is not None:
             bias = torch.empty((H, NTOK, NTOK), **f32)
             _lib.call("dhz_bias_gather", _p(table.contiguous()), _p(bias), H, _stream())
-        cx = torch.empty((T, C), **f32)
+        cx = torch.empty((T, C), device=dev, dtype=x.dtype)
         rank = torch.empty(((T // NTOK) * H * NTOK,), device=dev, dtype=torch.uint8)
         nW = mask.shape[0] if mask is not None else 1
         base = qkv.data_ptr()
@@ -220,14 +221,15 @@ class _AttnBranchChain(Function):
         if timing is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        _lib.call("dhz_ps_attn_fwd", base, base + 4 * C, base + 8 * C, 3 * C, _p(idx), _p(bias), _p(mask), _p(cx), C,
-                  _p(rank), T // NTOK, H, nW, d, _stream())
+        es = qkv.element_size()
+        _lib.call("dhz_ps_attn_fwd_dt", base, base + es * C, base + 2 * es * C, 3 * C, _p(idx), _p(bias), _p(mask), _p(cx), C,
+                  _p(rank), T // NTOK, H, nW, d, ops._dt(qkv), _stream())
         if timing is not None:
             e1.record()
             timing.append((e0, e1, (T // NTOK) * H))
         aw = ops.gemm_fwd(cx, wo, bo)
         out = torch.empty_like(x)
-        _lib.call("dhz_reverse_residual_fwd", _p(aw), _p(x), _p(dscale), _p(out), B, Hres, Wres, C, shift, 1, _stream())
+        _lib.call("dhz_reverse_residual_fwd_dt", _p(aw), _p(x), _p(dscale), _p(out), B, Hres, Wres, C, shift, 1, ops._dt(x), _stream())
         if grad_mode and any(ctx.needs_input_grad):
             ctx.save_for_backward(x, gamma, stats, xn, qkv, cx, rank, bias, mask, dscale, wq, wk, wv, wo)
             ctx.params = (wq, bq, wk, bk, wv, bv, wo, bo, gamma, beta, table)
@@ -245,8 +247,8 @@ class _AttnBranchChain(Function):
         T = B * Hres * Wres
         B_ = T // NTOK
         f32 = dict(device=dev, dtype=torch.float32)
-        daw = torch.empty((T, C), **f32)
-        _lib.call("dhz_reverse_residual_bwd", _p(dout), _p(dscale), _p(daw), B, Hres, Wres, C, shift, 1, _stream())
+        daw = torch.empty((T, C), device=dev, dtype=dout.dtype)
+        _lib.call("dhz_reverse_residual_bwd_dt", _p(dout), _p(dscale), _p(daw), B, Hres, Wres, C, shift, 1, ops._dt(dout), _stream())
         dctx = ops.gemm_dgrad(daw, wo_)
         g_wo, g_bo = _wgrad(daw, 0, cx, wo, bo)
         dqkv = torch.empty_like(qkv)
@@ -254,8 +256,9 @@ class _AttnBranchChain(Function):
         dpart = torch.empty((parts, NTOK, NTOK), **f32) if bias is not None else None
         nW = mask.shape[0] if mask is not None else 1
         base, gb = qkv.data_ptr(), dqkv.data_ptr()
-        _lib.call("dhz_ps_attn_bwd", base, base + 4 * C, base + 8 * C, 3 * C, _p(bias), _p(mask), _p(rank), _p(dctx), C,
-                  gb, gb + 4 * C, gb + 8 * C, 3 * C, _p(dpart), B_, H, nW, d, _stream())
+        es = qkv.element_size()
+        _lib.call("dhz_ps_attn_bwd_dt", base, base + es * C, base + 2 * es * C, 3 * C, _p(bias), _p(mask), _p(rank), _p(dctx), C,
+                  gb, gb + es * C, gb + 2 * es * C, 3 * C, _p(dpart), B_, H, nW, d, ops._dt(qkv), _stream())
         dtable = _table_backward(dpart, parts, table_p, H, dev) if bias is not None else None
         dxn = ops.gemm_dgrad(dqkv, ops.cat_rows([wq_.detach(), wk_.detach(), wv_.detach()]))
         g_wq, g_bq, g_wk, g_bk, g_wv, g_bv = _wgrad_qkv(dqkv, xn, C, [(wq, bq), (wk, bk), (wv, bv)])
@@ -270,7 +273,7 @@ def attn_branch(x, norm, layer, table, idx, mask, dscale, Hres, Wres, shift, hea
     q, k, v, o = layer.query_projection, layer.key_projection, layer.value_projection, layer.out_projection
     args = (x, norm.weight, norm.bias, q.weight, q.bias, k.weight, k.bias, v.weight, v.bias, o.weight, o.bias, table, idx,
             mask, dscale, Hres, Wres, shift, heads, torch.is_grad_enabled())
-    use_fused = ENABLED and C == 32 * heads and (C in (32, 64) or (C == 128 and Hres * Wres <= 1024))
+    use_fused = ENABLED and x.dtype == torch.float32 and C == 32 * heads and (C in (32, 64) or (C == 128 and Hres * Wres <= 1024))
     return (_FusedAttnBranch if use_fused else _AttnBranchChain).apply(*args)
 
 
@@ -295,8 +298,9 @@ class _LeffBranch(Function):
         wdc = wd.contiguous()
         out = torch.empty_like(x)
         tiled = Hres % 8 == 0 and Wres % 16 == 0
-        ctx.fused_bwd = LEFF_FUSED and LEFF_FUSED_BWD and C in (32, 64, 128) and tiled
-        if LEFF_FUSED and C in LEFF_FUSED_C and tiled:
+        fp32 = x.dtype == torch.float32                      # the fused LeFF kernels are fp32-only
+        ctx.fused_bwd = LEFF_FUSED and LEFF_FUSED_BWD and C in (32, 64, 128) and tiled and fp32
+        if LEFF_FUSED and C in LEFF_FUSED_C and tiled and fp32:
             # one kernel: norm2, linear1, GELU, depthwise 3x3, GELU, linear2, DropPath scale, residual (csrc/leff_fused.hip)
             xn = stats = u = tg = z = None
             if train:
@@ -308,15 +312,15 @@ class _LeffBranch(Function):
             _lib.call("dhz_leff_fused_fwd", _p(x), _p(gamma), _p(beta), _p(w1), _p(b1), _p(wdc), _p(bd), _p(w2), _p(b2),
                       _p(dscale), _p(out), _p(xn), _p(stats), _p(u), _p(tg), _p(z), B, Hres, Wres, C, _stream())
         else:
-            xn = torch.empty((T, C), **f32)
+            xn = torch.empty((T, C), device=dev, dtype=x.dtype)
             stats = torch.empty((T, 2), **f32)
-            _lib.call("dhz_ln_partition_fwd", _p(x), _p(gamma), _p(beta), _p(xn), _p(stats), B, L, 1, C, 0, 0, _stream())
+            _lib.call("dhz_ln_partition_fwd_dt", _p(x), _p(gamma), _p(beta), _p(xn), _p(stats), B, L, 1, C, 0, 0, ops._dt(x), _stream())
             u = ops.gemm_fwd(xn, w1, b1)
             z = torch.empty_like(u)
             tg = torch.empty_like(u) if train else None
-            _lib.call("dhz_leff_dwconv_fwd", _p(u), _p(wdc), _p(bd), _p(tg), _p(z), B, Hres, Wres, Ch, _stream())
+            _lib.call("dhz_leff_dwconv_fwd_dt", _p(u), _p(wdc), _p(bd), _p(tg), _p(z), B, Hres, Wres, Ch, ops._dt(u), _stream())
             y = ops.gemm_fwd(z, w2, b2)
-            _lib.call("dhz_reverse_residual_fwd", _p(y), _p(x), _p(dscale), _p(out), B, L, 1, C, 0, 0, _stream())
+            _lib.call("dhz_reverse_residual_fwd_dt", _p(y), _p(x), _p(dscale), _p(out), B, L, 1, C, 0, 0, ops._dt(x), _stream())
         if train:
             ctx.save_for_backward(x, gamma, stats, xn, u, tg, z, dscale, w1, wdc, w2)
             ctx.params = (w1, b1, wd, bd, w2, b2, gamma, beta)
@@ -354,22 +358,22 @@ class _LeffBranch(Function):
             dx, dgamma, dbeta = _ln_backward(dxn, x, gamma_p, beta_p, gamma, stats, dout, B, L, 1, C, 0, 0)
             return (dx, dgamma, dbeta, g_w1, g_b1, g_wd, g_bd, g_w2, g_b2, None, None, None, None)
         if dscale is not None:
-            dy = torch.empty((T, C), **f32)
-            _lib.call("dhz_reverse_residual_bwd", _p(dout), _p(dscale), _p(dy), B, L, 1, C, 0, 0, _stream())
+            dy = torch.empty((T, C), device=dev, dtype=dout.dtype)
+            _lib.call("dhz_reverse_residual_bwd_dt", _p(dout), _p(dscale), _p(dy), B, L, 1, C, 0, 0, ops._dt(dout), _stream())
         else:
             dy = dout.view(T, C)
         dz = ops.gemm_dgrad(dy, w2_)
         g_w2, g_b2 = _wgrad(dy, 0, z, w2, b2)
         du = torch.empty_like(u)
         if gwd is not None and gbd is not None:          # depthwise weight / bias gradients straight into .grad
-            _lib.call("dhz_leff_dwconv_bwd", _p(dz), _p(u), _p(tg), _p(wdc), _p(du), _p(gwd), _p(gbd), B, Hres, Wres, Ch,
-                      _stream())
+            _lib.call("dhz_leff_dwconv_bwd_dt", _p(dz), _p(u), _p(tg), _p(wdc), _p(du), _p(gwd), _p(gbd), B, Hres, Wres, Ch,
+                      ops._dt(u), _stream())
             _ready(wd, bd)
             g_wd = g_bd = None
         else:
             dwb = torch.zeros((Ch * 10,), **f32)
-            _lib.call("dhz_leff_dwconv_bwd", _p(dz), _p(u), _p(tg), _p(wdc), _p(du), dwb.data_ptr(),
-                      dwb.data_ptr() + 4 * Ch * 9, B, Hres, Wres, Ch, _stream())
+            _lib.call("dhz_leff_dwconv_bwd_dt", _p(dz), _p(u), _p(tg), _p(wdc), _p(du), dwb.data_ptr(),
+                      dwb.data_ptr() + 4 * Ch * 9, B, Hres, Wres, Ch, ops._dt(u), _stream())
             g_wd, g_bd = dwb[:Ch * 9].view(Ch, 1, 3, 3), dwb[Ch * 9:]
         dxn = ops.gemm_dgrad(du, w1_)
         g_w1, g_b1 = _wgrad(du, 0, xn, w1, b1)

@@ -356,6 +356,9 @@ class Downsample(nn.Module):
         self.in_channel, self.out_channel = in_channel, out_channel
 
     def forward(self, x):
+        if x.dtype == torch.bfloat16:       # config 4: library convolution in bf16 (weights cast by autocast, fp32 masters)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                return _map_to_tokens(self.conv(_tokens_to_map(x)))
         return _map_to_tokens(self.conv(_tokens_to_map(x)))
 
 
@@ -445,6 +448,9 @@ class OutputProj(nn.Module):
             # forward / backward-data / weight-gradient kernels on the token layout (csrc/thin_conv.hip)
             s_ = int(math.sqrt(x.shape[1]))
             x = ops.thin_conv3x3(x, conv.weight, conv.bias, s_, s_)
+        elif x.dtype == torch.bfloat16:
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                x = self.proj(_tokens_to_map(x)).float()
         elif x.is_cuda and len(self.proj) == 1 and conv.bias is not None:
             # the convolution without its bias + an explicit bias add whose backward sums in two stages: the library's
             # bias gradient of a 3-channel map is ONE 4-block reduction over the whole gradient image (190 us per step)
@@ -472,6 +478,11 @@ class Uformer(nn.Module):
     """U-shaped encoder/decoder of LeWin blocks (M1:955-1207); constructor signature of M1:961-967."""
 
     variant = "probsparse"
+    # Storage type of the token tensors between kernels: torch.float32 (BASELINE configs 1-3, 5) or torch.bfloat16 (config 4:
+    # bf16 activations and bf16 weight copies in HBM, fp32 accumulation, fp32 LayerNorm statistics / sparsity measure / softmax,
+    # fp32 master parameters and parameter gradients - the role fp16 autocast + GradScaler play in the reference, TR:224,249;
+    # bf16 keeps fp32's exponent range, so no loss scaling).  Set on the instance: model.act_dtype = torch.bfloat16.
+    act_dtype = torch.float32
 
     def __init__(self, img_size=128, in_chans=3, embed_dim=32, depths=[2, 2, 2, 2, 2, 2, 2, 2, 2],
                  num_heads=[1, 2, 4, 8, 16, 16, 8, 4, 2], win_size=8, mlp_ratio=4., qkv_bias=True, qk_scale=None,
@@ -581,6 +592,8 @@ class Uformer(nn.Module):
         self._stage_sample_indices(x.device)
         self._stage_drop_path(x)
         y = self.pos_drop(self.input_proj(x))
+        if self.act_dtype == torch.bfloat16 and y.is_cuda:
+            y = y.to(torch.bfloat16)
         skips = []
         for s in range(4):
             y = getattr(self, f"encoderlayer_{s}")(y, mask=mask)
@@ -590,7 +603,7 @@ class Uformer(nn.Module):
         for s in range(4):
             y = getattr(self, f"upsample_{s}")(y, skips[3 - s])
             y = getattr(self, f"decoderlayer_{s}")(y, mask=mask)
-        return x + self.output_proj(y)
+        return x + self.output_proj(y).float()
 
 
 class UformerDense(Uformer):

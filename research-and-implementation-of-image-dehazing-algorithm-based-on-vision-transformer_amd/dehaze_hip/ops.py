@@ -33,8 +33,21 @@ def _require_gpu(*tensors):
         if t is not None and not t.is_cuda:
             raise RuntimeError("dehaze_hip: this op runs only on a HIP device (got a CPU tensor); "
                                "there is deliberately no CPU/PyTorch fallback")
-        if t is not None and t.dtype not in (torch.float32, torch.uint8):
-            raise RuntimeError(f"dehaze_hip: fp32 tensors expected, got {t.dtype}")
+        if t is not None and t.dtype not in (torch.float32, torch.uint8, torch.bfloat16):
+            raise RuntimeError(f"dehaze_hip: fp32 (or bf16 token tensors, BASELINE config 4) expected, got {t.dtype}")
+
+
+BF16 = torch.bfloat16
+
+
+def _dt(t):
+    """dtype code of the dhz_*_dt entry points (include/dehaze_hip.h: DHZ_F32 = 0, DHZ_BF16 = 1)."""
+    return 1 if t.dtype == BF16 else 0
+
+
+def bf16_copy(W):
+    """bf16 copy of an fp32 master weight for the bf16 GEMMs (one small cast kernel per use; parameters stay fp32)."""
+    return W if W.dtype == BF16 else W.detach().to(BF16)
 
 
 def gemm_fwd(x, W, b=None):
@@ -45,8 +58,11 @@ def gemm_fwd(x, W, b=None):
     N = W.shape[0]
     assert x.stride(1) == 1 and W.shape[1] == K
     W = W if W.is_contiguous() else W.contiguous()
-    y = torch.empty((T, N), device=x.device, dtype=torch.float32)
-    _lib.call("dhz_linear_fwd", _p(x), x.stride(0), _p(W), _p(b), _p(y), N, T, N, K, _stream())
+    y = torch.empty((T, N), device=x.device, dtype=x.dtype)
+    if x.dtype == BF16:                     # bf16 activations x bf16 weight copy, fp32 accumulate, fp32 bias (config 4)
+        _lib.call("dhz_linear_fwd_bf16", _p(x), x.stride(0), _p(bf16_copy(W)), _p(b), _p(y), N, T, N, K, _stream())
+    else:
+        _lib.call("dhz_linear_fwd", _p(x), x.stride(0), _p(W), _p(b), _p(y), N, T, N, K, _stream())
     return y
 
 
@@ -57,8 +73,11 @@ def gemm_dgrad(dy, W):
     K = W.shape[1]
     assert dy.stride(1) == 1 and W.shape[0] == N
     W = W if W.is_contiguous() else W.contiguous()
-    dx = torch.empty((T, K), device=dy.device, dtype=torch.float32)
-    _lib.call("dhz_linear_dgrad", _p(dy), dy.stride(0), _p(W), _p(dx), K, T, N, K, _stream())
+    dx = torch.empty((T, K), device=dy.device, dtype=dy.dtype)
+    if dy.dtype == BF16:
+        _lib.call("dhz_linear_dgrad_bf16", _p(dy), dy.stride(0), _p(bf16_copy(W)), _p(dx), K, T, N, K, _stream())
+    else:
+        _lib.call("dhz_linear_dgrad", _p(dy), dy.stride(0), _p(W), _p(dx), K, T, N, K, _stream())
     return dx
 
 
@@ -78,20 +97,20 @@ class _PSWindowAttention(Function):
         C = H * d
         assert C3 == 3 * C and T % NTOK == 0 and qkv.is_contiguous()
         B_ = T // NTOK
-        out = torch.empty((T, C), device=qkv.device, dtype=torch.float32)
+        out = torch.empty((T, C), device=qkv.device, dtype=qkv.dtype)
         rank = torch.empty((B_ * H * NTOK,), device=qkv.device, dtype=torch.uint8)
         bias = None
         if table is not None:
             bias = torch.empty((H, NTOK, NTOK), device=qkv.device, dtype=torch.float32)
             _lib.call("dhz_bias_gather", _p(table.contiguous()), _p(bias), H, _stream())
         nW = mask.shape[0] if mask is not None else 1
-        base = qkv.data_ptr()
+        base, es = qkv.data_ptr(), qkv.element_size()
         timing = KERNEL_TIMING.get("dhz_ps_attn_fwd") if KERNEL_TIMING is not None else None
         if timing is not None:      # HIP events on the launch stream, bracketing exactly this kernel
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        _lib.call("dhz_ps_attn_fwd", base, base + 4 * C, base + 8 * C, 3 * C, _p(idx), _p(bias), _p(mask), _p(out), C,
-                  _p(rank), B_, H, nW, d, _stream())
+        _lib.call("dhz_ps_attn_fwd_dt", base, base + es * C, base + 2 * es * C, 3 * C, _p(idx), _p(bias), _p(mask), _p(out), C,
+                  _p(rank), B_, H, nW, d, _dt(qkv), _stream())
         if timing is not None:
             e1.record()
             timing.append((e0, e1, B_ * H))
@@ -111,9 +130,9 @@ class _PSWindowAttention(Function):
         parts = lib.dhz_ps_attn_bwd_parts(B_, H)
         if bias is not None:
             dpart = torch.empty((parts, NTOK, NTOK), device=qkv.device, dtype=torch.float32)
-        base, gb = qkv.data_ptr(), dqkv.data_ptr()
-        _lib.call("dhz_ps_attn_bwd", base, base + 4 * C, base + 8 * C, 3 * C, _p(bias), _p(mask), _p(rank), _p(dout), C,
-                  gb, gb + 4 * C, gb + 8 * C, 3 * C, _p(dpart), B_, H, nW, d, _stream())
+        base, gb, es = qkv.data_ptr(), dqkv.data_ptr(), qkv.element_size()
+        _lib.call("dhz_ps_attn_bwd_dt", base, base + es * C, base + 2 * es * C, 3 * C, _p(bias), _p(mask), _p(rank), _p(dout), C,
+                  gb, gb + es * C, gb + 2 * es * C, 3 * C, _p(dpart), B_, H, nW, d, _dt(qkv), _stream())
         if bias is not None:
             dtable = torch.empty((225, H), device=qkv.device, dtype=torch.float32)
             _lib.call("dhz_bias_table_grad", _p(dpart), parts, _p(dtable), H, 0, _stream())
@@ -210,7 +229,19 @@ def _accumulate_param_grads(dy, ldy_off, x, params):
     N = params[0][0].shape[0]
     same = 1 < len(params) <= 4 and all(W.shape[0] == N for W, _ in params) and \
         len({b is None for _, b in params}) == 1
-    if same:
+    if dy.dtype == BF16:
+        # bf16 dy / x, fp32 accumulation straight into the fp32 .grad buffers; equal-shaped parameters share one launch
+        groups = [params] if (same or len(params) == 1) else [[pr] for pr in params]
+        off = ldy_off
+        for grp in groups:
+            n = len(grp)
+            Ng = grp[0][0].shape[0]
+            dws = (ctypes.c_void_p * n)(*[W.grad.data_ptr() for W, _ in grp])
+            dbs = (ctypes.c_void_p * n)(*[(b.grad.data_ptr() if b is not None else None) for _, b in grp])
+            _lib.call("dhz_linear_wgrad_bf16", dy.data_ptr() + 2 * off, dy.stride(0), _p(x), x.stride(0), T, n, Ng, K,
+                      ctypes.cast(dws, ctypes.c_void_p), ctypes.cast(dbs, ctypes.c_void_p), _stream())
+            off += n * Ng
+    elif same:
         n = len(params)
         dws = (ctypes.c_void_p * n)(*[W.grad.data_ptr() for W, _ in params])
         dbs = (ctypes.c_void_p * n)(*[(b.grad.data_ptr() if b is not None else None) for _, b in params])
@@ -227,6 +258,18 @@ def _accumulate_param_grads(dy, ldy_off, x, params):
             GRAD_READY(W)
             if b is not None:
                 GRAD_READY(b)
+
+
+def wgrad_into(dy, off, x, N, dw, db):
+    """dw[N,K] += dy[:, off:off+N]^T x, db += column sums (fp32 accumulators) for fp32 or bf16 dy / x."""
+    T, K = x.shape
+    if dy.dtype == BF16:
+        dws = (ctypes.c_void_p * 1)(dw.data_ptr())
+        dbs = (ctypes.c_void_p * 1)(db.data_ptr() if db is not None else None)
+        _lib.call("dhz_linear_wgrad_bf16", dy.data_ptr() + 2 * off, dy.stride(0), _p(x), x.stride(0), T, 1, N, K,
+                  ctypes.cast(dws, ctypes.c_void_p), ctypes.cast(dbs, ctypes.c_void_p), _stream())
+    else:
+        _lib.call("dhz_linear_wgrad", dy.data_ptr() + 4 * off, dy.stride(0), _p(x), x.stride(0), T, N, K, _p(dw), _p(db), _stream())
 
 
 _NO_CAT_VIEW = bool(__import__("os").environ.get("DHZ_NO_CAT_VIEW"))     # A/B switch: always copy
@@ -267,6 +310,8 @@ class _LinearTokens(Function):
         else:
             W = cat_rows([w.detach() for w, _ in params])
             b = cat_rows([b_.detach() for _, b_ in params])
+        if x.dtype == BF16:
+            W = bf16_copy(W)                # one cast per Linear and step: the copy is saved for the backward-data GEMM
         y = gemm_fwd(x, W, b)
         ctx.save_for_backward(x, W)
         ctx.params = params
@@ -280,7 +325,8 @@ class _LinearTokens(Function):
         T, K = x.shape
         grads = []
         off = 0
-        if T % 32 == 0 and K % 32 == 0 and all(w.shape[0] % 32 == 0 and w.is_leaf and w.requires_grad
+        q = 64 if dy.dtype == BF16 else 32
+        if T % q == 0 and K % q == 0 and all(w.shape[0] % q == 0 and w.is_leaf and w.requires_grad
                                                and (b is None or (b.is_leaf and b.requires_grad)) for w, b in ctx.params):
             _accumulate_param_grads(dy, 0, x, ctx.params)           # one launch for equal-shaped parameters (Q / K / V)
             return (dx,) + (None, None) * len(ctx.params)
@@ -289,7 +335,7 @@ class _LinearTokens(Function):
             # measured on MI355X (tools/bench_wgrad.py): the split-T kernel wins 2-18x for T >= 16k tokens; on the deep
             # stages (T <= 8k) it is within 0.9-1.2x of the library's TN GEMM and delivers the bias gradient for free
             # (the library path pays a separate ~20 us column-sum kernel), so it is used everywhere
-            mine = T % 32 == 0 and N % 32 == 0 and K % 32 == 0      # (the kernel's shape contract; always true on this model)
+            mine = T % q == 0 and N % q == 0 and K % q == 0         # (the kernel's shape contract; always true on this model)
             if not w.requires_grad and (b is None or not b.requires_grad):
                 grads += [None, None]                                 # frozen Linear
             elif mine and w.is_leaf and w.requires_grad and (b is None or (b.is_leaf and b.requires_grad)):
@@ -298,8 +344,7 @@ class _LinearTokens(Function):
             elif mine:
                 dw = torch.zeros_like(w, memory_format=torch.contiguous_format)
                 db = torch.zeros_like(b) if b is not None else None
-                _lib.call("dhz_linear_wgrad", dy.data_ptr() + 4 * off, dy.shape[1], _p(x), K, T, N, K, _p(dw), _p(db),
-                          _stream())
+                wgrad_into(dy, off, x, N, dw, db)
                 grads += [dw, db]
             else:
                 raise RuntimeError(f"dehaze_hip: Linear weight gradient for T={T}, N={N}, K={K}: the HIP kernel needs "
@@ -326,10 +371,10 @@ class _LNPartition(Function):
         x = x.contiguous()
         B, L, C = x.shape
         assert L == Hres * Wres
-        y = torch.empty((B * L, C), device=x.device, dtype=torch.float32)
+        y = torch.empty((B * L, C), device=x.device, dtype=x.dtype)
         stats = torch.empty((B * L, 2), device=x.device, dtype=torch.float32)
-        _lib.call("dhz_ln_partition_fwd", _p(x), _p(gamma), _p(beta), _p(y), _p(stats), B, Hres, Wres, C, shift,
-                  int(partition), _stream())
+        _lib.call("dhz_ln_partition_fwd_dt", _p(x), _p(gamma), _p(beta), _p(y), _p(stats), B, Hres, Wres, C, shift,
+                  int(partition), _dt(x), _stream())
         ctx.save_for_backward(x, gamma, stats)
         ctx.geom = (B, Hres, Wres, C, shift, int(partition))
         return y
@@ -341,8 +386,8 @@ class _LNPartition(Function):
         dy = dy.contiguous()
         dx = torch.empty_like(x)
         dgb = torch.zeros((2, C), device=x.device, dtype=torch.float32)
-        _lib.call("dhz_ln_partition_bwd", _p(dy), _p(x), _p(gamma), _p(stats), None, _p(dx), dgb[0].data_ptr(),
-                  dgb[1].data_ptr(), B, Hres, Wres, C, shift, partition, _stream())
+        _lib.call("dhz_ln_partition_bwd_dt", _p(dy), _p(x), _p(gamma), _p(stats), None, _p(dx), dgb[0].data_ptr(),
+                  dgb[1].data_ptr(), B, Hres, Wres, C, shift, partition, _dt(x), _stream())
         return dx, dgb[0], dgb[1], None, None, None, None
 
 
@@ -365,8 +410,8 @@ class _ReverseResidual(Function):
         yw = yw.contiguous()
         B, L, C = shortcut.shape
         out = torch.empty_like(shortcut)
-        _lib.call("dhz_reverse_residual_fwd", _p(yw), _p(shortcut), _p(scale), _p(out), B, Hres, Wres, C, shift,
-                  int(partition), _stream())
+        _lib.call("dhz_reverse_residual_fwd_dt", _p(yw), _p(shortcut), _p(scale), _p(out), B, Hres, Wres, C, shift,
+                  int(partition), _dt(shortcut), _stream())
         ctx.save_for_backward(scale)
         ctx.geom = (B, Hres, Wres, C, shift, int(partition), tuple(yw.shape))
         return out
@@ -376,9 +421,9 @@ class _ReverseResidual(Function):
         (scale,) = ctx.saved_tensors
         B, Hres, Wres, C, shift, partition, yshape = ctx.geom
         dout = dout.contiguous()
-        dyw = torch.empty(yshape, device=dout.device, dtype=torch.float32)
-        _lib.call("dhz_reverse_residual_bwd", _p(dout), _p(scale), _p(dyw), B, Hres, Wres, C, shift, partition,
-                  _stream())
+        dyw = torch.empty(yshape, device=dout.device, dtype=dout.dtype)
+        _lib.call("dhz_reverse_residual_bwd_dt", _p(dout), _p(scale), _p(dyw), B, Hres, Wres, C, shift, partition,
+                  _dt(dout), _stream())
         return dyw, dout, None, None, None, None, None
 
 
@@ -404,7 +449,7 @@ class _LeffDwconv(Function):
         keep = any(ctx.needs_input_grad)
         t = torch.empty_like(u) if keep else None
         w = w.contiguous()
-        _lib.call("dhz_leff_dwconv_fwd", _p(u), _p(w), _p(b), _p(t), _p(z), B, Hres, Wres, Ch, _stream())
+        _lib.call("dhz_leff_dwconv_fwd_dt", _p(u), _p(w), _p(b), _p(t), _p(z), B, Hres, Wres, Ch, _dt(u), _stream())
         if keep:
             ctx.save_for_backward(u, t, w)
         ctx.geom = (B, Hres, Wres, Ch)
@@ -417,8 +462,8 @@ class _LeffDwconv(Function):
         dz = dz.contiguous()
         du = torch.empty_like(u)
         dwb = torch.zeros((Ch * 10,), device=u.device, dtype=torch.float32)
-        _lib.call("dhz_leff_dwconv_bwd", _p(dz), _p(u), _p(t), _p(w), _p(du), dwb.data_ptr(),
-                  dwb.data_ptr() + 4 * Ch * 9, B, Hres, Wres, Ch, _stream())
+        _lib.call("dhz_leff_dwconv_bwd_dt", _p(dz), _p(u), _p(t), _p(w), _p(du), dwb.data_ptr(),
+                  dwb.data_ptr() + 4 * Ch * 9, B, Hres, Wres, Ch, _dt(u), _stream())
         return du, dwb[:Ch * 9].view(Ch, 1, 3, 3), dwb[Ch * 9:], None, None
 
 
