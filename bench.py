@@ -33,6 +33,7 @@ import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_F32_PEAK_TF = 157.3       # fp32-input MFMA dense peak
+MFMA_BF16_PEAK_TF = 2500.0     # bf16 MFMA dense peak (MI355X_MICROARCH.md: ~2.5 PF dense)
 
 
 def _cpu_steps(P, params, opt, hazy, gt, vggW, w_cr, steps):
@@ -90,6 +91,8 @@ def main():
     ap.add_argument("--strong", action="store_true", help="strong scaling (SURVEY 8d): GLOBAL batch = --batch, split over the ranks")
     ap.add_argument("--embed_dim", type=int, default=32)
     ap.add_argument("--ps", type=int, default=128)
+    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
+                    help="storage type of the token tensors: f32 (BASELINE configs 2/3) or bf16 (config 4: --embed_dim 64 --ps 256 --batch 8)")
     ap.add_argument("--no-cr", action="store_true", help="Charbonnier only (NOT the headline config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
@@ -127,6 +130,8 @@ def main():
     model = M1.Uformer(img_size=args.ps, embed_dim=args.embed_dim, win_size=8, token_projection='linear',
                        token_mlp='leff').to(dev)
     model.train()
+    if args.dtype == "bf16":
+        model.act_dtype = torch.bfloat16          # bf16 activations / weight copies, fp32 accumulation and master weights
     opt = FlatAdamW(model, lr=2e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.02)
     opt.zero_grad()
     reducer = GradReducer(opt) if world > 1 else None
@@ -162,7 +167,8 @@ def main():
     # product path records no events; ~180 event records per step would be work the timed steps do not do)
     timing = None
     if not args.no_kernel_timing and rank == 0:
-        ops.KERNEL_TIMING = {"dhz_ps_attn_fwd": [], "dhz_fused_window_attn_fwd": [], "dhz_winograd_conv3x3": []}
+        ops.KERNEL_TIMING = {"dhz_ps_attn_fwd": [], "dhz_fused_window_attn_fwd": [], "dhz_winograd_conv3x3": [],
+                             "dhz_linear_bf16": []}
     if not args.no_kernel_timing:
         for _ in range(min(args.steps, 5)):
             step()                                # every rank runs it (the step holds a collective)
@@ -172,13 +178,15 @@ def main():
     if rank == 0:
         total = args.batch * world * args.steps
         out = {
-            "metric": "train patches/sec (128x128, embed_dim=32)", "value": round(total / elapsed, 3),
+            "metric": f"train patches/sec ({args.ps}x{args.ps}, embed_dim={args.embed_dim})", "value": round(total / elapsed, 3),
             "unit": "patches/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "strong" if args.strong else "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"Uformer_ProbSparse train step E={args.embed_dim} ps={args.ps} per-GPU bs={args.batch} "
-                                   f"fp32 {'Charbonnier' if args.no_cr else 'Charbonnier+CR(VGG19, seeded-random weights)'} "
-                                   "+ AdamW (BASELINE configs[1])",
+                                   f"{'fp32' if args.dtype == 'f32' else 'bf16 activations + bf16 weight copies, fp32 accumulation / master weights,'} "
+                                   f"{'Charbonnier' if args.no_cr else 'Charbonnier+CR(VGG19, seeded-random weights)'} + AdamW "
+                                   + ("(BASELINE configs[1])" if (args.dtype, args.embed_dim, args.ps, args.batch) == ("f32", 32, 128, 32)
+                                      else "(BASELINE configs[3])" if (args.dtype, args.embed_dim, args.ps) == ("bf16", 64, 256) else "(not a BASELINE config)"),
                        "global_batch": args.batch * world, "parallelism": f"dp{world}", "miopen_find": bool(torch.backends.cudnn.benchmark),
                        "loss_last_step": round(float(loss), 6)},
         }
@@ -188,6 +196,17 @@ def main():
             pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
         except Exception:
             pass
+        if timing and timing.get("dhz_linear_bf16"):
+            # config 4: the token-Linear GEMMs on v_mfma_f32_16x16x32_bf16 (forward + backward-data launches), against the dense
+            # bf16 matrix peak; most of their shapes are HBM-bound at bf16 MFMA rates, so the HBM view is given beside it
+            ev = timing["dhz_linear_bf16"]
+            ms = sum(a.elapsed_time(b_) for a, b_, _ in ev)
+            flops = sum(f for _, _, f in ev)
+            tf = flops / (ms * 1e-3) / 1e12
+            out["roofline"] = {"kernel": "gemm_bf16_kernel<WM,WN,BTR> (dhz_linear_fwd_bf16 / dhz_linear_dgrad_bf16)", "bound": "mfma",
+                               "achieved": round(tf, 1), "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s",
+                               "frac": round(tf / MFMA_BF16_PEAK_TF, 4), "traffic": None, "launches": len(ev),
+                               "avg_launch_us": round(1e3 * ms / len(ev), 2), "alg_flops_per_launch": int(flops / len(ev))}
         if timing and timing.get("dhz_fused_window_attn_fwd"):
             # the window-attention kernel of the north star: LN + QKV + ProbSparse core + out-proj + residual, fused.
             # algorithmic FLOPs per window = 2*64*(4C^2 + 75C) (four CxC projections + 3x(25x64x32) core)
@@ -208,11 +227,10 @@ def main():
             # the stand-alone ProbSparse core (stages the fused kernel does not cover): HBM-bound, 32 KiB / window-head
             ev = timing["dhz_ps_attn_fwd"]
             ms = sum(a.elapsed_time(b) for a, b, _ in ev)
-            wh = sum(n for _, _, n in ev)
-            bytes_alg = wh * (4 * 64 * 32 * 4)
+            bytes_alg = sum(n for _, _, n in ev)          # Q, K, V in + context out per window-head: 4 * 64 * d * element size
             gbs = bytes_alg / (ms * 1e-3) / 1e9
-            traffic = pmc.get("ps_attn_fwd_kernel<32>", {}).get("hbm_bytes_per_launch")
-            entry = {"kernel": "ps_attn_fwd_kernel<32> (dhz_ps_attn_fwd)", "bound": "hbm", "achieved": round(gbs, 1),
+            traffic = pmc.get("ps_attn_fwd_kernel<32>", {}).get("hbm_bytes_per_launch") if args.dtype == "f32" and args.embed_dim == 32 else None
+            entry = {"kernel": "ps_attn_fwd_kernel<d,T> (dhz_ps_attn_fwd)", "bound": "hbm", "achieved": round(gbs, 1),
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
                      "traffic": round(traffic) if traffic else None, "launches": len(ev),
                      "avg_launch_us": round(1e3 * ms / len(ev), 2), "alg_bytes_per_launch": bytes_alg // len(ev)}

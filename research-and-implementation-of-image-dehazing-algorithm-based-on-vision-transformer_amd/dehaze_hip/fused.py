@@ -226,7 +226,7 @@ class _AttnBranchChain(Function):
                   _p(rank), T // NTOK, H, nW, d, ops._dt(qkv), _stream())
         if timing is not None:
             e1.record()
-            timing.append((e0, e1, (T // NTOK) * H))
+            timing.append((e0, e1, (T // NTOK) * H * 4 * NTOK * d * qkv.element_size()))
         aw = ops.gemm_fwd(cx, wo, bo)
         out = torch.empty_like(x)
         _lib.call("dhz_reverse_residual_fwd_dt", _p(aw), _p(x), _p(dscale), _p(out), B, Hres, Wres, C, shift, 1, ops._dt(x), _stream())

@@ -50,6 +50,23 @@ def bf16_copy(W):
     return W if W.dtype == BF16 else W.detach().to(BF16)
 
 
+def _timed(name):
+    """(list, start event) when bench.py collects HIP-event timings for this entry point, else None."""
+    lst = KERNEL_TIMING.get(name) if KERNEL_TIMING is not None else None
+    if lst is None:
+        return None
+    e0 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    return lst, e0
+
+
+def _timed_end(ev, units):
+    if ev is not None:
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        ev[0].append((ev[1], e1, units))
+
+
 def gemm_fwd(x, W, b=None):
     """y[T,N] = x[T,K] W[N,K]^T + b on the fp32 matrix pipe (dhz_linear_fwd).  x: rows of K contiguous floats (any row
     stride), W contiguous."""
@@ -60,7 +77,10 @@ def gemm_fwd(x, W, b=None):
     W = W if W.is_contiguous() else W.contiguous()
     y = torch.empty((T, N), device=x.device, dtype=x.dtype)
     if x.dtype == BF16:                     # bf16 activations x bf16 weight copy, fp32 accumulate, fp32 bias (config 4)
-        _lib.call("dhz_linear_fwd_bf16", _p(x), x.stride(0), _p(bf16_copy(W)), _p(b), _p(y), N, T, N, K, _stream())
+        Wb = bf16_copy(W)
+        ev = _timed("dhz_linear_bf16")
+        _lib.call("dhz_linear_fwd_bf16", _p(x), x.stride(0), _p(Wb), _p(b), _p(y), N, T, N, K, _stream())
+        _timed_end(ev, 2.0 * T * N * K)
     else:
         _lib.call("dhz_linear_fwd", _p(x), x.stride(0), _p(W), _p(b), _p(y), N, T, N, K, _stream())
     return y
@@ -75,7 +95,10 @@ def gemm_dgrad(dy, W):
     W = W if W.is_contiguous() else W.contiguous()
     dx = torch.empty((T, K), device=dy.device, dtype=dy.dtype)
     if dy.dtype == BF16:
-        _lib.call("dhz_linear_dgrad_bf16", _p(dy), dy.stride(0), _p(bf16_copy(W)), _p(dx), K, T, N, K, _stream())
+        Wb = bf16_copy(W)
+        ev = _timed("dhz_linear_bf16")
+        _lib.call("dhz_linear_dgrad_bf16", _p(dy), dy.stride(0), _p(Wb), _p(dx), K, T, N, K, _stream())
+        _timed_end(ev, 2.0 * T * N * K)
     else:
         _lib.call("dhz_linear_dgrad", _p(dy), dy.stride(0), _p(W), _p(dx), K, T, N, K, _stream())
     return dx
@@ -113,7 +136,7 @@ class _PSWindowAttention(Function):
                   _p(rank), B_, H, nW, d, _dt(qkv), _stream())
         if timing is not None:
             e1.record()
-            timing.append((e0, e1, B_ * H))
+            timing.append((e0, e1, B_ * H * 4 * NTOK * d * qkv.element_size()))
         ctx.save_for_backward(qkv, bias, mask, rank)
         ctx.dims = (B_, H, d, nW)
         return out

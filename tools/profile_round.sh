@@ -6,7 +6,7 @@ N=${1:?name}
 R=$(pwd); O=$R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 rm -rf $O/p_*
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/p_trace -- python3 $R/bench.py --steps 6 --warmup 4 --no-cpu-baseline > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/p_trace -- python3 $R/bench.py --steps 6 --warmup 4 --no-cpu-baseline $BENCH_ARGS > /dev/null 2>&1
 if [ "$2" = "trace" ]; then
   cd $R
   T=$(ls $O/p_trace/*/*kernel_trace.csv | head -1)
