@@ -209,7 +209,7 @@ int dispatch(const char* who, const float* A, int lda, const float* W, int ldw, 
     DHZ_REQUIRE(lda % 4 == 0 && ldy % 4 == 0 && ldw % 4 == 0 && lda >= K && ldy >= N, "%s: bad leading dimensions", who);
     DHZ_REQUIRE((((uintptr_t)A | (uintptr_t)Y) & 15) == 0 && (((uintptr_t)W | (uintptr_t)bias) & 3) == 0,
                 "%s: activations must be 16-byte aligned (weights: 4-byte)", who);
-    // largest tile that still gives every CU a block: 128 x 128 down to 64 x 32 (tile width must divide N)
+    // largest tile that still gives every CU two blocks: 128 x 128 down to 64 x 32 (tile width must divide N)
     int wm = 2, wn = 1;
     {
         static const int cand[8][2] = {{4, 4}, {4, 3}, {4, 2}, {2, 4}, {2, 3}, {2, 2}, {4, 1}, {2, 1}};
@@ -218,7 +218,7 @@ int dispatch(const char* who, const float* A, int lda, const float* W, int ldw, 
             const int a = cand[i][0], b = cand[i][1];
             if (N % (32 * b)) continue;
             const long blocks = (long)((M + 32 * a - 1) / (32 * a)) * (N / (32 * b));
-            if (blocks >= 256) { wm = a; wn = b; break; }
+            if (blocks >= 512) { wm = a; wn = b; break; }      // two resident workgroups per CU (256 / 384 / 512: 1838 / 1822 / 1809 us over the deep stages)
             if (blocks > best_blocks) { best_blocks = blocks; wm = a; wn = b; }
         }
     }
