@@ -95,6 +95,15 @@ def test_my_train_on_png_tree(tmp_path):
                 shape = (144, 160, 3) if split == "train" else (128, 128, 3)       # validation runs whole (square) patches
                 utils.save_img(str(tmp_path / split / sub / f"{i + 1}_1.png"), rng.integers(0, 256, shape, dtype=np.uint8))
     env = dict(os.environ, PYTHONPATH=PKG)
+    env.pop("DEHAZE_VGG19_WEIGHTS", None); env.pop("DEHAZE_ALLOW_RANDOM_VGG", None)
+    cmd = [sys.executable, os.path.join(PKG, "My_train.py"), "--arch", "Uformer", "--batch_size", "2", "--train_ps", "128",
+           "--embed_dim", "32", "--nepoch", "1", "--warmup", "--env", "_pngtest", "--train_dir", str(tmp_path / "train"),
+           "--val_dir", str(tmp_path / "val"), "--log_every", "1"]
+    # real data + contrastive loss without the ImageNet VGG19 checkpoint: refuses to train against random features ...
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and "DEHAZE_VGG19_WEIGHTS" in (r.stdout + r.stderr)
+    # ... unless told to (there is no network here for the checkpoint the reference downloads)
+    env["DEHAZE_ALLOW_RANDOM_VGG"] = "1"
     cmd = [sys.executable, os.path.join(PKG, "My_train.py"), "--arch", "Uformer", "--batch_size", "2", "--train_ps", "128",
            "--embed_dim", "32", "--nepoch", "1", "--warmup", "--env", "_pngtest", "--train_dir", str(tmp_path / "train"),
            "--val_dir", str(tmp_path / "val"), "--log_every", "1"]
