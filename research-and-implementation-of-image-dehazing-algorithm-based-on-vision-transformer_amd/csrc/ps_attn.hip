@@ -88,28 +88,48 @@ __global__ __launch_bounds__(256) void ps_attn_fwd_kernel(const T* __restrict__ 
                                                           const uint8_t* __restrict__ idx,
                                                           const float* __restrict__ bias,
                                                           const float* __restrict__ mask, T* __restrict__ out,
-                                                          int ldo, uint8_t* __restrict__ rank_out, int H, int nW) {
+                                                          int ldo, uint8_t* __restrict__ rank_out, int H, int nW, int nwh) {
     constexpr int DS = D + 4;
     constexpr int F = D / 4;            // float4 per row
     constexpr int RPP = 256 / F;        // rows per load pass
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     FwdSmem<D>& sm = *reinterpret_cast<FwdSmem<D>*>(smem_raw);
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-    const int b = blockIdx.x / H, h = blockIdx.x % H;
+    // Persistent workgroups walk the window-heads wh = blockIdx.x, + gridDim.x, ...; the Q, K, V rows of the NEXT window-head are
+    // fetched into registers (native vectors, so that they stay there) while the current one runs its six barrier-separated
+    // phases - otherwise every window-head opens with the full HBM latency exposed (the backward kernel does the same).
+    constexpr int NR = NT / RPP;                       // staged rows per thread and tensor
+    f32x4 pq[NR], pk[NR], pv[NR];
+    auto prefetch = [&](int wh_) {
+        const size_t tk0 = (size_t)(wh_ / H) * NT;
+        const int hh = wh_ % H, c4 = t % F;
+#pragma unroll
+        for (int p = 0; p < NR; ++p) {
+            const size_t g = (tk0 + p * RPP + t / F) * ld + hh * D + c4 * 4;
+            pq[p] = ld4v(q + g);
+            pk[p] = ld4v(k + g);
+            pv[p] = ld4v(v + g);
+        }
+    };
+    if (t < NT * NU / 16) reinterpret_cast<uint4*>(sm.idx)[t] = reinterpret_cast<const uint4*>(idx)[t];   // shared by all window-heads
+    if ((int)blockIdx.x < nwh) prefetch(blockIdx.x);
+#pragma unroll 1
+    for (int wh = blockIdx.x; wh < nwh; wh += gridDim.x) {
+    const int b = wh / H, h = wh % H;
     const size_t tok0 = (size_t)b * NT;
+    __syncthreads();                                   // the previous window-head's scatter has read O / rank
 
-    // ---- stage Q,K,V (+ the shared sample index table) into LDS
+    // ---- stage Q,K,V into LDS, then start the next window-head's loads
     {
         const int c4 = t % F;
 #pragma unroll
-        for (int p = 0; p < NT / RPP; ++p) {
+        for (int p = 0; p < NR; ++p) {
             const int row = p * RPP + t / F;
-            const size_t g = (tok0 + row) * ld + h * D + c4 * 4;
-            *reinterpret_cast<float4*>(&sm.q[row * DS + c4 * 4]) = ld4(q + g);
-            *reinterpret_cast<float4*>(&sm.k[row * DS + c4 * 4]) = ld4(k + g);
-            *reinterpret_cast<float4*>(&sm.v[row * DS + c4 * 4]) = ld4(v + g);
+            *reinterpret_cast<f32x4*>(&sm.q[row * DS + c4 * 4]) = pq[p];
+            *reinterpret_cast<f32x4*>(&sm.k[row * DS + c4 * 4]) = pk[p];
+            *reinterpret_cast<f32x4*>(&sm.v[row * DS + c4 * 4]) = pv[p];
         }
-        if (t < NT * NU / 16) reinterpret_cast<uint4*>(sm.idx)[t] = reinterpret_cast<const uint4*>(idx)[t];
+        if (wh + (int)gridDim.x < nwh) prefetch(wh + gridDim.x);
     }
     __syncthreads();
 
@@ -219,9 +239,10 @@ __global__ __launch_bounds__(256) void ps_attn_fwd_kernel(const T* __restrict__ 
             const int r = sm.rank[row] < NU ? sm.rank[row] : NU;
             st4(out + (tok0 + row) * ldo + h * D + c4 * 4, *reinterpret_cast<const float4*>(&O[r * DS + c4 * 4]));
         }
-        if (t < NT / 4) reinterpret_cast<uint32_t*>(rank_out + (size_t)blockIdx.x * NT)[t] =
+        if (t < NT / 4) reinterpret_cast<uint32_t*>(rank_out + (size_t)wh * NT)[t] =
             reinterpret_cast<const uint32_t*>(sm.rank)[t];
     }
+    }   // window-head loop
 }
 
 // ------------------------------------------------------------------------------------------------ backward
@@ -560,14 +581,17 @@ static int ps_attn_fwd_t(const T* q, const T* k, const T* v, int ld, const uint8
     DHZ_REQUIRE(ld % 4 == 0 && ldo % 4 == 0 && ld >= H * d && ldo >= H * d, "dhz_ps_attn_fwd: bad ld %d/%d", ld, ldo);
     DHZ_REQUIRE(!mask || (nW > 0 && B_ % nW == 0), "dhz_ps_attn_fwd: B_=%d not a multiple of nW=%d", B_, nW);
     hipStream_t s = (hipStream_t)stream;
+    // persistent: as many workgroups as stay resident (LDS: 48.6 KiB at d = 32 -> 3 per CU, 66.6 KiB at d = 64 -> 2 per CU)
+    const int resident = 256 * (d == 32 ? 3 : 2);
+    const int grid = B_ * H < resident ? B_ * H : resident;
     if (d == 32) {
         allow_smem(reinterpret_cast<const void*>(&ps_attn_fwd_kernel<32, T>), sizeof(FwdSmem<32>));
-        hipLaunchKernelGGL((ps_attn_fwd_kernel<32, T>), dim3(B_ * H), dim3(256), sizeof(FwdSmem<32>), s, q, k, v, ld, idx,
-                           bias, mask, out, ldo, rank, H, nW > 0 ? nW : 1);
+        hipLaunchKernelGGL((ps_attn_fwd_kernel<32, T>), dim3(grid), dim3(256), sizeof(FwdSmem<32>), s, q, k, v, ld, idx,
+                           bias, mask, out, ldo, rank, H, nW > 0 ? nW : 1, B_ * H);
     } else {
         allow_smem(reinterpret_cast<const void*>(&ps_attn_fwd_kernel<64, T>), sizeof(FwdSmem<64>));
-        hipLaunchKernelGGL((ps_attn_fwd_kernel<64, T>), dim3(B_ * H), dim3(256), sizeof(FwdSmem<64>), s, q, k, v, ld, idx,
-                           bias, mask, out, ldo, rank, H, nW > 0 ? nW : 1);
+        hipLaunchKernelGGL((ps_attn_fwd_kernel<64, T>), dim3(grid), dim3(256), sizeof(FwdSmem<64>), s, q, k, v, ld, idx,
+                           bias, mask, out, ldo, rank, H, nW > 0 ? nW : 1, B_ * H);
     }
     DHZ_CHECK_LAUNCH("dhz_ps_attn_fwd");
     return DHZ_OK;
