@@ -44,10 +44,11 @@ struct FwdCfg {
     static constexpr int W1_F = HC * C, W2_F = C * HC;
     static constexpr int G_F = NPOS * HC, Z_F = NINT * HC;
     static constexpr int OFF_W1 = XN_F, OFF_W2 = OFF_W1 + W1_F, OFF_G = OFF_W2 + W2_F, OFF_Z = OFF_G + G_F;
-    static constexpr int TOTAL_F = OFF_Z + Z_F;
+    static constexpr int OFF_U = OFF_Z + Z_F;             // raw u of the interior tokens (training): stored by P3 as full lines
+    static constexpr int TOTAL_F = OFF_U + Z_F;
     static constexpr size_t SMEM = (size_t)TOTAL_F * sizeof(float);
     static_assert(NINT * (C + 4) <= XN_F, "epilogue staging must fit in the xn image");
-    static_assert(12 * 16 * C <= TOTAL_F, "padded rows of the xn image must stay inside the allocation");
+    static_assert(12 * 16 * C <= OFF_U, "padded rows of the xn image must stay inside the allocation");
 };
 
 template <int C, int HC, int NW>
@@ -69,6 +70,7 @@ __global__ __launch_bounds__(64 * NW) void leff_fused_fwd_kernel(
     float* const XN = smem;
     float* const GS = smem + Cfg::OFF_G;
     float* const ZS = smem + Cfg::OFF_Z;
+    float* const US = smem + Cfg::OFF_U;
 
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int i16 = lane & 15, g = lane >> 4;
@@ -162,7 +164,7 @@ __global__ __launch_bounds__(64 * NW) void leff_fused_fwd_kernel(
 
     // ---- per-lane bookkeeping of the P1 rows this lane owns in the accumulator layout: row = 16 (rt0 + a) + 4 g + j
     const int rt0 = 3 * (w & 3), ct1 = w >> 2;
-    int tokoff[3][4];          // token offset inside the image for interior rows, -1 otherwise
+    int tokoff[3][4];          // interior rows: index of the token inside the 8 x 16 tile (0..127), -1 otherwise
     unsigned inmask = 0;       // bit (4 a + j): row is inside the image (and < 180)
 #pragma unroll
     for (int a = 0; a < 3; ++a)
@@ -174,7 +176,7 @@ __global__ __launch_bounds__(64 * NW) void leff_fused_fwd_kernel(
             const bool in = r < NPOS && yy >= 0 && yy < Hres && xx >= 0 && xx < Wres;
             const bool interior = hy >= 1 && hy <= TH && hx >= 1 && hx <= TW;
             if (in) inmask |= 1u << (4 * a + j);
-            tokoff[a][j] = (in && interior) ? yy * Wres + xx : -1;
+            tokoff[a][j] = (in && interior) ? (hy - 1) * TW + (hx - 1) : -1;
         }
 
     f32x4 yacc[RT2][CT2];
@@ -223,7 +225,7 @@ __global__ __launch_bounds__(64 * NW) void leff_fused_fwd_kernel(
                 for (int j = 0; j < 4; ++j) {
                     const int r = 16 * (rt0 + a) + 4 * g + j;
                     const float u = acc[a][j] + b1v;
-                    if (train && tokoff[a][j] >= 0) u_save[(tokbase + tokoff[a][j]) * Ch + hc0 + hcol] = u;
+                    if (train && tokoff[a][j] >= 0) US[tokoff[a][j] * HC + hcol] = u;     // -> P3 stores it with z and gelu'(t)
                     const float gv = ((inmask >> (4 * a + j)) & 1) ? gelu_f(u) : 0.f;
                     if (r < NPOS) GS[r * HC + hcol] = gv;
                 }
@@ -255,6 +257,7 @@ __global__ __launch_bounds__(64 * NW) void leff_fused_fwd_kernel(
                 const size_t o = (tokbase + (size_t)(y0 + 1 + py) * Wres + (x0 + 1 + px)) * Ch + hc0 + 4 * c4;
                 *reinterpret_cast<f32x4*>(z_save + o) = zz;
                 *reinterpret_cast<f32x4*>(tp_save + o) = zp;
+                *reinterpret_cast<f32x4*>(u_save + o) = *reinterpret_cast<const f32x4*>(&US[p * HC + 4 * c4]);
             }
         }
         __syncthreads();
@@ -305,7 +308,9 @@ int launch_fwd(const float* x, const float* gamma, const float* beta, const floa
     const int tiles_x = Wres / TW, tiles_y = Hres / TH;
     auto kern = &leff_fused_fwd_kernel<C, HC, NW>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::SMEM);
-    hipLaunchKernelGGL(kern, dim3(B * tiles_x * tiles_y), dim3(Cfg::NTHR), Cfg::SMEM, s, x, gamma, beta, W1, b1, wd, bd, W2, b2,
+    // the raw-u staging image is the last LDS region and only exists in training mode (two inference workgroups fit a CU without it)
+    const size_t smem = u_save ? Cfg::SMEM : Cfg::SMEM - (size_t)Cfg::Z_F * sizeof(float);
+    hipLaunchKernelGGL(kern, dim3(B * tiles_x * tiles_y), dim3(Cfg::NTHR), smem, s, x, gamma, beta, W1, b1, wd, bd, W2, b2,
                        scale, out, xn_save, stats_save, u_save, tp_save, z_save, Hres, Wres, tiles_x, tiles_y);
     return 0;
 }
