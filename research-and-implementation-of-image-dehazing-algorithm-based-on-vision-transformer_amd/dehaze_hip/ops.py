@@ -45,9 +45,22 @@ def _dt(t):
     return 1 if t.dtype == BF16 else 0
 
 
+# (flat fp32 parameter buffer, its bf16 shadow) when FlatAdamW keeps one (config 4): a weight that is a view of the flat buffer
+# gets the matching view of the shadow - one cast launch per step for all parameters instead of one per Linear and pass.
+BF16_SHADOW = None
+
+
 def bf16_copy(W):
-    """bf16 copy of an fp32 master weight for the bf16 GEMMs (one small cast kernel per use; parameters stay fp32)."""
-    return W if W.dtype == BF16 else W.detach().to(BF16)
+    """bf16 copy of an fp32 master weight for the bf16 GEMMs (parameters stay fp32)."""
+    if W.dtype == BF16:
+        return W
+    sh = BF16_SHADOW
+    if sh is not None and W.is_contiguous():
+        f32, b16 = sh
+        off = W.data_ptr() - f32.data_ptr()
+        if 0 <= off < 4 * f32.numel() and W.untyped_storage().data_ptr() == f32.untyped_storage().data_ptr():
+            return b16[off // 4: off // 4 + W.numel()].view(W.shape)
+    return W.detach().to(BF16)
 
 
 def _timed(name):

@@ -50,17 +50,17 @@ class FlatAdamW(torch.optim.Optimizer):
             return
         order = self._qkv_adjacent(list(reversed(self._live)))
         dev = order[0].device
-        # every parameter starts on a 16-byte boundary (the kernels read weights with 16-byte loads; the only sizes that are
-        # not multiples of 4 floats are the 225 x H bias tables of the 1- and 2-head stages): the pad floats stay zero in all
-        # four buffers (zero gradient -> zero moments -> zero update)
-        n = sum((p.numel() + 3) // 4 * 4 for p in order)
+        # every parameter starts on a 32-byte boundary: the kernels read weights with 16-byte loads, and the bf16 shadow of this
+        # buffer (config 4) must be 16-byte aligned too; the only sizes that are not multiples of 8 floats are the 225 x H bias
+        # tables.  The pad floats stay zero in all four buffers (zero gradient -> zero moments -> zero update)
+        n = sum((p.numel() + 7) // 8 * 8 for p in order)
         npad = n
         fp = torch.zeros(npad, device=dev, dtype=torch.float32)
         fg = torch.zeros(npad, device=dev, dtype=torch.float32)
         self._offsets = {}
         off = 0
         for p in order:
-            off = (off + 3) // 4 * 4
+            off = (off + 7) // 8 * 8
             k = p.numel()
             fp[off:off + k].copy_(p.data.reshape(-1))
             if p.grad is not None:
@@ -116,6 +116,17 @@ class FlatAdamW(torch.optim.Optimizer):
         f = self._flat
         ops.adamw_step_(f["p"], f["g"], f["m"], f["v"], g["lr"], g["betas"][0], g["betas"][1], g["eps"],
                         g["weight_decay"], self._step, self.grad_scale)
+        if "p16" in f:
+            f["p16"].copy_(f["p"])                   # refresh the bf16 shadow the bf16 GEMMs read (one cast launch)
+
+    def enable_bf16_shadow(self):
+        """Keep a bf16 copy of the flat parameter buffer, refreshed after every update, and let ops.bf16_copy hand out views
+        of it (BASELINE config 4)."""
+        self._ensure_flat()
+        f = self._flat
+        if "p16" not in f:
+            f["p16"] = f["p"].to(torch.bfloat16)
+        ops.BF16_SHADOW = (f["p"], f["p16"])
 
     # -- torch.optim.AdamW-compatible (positional) state
     def state_dict(self):
@@ -280,6 +291,9 @@ def train_step(model, char_loss, cr_loss, optimizer, reducer, input_, target, w_
     clamp(0,1) -> w_char*Charbonnier + w_cr*Contrast -> backward (bucketed all-reduce overlapped) ->
     AdamW.  Returns (loss, loss_rec, loss_cr) as device scalars (no host sync here; the reference's
     per-step .item() calls, TR:250-254, are left to the caller's logging cadence)."""
+    if getattr(model, "act_dtype", None) == torch.bfloat16 and isinstance(optimizer, FlatAdamW) and \
+            (ops.BF16_SHADOW is None or ops.BF16_SHADOW[0] is not optimizer._flat["p"]):
+        optimizer.enable_bf16_shadow()
     standalone = reducer is not None and reducer.opt is None          # torch optimizer + stand-alone reducer (--optimizer adam)
     if standalone:
         reducer.zero_grad()

@@ -146,7 +146,7 @@ def test_flat_buffer_layout_packs_qkv():
     assert len(sl) == len(live) and {id(p) for p, _, _ in sl} == {id(p) for p in live}
     off = 0
     for p, o, k in sl:
-        assert o == (off + 3) // 4 * 4 and k == p.numel()          # 16-byte aligned, back to back otherwise
+        assert o == (off + 7) // 8 * 8 and k == p.numel()          # 32-byte aligned, back to back otherwise
         off = o + k
     layers = [m for m in model.modules() if hasattr(m, "query_projection")]
     assert len(layers) == 18
