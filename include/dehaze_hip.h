@@ -112,6 +112,20 @@ int dhz_bias_gather(const float* table, float* bias, int H, void* stream);
 int dhz_bias_table_grad(const float* dbias_part, int parts, float* dtable, int H, int accumulate,
                         void* stream);
 
+/* K8  Downsample: Conv2d(Cin, Cout, kernel 4, stride 2, padding 1) on the token layout, M1:606-622, as implicit GEMMs on the fp32
+ *     matrix pipe (no im2col matrix: a tap of an output pixel is one contiguous run of Cin floats of a token).
+ *     x [B, H*W, Cin] -> y [B, (H/2)*(W/2), Cout].  wp = weight.permute(0,2,3,1) as [Cout, 16*Cin] (taps-major, channels
+ *     contiguous), wq = weight.permute(2,3,0,1) as [16*Cout, Cin]; H, W even; Cin, Cout multiples of 32.
+ *     dhz_conv4s2_fwd  : replaces aten::convolution (MIOpen implicit GEMM)             bias [Cout] or NULL
+ *     dhz_conv4s2_dgrad: dx [B, H*W, Cin] from dy [B, (H/2)*(W/2), Cout] (every element written; four parity-class GEMMs)
+ *     dhz_conv4s2_wgrad: dwp [Cout, 16*Cin] += dy^T xcol, db [Cout] += column sums (ACCUMULATED, fp32 atomics; db may be NULL);
+ *                        the output map sizes must be powers of two (training patch sizes 128 / 256). */
+int dhz_conv4s2_fwd(const float* x, const float* wp, const float* bias, float* y, int B, int H, int W, int Cin, int Cout,
+                    void* stream);
+int dhz_conv4s2_dgrad(const float* dy, const float* wq, float* dx, int B, int H, int W, int Cin, int Cout, void* stream);
+int dhz_conv4s2_wgrad(const float* dy, const float* x, float* dwp, float* db, int B, int H, int W, int Cin, int Cout,
+                      void* stream);
+
 /* K5 fused  The whole LeFF branch of a LeWin block for C = 32, 64, 128 (hidden width 4C), forward, in one kernel:
  *     out = x + drop_scale[b] * linear2(gelu(dwconv3x3(gelu(linear1(norm2(x))))))          replaces M1:873 + M1:496-534
  *     (LayerNorm, both Linears on the fp32 matrix pipe around an LDS-resident 8x16-pixel tile + halo, both GELUs, the

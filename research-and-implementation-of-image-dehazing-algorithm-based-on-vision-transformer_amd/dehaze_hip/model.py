@@ -356,6 +356,12 @@ class Downsample(nn.Module):
         self.in_channel, self.out_channel = in_channel, out_channel
 
     def forward(self, x):
+        conv = self.conv[0]
+        s_ = int(math.sqrt(x.shape[1]))
+        need_grad = torch.is_grad_enabled() and (x.requires_grad or conv.weight.requires_grad)
+        if s_ * s_ == x.shape[1] and ops.conv4s2_supported(x, s_, s_, need_grad) and self.out_channel % 32 == 0:
+            # implicit GEMM on the fp32 matrix pipe straight from / to the token layout (csrc/conv_gemm.hip)
+            return ops.conv4s2_tokens(x, conv.weight, conv.bias, s_, s_)
         if x.dtype == torch.bfloat16:       # config 4: library convolution in bf16 (weights cast by autocast, fp32 masters)
             with torch.autocast("cuda", dtype=torch.bfloat16):
                 return _map_to_tokens(self.conv(_tokens_to_map(x)))

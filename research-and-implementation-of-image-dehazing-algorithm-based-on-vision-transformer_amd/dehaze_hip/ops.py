@@ -607,3 +607,72 @@ class _ThinConv(Function):
 
 def thin_conv3x3(x, w, b, H, W):
     return _ThinConv.apply(x, w, b, H, W)
+
+
+# ----------------------------------------------------------------------------- K8: 4x4 / stride-2 down-sampling convolution
+def conv4s2_supported(x, H, W, need_grad):
+    """Shapes the implicit-GEMM kernels take (csrc/conv_gemm.hip): fp32 tokens, even map, channels multiples of 32; the weight
+    gradient additionally wants power-of-two output maps (the training patch sizes 128 / 256)."""
+    Cin = x.shape[-1]
+    ok = x.is_cuda and x.dtype == torch.float32 and H % 2 == 0 and W % 2 == 0 and Cin % 32 == 0
+    if ok and need_grad:
+        Ho, Wo = H // 2, W // 2
+        ok = (Ho & (Ho - 1)) == 0 and (Wo & (Wo - 1)) == 0 and (x.shape[0] * Ho * Wo) % 32 == 0
+    return ok
+
+
+class _Conv4s2(Function):
+    """Downsample.conv on the token layout (M1:606-622): x [B, H*W, Cin] -> [B, (H/2)*(W/2), Cout]."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, H, W):
+        _require_gpu(x, w, b)
+        x = x.contiguous()
+        B, L, Cin = x.shape
+        Cout = w.shape[0]
+        assert L == H * W and tuple(w.shape) == (Cout, Cin, 4, 4)
+        wp = w.detach().permute(0, 2, 3, 1).reshape(Cout, 16 * Cin).contiguous()      # [co][(ky, kx, ci)]
+        y = torch.empty((B, L // 4, Cout), device=x.device, dtype=torch.float32)
+        _lib.call("dhz_conv4s2_fwd", _p(x), _p(wp), _p(b), _p(y), B, H, W, Cin, Cout, _stream())
+        ctx.save_for_backward(x, w)
+        ctx.params, ctx.geom = (w, b), (B, H, W, Cin, Cout)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w_ = ctx.saved_tensors
+        w, b = ctx.params
+        B, H, W, Cin, Cout = ctx.geom
+        dy = dy.contiguous()
+        dx = None
+        if ctx.needs_input_grad[0]:
+            wq = w_.detach().permute(2, 3, 0, 1).contiguous()                         # [(ky, kx, co)][ci]
+            dx = torch.empty_like(x)
+            _lib.call("dhz_conv4s2_dgrad", _p(dy), _p(wq), _p(dx), B, H, W, Cin, Cout, _stream())
+        gw = gb = None
+        if w.requires_grad or (b is not None and b.requires_grad):
+            dwp = torch.zeros((Cout, 16 * Cin), device=x.device, dtype=torch.float32)
+            inplace_b = b is not None and b.is_leaf and b.requires_grad
+            if inplace_b and b.grad is None:
+                b.grad = torch.zeros_like(b)
+            dbv = b.grad if inplace_b else (torch.zeros_like(b) if b is not None else None)
+            _lib.call("dhz_conv4s2_wgrad", _p(dy), _p(x), _p(dwp), _p(dbv), B, H, W, Cin, Cout, _stream())
+            dw = dwp.view(Cout, 4, 4, Cin).permute(0, 3, 1, 2)                        # back to [co][ci][ky][kx]
+            if w.is_leaf and w.requires_grad:
+                if w.grad is None:
+                    w.grad = torch.zeros_like(w, memory_format=torch.contiguous_format)
+                w.grad.add_(dw)
+                if GRAD_READY is not None:
+                    GRAD_READY(w)
+            else:
+                gw = dw.contiguous()
+            if inplace_b:
+                if GRAD_READY is not None:
+                    GRAD_READY(b)
+            else:
+                gb = dbv
+        return dx, gw, gb, None, None
+
+
+def conv4s2_tokens(x, w, b, H, W):
+    return _Conv4s2.apply(x, w, b, H, W)
