@@ -3,7 +3,7 @@
 PyTorch is plumbing here: it owns device memory (caching allocator), the current HIP stream and the
 autograd tape; the ops below run hand-written gfx950 kernels through ctypes (the token-Linear GEMMs included:
 dhz_linear_fwd / dhz_linear_dgrad / dhz_linear_wgrad).  What still runs on vendor libraries is listed in DESIGN.md §4
-(the 4x4/stride-2 down-sampling and 3->E input convolutions on MIOpen).  CPU tensors are rejected - there is no
+(the 3->E input convolution and the 8x8 last VGG layer on MIOpen; the library convolutions of the bf16 mode).  CPU tensors are rejected - there is no
 fallback path.
 """
 import ctypes
