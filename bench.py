@@ -66,18 +66,23 @@ def cpu_baseline(bs=2):
     opt = torch.optim.AdamW(params, lr=2e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.02)
     gt, hazy = synthetic_batch(bs, 128, seed=99)
     cores = torch.get_num_threads()
-    med_n = _cpu_steps(P, params, opt, hazy, gt, None, 0.0, 3)
+    med = {}
+    med[cores] = _cpu_steps(P, params, opt, hazy, gt, None, 0.0, 3)
     med_cr = _cpu_steps(P, params, opt, hazy, gt, O.seeded_vgg_weights(), 1.0, 2)
-    torch.set_num_threads(1)
     try:
-        med_1 = _cpu_steps(P, params, opt, hazy, gt, None, 0.0, 1)
+        for n in (8, 1):                                 # the survey container's 8 threads, and one thread
+            if n < cores:
+                torch.set_num_threads(n)
+                med[n] = _cpu_steps(P, params, opt, hazy, gt, None, 0.0, 2 if n > 1 else 1)
     finally:
         torch.set_num_threads(cores)
-    return {"value": round(bs / med_n, 4), "unit": "patches/s", "cores": cores, "kind": "port",
-            "sample": f"CPU oracle, E=32 ps=128 bs={bs} fp32 AdamW, median of the timed steps after 1 warm-up: config-1 recipe "
-                      f"(Charbonnier only) {med_n:.3f} s/step at {cores} threads (3 steps) and {med_1:.3f} s/step at 1 thread "
-                      f"(1 step); config-2 step (Charbonnier + VGG19 contrastive loss) {med_cr:.3f} s/step at {cores} threads (2 steps)",
-            "value_1_thread": round(bs / med_1, 4), "value_config2_with_cr": round(bs / med_cr, 4),
+    best = min(med, key=med.get)                          # a shared many-core host can be slower at every core than at one
+    per_threads = {str(n): round(bs / t, 4) for n, t in sorted(med.items())}
+    return {"value": round(bs / med[best], 4), "unit": "patches/s", "cores": best, "kind": "port",
+            "sample": f"CPU oracle, E=32 ps=128 bs={bs} fp32 AdamW, config-1 recipe (Charbonnier only), median s/step after 1 warm-up: "
+                      + ", ".join(f"{t:.3f} at {n} thread{'s' if n > 1 else ''}" for n, t in sorted(med.items()))
+                      + f"; value = the fastest; config-2 step (Charbonnier + VGG19 contrastive loss) {med_cr:.3f} s/step at {cores} threads",
+            "patches_per_s_by_threads": per_threads, "value_config2_with_cr": round(bs / med_cr, 4),
             "survey_container_reference": {"patches_per_s_8_threads": 1.98, "patches_per_s_1_thread": 0.40,
                                            "note": "the reference's own My_model_1.Uformer, config-1 recipe, BASELINE.md section 2"}}
 
