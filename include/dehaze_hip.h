@@ -112,6 +112,16 @@ int dhz_bias_gather(const float* table, float* bias, int H, void* stream);
 int dhz_bias_table_grad(const float* dbias_part, int parts, float* dtable, int H, int accumulate,
                         void* stream);
 
+/* K9  InputProj: Conv2d(3, E, 3x3, padding 1) + LeakyReLU(slope) from the NCHW image into the token layout, M1:659-682
+ *     (replaces aten::convolution + aten::leaky_relu_ + the NCHW -> token copy), E = 32 or 64.
+ *     dhz_input_proj_fwd: img [B,3,H,W], w [E,3,3,3], bias [E] -> y [B, H*W, E].
+ *     dhz_input_proj_bwd: dy, y (the forward output: the LeakyReLU mask is its sign) -> dw [E,3,3,3], db [E] ACCUMULATED (fp32
+ *     atomics, caller zeroes).  The image needs no gradient on this path (M1:1169). */
+int dhz_input_proj_fwd(const float* img, const float* w, const float* bias, float* y, int B, int H, int W, int E, float slope,
+                       void* stream);
+int dhz_input_proj_bwd(const float* dy, const float* y, const float* img, float* dw, float* db, int B, int H, int W, int E,
+                       float slope, void* stream);
+
 /* K8  Downsample: Conv2d(Cin, Cout, kernel 4, stride 2, padding 1) on the token layout, M1:606-622, as implicit GEMMs on the fp32
  *     matrix pipe (no im2col matrix: a tap of an output pixel is one contiguous run of Cin floats of a token).
  *     x [B, H*W, Cin] -> y [B, (H/2)*(W/2), Cout].  wp = weight.permute(0,2,3,1) as [Cout, 16*Cin] (taps-major, channels

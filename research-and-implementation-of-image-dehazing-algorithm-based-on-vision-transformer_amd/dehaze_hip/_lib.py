@@ -47,6 +47,8 @@ SIGNATURES = {
     "dhz_leff_fused_bwd": [c_f] * 12 + [c_i, c_i, c_i, c_i, c_p],
     "dhz_linear_fwd": [c_f, c_i, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_p],
     "dhz_linear_dgrad": [c_f, c_i, c_f, c_f, c_i, c_i, c_i, c_i, c_p],
+    "dhz_input_proj_fwd": [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_fl, c_p],
+    "dhz_input_proj_bwd": [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_fl, c_p],
     "dhz_conv4s2_fwd": [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_p],
     "dhz_conv4s2_dgrad": [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_p],
     "dhz_conv4s2_wgrad": [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_p],

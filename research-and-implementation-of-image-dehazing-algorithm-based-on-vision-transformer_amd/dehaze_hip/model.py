@@ -431,7 +431,13 @@ class InputProj(nn.Module):
         self.in_channel, self.out_channel = in_channel, out_channel
 
     def forward(self, x):
-        x = _map_to_tokens(self.proj(x.contiguous(memory_format=torch.channels_last)))
+        conv, act = self.proj[0], self.proj[1]
+        if (x.is_cuda and x.dtype == torch.float32 and self.in_channel == 3 and self.out_channel in (32, 64)
+                and conv.stride == (1, 1) and isinstance(act, nn.LeakyReLU) and not x.requires_grad):
+            # convolution + LeakyReLU straight into the token layout (csrc/input_proj.hip)
+            x = ops.input_proj(x, conv.weight, conv.bias, act.negative_slope)
+        else:
+            x = _map_to_tokens(self.proj(x.contiguous(memory_format=torch.channels_last)))
         return self.norm(x) if self.norm is not None else x
 
 

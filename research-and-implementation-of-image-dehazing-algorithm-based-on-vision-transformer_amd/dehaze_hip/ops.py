@@ -3,7 +3,7 @@
 PyTorch is plumbing here: it owns device memory (caching allocator), the current HIP stream and the
 autograd tape; the ops below run hand-written gfx950 kernels through ctypes (the token-Linear GEMMs included:
 dhz_linear_fwd / dhz_linear_dgrad / dhz_linear_wgrad).  What still runs on vendor libraries is listed in DESIGN.md §4
-(the 3->E input convolution and the 8x8 last VGG layer on MIOpen; the library convolutions of the bf16 mode).  CPU tensors are rejected - there is no
+(the 8x8 last VGG layer on MIOpen; the library convolutions of the bf16 mode).  CPU tensors are rejected - there is no
 fallback path.
 """
 import ctypes
@@ -676,3 +676,48 @@ class _Conv4s2(Function):
 
 def conv4s2_tokens(x, w, b, H, W):
     return _Conv4s2.apply(x, w, b, H, W)
+
+
+# ----------------------------------------------------------------------------- K9: input projection
+class _InputProj(Function):
+    """Conv2d(3, E, 3x3, pad 1) + LeakyReLU from the NCHW image into tokens [B, H*W, E] (M1:659-682)."""
+
+    @staticmethod
+    def forward(ctx, img, w, b, slope):
+        _require_gpu(img, w, b)
+        img = img.contiguous()
+        B, _, H, W = img.shape
+        E = w.shape[0]
+        y = torch.empty((B, H * W, E), device=img.device, dtype=torch.float32)
+        _lib.call("dhz_input_proj_fwd", _p(img), _p(w.contiguous()), _p(b), _p(y), B, H, W, E, float(slope), _stream())
+        ctx.save_for_backward(img, y)
+        ctx.params, ctx.slope = (w, b), float(slope)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        img, y = ctx.saved_tensors
+        w, b = ctx.params
+        if ctx.needs_input_grad[0]:
+            raise RuntimeError("dehaze_hip: InputProj has no backward-data kernel (the image never needs a gradient on this path)")
+        B, _, H, W = img.shape
+        E = w.shape[0]
+        inplace = w.is_leaf and w.requires_grad and b.is_leaf and b.requires_grad
+        if inplace:
+            for p_ in (w, b):
+                if p_.grad is None:
+                    p_.grad = torch.zeros_like(p_, memory_format=torch.contiguous_format)
+            inplace = w.grad.is_contiguous()
+        gw = w.grad if inplace else torch.zeros_like(w, memory_format=torch.contiguous_format)
+        gb = b.grad if inplace else torch.zeros_like(b)
+        _lib.call("dhz_input_proj_bwd", _p(dy.contiguous()), _p(y), _p(img), _p(gw), _p(gb), B, H, W, E, ctx.slope, _stream())
+        if inplace:
+            if GRAD_READY is not None:
+                GRAD_READY(w)
+                GRAD_READY(b)
+            return None, None, None, None
+        return None, gw, gb, None
+
+
+def input_proj(img, w, b, slope=0.01):
+    return _InputProj.apply(img, w, b, slope)

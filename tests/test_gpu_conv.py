@@ -78,3 +78,24 @@ def test_downsample_module_matches_library_conv():
     ya2 = ds(x.clone().requires_grad_())
     ya2.backward(gout)
     assert torch.allclose(ds.conv[0].weight.grad, 2 * ga[0], atol=4e-3, rtol=1e-3)
+
+
+@pytest.mark.parametrize("B,H,W,E", [(2, 32, 32, 32), (1, 48, 40, 64), (3, 16, 16, 32), (1, 128, 128, 32)])
+def test_input_proj_vs_torch(B, H, W, E):
+    """InputProj (conv3x3 3 -> E + LeakyReLU into tokens, csrc/input_proj.hip) against fp64 conv2d + leaky_relu and autograd,
+    through the module (weight / bias gradients accumulated in place) - maps that are not multiples of the 16 x 16 tile included."""
+    import My_model_1 as M1
+    dev = torch.device("cuda:0")
+    torch.manual_seed(B + H + E)
+    ip = M1.InputProj(in_channel=3, out_channel=E, kernel_size=3, stride=1, act_layer=torch.nn.LeakyReLU).to(dev)
+    img = torch.rand(B, 3, H, W, device=dev)
+    gout = torch.randn(B, H * W, E, device=dev)
+    y = ip(img)
+    y.backward(gout)
+    w64, b64 = ip.proj[0].weight.detach().double().cpu().requires_grad_(), ip.proj[0].bias.detach().double().cpu().requires_grad_()
+    yr = F.leaky_relu(F.conv2d(img.double().cpu(), w64, b64, padding=1), 0.01).permute(0, 2, 3, 1).reshape(B, H * W, E)
+    (yr * gout.double().cpu()).sum().backward()
+    assert (y.detach().cpu().double() - yr.detach()).abs().max() < 2e-5
+    T = B * H * W
+    assert (ip.proj[0].weight.grad.cpu().double() - w64.grad).abs().max() < 3e-6 * T ** 0.5 * max(1.0, w64.grad.abs().max().item() / T ** 0.5) + 1e-4
+    assert (ip.proj[0].bias.grad.cpu().double() - b64.grad).abs().max() < 3e-5 * T ** 0.5 + 1e-4
