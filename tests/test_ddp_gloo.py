@@ -84,6 +84,22 @@ def _worker(rank, world, port, q):
         bool(torch.allclose(p.grad, g_, atol=1e-5, rtol=1e-5)) for p, g_ in zip(params[1:], grads[1:]))
     w_grad_inplace = params[0].grad.clone()
     grads = grads + [w_grad_inplace]
+    # the `--optimizer adam` path of My_train.py: a torch optimizer's zero_grad() drops the .grad views (set_to_none); the
+    # reducer's zero_grad() re-binds them to its flat buffer, and one averaged step leaves the replicas identical
+    opt = torch.optim.Adam(params, lr=1e-2)
+    opt.zero_grad()
+    assert all(p.grad is None for p in params)
+    red.zero_grad()
+    ok_inplace = ok_inplace and all(p.grad is not None and red.flat.data_ptr() <= p.grad.data_ptr() < red.flat.data_ptr() + 4 * red.flat.numel()
+                                    for p in params)
+    ((net(xs) - ys) ** 2).sum().backward()
+    red.wait()
+    red.average_()
+    opt.step()
+    sums = torch.stack([p.detach().double().sum() for p in params])
+    both = [torch.zeros_like(sums) for _ in range(world)]
+    dist.all_gather(both, sums)
+    ok_inplace = ok_inplace and bool(torch.equal(both[0], both[1]))
     q.put((rank, [g.numpy().copy() for g in grads], ok_inplace))     # by value: torch tensors would travel as shm handles
                                                                      # that die with this process
     dist.barrier()
