@@ -291,9 +291,12 @@ def train_step(model, char_loss, cr_loss, optimizer, reducer, input_, target, w_
     clamp(0,1) -> w_char*Charbonnier + w_cr*Contrast -> backward (bucketed all-reduce overlapped) ->
     AdamW.  Returns (loss, loss_rec, loss_cr) as device scalars (no host sync here; the reference's
     per-step .item() calls, TR:250-254, are left to the caller's logging cadence)."""
-    if getattr(model, "act_dtype", None) == torch.bfloat16 and isinstance(optimizer, FlatAdamW) and \
-            (ops.BF16_SHADOW is None or ops.BF16_SHADOW[0] is not optimizer._flat["p"]):
-        optimizer.enable_bf16_shadow()
+    if getattr(model, "act_dtype", None) == torch.bfloat16 and isinstance(optimizer, FlatAdamW):
+        if ops.BF16_SHADOW is None or optimizer._flat is None or ops.BF16_SHADOW[0] is not optimizer._flat["p"]:
+            optimizer.enable_bf16_shadow()
+        else:
+            optimizer._flat["p16"].copy_(optimizer._flat["p"])    # one cast launch: parameters written outside step() (a loaded
+                                                                  # checkpoint, a landscape probe) must reach the bf16 GEMMs too
     standalone = reducer is not None and reducer.opt is None          # torch optimizer + stand-alone reducer (--optimizer adam)
     if standalone:
         reducer.zero_grad()

@@ -70,3 +70,17 @@ def test_bench_two_ranks_rccl():
     assert r.returncode == 0, r.stderr[-3000:]
     d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["global_batch"] == 64
+
+
+@pytest.mark.timeout(900)
+def test_bench_bf16_contract_line():
+    """bench.py --dtype bf16 (BASELINE config 4's recipe at a reduced size here: E = 64, 128 x 128, two patches): the contract line
+    with dtype "bf16" and the bf16-GEMM roofline object against the dense bf16 matrix peak."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "2", "--embed_dim", "64",
+                        "--ps", "128", "--batch", "2", "--dtype", "bf16", "--no-cpu-baseline"], capture_output=True, text=True,
+                       timeout=800, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert d["dtype"] == "bf16" and d["metric"] == "train patches/sec (128x128, embed_dim=64)" and d["config"]["global_batch"] == 2
+    ro = d["roofline"]
+    assert "bf16" in ro["kernel"] and ro["peak"] == 2500.0 and ro["unit"] == "TFLOP/s" and 0 < ro["frac"] < 1 and ro["launches"] > 0
