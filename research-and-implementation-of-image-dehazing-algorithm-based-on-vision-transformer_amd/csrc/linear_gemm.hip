@@ -11,13 +11,20 @@
 //   * W when !WT: [32 k][BN + 4] (row stride = 4 mod 8 floats -> the g = 0 / 1 halves of a ds_read_b32 hit disjoint banks).
 // Workgroups are persistent (two per CU) and pipeline across their tiles; the epilogue (+ bias) stores straight from the
 // accumulators.
+#include <stdlib.h>
 #include "common.h"
 
 namespace {
 
 constexpr int BK = 32;
+#ifndef DHZ_GEMM_NT
+#define DHZ_GEMM_NT 0
+#endif
+#ifndef DHZ_GEMM_ABL
+#define DHZ_GEMM_ABL 0           // timing diagnostics (tools/gemm_phases.sh): 1 = no epilogue stores, 2 = no MFMAs, 4 = no global operand loads
+#endif
 
-template <int WM, int WN, bool WT>
+template <int WM, int WN, bool WT, bool TR>
 __global__ __launch_bounds__(256) void linear_gemm_kernel(const float* __restrict__ A, int lda,
                                                           const float* __restrict__ W, int ldw,
                                                           const float* __restrict__ bias, float* __restrict__ Y, int ldy,
@@ -35,6 +42,7 @@ __global__ __launch_bounds__(256) void linear_gemm_kernel(const float* __restric
     const int i16 = lane & 15, g = lane >> 4;
     const int wm = w >> 1, wn = w & 1;
     const int nst = K / BK;
+    constexpr int abl = DHZ_GEMM_ABL;
 
     // Persistent workgroups: a workgroup walks the tiles bid, bid + grid, ... and treats their (tile, stage) pairs as ONE
     // stream of stages, so the loads of the next tile's first stage are in flight while the current tile finishes and its
@@ -75,6 +83,7 @@ __global__ __launch_bounds__(256) void linear_gemm_kernel(const float* __restric
         }
     };
     auto gload = [&](int k0) {
+        if (abl & 4) return;
 #pragma unroll
         for (int i = 0; i < NA; ++i) ra[i] = *reinterpret_cast<const f32x4*>(pa[i] + k0);
 #pragma unroll
@@ -144,7 +153,9 @@ __global__ __launch_bounds__(256) void linear_gemm_kernel(const float* __restric
 #pragma unroll
                     for (int a = 0; a < WM; ++a)
 #pragma unroll
-                        for (int b = 0; b < WN; ++b) acc[a][b] = mfma16(af[a][j], bf[b][j], acc[a][b]);
+                        for (int b = 0; b < WN; ++b)
+                            if (abl & 2) acc[a][b][j] += af[a][j] + bf[b][j];
+                            else acc[a][b] = TR ? mfma16(bf[b][j], af[a][j], acc[a][b]) : mfma16(af[a][j], bf[b][j], acc[a][b]);
             }
             if (more) {
                 swrite(buf ^ 1);
@@ -152,10 +163,37 @@ __global__ __launch_bounds__(256) void linear_gemm_kernel(const float* __restric
                 buf ^= 1;
             }
         }
-        // ---- tile epilogue straight from the accumulators: acc[a][b][j] = C[16 a + 4 g + j][16 b + i16]; the 16 lanes of a row
-        //      write 64 contiguous bytes and the b sweep completes the lines, which the L2 merges before they leave.  The stores
-        //      drain behind the next tile's matrix work (its first stage is already in LDS).
-        {
+        // ---- tile epilogue straight from the accumulators; the stores drain behind the next tile's matrix work (its first
+        //      stage is already in LDS).
+        //      !TR: acc[a][b][j] = C[16 a + 4 g + j][16 b + i16]: the 16 lanes of a row write 64 contiguous bytes, the b sweep
+        //           completes the lines (4-byte stores, 64 per wave at the 128 x 128 tile).
+        //      TR : the MFMAs took the WEIGHT fragment as their first operand, so a 16 x 16 block arrives transposed:
+        //           acc[a][b][j] = C[token 16 a + i16][feature 16 b + 4 g + j] - a lane owns four CONSECUTIVE features of one
+        //           token and stores them as one 16-byte vector (4 x fewer store instructions and address computations).
+        if (TR) {
+            const int m0 = tm * BM + wm * WM * 16 + i16, n0 = tn * BN + wn * WN * 16 + 4 * g;
+            f32x4 bv[WN];
+#pragma unroll
+            for (int b = 0; b < WN; ++b)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) bv[b][j] = bias ? bias[n0 + 16 * b + j] : 0.f;
+#pragma unroll
+            for (int a = 0; a < WM; ++a) {
+                const int m = m0 + 16 * a;
+                if (m < M && (!(abl & 1) || acc[a][0][0] == 12345.678f)) {
+                    float* yr = Y + (size_t)m * ldy + n0;
+#pragma unroll
+                    for (int b = 0; b < WN; ++b) {
+                        const f32x4 v = acc[a][b] + bv[b];
+#if DHZ_GEMM_NT
+                        __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(yr + 16 * b));
+#else
+                        *reinterpret_cast<f32x4*>(yr + 16 * b) = v;
+#endif
+                    }
+                }
+            }
+        } else {
             const int m0 = tm * BM + wm * WM * 16 + 4 * g, n0 = tn * BN + wn * WN * 16 + i16;
             float bv[WN];
 #pragma unroll
@@ -165,24 +203,30 @@ __global__ __launch_bounds__(256) void linear_gemm_kernel(const float* __restric
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int m = m0 + 16 * a + j;
-                    if (m < M) {
+                    if (m < M && (!(abl & 1) || acc[a][0][0] == 12345.678f)) {
                         float* yr = Y + (size_t)m * ldy + n0;
 #pragma unroll
-                        for (int b = 0; b < WN; ++b) yr[16 * b] = acc[a][b][j] + bv[b];
+                        for (int b = 0; b < WN; ++b) {
+#if DHZ_GEMM_NT
+                            __builtin_nontemporal_store(acc[a][b][j] + bv[b], yr + 16 * b);
+#else
+                            yr[16 * b] = acc[a][b][j] + bv[b];
+#endif
+                        }
                     }
                 }
-#pragma unroll
-            for (int a = 0; a < WM; ++a)
-#pragma unroll
-                for (int b = 0; b < WN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
+#pragma unroll
+        for (int a = 0; a < WM; ++a)
+#pragma unroll
+            for (int b = 0; b < WN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (ntile < 0) break;
         tile = ntile;
         ++ti;
     }
 }
 
-template <int WM, int WN, bool WT>
+template <int WM, int WN, bool WT, bool TR>
 void launch(const float* A, int lda, const float* W, int ldw, const float* bias, float* Y, int ldy, int M, int N, int K,
             hipStream_t s) {
     constexpr int BM = 32 * WM, BN = 32 * WN;
@@ -194,9 +238,9 @@ void launch(const float* A, int lda, const float* W, int ldw, const float* bias,
     const int slots = 512;
     const int grid = ntiles < slots ? ntiles : slots;
     if (smem > 48 * 1024)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_gemm_kernel<WM, WN, WT>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_gemm_kernel<WM, WN, WT, TR>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    hipLaunchKernelGGL((linear_gemm_kernel<WM, WN, WT>), dim3(grid), dim3(256), smem, s, A, lda, W, ldw, bias, Y, ldy, M, N,
+    hipLaunchKernelGGL((linear_gemm_kernel<WM, WN, WT, TR>), dim3(grid), dim3(256), smem, s, A, lda, W, ldw, bias, Y, ldy, M, N,
                        K, tiles_n, ntiles);
 }
 
@@ -222,8 +266,18 @@ int dispatch(const char* who, const float* A, int lda, const float* W, int ldw, 
             if (blocks > best_blocks) { best_blocks = blocks; wm = a; wn = b; }
         }
     }
-#define CASE(a, b) \
-    if (wm == a && wn == b) launch<a, b, WT>(A, lda, W, ldw, bias, Y, ldy, M, N, K, s);
+    // epilogue form (measured per shape, tools/bench_gemm_ab.py): the 16-byte transposed stores win while an output row is at
+    // most a few cache lines (16 consecutive rows of a store instruction then stay within one DRAM page), the 4-byte form wins on
+    // wide rows
+    bool tr = WT ? N <= 96 : (N <= 32 || (N <= 64 && K <= 64));
+#ifdef DHZ_DIAG
+    if (const char* e = getenv("DHZ_GEMM_TR")) tr = atoi(e) != 0;
+#endif
+#define CASE(a, b)                                                                      \
+    if (wm == a && wn == b) {                                                           \
+        if (tr) launch<a, b, WT, true>(A, lda, W, ldw, bias, Y, ldy, M, N, K, s);       \
+        else launch<a, b, WT, false>(A, lda, W, ldw, bias, Y, ldy, M, N, K, s);         \
+    }
     CASE(4, 1) CASE(4, 2) CASE(4, 3) CASE(4, 4) CASE(2, 1) CASE(2, 2) CASE(2, 3) CASE(2, 4)
 #undef CASE
     DHZ_CHECK_LAUNCH(who);

@@ -58,13 +58,18 @@ __device__ __forceinline__ void wave_sync() {
 // Epilogue: y = conv(x) [+ bias] [ReLU]  (forward)   or   y = mask > 0 ? conv(x) + addend : 0  (backward data: `mask` is
 // the saved post-ReLU activation at the OUTPUT positions, i.e. the ReLU of the layer below, `addend` the gradient that
 // reaches that activation from a loss tap) - so the hot loop is the same for both passes.
-template <bool FWD>
+//
+// Q8: 8 x 8 maps (the last VGG layer of the loss, conv5_1).  FOUR images form one virtual 16 x 16 block (2 x 2 arrangement): the
+// patch offsets carry the image of every pixel, the 4 x 4 input window of a tile is masked where it reaches into the
+// neighbouring image (that is where the tile's own image has its zero padding), and the stores scatter back per image.
+template <bool FWD, bool Q8>
 __global__ __launch_bounds__(512) void winograd_conv3x3_kernel(const float* __restrict__ x,
                                                            const float* __restrict__ upack,
                                                            const float* __restrict__ bias, int relu,
                                                            const float* __restrict__ out_mask,
                                                            const float* __restrict__ out_addend,
-                                                           float* __restrict__ y, int H, int W, int C, int K, int nblk, int xcd_group) {
+                                                           float* __restrict__ y, int H, int W, int C, int K, int nblk, int xcd_group,
+                                                           int nimg) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int t = threadIdx.x, lane = t & 63, w = t >> 6, half = w >> 2, wl = w & 3;
     const int i16 = lane & 15, g = lane >> 4;
@@ -81,8 +86,8 @@ __global__ __launch_bounds__(512) void winograd_conv3x3_kernel(const float* __re
     int blk = (lid / KBn) * 2 + half;
     const bool live = blk < nblk;                       // odd block count: the last workgroup's second half recomputes, stores nothing
     if (!live) blk = nblk - 1;
-    const int bx_n = W / 16, by_n = H / 16;
-    const int bimg = blk / (bx_n * by_n);
+    const int bx_n = Q8 ? 1 : W / 16, by_n = Q8 ? 1 : H / 16;
+    const int bimg = Q8 ? 0 : blk / (bx_n * by_n);              // Q8: the image is a property of the pixel (below)
     const int by = (blk / bx_n) % by_n, bx = blk % bx_n;
     const int wy0 = by * 16 + 4 * wl, ox0 = bx * 16;        // the wave's output rows wy0..wy0+3; patch origin (wy0-1, ox0-1)
     const size_t plane = (size_t)H * W * 8;                 // floats per (image, channel-group) plane
@@ -104,8 +109,12 @@ __global__ __launch_bounds__(512) void winograd_conv3x3_kernel(const float* __re
         const int hf = e & 1, p = e >> 1;
         const int py = p / 18, px = p % 18;
         const int iy = wy0 - 1 + py, ix = ox0 - 1 + px;
-        const bool in = e < 6 * 18 * 2 && iy >= 0 && iy < H && ix >= 0 && ix < W;
-        poff[i] = in ? (unsigned)((iy * W + ix) * 8 + hf * 4) : 0u;
+        const bool in = e < 6 * 18 * 2 && iy >= 0 && iy < (Q8 ? 16 : H) && ix >= 0 && ix < (Q8 ? 16 : W);
+        if (Q8) {
+            const int img = min(4 * blk + 2 * (iy >> 3) + (ix >> 3), nimg - 1);
+            poff[i] = in ? (unsigned)(img * (C / CC) * 512 + ((iy & 7) * 8 + (ix & 7)) * 8 + hf * 4) : 0u;
+        } else
+            poff[i] = in ? (unsigned)((iy * W + ix) * 8 + hf * 4) : 0u;
         pdst[i] = (2 * hf) * PPL + (in ? py * RS + px * 2 : 6 * RS + (lane & 15) * 2);
     }
     {
@@ -140,11 +149,23 @@ __global__ __launch_bounds__(512) void winograd_conv3x3_kernel(const float* __re
     // ---- input transform of the lane's (channel pair g, tile i16), both channels packed: d rows -> B^T d -> (B^T d) B
     f32x2 d[4][4];                                       // patch values, then B^T d, then the 16 V values (in place)
     const float* pread = pw + g * PPL + (2 * (i16 >> 3)) * RS + (i16 & 7) * 4;
+    // Q8: window row 0 / 3 (column 0 / 3) of a tile that starts / ends an 8-pixel image belongs to the neighbouring image
+    float fr0 = 1.f, fr3 = 1.f, fc0 = 1.f, fc3 = 1.f;
+    if (Q8) {
+        const int r0 = 4 * wl + 2 * (i16 >> 3), c0 = 2 * (i16 & 7);
+        fr0 = (r0 & 7) == 0 ? 0.f : 1.f; fr3 = ((r0 + 2) & 7) == 0 ? 0.f : 1.f;
+        fc0 = (c0 & 7) == 0 ? 0.f : 1.f; fc3 = ((c0 + 2) & 7) == 0 ? 0.f : 1.f;
+    }
     auto read_row = [&](int a) {
         const float4 q0 = *reinterpret_cast<const float4*>(pread + a * RS);       // px 0,1 x (c0,c1)
         const float4 q1 = *reinterpret_cast<const float4*>(pread + a * RS + 4);   // px 2,3
         d[a][0] = f32x2{q0.x, q0.y}; d[a][1] = f32x2{q0.z, q0.w};
         d[a][2] = f32x2{q1.x, q1.y}; d[a][3] = f32x2{q1.z, q1.w};
+        if (Q8) {
+            const float fr = a == 0 ? fr0 : a == 3 ? fr3 : 1.f;
+            d[a][0] *= fr * fc0; d[a][3] *= fr * fc3;
+            if (a == 0 || a == 3) { d[a][1] *= fr; d[a][2] *= fr; }
+        }
     };
     auto col_transform = [&](int b) {                    // B^T d, column b
         const f32x2 d0 = d[0][b], d1 = d[1][b], d2 = d[2][b], d3 = d[3][b];
@@ -312,7 +333,13 @@ __global__ __launch_bounds__(512) void winograd_conv3x3_kernel(const float* __re
             const int hf = e & 1, px = (e >> 1) & 15, py = (e >> 5) & 3, kg = e >> 7;
             const float* s0 = ys + (kg * 8 + hf * 4) * YS + py * 16 + px;
             float4 v4 = make_float4(s0[0], s0[YS], s0[2 * YS], s0[3 * YS]);
-            const size_t o = (((size_t)bimg * KG + kb * 4 + kg) * H + wy0 + py) * W * 8 + (size_t)(ox0 + px) * 8 + hf * 4;
+            size_t o;
+            if (Q8) {
+                const int vy = wy0 + py, img = 4 * blk + 2 * (vy >> 3) + (px >> 3);
+                if (img >= nimg) continue;
+                o = ((((size_t)img * KG + kb * 4 + kg) * 8 + (vy & 7)) * 8 + (px & 7)) * 8 + hf * 4;
+            } else
+                o = (((size_t)bimg * KG + kb * 4 + kg) * H + wy0 + py) * W * 8 + (size_t)(ox0 + px) * 8 + hf * 4;
             if (!FWD) {
                 if (out_addend) {
                     const float4 ad = *reinterpret_cast<const float4*>(out_addend + o);
@@ -494,11 +521,12 @@ extern "C" int dhz_winograd_prepack(const float* weight, float* upack, int Kout,
 extern "C" int dhz_winograd_conv3x3(const float* x, const float* upack, const float* bias, int relu, const float* out_mask,
                                     const float* out_addend, float* y, int B, int H, int W, int C, int K, void* stream) {
     DHZ_REQUIRE(x && upack && y, "dhz_winograd_conv3x3: null pointer");
-    DHZ_REQUIRE(B > 0 && H % 16 == 0 && W % 16 == 0 && C % CC == 0 && K % KB == 0,
+    const bool q8 = H == 8 && W == 8;                             // four 8 x 8 images per 16 x 16 block
+    DHZ_REQUIRE(B > 0 && ((H % 16 == 0 && W % 16 == 0) || q8) && C % CC == 0 && K % KB == 0,
                 "dhz_winograd_conv3x3: unsupported shape B=%d H=%d W=%d C=%d K=%d", B, H, W, C, K);
     const bool fwd = !(out_mask || out_addend);
     DHZ_REQUIRE(fwd || !(bias || relu), "dhz_winograd_conv3x3: bias/relu and out_mask/out_addend are exclusive");
-    const int nblk = B * (H / 16) * (W / 16);                     // 16x16-pixel output blocks, two per workgroup
+    const int nblk = q8 ? (B + 3) / 4 : B * (H / 16) * (W / 16);  // 16x16-pixel output blocks, two per workgroup
     const int grid = ((nblk + 1) / 2) * (K / KB);
     hipStream_t s = (hipStream_t)stream;
 #ifdef DHZ_DIAG
@@ -510,14 +538,15 @@ extern "C" int dhz_winograd_conv3x3(const float* x, const float* upack, const fl
     // measured (FETCH_SIZE, batch 64): 2-4x fewer HBM reads on the K <= 256 layers (reads ~= the input once), no change
     // at K = 512, never slower
     const int xcd_group = (grid % 8 == 0) && (xcd_env >= 0 ? xcd_env : 1);
-#define GO(F)                                                                                                      \
+#define GO(F, Q)                                                                                                   \
     do {                                                                                                           \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&winograd_conv3x3_kernel<F>),                      \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&winograd_conv3x3_kernel<F, Q>),                   \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)WINO_SMEM);                     \
-        hipLaunchKernelGGL((winograd_conv3x3_kernel<F>), dim3(grid), dim3(512), WINO_SMEM, s, x, upack, bias, relu,  \
-                           out_mask, out_addend, y, H, W, C, K, nblk, xcd_group);                                             \
+        hipLaunchKernelGGL((winograd_conv3x3_kernel<F, Q>), dim3(grid), dim3(512), WINO_SMEM, s, x, upack, bias, relu, \
+                           out_mask, out_addend, y, H, W, C, K, nblk, xcd_group, B);                               \
     } while (0)
-    if (fwd) GO(true); else GO(false);
+    if (q8) { if (fwd) GO(true, true); else GO(false, true); }
+    else { if (fwd) GO(true, false); else GO(false, false); }
 #undef GO
     DHZ_CHECK_LAUNCH("dhz_winograd_conv3x3");
     return DHZ_OK;

@@ -1,9 +1,9 @@
 """VGG19[:30] feature stack of the contrastive loss (My_CR.py:56-86) on the Winograd-MFMA convolution kernel.
 
-conv 12 (512 -> 512 on 8x8 maps, smaller than the Winograd kernel's 16x16 block) stays on the library; conv 0 (3 -> 64) runs
-thin-input kernels (dhz_conv3x3_in3_blocked forward with bias + ReLU straight into the blocked layout,
-dhz_thin_conv3x3_dgrad_blocked backward-data straight from it); convs 1..11 - 99 % of the FLOPs - run
-dhz_winograd_conv3x3 with bias + ReLU fused, in the channel-blocked NCHW8c layout end to end.  The filters are frozen
+conv 0 (3 -> 64) runs thin-input kernels (dhz_conv3x3_in3_blocked forward with bias + ReLU straight into the blocked layout,
+dhz_thin_conv3x3_dgrad_blocked backward-data straight from it); convs 1..12 run dhz_winograd_conv3x3 with bias + ReLU fused,
+in the channel-blocked NCHW8c layout end to end (conv 12 works on 8x8 maps for 128x128 patches: the kernel then packs four
+images into one of its 16x16 blocks).  The filters are frozen
 (My_CR.py:75-77), so their transform-domain forms (forward and backward-data) are prepacked once per device.
 
 Forward-only passes (target / hazy input, My_CR.py:102) save nothing; the pass on the restored image is one autograd
@@ -118,9 +118,8 @@ class VggEngine:
 
     # ---- full stack, forward only
     def forward_taps(self, x, save=None):
-        """x: [B,3,H,W] NCHW.  Returns the 5 tap features: taps 1-4 blocked [B,C/8,H,W,8], tap 5 NCHW.
-        `save` (dict) receives what the backward needs."""
-        c0, c12 = self.convs[0], self.convs[12]
+        """x: [B,3,H,W] NCHW.  Returns the 5 tap features, blocked [B,C/8,H,W,8].  `save` (dict) receives what the backward needs."""
+        c0 = self.convs[0]
         # first layer (3 -> 64): thin on the input side - convolution + bias + ReLU straight into the blocked layout
         xc = x.contiguous()
         cur = torch.empty((xc.shape[0], 8, xc.shape[2], xc.shape[3], 8), device=x.device, dtype=torch.float32)
@@ -128,18 +127,15 @@ class VggEngine:
                   xc.shape[3], 64, 1, _stream())
         acts = {0: cur}
         taps = [cur]
-        for i in range(1, 12):
+        for i in range(1, 13):
             cur = self.conv(i, cur)
             acts[i] = cur
             if i in TAPS:
                 taps.append(cur)
             if i in POOL_AFTER:
                 cur = pool_fwd(cur)
-        x12 = to_plain(cur)
-        a12 = F.relu(F.conv2d(x12, c12.weight, c12.bias, padding=1))
-        taps.append(a12)
         if save is not None:
-            save.update(x=x, acts=acts, x12=x12, a12=a12)
+            save.update(x=x, acts=acts)
         return taps
 
 
@@ -159,16 +155,11 @@ class _VggTaps(Function):
         eng, sv = ctx.engine, ctx.saved
         acts = sv["acts"]
         tap_grad = {0: g1, 2: g2, 4: g3, 8: g4}
-        c0, c12 = eng.convs[0], eng.convs[12]
+        c0 = eng.convs[0]
         with torch.no_grad():
             # G = gradient w.r.t. the PRE-activation of conv i (None while nothing has arrived from above)
-            G = None
-            if g5 is not None:                                               # conv 12 (library) -> pooled a11 -> a11, ReLU 11
-                g12 = g5 * (sv["a12"] > 0)
-                gx12 = torch.ops.aten.convolution_backward(g12, sv["x12"], c12.weight, None, [1, 1], [1, 1], [1, 1], False,
-                                                           [0, 0], 1, [True, False, False])[0]
-                G = pool_bwd_relu(to_blocked(gx12), acts[11])
-            for i in range(11, 0, -1):
+            G = g5 * (acts[12] > 0) if g5 is not None else None
+            for i in range(12, 0, -1):
                 below = i - 1                                                # conv i's input is a_{i-1} (pooled if i-1 in POOL_AFTER)
                 tg = tap_grad.get(below)
                 if G is None:

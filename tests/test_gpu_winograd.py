@@ -23,7 +23,10 @@ def _plain(xb, C):
     return out
 
 
-@pytest.mark.parametrize("B,C,K,H", [(2, 64, 64, 32), (1, 64, 128, 16), (2, 128, 128, 16), (1, 256, 512, 16), (3, 8, 32, 48)])
+# H = 8: the conv5_1 geometry - four 8 x 8 images share one 16 x 16 block of the kernel (B = 8: whole blocks; 5 and 3: a ragged
+# last block, odd block counts; 1: a single image)
+@pytest.mark.parametrize("B,C,K,H", [(2, 64, 64, 32), (1, 64, 128, 16), (2, 128, 128, 16), (1, 256, 512, 16), (3, 8, 32, 48),
+                                     (8, 64, 64, 8), (5, 32, 64, 8), (3, 128, 32, 8), (1, 32, 32, 8)])
 def test_winograd_forward_and_dgrad(B, C, K, H):
     from dehaze_hip import _lib
     dev = torch.device("cuda:0")
@@ -106,7 +109,8 @@ def test_contrast_loss_engine_vs_oracle(ablation):
     ref = a64.grad.float()
     err = (ad.grad.cpu() - ref).abs()
     assert err.max().item() < 3e-2 * ref.abs().max().item(), (err.max().item(), ref.abs().max().item())
-    assert err.mean().item() < 3e-3 * ref.abs().mean().item(), (err.mean().item(), ref.abs().mean().item())
+    # (mean: 4.4e-3 measured - every layer incl. conv5_1 now has the F(2x2,3x3) rounding error, 4.4e-7 absolute on O(1) features)
+    assert err.mean().item() < 8e-3 * ref.abs().mean().item(), (err.mean().item(), ref.abs().mean().item())
 
     feats = cl.vgg(a.to(dev))
     feats_o = O.vgg19_features(a.double(), W)

@@ -25,7 +25,8 @@ def timeit(fs, rounds=5, reps=5):
     return best
 
 
-only = sys.argv[1:] and [int(a) for a in sys.argv[1:]]
+nolib = "nolib" in sys.argv[1:]            # phase-ablation runs: only this library's kernels
+only = [int(a) for a in sys.argv[1:] if a != "nolib"]
 print(f"{'T':>7} {'K':>5} {'N':>5} | fwd: lib us  mine us   TB/s    TF | dgrad: lib us  mine us   TB/s    TF")
 tot = [0, 0, 0, 0]
 for T, C in [(524288, 32), (131072, 64), (32768, 128), (8192, 256), (2048, 512), (8192, 512), (32768, 256), (131072, 128), (524288, 64)]:
@@ -34,7 +35,10 @@ for T, C in [(524288, 32), (131072, 64), (32768, 128), (8192, 256), (2048, 512),
     for K, N in [(C, 3 * C), (C, C), (C, 4 * C), (4 * C, C)]:
         x = torch.randn(T, K, device=dev); W = torch.randn(N, K, device=dev) * 0.1; b = torch.randn(N, device=dev)
         dy = torch.randn(T, N, device=dev)
-        r = timeit([lambda: torch.addmm(b, x, W.t()), lambda: ops.gemm_fwd(x, W, b), lambda: dy @ W, lambda: ops.gemm_dgrad(dy, W)])
+        fs = [lambda: torch.addmm(b, x, W.t()), lambda: ops.gemm_fwd(x, W, b), lambda: dy @ W, lambda: ops.gemm_dgrad(dy, W)]
+        if nolib:
+            fs[0] = fs[1]; fs[2] = fs[3]
+        r = timeit(fs)
         gb = T * (N + K) * 4 / 1e12; tf = 2 * T * N * K / 1e12
         for i in range(4):
             tot[i] += r[i]
