@@ -261,6 +261,15 @@ int dhz_thin_conv3x3_dgrad_blocked(const float* gb, const float* w, float* dx, i
 int dhz_l1_pair_fwd(const float* a, const float* p, const float* n, float* sums, int64_t count, void* stream);
 int dhz_l1_pair_bwd(const float* a, const float* p, const float* n, const float* g, float* da, int64_t count, void* stream);
 
+/* K11c the scalar side of ContrastLoss.forward (My_CR.py:104-123) over k feature taps: d[i] = (ap_i, an_i) = sums[i] * inv_cnt[i];
+ *      out = (sum_i w_i ap_i / (an_i + 1e-7)  [ablation: sum_i w_i ap_i],  sum_i ap_i,  sum_i an_i).  Backward: g[i] = gradient of
+ *      (out . (g_loss, g_ap, g_an)) w.r.t. (ap_i, an_i); a NULL upstream gradient counts as zero.  Replaces the [k]-vector
+ *      mul / div / add / sum chain of torch ops.  1 <= k <= 64; all pointers device memory. */
+int dhz_contrast_combine_fwd(const float* sums, const float* inv_cnt, const float* w, int k, int ablation, float* d, float* out,
+                             void* stream);
+int dhz_contrast_combine_bwd(const float* d, const float* w, int k, int ablation, const float* g_loss, const float* g_ap,
+                             const float* g_an, float* g, void* stream);
+
 /* F2  training feed (dataset.py:17-77): batch item t = table[t] = (patch id, r, c, k) -> ps x ps crop at (r, c) of the
  *     uint8 [N,Hs,Ws,3] RGB patch pair in HBM, augmentation k of utils/dataset_utils.py:6-40 (0 id, 1-3 rot90 k with
  *     dims=[-1,-2], 4-7 the same followed by flip(-2)), float32 [n,3,ps,ps] = value / 255. */

@@ -207,6 +207,12 @@ __global__ __launch_bounds__(256) void reverse_residual_kernel(const T* __restri
 }
 
 // ------------------------------------------------------------------------------------------------ K5 middle
+#ifndef DWB_WAVES
+#define DWB_WAVES 3        // waves per SIMD the backward kernel is compiled for (3 workgroups per CU)
+#endif
+#ifndef DW_ABL
+#define DW_ABL 0        // timing diagnostics of leff_dwconv_bwd (tools/variants.sh): 2 no dw accumulation, 4 no u load, 8 no GELU
+#endif
 constexpr int TW = 16, TH = 8;                 // spatial tile (positions)
 constexpr int HWID = TW + 2, HHGT = TH + 2;    // with halo
 constexpr int CT = 32;                         // channels per workgroup (128 B per position)
@@ -281,14 +287,19 @@ __global__ __launch_bounds__(256) void leff_dwconv_fwd_kernel(const T* __restric
 
 // Backward: persistent over tiles of one channel group so that dw/db are accumulated in registers and
 // hit global memory with one atomic per (channel, tap) per workgroup.
+//   du[p]  = gelu'(u[p]) * sum_k w[k] dt[p - off(k)]          (transpose of the forward correlation), dt = dz * gelu'(t)
+//   dw[k]  = sum_q dt[q] g[q + off(k)] = sum_p g[p] dt[p - off(k)],  g = gelu(u)   (g and dt are zero outside the image)
+// Written over p, BOTH sums use the same nine dt neighbours of a position and only its own u: the tile stages dt (with a
+// one-pixel halo) in LDS, u is read once per position straight into registers and one GELU evaluation yields g and g'.
+// (The earlier form staged gelu(u) with a halo as well: 19 LDS reads and 2.4 GELU evaluations per element, 3.6 TB/s.)
 template <typename T>
-__global__ __launch_bounds__(256) void leff_dwconv_bwd_kernel(const T* __restrict__ dz, const T* __restrict__ u,
+__global__ __launch_bounds__(256, DWB_WAVES) void leff_dwconv_bwd_kernel(const T* __restrict__ dz, const T* __restrict__ u,
                                                               const T* __restrict__ tpre, const float* __restrict__ w,
                                                               T* __restrict__ du, float* __restrict__ dw,
                                                               float* __restrict__ db, int B, int Hres, int Wres, int Ch,
                                                               int tiles_x, int tiles_y, int wg_per_cg) {
-    __shared__ __attribute__((aligned(16))) float gs[HHGT * HWID * CT];    // gelu(u) with halo
     __shared__ __attribute__((aligned(16))) float ds[HHGT * HWID * CT];    // dt = dz * gelu'(t) with halo
+    __shared__ __attribute__((aligned(16))) float us[TH * TW * CT];        // u of the tile: each thread parks ITS OWN loads here
     __shared__ float red[32][CT];                                           // [pos-slot][channel] reduction scratch
     const int t = threadIdx.x;
     const int cg = blockIdx.x % (Ch / CT);
@@ -300,17 +311,28 @@ __global__ __launch_bounds__(256) void leff_dwconv_bwd_kernel(const T* __restric
 #pragma unroll
         for (int kk = 0; kk < 9; ++kk) { wk[c][kk] = w[(ch0 + c) * 9 + kk]; dwk[c][kk] = 0.f; }
     const int ntiles = B * tiles_x * tiles_y;
+    constexpr int NIT = TH * TW / 32;                                       // interior positions per thread
     for (int tile = wslot; tile < ntiles; tile += wg_per_cg) {
         const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, bimg = tile / (tiles_x * tiles_y);
         const int x0 = tx * TW - 1, y0 = ty * TH - 1;
         const size_t ib = (size_t)bimg * Hres * Wres;
         __syncthreads();
-        // staging in two batches of 3 positions per thread: all 9 loads of a batch are issued before any is
-        // consumed (branch-free, addresses clamped into the image) so that their latencies overlap
+        // this thread's u values (interior positions; clamped addresses, masked at the store): in flight across the staging
+        float4 uv[NIT];
+        if (!(DW_ABL & 4)) {
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int pos = (t >> 3) + 32 * it;
+                const int yy = min(ty * TH + pos / TW, Hres - 1), xx = min(tx * TW + pos % TW, Wres - 1);
+                uv[it] = ld4(u + (ib + (size_t)yy * Wres + xx) * Ch + ch0);
+            }
+        }
+        // staging of dt in two batches of 3 positions per thread: all loads of a batch are issued before any is consumed
+        // (branch-free, addresses clamped into the image) so that their latencies overlap
         constexpr int NPOS = HHGT * HWID;
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
-            float4 ru[3], rt[3], rz[3];
+            float4 rt[3], rz[3];
             bool ok[3];
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
@@ -320,38 +342,42 @@ __global__ __launch_bounds__(256) void leff_dwconv_bwd_kernel(const T* __restric
                 ok[i] = pos < NPOS && yy >= 0 && yy < Hres && xx >= 0 && xx < Wres;
                 const int yc = min(max(yy, 0), Hres - 1), xc = min(max(xx, 0), Wres - 1);
                 const size_t o = (ib + (size_t)yc * Wres + xc) * Ch + ch0;
-                ru[i] = ld4(u + o);
-                rt[i] = ld4(tpre + o);
+                rt[i] = ld4(tpre + o);                                   // tpre holds gelu'(t)
                 rz[i] = ld4(dz + o);
             }
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
                 const int pos = (t >> 3) + 32 * (3 * half + i);
                 if (pos < NPOS) {
-                    float4 gv = make_float4(0, 0, 0, 0), dv = make_float4(0, 0, 0, 0);
-                    if (ok[i]) {
-                        gv = make_float4(gelu_f(ru[i].x), gelu_f(ru[i].y), gelu_f(ru[i].z), gelu_f(ru[i].w));
-                        dv = make_float4(rz[i].x * rt[i].x, rz[i].y * rt[i].y, rz[i].z * rt[i].z, rz[i].w * rt[i].w);
-                    }
-                    *reinterpret_cast<float4*>(&gs[pos * CT + c4 * 4]) = gv;      // tpre holds gelu'(t)
+                    float4 dv = make_float4(0, 0, 0, 0);
+                    if (ok[i]) dv = make_float4(rz[i].x * rt[i].x, rz[i].y * rt[i].y, rz[i].z * rt[i].z, rz[i].w * rt[i].w);
                     *reinterpret_cast<float4*>(&ds[pos * CT + c4 * 4]) = dv;
                 }
             }
         }
+        if (!(DW_ABL & 4)) {
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) *reinterpret_cast<float4*>(&us[((t >> 3) + 32 * it) * CT + c4 * 4]) = uv[it];
+        }
         __syncthreads();
+        // the position loop is NOT unrolled (unrolled, the 36 neighbour reads of four positions are hoisted: 222 VGPRs, two
+        // workgroups per CU instead of three)
 #pragma unroll 1
-        for (int it = 0; it < TH * TW / 32; ++it) {
+        for (int it = 0; it < NIT; ++it) {
             const int pos = (t >> 3) + 32 * it;
             const int py = pos / TW, px = pos % TW;
             const int yy = ty * TH + py, xx = tx * TW + px;
             if (yy >= Hres || xx >= Wres) continue;
             const size_t o = (ib + (size_t)yy * Wres + xx) * Ch + ch0;
-            // centre value of u (for gelu'(u)): an L2 hit issued now, consumed after the tap loop.  The position loop is
-            // NOT unrolled: unrolled, the kernel needed 250 VGPRs = 2 workgroups per CU; this way 3 fit (LDS-limited).
-            const float4 uv = ld4(u + o);
-            // dg[p] = sum_k w[k] * dt[p - off(k)]   (transpose of the forward correlation)
+            const float4 uc = (DW_ABL & 4) ? *reinterpret_cast<const float4*>(&ds[((py + 1) * HWID + px + 1) * CT + c4 * 4])
+                                           : *reinterpret_cast<const float4*>(&us[pos * CT + c4 * 4]);
+            float4 gc, gp;                                               // gelu(u), gelu'(u) of this position
+            if (DW_ABL & 8) { gc = uc; gp = uc; }
+            else {
+                gelu_both(uc.x, gc.x, gp.x); gelu_both(uc.y, gc.y, gp.y);
+                gelu_both(uc.z, gc.z, gp.z); gelu_both(uc.w, gc.w, gp.w);
+            }
             float4 dg = make_float4(0, 0, 0, 0);
-            const float4 dtc = *reinterpret_cast<const float4*>(&ds[((py + 1) * HWID + px + 1) * CT + c4 * 4]);
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
@@ -359,13 +385,12 @@ __global__ __launch_bounds__(256) void leff_dwconv_bwd_kernel(const T* __restric
                     const float4 dn = *reinterpret_cast<const float4*>(&ds[((py + 2 - ky) * HWID + px + 2 - kx) * CT + c4 * 4]);
                     dg.x += wk[0][ky * 3 + kx] * dn.x; dg.y += wk[1][ky * 3 + kx] * dn.y;
                     dg.z += wk[2][ky * 3 + kx] * dn.z; dg.w += wk[3][ky * 3 + kx] * dn.w;
-                    const float4 gn = *reinterpret_cast<const float4*>(&gs[((py + ky) * HWID + px + kx) * CT + c4 * 4]);
-                    dwk[0][ky * 3 + kx] += dtc.x * gn.x; dwk[1][ky * 3 + kx] += dtc.y * gn.y;
-                    dwk[2][ky * 3 + kx] += dtc.z * gn.z; dwk[3][ky * 3 + kx] += dtc.w * gn.w;
+                    if (ky == 1 && kx == 1) { dbk[0] += dn.x; dbk[1] += dn.y; dbk[2] += dn.z; dbk[3] += dn.w; }
+                    if (DW_ABL & 2) continue;
+                    dwk[0][ky * 3 + kx] += gc.x * dn.x; dwk[1][ky * 3 + kx] += gc.y * dn.y;
+                    dwk[2][ky * 3 + kx] += gc.z * dn.z; dwk[3][ky * 3 + kx] += gc.w * dn.w;
                 }
-            dbk[0] += dtc.x; dbk[1] += dtc.y; dbk[2] += dtc.z; dbk[3] += dtc.w;
-            st4(du + o, make_float4(dg.x * gelu_grad_f(uv.x), dg.y * gelu_grad_f(uv.y), dg.z * gelu_grad_f(uv.z),
-                                    dg.w * gelu_grad_f(uv.w)));
+            st4(du + o, make_float4(dg.x * gp.x, dg.y * gp.y, dg.z * gp.z, dg.w * gp.w));
         }
     }
     // reduce the 32 position-slots (t>>3) that share a channel quad, one quantity at a time
@@ -467,6 +492,44 @@ __global__ __launch_bounds__(256) void l1_pair_bwd_kernel(const float* __restric
         }
         reinterpret_cast<float4*>(da)[e] = r;
     }
+}
+
+
+// The scalar side of ContrastLoss.forward (My_CR.py:104-123) over the k taps, one launch each way instead of a dozen [k]-vector
+// torch ops: means d_i = sums_i / count_i;  loss = sum_i w_i ap_i / (an_i + 1e-7)  (ablation: sum_i w_i ap_i), all_ap, all_an;
+// backward: g[i] = d(loss g_loss + all_ap g_ap + all_an g_an) / d(ap_i, an_i).  k <= 64, one wave.
+__global__ __launch_bounds__(64) void contrast_combine_fwd_kernel(const float* __restrict__ sums, const float* __restrict__ inv_cnt,
+                                                                  const float* __restrict__ w, int k, int ablation,
+                                                                  float* __restrict__ d, float* __restrict__ out) {
+    const int i = threadIdx.x;
+    float ap = 0.f, an = 0.f, term = 0.f;
+    if (i < k) {
+        ap = sums[2 * i] * inv_cnt[i]; an = sums[2 * i + 1] * inv_cnt[i];
+        d[2 * i] = ap; d[2 * i + 1] = an;
+        term = w[i] * (ablation ? ap : ap / (an + 1e-7f));
+    }
+    term = wave_sum(term); ap = wave_sum(ap); an = wave_sum(an);
+    if (i == 0) { out[0] = term; out[1] = ap; out[2] = an; }
+}
+
+__global__ __launch_bounds__(64) void contrast_combine_bwd_kernel(const float* __restrict__ d, const float* __restrict__ w, int k,
+                                                                  int ablation, const float* __restrict__ g_loss,
+                                                                  const float* __restrict__ g_ap, const float* __restrict__ g_an,
+                                                                  float* __restrict__ g) {
+    const int i = threadIdx.x;
+    if (i >= k) return;
+    float g0 = 0.f, g1 = 0.f;
+    if (g_loss) {
+        if (ablation) g0 = g_loss[0] * w[i];
+        else {
+            const float den = d[2 * i + 1] + 1e-7f;
+            g0 = g_loss[0] * w[i] / den;
+            g1 = -g0 * d[2 * i] / den;
+        }
+    }
+    if (g_ap) g0 += g_ap[0];
+    if (g_an) g1 += g_an[0];
+    g[2 * i] = g0; g[2 * i + 1] = g1;
 }
 
 // ------------------------------------------------------------------------------------------------ K12
@@ -674,6 +737,22 @@ extern "C" int dhz_adamw_step(float* p, const float* g, float* m, float* v, int6
     hipLaunchKernelGGL(adamw_kernel, dim3(grid_for((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr,
                        beta1, beta2, eps, wd, step_size, bc2_sqrt, grad_scale);
     DHZ_CHECK_LAUNCH("dhz_adamw_step");
+    return DHZ_OK;
+}
+
+extern "C" int dhz_contrast_combine_fwd(const float* sums, const float* inv_cnt, const float* w, int k, int ablation, float* d,
+                                        float* out, void* stream) {
+    DHZ_REQUIRE(sums && inv_cnt && w && d && out && k > 0 && k <= 64, "dhz_contrast_combine_fwd: bad arguments (1 <= k <= 64)");
+    hipLaunchKernelGGL(contrast_combine_fwd_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, sums, inv_cnt, w, k, ablation, d, out);
+    DHZ_CHECK_LAUNCH("dhz_contrast_combine_fwd");
+    return DHZ_OK;
+}
+
+extern "C" int dhz_contrast_combine_bwd(const float* d, const float* w, int k, int ablation, const float* g_loss, const float* g_ap,
+                                        const float* g_an, float* g, void* stream) {
+    DHZ_REQUIRE(d && w && g && k > 0 && k <= 64, "dhz_contrast_combine_bwd: bad arguments (1 <= k <= 64)");
+    hipLaunchKernelGGL(contrast_combine_bwd_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, d, w, k, ablation, g_loss, g_ap, g_an, g);
+    DHZ_CHECK_LAUNCH("dhz_contrast_combine_bwd");
     return DHZ_OK;
 }
 

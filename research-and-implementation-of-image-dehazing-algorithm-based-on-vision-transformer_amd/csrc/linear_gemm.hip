@@ -17,9 +17,6 @@
 namespace {
 
 constexpr int BK = 32;
-#ifndef DHZ_GEMM_NT
-#define DHZ_GEMM_NT 0
-#endif
 #ifndef DHZ_GEMM_ABL
 #define DHZ_GEMM_ABL 0           // timing diagnostics (tools/gemm_phases.sh): 1 = no epilogue stores, 2 = no MFMAs, 4 = no global operand loads
 #endif
@@ -183,14 +180,7 @@ __global__ __launch_bounds__(256) void linear_gemm_kernel(const float* __restric
                 if (m < M && (!(abl & 1) || acc[a][0][0] == 12345.678f)) {
                     float* yr = Y + (size_t)m * ldy + n0;
 #pragma unroll
-                    for (int b = 0; b < WN; ++b) {
-                        const f32x4 v = acc[a][b] + bv[b];
-#if DHZ_GEMM_NT
-                        __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(yr + 16 * b));
-#else
-                        *reinterpret_cast<f32x4*>(yr + 16 * b) = v;
-#endif
-                    }
+                    for (int b = 0; b < WN; ++b) *reinterpret_cast<f32x4*>(yr + 16 * b) = acc[a][b] + bv[b];
                 }
             }
         } else {
@@ -206,13 +196,7 @@ __global__ __launch_bounds__(256) void linear_gemm_kernel(const float* __restric
                     if (m < M && (!(abl & 1) || acc[a][0][0] == 12345.678f)) {
                         float* yr = Y + (size_t)m * ldy + n0;
 #pragma unroll
-                        for (int b = 0; b < WN; ++b) {
-#if DHZ_GEMM_NT
-                            __builtin_nontemporal_store(acc[a][b][j] + bv[b], yr + 16 * b);
-#else
-                            yr[16 * b] = acc[a][b][j] + bv[b];
-#endif
-                        }
+                        for (int b = 0; b < WN; ++b) yr[16 * b] = acc[a][b][j] + bv[b];
                     }
                 }
         }

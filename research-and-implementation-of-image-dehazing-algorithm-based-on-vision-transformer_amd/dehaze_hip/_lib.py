@@ -37,6 +37,8 @@ SIGNATURES = {
     "dhz_thin_conv3x3_wgrad": [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_p],
     "dhz_l1_pair_fwd": [c_f, c_f, c_f, c_f, c_l, c_p],
     "dhz_l1_pair_bwd": [c_f, c_f, c_f, c_f, c_f, c_l, c_p],
+    "dhz_contrast_combine_fwd": [c_f, c_f, c_f, c_i, c_i, c_f, c_f, c_p],
+    "dhz_contrast_combine_bwd": [c_f, c_f, c_i, c_i, c_f, c_f, c_f, c_f, c_p],
     "dhz_crop_augment_pair": [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_p],
     "dhz_winograd_prepack": [c_f, c_f, c_i, c_i, c_i, c_p],
     "dhz_winograd_conv3x3": [c_f, c_f, c_f, c_i, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_p],

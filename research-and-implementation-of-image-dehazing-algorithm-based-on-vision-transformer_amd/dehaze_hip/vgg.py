@@ -238,7 +238,7 @@ class _ContrastTaps(Function):
         loss = sum_i w_i * ap_i / (an_i + 1e-7)   (ablation: sum_i w_i * ap_i),  all_ap = sum_i ap_i,  all_an = sum_i an_i
     with ap_i / an_i the L1 means of tap i (dhz_l1_pair_fwd, one pass over a, p, n per tap).  As separate autograd scalars the
     five taps cost ~100 launches of 4-8 us per step (0-dim add / div / mul / neg, select_backward, zero fills); here the
-    combination and the ten backward coefficients are a handful of [5]-vector ops."""
+    combination and the ten backward coefficients are one small kernel each way (dhz_contrast_combine_fwd / _bwd)."""
 
     @staticmethod
     def forward(ctx, weights, ablation, B, *feats):
@@ -259,13 +259,13 @@ class _ContrastTaps(Function):
                       a[i].numel(), _stream())
             ps.append(p)
             ns.append(n)
-        d = sums * inv_cnt                                            # [k, 2] means
-        ratio = d[:, 0] if ablation else d[:, 0] / (d[:, 1] + 1e-7)
-        tot = d.sum(0)
+        d = torch.empty((k, 2), device=dev, dtype=torch.float32)       # [k, 2] means
+        out = torch.empty(3, device=dev, dtype=torch.float32)
+        _lib.call("dhz_contrast_combine_fwd", _p(sums), _p(inv_cnt), _p(w), k, int(ablation), _p(d), _p(out), _stream())
         ctx.set_materialize_grads(False)
         ctx.k, ctx.ablation = k, ablation
         ctx.save_for_backward(d, w, *a, *ps, *([] if ablation else ns))
-        return (w * ratio).sum(), tot[0], tot[1]
+        return out[0], out[1], out[2]
 
     @staticmethod
     def backward(ctx, g_loss, g_ap, g_an):
@@ -274,19 +274,9 @@ class _ContrastTaps(Function):
         d, w = saved[0], saved[1]
         a, ps = saved[2:2 + k], saved[2 + k:2 + 2 * k]
         ns = [None] * k if ablation else saved[2 + 2 * k:2 + 3 * k]
-        g = torch.zeros((k, 2), device=d.device, dtype=torch.float32)          # d loss / d (ap_i, an_i)
-        if g_loss is not None:
-            if ablation:
-                g[:, 0] = g_loss * w
-            else:
-                den = d[:, 1] + 1e-7
-                c0 = g_loss * w / den
-                g[:, 0] = c0
-                g[:, 1] = -c0 * d[:, 0] / den
-        if g_ap is not None:
-            g[:, 0] += g_ap
-        if g_an is not None:
-            g[:, 1] += g_an
+        g = torch.empty((k, 2), device=d.device, dtype=torch.float32)          # d loss / d (ap_i, an_i)
+        f32 = lambda t: None if t is None else _p(t.to(torch.float32).contiguous())
+        _lib.call("dhz_contrast_combine_bwd", _p(d), _p(w), k, int(ablation), f32(g_loss), f32(g_ap), f32(g_an), _p(g), _stream())
         das = []
         for i in range(k):
             da = torch.empty_like(a[i])
