@@ -127,6 +127,11 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const uint16_t* __restri
     while (true) {
         const int ntile = tile_of(ti + 1);
         const int tn = tile % tiles_n, tm = tile / tiles_n;
+        f32x4 bv[WN];                                                    // bias of this tile's columns in the epilogue's lane layout
+#pragma unroll
+        for (int b = 0; b < WN; ++b)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bv[b][j] = bias ? bias[tn * BN + wn * WN * 16 + 4 * g + 16 * b + j] : 0.f;
         for (int st = 0; st < nst; ++st) {
             const bool last = st + 1 == nst;
             const bool more = !last || ntile >= 0;
@@ -148,7 +153,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const uint16_t* __restri
 #pragma unroll
                 for (int a = 0; a < WM; ++a)
 #pragma unroll
-                    for (int b = 0; b < WN; ++b) acc[a][b] = mfma_bf16(af[a], bf[b], acc[a][b]);
+                    for (int b = 0; b < WN; ++b) acc[a][b] = mfma_bf16(bf[b], af[a], acc[a][b]);    // D = C^T block (epilogue)
             }
             if (more) {
                 swrite(buf ^ 1);
@@ -156,22 +161,33 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const uint16_t* __restri
                 buf ^= 1;
             }
         }
-        {   // epilogue from the accumulators: acc[a][b][j] = C[16 a + 4 g + j][16 b + i16]
-            const int m0 = tm * BM + wm * WM * 16 + 4 * g, n0 = tn * BN + wn * WN * 16 + i16;
-            float bv[WN];
+        {   // epilogue from the accumulators.  The MFMAs take the B (feature) fragment as their first operand, so a 16 x 16 block
+            // arrives transposed: acc[a][b][j] = C[token 16 a + i16][feature 16 b + 4 g + j] - a lane owns four CONSECUTIVE features
+            // of one token and stores them as one 8-byte vector (2-byte scalar stores in the untransposed form: 4 x the store
+            // instructions).  Full tiles store without per-row guards and the bias was loaded at the top of the tile: behind a
+            // divergent guard or a load hipcc waits for vmcnt(0), i.e. for the acknowledgement of all earlier stores.
+            const int m0 = tm * BM + wm * WM * 16 + i16, n0 = tn * BN + wn * WN * 16 + 4 * g;
+            uint16_t* c0 = C + (size_t)m0 * ldc + n0;
+            auto pack = [&](int a, int b) {
+                const f32x4 v = acc[a][b] + bv[b];
+                uint2 r;
+                r.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+                r.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+                return r;
+            };
+            if (tm * BM + BM <= M) {                                     // wave-uniform
 #pragma unroll
-            for (int b = 0; b < WN; ++b) bv[b] = bias ? bias[n0 + 16 * b] : 0.f;
+                for (int a = 0; a < WM; ++a)
 #pragma unroll
-            for (int a = 0; a < WM; ++a)
+                    for (int b = 0; b < WN; ++b) *reinterpret_cast<uint2*>(c0 + (size_t)(16 * a) * ldc + 16 * b) = pack(a, b);
+            } else {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int m = m0 + 16 * a + j;
-                    if (m < M) {
-                        uint16_t* cr = C + (size_t)m * ldc + n0;
+                for (int a = 0; a < WM; ++a)
+                    if (m0 + 16 * a < M) {
 #pragma unroll
-                        for (int b = 0; b < WN; ++b) cr[16 * b] = f32_to_bf16(acc[a][b][j] + bv[b]);
+                        for (int b = 0; b < WN; ++b) *reinterpret_cast<uint2*>(c0 + (size_t)(16 * a) * ldc + 16 * b) = pack(a, b);
                     }
-                }
+            }
 #pragma unroll
             for (int a = 0; a < WM; ++a)
 #pragma unroll
@@ -204,8 +220,8 @@ int dispatch_gemm(const char* who, const uint16_t* A, int lda, const uint16_t* B
     DHZ_REQUIRE(A && B && C, "%s: null pointer", who);
     DHZ_REQUIRE(M > 0 && N > 0 && K > 0 && N % 64 == 0 && K % 64 == 0, "%s: T=%d N=%d K=%d (N, K must be multiples of 64)", who, M, N,
                 K);
-    DHZ_REQUIRE(lda % 8 == 0 && ldb % 8 == 0 && ldc >= N && lda >= K, "%s: bad leading dimensions", who);
-    DHZ_REQUIRE((((uintptr_t)A | (uintptr_t)B) & 15) == 0 && ((uintptr_t)C & 1) == 0, "%s: operands must be 16-byte aligned", who);
+    DHZ_REQUIRE(lda % 8 == 0 && ldb % 8 == 0 && ldc % 4 == 0 && ldc >= N && lda >= K, "%s: bad leading dimensions", who);
+    DHZ_REQUIRE((((uintptr_t)A | (uintptr_t)B) & 15) == 0 && ((uintptr_t)C & 7) == 0, "%s: operands must be 16-byte aligned (output: 8)", who);
     const int wn = N % 128 == 0 ? 4 : 2;
     const long blocks128 = (long)((M + 127) / 128) * (N / (32 * wn));
     const int wm = blocks128 >= 256 ? 4 : 2;

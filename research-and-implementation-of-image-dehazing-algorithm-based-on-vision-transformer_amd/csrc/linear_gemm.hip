@@ -11,6 +11,7 @@
 //   * W when !WT: [32 k][BN + 4] (row stride = 4 mod 8 floats -> the g = 0 / 1 halves of a ds_read_b32 hit disjoint banks).
 // Workgroups are persistent (two per CU) and pipeline across their tiles; the epilogue (+ bias) stores straight from the
 // accumulators.
+#include <stdio.h>
 #include <stdlib.h>
 #include "common.h"
 
@@ -121,6 +122,18 @@ __global__ __launch_bounds__(256) void linear_gemm_kernel(const float* __restric
     while (true) {
         const int ntile = tile_of(ti + 1);
         const int tn = tile % tiles_n, tm = tile / tiles_n;
+        // bias of this tile's columns, in the epilogue's lane layout (TR: four consecutive features per lane)
+        f32x4 bvt[TR ? WN : 1];
+        float bvs[TR ? 1 : WN];
+        if (TR) {
+#pragma unroll
+            for (int b = 0; b < WN; ++b)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) bvt[b][j] = bias ? bias[tn * BN + wn * WN * 16 + 4 * g + 16 * b + j] : 0.f;
+        } else {
+#pragma unroll
+            for (int b = 0; b < WN; ++b) bvs[b] = bias ? bias[tn * BN + wn * WN * 16 + i16 + 16 * b] : 0.f;
+        }
         for (int st = 0; st < nst; ++st) {
             // next stage of the stream: the same tile, or the first stage of this workgroup's next tile
             const bool last = st + 1 == nst;
@@ -167,38 +180,50 @@ __global__ __launch_bounds__(256) void linear_gemm_kernel(const float* __restric
         //      TR : the MFMAs took the WEIGHT fragment as their first operand, so a 16 x 16 block arrives transposed:
         //           acc[a][b][j] = C[token 16 a + i16][feature 16 b + 4 g + j] - a lane owns four CONSECUTIVE features of one
         //           token and stores them as one 16-byte vector (4 x fewer store instructions and address computations).
+        //      Full tiles (every tile unless T is ragged) store without per-row guards: behind a divergent guard hipcc waits for
+        //      vmcnt(0) - i.e. for the acknowledgement of ALL earlier stores - before every guarded group, which serialised the
+        //      epilogue into 16 memory round trips per tile (211 -> 150 us at T = 524288, K = 64, N = 256).  The bias values are
+        //      loaded at the top of the tile for the same reason (no load result is waited for between the stores).
+        const bool full = tm * BM + BM <= M;                          // wave-uniform
         if (TR) {
             const int m0 = tm * BM + wm * WM * 16 + i16, n0 = tn * BN + wn * WN * 16 + 4 * g;
-            f32x4 bv[WN];
+            float* y0 = Y + (size_t)m0 * ldy + n0;
+            if (full) {
 #pragma unroll
-            for (int b = 0; b < WN; ++b)
+                for (int a = 0; a < WM; ++a)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) bv[b][j] = bias ? bias[n0 + 16 * b + j] : 0.f;
+                    for (int b = 0; b < WN; ++b)
+                        if (!(abl & 1) || acc[a][0][0] == 12345.678f)
+                            *reinterpret_cast<f32x4*>(y0 + (size_t)(16 * a) * ldy + 16 * b) = acc[a][b] + bvt[b];
+            } else {
 #pragma unroll
-            for (int a = 0; a < WM; ++a) {
-                const int m = m0 + 16 * a;
-                if (m < M && (!(abl & 1) || acc[a][0][0] == 12345.678f)) {
-                    float* yr = Y + (size_t)m * ldy + n0;
+                for (int a = 0; a < WM; ++a)
+                    if (m0 + 16 * a < M) {
 #pragma unroll
-                    for (int b = 0; b < WN; ++b) *reinterpret_cast<f32x4*>(yr + 16 * b) = acc[a][b] + bv[b];
-                }
+                        for (int b = 0; b < WN; ++b) *reinterpret_cast<f32x4*>(y0 + (size_t)(16 * a) * ldy + 16 * b) = acc[a][b] + bvt[b];
+                    }
             }
         } else {
             const int m0 = tm * BM + wm * WM * 16 + 4 * g, n0 = tn * BN + wn * WN * 16 + i16;
-            float bv[WN];
+            float* y0 = Y + (size_t)m0 * ldy + n0;
+            if (full) {
 #pragma unroll
-            for (int b = 0; b < WN; ++b) bv[b] = bias ? bias[n0 + 16 * b] : 0.f;
+                for (int a = 0; a < WM; ++a)
 #pragma unroll
-            for (int a = 0; a < WM; ++a)
+                    for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int m = m0 + 16 * a + j;
-                    if (m < M && (!(abl & 1) || acc[a][0][0] == 12345.678f)) {
-                        float* yr = Y + (size_t)m * ldy + n0;
+                        for (int b = 0; b < WN; ++b)
+                            if (!(abl & 1) || acc[a][0][0] == 12345.678f) y0[(size_t)(16 * a + j) * ldy + 16 * b] = acc[a][b][j] + bvs[b];
+            } else {
 #pragma unroll
-                        for (int b = 0; b < WN; ++b) yr[16 * b] = acc[a][b][j] + bv[b];
-                    }
-                }
+                for (int a = 0; a < WM; ++a)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (m0 + 16 * a + j < M) {
+#pragma unroll
+                            for (int b = 0; b < WN; ++b) y0[(size_t)(16 * a + j) * ldy + 16 * b] = acc[a][b][j] + bvs[b];
+                        }
+            }
         }
 #pragma unroll
         for (int a = 0; a < WM; ++a)
@@ -219,7 +244,11 @@ void launch(const float* A, int lda, const float* W, int ldw, const float* bias,
     const int tiles_n = N / BN, tiles_m = (M + BM - 1) / BM;
     const int ntiles = tiles_n * tiles_m;
     // two workgroups per CU when the LDS allows (it does for every tile shape: <= 66.5 KiB per workgroup)
+#ifdef DHZ_DIAG
+    const int slots = getenv("DHZ_GEMM_SLOTS") ? atoi(getenv("DHZ_GEMM_SLOTS")) : 512;
+#else
     const int slots = 512;
+#endif
     const int grid = ntiles < slots ? ntiles : slots;
     if (smem > 48 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_gemm_kernel<WM, WN, WT, TR>),
@@ -256,6 +285,10 @@ int dispatch(const char* who, const float* A, int lda, const float* W, int ldw, 
     bool tr = WT ? N <= 96 : (N <= 32 || (N <= 64 && K <= 64));
 #ifdef DHZ_DIAG
     if (const char* e = getenv("DHZ_GEMM_TR")) tr = atoi(e) != 0;
+    if (const char* e = getenv("DHZ_GEMM_TILE")) {               // "wm,wn" (ignored where wn does not divide N / 32)
+        int a = 0, b = 0;
+        if (sscanf(e, "%d,%d", &a, &b) == 2 && N % (32 * b) == 0) { wm = a; wn = b; }
+    }
 #endif
 #define CASE(a, b)                                                                      \
     if (wm == a && wn == b) {                                                           \

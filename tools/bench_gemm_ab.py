@@ -7,6 +7,7 @@ import torch
 from dehaze_hip import ops
 dev = torch.device("cuda:0")
 var, vals = sys.argv[1], sys.argv[2:]
+only_c = [int(c) for c in os.environ.get("ONLY_C", "").split(",") if c]
 
 
 def timeit(f, reps=5):
@@ -22,6 +23,8 @@ def timeit(f, reps=5):
 print(f"{'T':>7} {'K':>5} {'N':>5} | fwd " + " ".join(f"{var}={v:>3}" for v in vals) + " | dgrad " + " ".join(f"{var}={v:>3}" for v in vals))
 tot = [[0.0] * len(vals), [0.0] * len(vals)]
 for T, C in [(524288, 32), (131072, 64), (32768, 128), (8192, 256), (2048, 512), (8192, 512), (32768, 256), (131072, 128), (524288, 64)]:
+    if only_c and C not in only_c:
+        continue
     for K, N in [(C, 3 * C), (C, C), (C, 4 * C), (4 * C, C)]:
         x = torch.randn(T, K, device=dev); W = torch.randn(N, K, device=dev) * 0.1; b = torch.randn(N, device=dev)
         dy = torch.randn(T, N, device=dev)
