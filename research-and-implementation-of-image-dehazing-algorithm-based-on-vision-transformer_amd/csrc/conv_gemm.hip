@@ -180,28 +180,45 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const float* __restrict_
                 buf ^= 1;
             }
         }
-        {   // epilogue: acc[a][b][j] = C[16 a + 4 g + j][16 b + i16]
+        {   // epilogue: acc[a][b][j] = C[16 a + 4 g + j][16 b + i16].  Full tiles store without per-row guards (behind a
+            // divergent guard hipcc waits for vmcnt(0) - all earlier stores acknowledged - before every guarded group)
             const int m0 = tm * BM + wm * WM * 16 + 4 * g, n0 = tn * BN + wn * WN * 16 + i16;
             float bv[WN];
 #pragma unroll
             for (int b = 0; b < WN; ++b) bv[b] = bias ? bias[n0 + 16 * b] : 0.f;
-#pragma unroll
-            for (int a = 0; a < WM; ++a)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int m = m0 + 16 * a + j;
-                    if (m < M) {
-                        size_t orow = m;
-                        if (MODE == 2) {        // row (b, iy2, ix2) of this parity class -> token (b, 2 iy2 + py, 2 ix2 + px)
-                            const int b = m / (G.Ho * G.Wo), r = m - b * (G.Ho * G.Wo);
-                            const int iy2 = r / G.Wo, ix2 = r - iy2 * G.Wo;
-                            orow = ((size_t)b * G.H + 2 * iy2 + G.py) * G.W + 2 * ix2 + G.px;
-                        }
-                        float* yr = Y + orow * N + n0;
-#pragma unroll
-                        for (int b = 0; b < WN; ++b) yr[16 * b] = acc[a][b][j] + bv[b];
-                    }
+            auto out_row = [&](int m) -> size_t {
+                if (MODE == 2) {                // row (b, iy2, ix2) of this parity class -> token (b, 2 iy2 + py, 2 ix2 + px)
+                    const int b = m / (G.Ho * G.Wo), r = m - b * (G.Ho * G.Wo);
+                    const int iy2 = r / G.Wo, ix2 = r - iy2 * G.Wo;
+                    return ((size_t)b * G.H + 2 * iy2 + G.py) * G.W + 2 * ix2 + G.px;
                 }
+                return (size_t)m;
+            };
+            if (tm * BM + BM <= M) {                                     // wave-uniform
+                float* yr[WM][4];
+#pragma unroll
+                for (int a = 0; a < WM; ++a)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) yr[a][j] = Y + out_row(m0 + 16 * a + j) * N + n0;
+#pragma unroll
+                for (int a = 0; a < WM; ++a)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int b = 0; b < WN; ++b) yr[a][j][16 * b] = acc[a][b][j] + bv[b];
+            } else {
+#pragma unroll
+                for (int a = 0; a < WM; ++a)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int m = m0 + 16 * a + j;
+                        if (m < M) {
+                            float* yr = Y + out_row(m) * N + n0;
+#pragma unroll
+                            for (int b = 0; b < WN; ++b) yr[16 * b] = acc[a][b][j] + bv[b];
+                        }
+                    }
+            }
 #pragma unroll
             for (int a = 0; a < WM; ++a)
 #pragma unroll

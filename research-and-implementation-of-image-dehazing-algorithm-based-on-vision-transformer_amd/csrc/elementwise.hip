@@ -225,8 +225,12 @@ __global__ __launch_bounds__(256) void leff_dwconv_fwd_kernel(const T* __restric
                                                               int tiles_x, int tiles_y) {
     __shared__ __attribute__((aligned(16))) float g[HHGT * HWID * CT];
     const int t = threadIdx.x;
-    const int cg = blockIdx.x % (Ch / CT);
-    int rest = blockIdx.x / (Ch / CT);
+    // workgroups are dealt round-robin to the 8 XCDs: renumber so that the channel groups of one tile - the 128-byte pieces of
+    // the same token rows - run on ONE XCD (its L2 then sees whole rows): 4.6 -> 5.1 TB/s.  (The persistent backward kernel
+    // measured 5 % SLOWER with the same renumbering and keeps the plain order.)
+    const int lid = (gridDim.x & 7) == 0 ? (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+    const int cg = lid % (Ch / CT);
+    int rest = lid / (Ch / CT);
     const int tx = rest % tiles_x; rest /= tiles_x;
     const int ty = rest % tiles_y;
     const int bimg = rest / tiles_y;
