@@ -13,6 +13,9 @@
 
 namespace {
 
+#ifndef WG_ABL
+#define WG_ABL 0          // timing diagnostics (tools/variants.sh): 1 no epilogue atomics, 2 no MFMAs, 4 no global loads, 8 no bias sums
+#endif
 constexpr int TK = 32;   // tokens per LDS stage
 constexpr int MAXMAT = 4;
 
@@ -74,6 +77,7 @@ __global__ __launch_bounds__(128 * NWM * TG) void linear_wgrad_kernel(const floa
     const bool do_db = (db != nullptr) && (tn == 0);
 
     auto gload = [&](int st) {
+        if (WG_ABL & 4) return;
         const size_t tok0 = (size_t)st * TK;
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
@@ -94,7 +98,7 @@ __global__ __launch_bounds__(128 * NWM * TG) void linear_wgrad_kernel(const floa
             const int e = tl + GT * i;
             if (TK * A4 % GT == 0 || e < TK * A4) {
                 *reinterpret_cast<f32x4*>(&As(buf)[(e / A4) * SA + (e % A4) * 4]) = ra[i];
-                dbacc[i].x += ra[i][0]; dbacc[i].y += ra[i][1]; dbacc[i].z += ra[i][2]; dbacc[i].w += ra[i][3];
+                if (!(WG_ABL & 8)) { dbacc[i].x += ra[i][0]; dbacc[i].y += ra[i][1]; dbacc[i].z += ra[i][2]; dbacc[i].w += ra[i][3]; }
             }
         }
 #pragma unroll
@@ -130,7 +134,10 @@ __global__ __launch_bounds__(128 * NWM * TG) void linear_wgrad_kernel(const floa
 #pragma unroll
                 for (int a = 0; a < WM; ++a)
 #pragma unroll
-                    for (int b = 0; b < WN; ++b) acc[a][b] = mfma16(af[a], bf[b], acc[a][b]);
+                    for (int b = 0; b < WN; ++b) {
+                        if (WG_ABL & 2) acc[a][b][0] += af[a] + bf[b];
+                        else acc[a][b] = mfma16(af[a], bf[b], acc[a][b]);
+                    }
             }
         }
         if (more) swrite(buf ^ 1);
@@ -156,7 +163,7 @@ __global__ __launch_bounds__(128 * NWM * TG) void linear_wgrad_kernel(const floa
     }
     for (int e = t; e < BM * BN; e += NTHR) {
         const int r = e / BN, c = e % BN;
-        atomicAdd(dw + (size_t)(nloc + r) * K + k0 + c, Cs[e]);
+        if (!(WG_ABL & 1) || Cs[e] == 12345.678f) atomicAdd(dw + (size_t)(nloc + r) * K + k0 + c, Cs[e]);
     }
     if (do_db) {
         // staged element e = tl + GT i sits at (row e / A4, float4-column e % A4) of every stage: dump the

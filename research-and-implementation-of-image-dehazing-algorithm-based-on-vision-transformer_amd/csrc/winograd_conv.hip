@@ -32,6 +32,10 @@
 #include <type_traits>
 #include "common.h"
 
+#ifndef WINO_ABL
+#define WINO_ABL 0      // timing diagnostics (tools/variants.sh): 1 no input transform, 2 no global loads in the loop, 4 no MFMAs, 8 no V / filter LDS traffic of the next group
+#endif
+
 namespace {
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -217,6 +221,9 @@ __global__ __launch_bounds__(512) void winograd_conv3x3_kernel(const float* __re
         const int cb2 = cb + 2 < CBn ? cb + 2 : CBn - 1;      // loads past the last group re-read it (never stored to LDS)
         auto slot = [&](int sidx) {
             if (!WITH_NEXT) return;
+            if ((WINO_ABL & 1) && sidx >= 13 && sidx <= 21) return;
+            if ((WINO_ABL & 2) && (sidx == 1 || sidx == 6)) { if (sidx == 6) wave_sync(); return; }
+            if ((WINO_ABL & 8) && (sidx == 0 || (sidx >= 2 && sidx <= 5) || (sidx >= 8 && sidx <= 11) || sidx >= 22)) return;
             switch (sidx) {
                 case 0: write_u(nbuf); break;                                  // loaded during the previous group
                 case 1: gload_u(cb2); break;
@@ -266,30 +273,34 @@ __global__ __launch_bounds__(512) void winograd_conv3x3_kernel(const float* __re
             }
             if (j == 1 || j == 5) { if (j == pbar) __syncthreads(); }
             __builtin_amdgcn_sched_barrier(0);
+            if (!(WINO_ABL & 4)) {
             acc[xi][0] = mfma16(a0.x, b0.x, acc[xi][0]);
-            acc[xi][1] = mfma16(a0.z, b0.x, acc[xi][1]);
+            acc[xi][1] = mfma16(a0.z, b0.x, acc[xi][1]); } else { acc[xi][0][0] += a0.x + b0.x; }
             __builtin_amdgcn_sched_barrier(0);
             slot(4 * j + 0);
             __builtin_amdgcn_sched_barrier(0);
+            if (!(WINO_ABL & 4)) {
             acc[xi + 1][0] = mfma16(a1.x, b1.x, acc[xi + 1][0]);
-            acc[xi + 1][1] = mfma16(a1.z, b1.x, acc[xi + 1][1]);
+            acc[xi + 1][1] = mfma16(a1.z, b1.x, acc[xi + 1][1]); } else { acc[xi + 1][0][0] += a1.x + b1.x; }
             __builtin_amdgcn_sched_barrier(0);
             slot(4 * j + 1);
             __builtin_amdgcn_sched_barrier(0);
+            if (!(WINO_ABL & 4)) {
             acc[xi][0] = mfma16(a0.y, b0.y, acc[xi][0]);
-            acc[xi][1] = mfma16(a0.w, b0.y, acc[xi][1]);
+            acc[xi][1] = mfma16(a0.w, b0.y, acc[xi][1]); } else { acc[xi][1][0] += a0.y + b0.y + a0.z + a0.w; }
             __builtin_amdgcn_sched_barrier(0);
             slot(4 * j + 2);
             __builtin_amdgcn_sched_barrier(0);
+            if (!(WINO_ABL & 4)) {
             acc[xi + 1][0] = mfma16(a1.y, b1.y, acc[xi + 1][0]);
-            acc[xi + 1][1] = mfma16(a1.w, b1.y, acc[xi + 1][1]);
+            acc[xi + 1][1] = mfma16(a1.w, b1.y, acc[xi + 1][1]); } else { acc[xi + 1][1][0] += a1.y + b1.y + a1.z + a1.w; }
             __builtin_amdgcn_sched_barrier(0);
             slot(4 * j + 3);
             __builtin_amdgcn_sched_barrier(0);
             a0 = a0n; a1 = a1n; b0 = b0n; b1 = b1n;
         }
         wave_sync();                                     // every MFMA of this group has read V
-        if (WITH_NEXT) { write_v2(12); write_v2(14); }
+        if (WITH_NEXT && !(WINO_ABL & 8)) { write_v2(12); write_v2(14); }
         wave_sync();
     };
     for (int cb = 0; cb + 1 < CBn; ++cb) group(cb, std::true_type{});

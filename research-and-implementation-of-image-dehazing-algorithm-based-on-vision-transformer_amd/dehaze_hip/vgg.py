@@ -3,7 +3,8 @@
 conv 0 (3 -> 64) runs thin-input kernels (dhz_conv3x3_in3_blocked forward with bias + ReLU straight into the blocked layout,
 dhz_thin_conv3x3_dgrad_blocked backward-data straight from it); convs 1..12 run dhz_winograd_conv3x3 with bias + ReLU fused,
 in the channel-blocked NCHW8c layout end to end (conv 12 works on 8x8 maps for 128x128 patches: the kernel then packs four
-images into one of its 16x16 blocks).  The filters are frozen
+images into one of its 16x16 blocks; for patch sizes whose conv-12 maps it does not tile, e.g. 24x24 at 384x384, that one layer
+falls back to the library).  The filters are frozen
 (My_CR.py:75-77), so their transform-domain forms (forward and backward-data) are prepacked once per device.
 
 Forward-only passes (target / hazy input, My_CR.py:102) save nothing; the pass on the restored image is one autograd
@@ -22,6 +23,11 @@ CONVS = ((3, 64), (64, 64), (64, 128), (128, 128), (128, 256), (256, 256), (256,
          (512, 512), (512, 512), (512, 512), (512, 512))
 POOL_AFTER = (1, 3, 7, 11)
 TAPS = (0, 2, 4, 8, 12)          # relu1_1, relu2_1, relu3_1, relu4_1, relu5_1
+
+
+def wino_supported(H, W):
+    """map sizes dhz_winograd_conv3x3 tiles: multiples of 16, or 8x8 (four images per block)"""
+    return (H % 16 == 0 and W % 16 == 0) or (H == 8 and W == 8)
 
 
 def to_blocked(x, bias=None, relu=False):
@@ -118,7 +124,8 @@ class VggEngine:
 
     # ---- full stack, forward only
     def forward_taps(self, x, save=None):
-        """x: [B,3,H,W] NCHW.  Returns the 5 tap features, blocked [B,C/8,H,W,8].  `save` (dict) receives what the backward needs."""
+        """x: [B,3,H,W] NCHW.  Returns the 5 tap features, blocked [B,C/8,H,W,8] (tap 5 NCHW when conv 12 ran on the library).
+        `save` (dict) receives what the backward needs."""
         c0 = self.convs[0]
         # first layer (3 -> 64): thin on the input side - convolution + bias + ReLU straight into the blocked layout
         xc = x.contiguous()
@@ -127,15 +134,22 @@ class VggEngine:
                   xc.shape[3], 64, 1, _stream())
         acts = {0: cur}
         taps = [cur]
+        x12 = None
         for i in range(1, 13):
-            cur = self.conv(i, cur)
+            if i == 12 and not wino_supported(cur.shape[2], cur.shape[3]):
+                # conv 12 on maps the kernel does not tile (e.g. 24x24 for 384x384 patches): library convolution, NCHW tap
+                c12 = self.convs[12]
+                x12 = to_plain(cur)
+                cur = F.relu(F.conv2d(x12, c12.weight, c12.bias, padding=1))
+            else:
+                cur = self.conv(i, cur)
             acts[i] = cur
             if i in TAPS:
                 taps.append(cur)
             if i in POOL_AFTER:
                 cur = pool_fwd(cur)
         if save is not None:
-            save.update(x=x, acts=acts)
+            save.update(x=x, acts=acts, x12=x12)
         return taps
 
 
@@ -159,7 +173,14 @@ class _VggTaps(Function):
         with torch.no_grad():
             # G = gradient w.r.t. the PRE-activation of conv i (None while nothing has arrived from above)
             G = g5 * (acts[12] > 0) if g5 is not None else None
-            for i in range(12, 0, -1):
+            top = 12
+            if sv["x12"] is not None:                                        # conv 12 ran on the library (see forward_taps)
+                top = 11
+                if G is not None:
+                    gx12 = torch.ops.aten.convolution_backward(G, sv["x12"], eng.convs[12].weight, None, [1, 1], [1, 1], [1, 1],
+                                                               False, [0, 0], 1, [True, False, False])[0]
+                    G = pool_bwd_relu(to_blocked(gx12), acts[11])
+            for i in range(top, 0, -1):
                 below = i - 1                                                # conv i's input is a_{i-1} (pooled if i-1 in POOL_AFTER)
                 tg = tap_grad.get(below)
                 if G is None:
