@@ -16,6 +16,10 @@
 // Forward / backward-data: persistent workgroups pipelined across tiles (as csrc/linear_gemm.hip); outputs leave as bf16.
 #include "common.h"
 
+#ifndef BF_ABL
+#define BF_ABL 0        // timing diagnostics (tools/variants.sh): 1 no epilogue stores, 2 no MFMAs, 4 no global operand loads
+#endif
+
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -95,6 +99,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const uint16_t* __restri
         }
     };
     auto gload = [&](int k0) {
+        if (BF_ABL & 4) return;
 #pragma unroll
         for (int i = 0; i < NA; ++i) ra[i] = *reinterpret_cast<const u32x4*>(pa[i] + k0);
 #pragma unroll
@@ -153,7 +158,10 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const uint16_t* __restri
 #pragma unroll
                 for (int a = 0; a < WM; ++a)
 #pragma unroll
-                    for (int b = 0; b < WN; ++b) acc[a][b] = mfma_bf16(bf[b], af[a], acc[a][b]);    // D = C^T block (epilogue)
+                    for (int b = 0; b < WN; ++b) {
+                        if (BF_ABL & 2) acc[a][b][0] += (float)(af[a][0] + bf[b][0]);
+                        else acc[a][b] = mfma_bf16(bf[b], af[a], acc[a][b]);    // D = C^T block (epilogue)
+                    }
             }
             if (more) {
                 swrite(buf ^ 1);
@@ -179,7 +187,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const uint16_t* __restri
 #pragma unroll
                 for (int a = 0; a < WM; ++a)
 #pragma unroll
-                    for (int b = 0; b < WN; ++b) *reinterpret_cast<uint2*>(c0 + (size_t)(16 * a) * ldc + 16 * b) = pack(a, b);
+                    for (int b = 0; b < WN; ++b)
+                        if (!(BF_ABL & 1) || acc[a][0][0] == 12345.678f) *reinterpret_cast<uint2*>(c0 + (size_t)(16 * a) * ldc + 16 * b) = pack(a, b);
             } else {
 #pragma unroll
                 for (int a = 0; a < WM; ++a)
