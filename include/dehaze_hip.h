@@ -129,13 +129,12 @@ int dhz_input_proj_bwd(const float* dy, const float* y, const float* img, float*
  *     dhz_conv4s2_fwd  : replaces aten::convolution (MIOpen implicit GEMM)             bias [Cout] or NULL
  *     dhz_conv4s2_dgrad: dx [B, H*W, Cin] from dy [B, (H/2)*(W/2), Cout] (every element written; four parity-class GEMMs)
  *     dhz_conv4s2_wgrad: dwp [Cout, 16*Cin] += dy^T xcol, db [Cout] += column sums (ACCUMULATED, fp32 atomics; db may be NULL);
- *                        native_layout != 0: dwp is the parameter gradient itself, [Cout, Cin, 4, 4] (no permuted temporary, no
- *                        add); the output map sizes must be powers of two (training patch sizes 128 / 256). */
+ *                        the output map sizes must be powers of two (training patch sizes 128 / 256). */
 int dhz_conv4s2_fwd(const float* x, const float* wp, const float* bias, float* y, int B, int H, int W, int Cin, int Cout,
                     void* stream);
 int dhz_conv4s2_dgrad(const float* dy, const float* wq, float* dx, int B, int H, int W, int Cin, int Cout, void* stream);
 int dhz_conv4s2_wgrad(const float* dy, const float* x, float* dwp, float* db, int B, int H, int W, int Cin, int Cout,
-                      int native_layout, void* stream);
+                      void* stream);
 
 /* K5 fused  The whole LeFF branch of a LeWin block for C = 32, 64, 128 (hidden width 4C), forward, in one kernel:
  *     out = x + drop_scale[b] * linear2(gelu(dwconv3x3(gelu(linear1(norm2(x))))))          replaces M1:873 + M1:496-534

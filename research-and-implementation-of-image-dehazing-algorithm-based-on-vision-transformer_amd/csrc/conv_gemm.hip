@@ -269,7 +269,7 @@ constexpr int TK = 32;
 template <int WM, int WN>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                          float* __restrict__ dw, float* __restrict__ db, ConvGeom G, int T, int N,
-                                                         int K, int nsplit, int lgWo, int lgHW, int native) {
+                                                         int K, int nsplit, int lgWo, int lgHW) {
     constexpr int BM = 32 * WM, BN = 32 * WN;
     constexpr int SA = BM + 16, SB = BN + 16;
     constexpr int A4 = BM / 4, B4 = BN / 4;
@@ -365,12 +365,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float* __restrict
 #pragma unroll
             for (int j = 0; j < 4; ++j) Cs[(wm * WM * 16 + a * 16 + 4 * g + j) * BN + wn * WN * 16 + b * 16 + i16] = acc[a][b][j];
     __syncthreads();
-    if (native) {     // dw is the parameter's own layout [Cout][Cin][4][4]: element (co, tap, ci) of the GEMM tile at co*16Cin + ci*16 + tap
-        for (int e = t; e < BM * BN; e += 256)
-            atomicAdd(dw + (size_t)(n0 + e / BN) * K + (size_t)(c0 + e % BN) * 16 + tap, Cs[e]);
-    } else {
-        for (int e = t; e < BM * BN; e += 256) atomicAdd(dw + (size_t)(n0 + e / BN) * K + k0 + e % BN, Cs[e]);
-    }
+    for (int e = t; e < BM * BN; e += 256) atomicAdd(dw + (size_t)(n0 + e / BN) * K + k0 + e % BN, Cs[e]);
     if (do_db) {
         __syncthreads();
         float* red = smem;                                 // [TK*A4][4]
@@ -389,7 +384,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float* __restrict
 
 template <int WM, int WN>
 void launch_wgrad(const float* dy, const float* x, float* dw, float* db, const ConvGeom& G, int T, int N, int K, int lgWo, int lgHW,
-                  int native, hipStream_t s) {
+                  hipStream_t s) {
     constexpr int BM = 32 * WM, BN = 32 * WN;
     constexpr size_t stage = (size_t)TK * (BM + 16 + BN + 16) * sizeof(float);
     constexpr size_t smem = 2 * stage > (size_t)BM * BN * 4 ? 2 * stage : (size_t)BM * BN * 4;
@@ -402,7 +397,7 @@ void launch_wgrad(const float* dy, const float* x, float* dw, float* db, const C
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<WM, WN>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)smem);
     hipLaunchKernelGGL((conv_wgrad_kernel<WM, WN>), dim3(tiles * nsplit), dim3(256), smem, s, dy, x, dw, db, G, T, N, K, nsplit, lgWo,
-                       lgHW, native);
+                       lgHW);
 }
 
 int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return (1 << l) == v ? l : -1; }
@@ -433,7 +428,7 @@ extern "C" int dhz_conv4s2_dgrad(const float* dy, const float* wq, float* dx, in
 }
 
 extern "C" int dhz_conv4s2_wgrad(const float* dy, const float* x, float* dwp, float* db, int B, int H, int W, int Cin, int Cout,
-                                 int native_layout, void* stream) {
+                                 void* stream) {
     DHZ_REQUIRE(dy && x && dwp, "dhz_conv4s2_wgrad: null pointer");
     DHZ_REQUIRE(B > 0 && H % 2 == 0 && W % 2 == 0 && Cin % 32 == 0 && Cout % 32 == 0 && Cin > 0 && Cout > 0,
                 "dhz_conv4s2_wgrad: map %dx%d (even sizes) Cin=%d Cout=%d (multiples of 32)", H, W, Cin, Cout);
@@ -447,7 +442,7 @@ extern "C" int dhz_conv4s2_wgrad(const float* dy, const float* x, float* dwp, fl
     const int wm = (N % 128 == 0) ? 4 : (N % 96 == 0) ? 3 : (N % 64 == 0) ? 2 : 1;
     const int wn = (Cin % 128 == 0) ? 4 : (Cin % 64 == 0) ? 2 : 1;               // a K tile stays inside one tap
 #define CASE(a, b) \
-    if (wm == a && wn == b) launch_wgrad<a, b>(dy, x, dwp, db, G, T, N, K, lgWo, lgHW, native_layout, (hipStream_t)stream);
+    if (wm == a && wn == b) launch_wgrad<a, b>(dy, x, dwp, db, G, T, N, K, lgWo, lgHW, (hipStream_t)stream);
     CASE(1, 1) CASE(1, 2) CASE(1, 4) CASE(2, 1) CASE(2, 2) CASE(2, 4) CASE(3, 1) CASE(3, 2) CASE(3, 4) CASE(4, 1) CASE(4, 2) CASE(4, 4)
 #undef CASE
     DHZ_CHECK_LAUNCH("dhz_conv4s2_wgrad");

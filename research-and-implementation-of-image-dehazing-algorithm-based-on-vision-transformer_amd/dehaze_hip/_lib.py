@@ -53,7 +53,7 @@ SIGNATURES = {
     "dhz_input_proj_bwd": [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_fl, c_p],
     "dhz_conv4s2_fwd": [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_p],
     "dhz_conv4s2_dgrad": [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_p],
-    "dhz_conv4s2_wgrad": [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
+    "dhz_conv4s2_wgrad": [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_p],
     "dhz_linear_fwd_bf16": [c_f, c_i, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_p],
     "dhz_linear_dgrad_bf16": [c_f, c_i, c_f, c_f, c_i, c_i, c_i, c_i, c_p],
     "dhz_linear_wgrad_bf16": [c_f, c_i, c_f, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p],

@@ -651,29 +651,21 @@ class _Conv4s2(Function):
             _lib.call("dhz_conv4s2_dgrad", _p(dy), _p(wq), _p(dx), B, H, W, Cin, Cout, _stream())
         gw = gb = None
         if w.requires_grad or (b is not None and b.requires_grad):
-            inplace_w = w.is_leaf and w.requires_grad
+            dwp = torch.zeros((Cout, 16 * Cin), device=x.device, dtype=torch.float32)
             inplace_b = b is not None and b.is_leaf and b.requires_grad
-            if inplace_w and w.grad is None:
-                w.grad = torch.zeros_like(w, memory_format=torch.contiguous_format)
             if inplace_b and b.grad is None:
                 b.grad = torch.zeros_like(b)
-            inplace_w = inplace_w and w.grad.is_contiguous()
-            # leaf parameters: accumulated straight into .grad in the parameter's own [Cout, Cin, 4, 4] layout (the optimizer's
-            # flat gradient buffer) - no permuted temporary, no zero fill, no add
-            dwp = w.grad if inplace_w else torch.zeros((Cout, 16 * Cin), device=x.device, dtype=torch.float32)
             dbv = b.grad if inplace_b else (torch.zeros_like(b) if b is not None else None)
-            _lib.call("dhz_conv4s2_wgrad", _p(dy), _p(x), _p(dwp), _p(dbv), B, H, W, Cin, Cout, int(inplace_w), _stream())
-            if inplace_w:
+            _lib.call("dhz_conv4s2_wgrad", _p(dy), _p(x), _p(dwp), _p(dbv), B, H, W, Cin, Cout, _stream())
+            dw = dwp.view(Cout, 4, 4, Cin).permute(0, 3, 1, 2)                        # back to [co][ci][ky][kx]
+            if w.is_leaf and w.requires_grad:
+                if w.grad is None:
+                    w.grad = torch.zeros_like(w, memory_format=torch.contiguous_format)
+                w.grad.add_(dw)
                 if GRAD_READY is not None:
                     GRAD_READY(w)
             else:
-                dw = dwp.view(Cout, 4, 4, Cin).permute(0, 3, 1, 2)                    # back to [co][ci][ky][kx]
-                if w.is_leaf and w.requires_grad:
-                    w.grad.add_(dw)
-                    if GRAD_READY is not None:
-                        GRAD_READY(w)
-                else:
-                    gw = dw.contiguous()
+                gw = dw.contiguous()
             if inplace_b:
                 if GRAD_READY is not None:
                     GRAD_READY(b)

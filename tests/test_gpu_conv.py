@@ -41,17 +41,14 @@ def test_conv4s2_c_abi(B, H, W, Cin, Cout):
     if (Ho & (Ho - 1)) == 0 and (Wo & (Wo - 1)) == 0 and (B * Ho * Wo) % 32 == 0:
         dwp = torch.full((Cout, 16 * Cin), 0.5, device=dev)
         db = torch.full((Cout,), -1.0, device=dev)
-        _lib.call("dhz_conv4s2_wgrad", dy.data_ptr(), xd.data_ptr(), dwp.data_ptr(), db.data_ptr(), B, H, W, Cin, Cout, 0, s)
-        dwn = torch.full((Cout, Cin, 4, 4), 0.25, device=dev)          # the parameter's own layout, accumulated in place
-        _lib.call("dhz_conv4s2_wgrad", dy.data_ptr(), xd.data_ptr(), dwn.data_ptr(), None, B, H, W, Cin, Cout, 1, s)
+        _lib.call("dhz_conv4s2_wgrad", dy.data_ptr(), xd.data_ptr(), dwp.data_ptr(), db.data_ptr(), B, H, W, Cin, Cout, s)
         dwref = wr.grad.permute(0, 2, 3, 1).reshape(Cout, 16 * Cin)
         T = B * Ho * Wo
         assert (dwp.cpu().double() - 0.5 - dwref).abs().max() < 3e-6 * T ** 0.5 * max(1.0, dwref.abs().max().item() / T ** 0.5) + 1e-4
         assert (db.cpu().double() + 1.0 - br.grad).abs().max() < 3e-5 * T ** 0.5 + 1e-4
-        assert (dwn.cpu().double() - 0.25 - wr.grad).abs().max() < 3e-6 * T ** 0.5 * max(1.0, wr.grad.abs().max().item() / T ** 0.5) + 1e-4
     else:
         dwp = torch.zeros(Cout, 16 * Cin, device=dev)
-        assert lib.dhz_conv4s2_wgrad(dy.data_ptr(), xd.data_ptr(), dwp.data_ptr(), None, B, H, W, Cin, Cout, 0, s) == -22
+        assert lib.dhz_conv4s2_wgrad(dy.data_ptr(), xd.data_ptr(), dwp.data_ptr(), None, B, H, W, Cin, Cout, s) == -22
     assert lib.dhz_conv4s2_fwd(xd.data_ptr(), wp.data_ptr(), None, y.data_ptr(), B, H + 1, W, Cin, Cout, s) == -22
 
 
