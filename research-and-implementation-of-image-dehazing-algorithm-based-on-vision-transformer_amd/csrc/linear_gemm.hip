@@ -22,7 +22,7 @@ constexpr int BK = 32;
 #define DHZ_GEMM_ABL 0           // timing diagnostics (tools/gemm_phases.sh): 1 = no epilogue stores, 2 = no MFMAs, 4 = no global operand loads
 #endif
 
-template <int WM, int WN, bool WT, bool TR>
+template <int WM, int WN, bool WT>
 __global__ __launch_bounds__(256) void linear_gemm_kernel(const float* __restrict__ A, int lda,
                                                           const float* __restrict__ W, int ldw,
                                                           const float* __restrict__ bias, float* __restrict__ Y, int ldy,
@@ -122,18 +122,10 @@ __global__ __launch_bounds__(256) void linear_gemm_kernel(const float* __restric
     while (true) {
         const int ntile = tile_of(ti + 1);
         const int tn = tile % tiles_n, tm = tile / tiles_n;
-        // bias of this tile's columns, in the epilogue's lane layout (TR: four consecutive features per lane)
-        f32x4 bvt[TR ? WN : 1];
-        float bvs[TR ? 1 : WN];
-        if (TR) {
+        // bias of this tile's columns, in the epilogue's lane layout (loaded here, not in the epilogue: see there)
+        float bvs[WN];
 #pragma unroll
-            for (int b = 0; b < WN; ++b)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) bvt[b][j] = bias ? bias[tn * BN + wn * WN * 16 + 4 * g + 16 * b + j] : 0.f;
-        } else {
-#pragma unroll
-            for (int b = 0; b < WN; ++b) bvs[b] = bias ? bias[tn * BN + wn * WN * 16 + i16 + 16 * b] : 0.f;
-        }
+        for (int b = 0; b < WN; ++b) bvs[b] = bias ? bias[tn * BN + wn * WN * 16 + i16 + 16 * b] : 0.f;
         for (int st = 0; st < nst; ++st) {
             // next stage of the stream: the same tile, or the first stage of this workgroup's next tile
             const bool last = st + 1 == nst;
@@ -165,7 +157,7 @@ __global__ __launch_bounds__(256) void linear_gemm_kernel(const float* __restric
 #pragma unroll
                         for (int b = 0; b < WN; ++b)
                             if (abl & 2) acc[a][b][j] += af[a][j] + bf[b][j];
-                            else acc[a][b] = TR ? mfma16(bf[b][j], af[a][j], acc[a][b]) : mfma16(af[a][j], bf[b][j], acc[a][b]);
+                            else acc[a][b] = mfma16(af[a][j], bf[b][j], acc[a][b]);
             }
             if (more) {
                 swrite(buf ^ 1);
@@ -174,36 +166,16 @@ __global__ __launch_bounds__(256) void linear_gemm_kernel(const float* __restric
             }
         }
         // ---- tile epilogue straight from the accumulators; the stores drain behind the next tile's matrix work (its first
-        //      stage is already in LDS).
-        //      !TR: acc[a][b][j] = C[16 a + 4 g + j][16 b + i16]: the 16 lanes of a row write 64 contiguous bytes, the b sweep
-        //           completes the lines (4-byte stores, 64 per wave at the 128 x 128 tile).
-        //      TR : the MFMAs took the WEIGHT fragment as their first operand, so a 16 x 16 block arrives transposed:
-        //           acc[a][b][j] = C[token 16 a + i16][feature 16 b + 4 g + j] - a lane owns four CONSECUTIVE features of one
-        //           token and stores them as one 16-byte vector (4 x fewer store instructions and address computations).
+        //      stage is already in LDS).  acc[a][b][j] = C[16 a + 4 g + j][16 b + i16]: the 16 lanes of a row write 64 contiguous
+        //      bytes, the b sweep completes the lines.
         //      Full tiles (every tile unless T is ragged) store without per-row guards: behind a divergent guard hipcc waits for
         //      vmcnt(0) - i.e. for the acknowledgement of ALL earlier stores - before every guarded group, which serialised the
-        //      epilogue into 16 memory round trips per tile (211 -> 150 us at T = 524288, K = 64, N = 256).  The bias values are
-        //      loaded at the top of the tile for the same reason (no load result is waited for between the stores).
+        //      epilogue into 16 memory round trips per tile.  The bias values are loaded at the top of the tile for the same
+        //      reason (no load result is waited for between the stores).
+        //      (Swapping the MFMA operands turns a lane's four values into four consecutive features = one 16-byte store: 10-20 %
+        //      faster in isolation on outputs of <= 96 features, slower on wide ones, and no gain in the training step - not kept.)
         const bool full = tm * BM + BM <= M;                          // wave-uniform
-        if (TR) {
-            const int m0 = tm * BM + wm * WM * 16 + i16, n0 = tn * BN + wn * WN * 16 + 4 * g;
-            float* y0 = Y + (size_t)m0 * ldy + n0;
-            if (full) {
-#pragma unroll
-                for (int a = 0; a < WM; ++a)
-#pragma unroll
-                    for (int b = 0; b < WN; ++b)
-                        if (!(abl & 1) || acc[a][0][0] == 12345.678f)
-                            *reinterpret_cast<f32x4*>(y0 + (size_t)(16 * a) * ldy + 16 * b) = acc[a][b] + bvt[b];
-            } else {
-#pragma unroll
-                for (int a = 0; a < WM; ++a)
-                    if (m0 + 16 * a < M) {
-#pragma unroll
-                        for (int b = 0; b < WN; ++b) *reinterpret_cast<f32x4*>(y0 + (size_t)(16 * a) * ldy + 16 * b) = acc[a][b] + bvt[b];
-                    }
-            }
-        } else {
+        {
             const int m0 = tm * BM + wm * WM * 16 + 4 * g, n0 = tn * BN + wn * WN * 16 + i16;
             float* y0 = Y + (size_t)m0 * ldy + n0;
             if (full) {
@@ -235,7 +207,7 @@ __global__ __launch_bounds__(256) void linear_gemm_kernel(const float* __restric
     }
 }
 
-template <int WM, int WN, bool WT, bool TR>
+template <int WM, int WN, bool WT>
 void launch(const float* A, int lda, const float* W, int ldw, const float* bias, float* Y, int ldy, int M, int N, int K,
             hipStream_t s) {
     constexpr int BM = 32 * WM, BN = 32 * WN;
@@ -251,9 +223,9 @@ void launch(const float* A, int lda, const float* W, int ldw, const float* bias,
 #endif
     const int grid = ntiles < slots ? ntiles : slots;
     if (smem > 48 * 1024)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_gemm_kernel<WM, WN, WT, TR>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_gemm_kernel<WM, WN, WT>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    hipLaunchKernelGGL((linear_gemm_kernel<WM, WN, WT, TR>), dim3(grid), dim3(256), smem, s, A, lda, W, ldw, bias, Y, ldy, M, N,
+    hipLaunchKernelGGL((linear_gemm_kernel<WM, WN, WT>), dim3(grid), dim3(256), smem, s, A, lda, W, ldw, bias, Y, ldy, M, N,
                        K, tiles_n, ntiles);
 }
 
@@ -279,22 +251,14 @@ int dispatch(const char* who, const float* A, int lda, const float* W, int ldw, 
             if (blocks > best_blocks) { best_blocks = blocks; wm = a; wn = b; }
         }
     }
-    // epilogue form (measured per shape, tools/bench_gemm_ab.py): the 16-byte transposed stores win while an output row is at
-    // most a few cache lines (16 consecutive rows of a store instruction then stay within one DRAM page), the 4-byte form wins on
-    // wide rows
-    bool tr = WT ? N <= 96 : (N <= 32 || (N <= 64 && K <= 64));
 #ifdef DHZ_DIAG
-    if (const char* e = getenv("DHZ_GEMM_TR")) tr = atoi(e) != 0;
     if (const char* e = getenv("DHZ_GEMM_TILE")) {               // "wm,wn" (ignored where wn does not divide N / 32)
         int a = 0, b = 0;
         if (sscanf(e, "%d,%d", &a, &b) == 2 && N % (32 * b) == 0) { wm = a; wn = b; }
     }
 #endif
-#define CASE(a, b)                                                                      \
-    if (wm == a && wn == b) {                                                           \
-        if (tr) launch<a, b, WT, true>(A, lda, W, ldw, bias, Y, ldy, M, N, K, s);       \
-        else launch<a, b, WT, false>(A, lda, W, ldw, bias, Y, ldy, M, N, K, s);         \
-    }
+#define CASE(a, b) \
+    if (wm == a && wn == b) launch<a, b, WT>(A, lda, W, ldw, bias, Y, ldy, M, N, K, s);
     CASE(4, 1) CASE(4, 2) CASE(4, 3) CASE(4, 4) CASE(2, 1) CASE(2, 2) CASE(2, 3) CASE(2, 4)
 #undef CASE
     DHZ_CHECK_LAUNCH(who);
