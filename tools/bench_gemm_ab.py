@@ -1,5 +1,5 @@
 """A/B of one DHZ_* switch of the DIAGNOSTIC library on the token-Linear GEMM shapes, interleaved in one process:
-   DHZ_LIB_PATH=gpurun_out/diag/libdehaze_hip_diag.so python tools/bench_gemm_ab.py DHZ_GEMM_TR 0 1"""
+   DHZ_LIB_PATH=gpurun_out/diag/libdehaze_hip_diag.so python tools/bench_gemm_ab.py DHZ_GEMM_TILE 4,4 4,2 2,2"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [os.path.join(ROOT, "research-and-implementation-of-image-dehazing-algorithm-based-on-vision-transformer_amd"), ROOT]
