@@ -229,7 +229,8 @@ int dhz_linear_wgrad_multi(const float* dy, int ldy, const float* x, int ldx, in
  *        where W' are the backward-data filters, out_mask (shape of y, may be NULL) is the saved post-ReLU activation
  *        at the OUTPUT positions - the ReLU of the layer below, fused into the store - and out_addend (shape of y, may
  *        be NULL) the gradient reaching that activation from a loss tap.
- *        H % 16 == 0, W % 16 == 0, C % 8 == 0, K % 32 == 0.
+ *        H % 16 == 0 and W % 16 == 0, or H == W == 8 (the conv5_1 geometry of 128 x 128 patches: four images share one
+ *        16 x 16 block of the kernel); C % 8 == 0, K % 32 == 0.
  *      dhz_maxpool2x2_blocked_fwd / _bwd: the 2x2/stride-2 max pooling between VGG stages in the same layout
  *        (N = B*C/8 planes of [H][W][8]); the backward routes gy to the first maximum of each window of the saved
  *        post-ReLU map `act` and applies that map's ReLU (act > 0) in the same pass. */
