@@ -14,6 +14,7 @@ from .ops import NTOK, _p, _require_gpu, _stream
 
 SUPPORTED_C = (32, 64, 128)
 ENABLED = True      # set False to force the unfused chain (tests compare the two)
+ATTN_FUSED_C128_MAX_HW = 1024   # C = 128 takes the fused attention forward up to this map size (32 x 32), the chain above
 # Fused LeFF kernels (csrc/leff_fused.hip).  Measured on MI355X (tools/bench_leff.py, bs 32): the fused forward wins at C = 32 / 64
 # (inference 0.76-0.85x of the chain, training 0.87-0.95x) and loses at C = 128; the fused backward-data kernel is correct
 # (tests/test_gpu_leff.py) but 1.5-2x slower than the kernel chain in fp32 - fp32-input MFMA and fp32 VALU instructions share the
@@ -273,7 +274,7 @@ def attn_branch(x, norm, layer, table, idx, mask, dscale, Hres, Wres, shift, hea
     q, k, v, o = layer.query_projection, layer.key_projection, layer.value_projection, layer.out_projection
     args = (x, norm.weight, norm.bias, q.weight, q.bias, k.weight, k.bias, v.weight, v.bias, o.weight, o.bias, table, idx,
             mask, dscale, Hres, Wres, shift, heads, torch.is_grad_enabled())
-    use_fused = ENABLED and x.dtype == torch.float32 and C == 32 * heads and (C in (32, 64) or (C == 128 and Hres * Wres <= 1024))
+    use_fused = ENABLED and x.dtype == torch.float32 and C == 32 * heads and (C in (32, 64) or (C == 128 and Hres * Wres <= ATTN_FUSED_C128_MAX_HW))
     return (_FusedAttnBranch if use_fused else _AttnBranchChain).apply(*args)
 
 
