@@ -198,6 +198,10 @@ int dhz_leff_dwconv_fwd_dt(const void* u, const float* w, const float* b, void* 
                            int dtype, void* stream);
 int dhz_leff_dwconv_bwd_dt(const void* dz, const void* u, const void* t, const float* w, void* du, float* dw, float* db, int B,
                            int Hres, int Wres, int Ch, int dtype, void* stream);
+/*      the same with dz multiplied by dz_scale[b] per image on the way in (the DropPath scale of M1:873 folded into this kernel;
+ *      dz_scale NULL = 1) */
+int dhz_leff_dwconv_bwd_scaled_dt(const void* dz, const void* u, const void* t, const float* w, void* du, float* dw, float* db,
+                                  const float* dz_scale, int B, int Hres, int Wres, int Ch, int dtype, void* stream);
 int dhz_ps_attn_fwd_dt(const void* q, const void* k, const void* v, int ld, const uint8_t* idx, const float* bias,
                        const float* mask, void* out, int ldo, uint8_t* rank, int B_, int H, int nW, int d, int dtype,
                        void* stream);
@@ -216,6 +220,10 @@ int dhz_linear_wgrad(const float* dy, int ldy, const float* x, int ldx, int T, i
 /*      Same contraction for nmat (1..4) parameters that share the input x - the Q / K / V projections of
  *      AttentionLayer.forward (ATT:385-461): columns [i*nper, (i+1)*nper) of dy belong to dw[i] / db[i] (HOST arrays of
  *      nmat device pointers; db may be NULL, or all of its entries NULL).  One launch reads x once instead of nmat times. */
+/*      dhz_linear_wgrad with row t of dy multiplied by row_scale[t / rows_per_scale] on the way in (per-image DropPath scale of the
+ *      branch output; rows_per_scale a multiple of 32 that divides T; row_scale NULL = plain dhz_linear_wgrad). */
+int dhz_linear_wgrad_rs(const float* dy, int ldy, const float* x, int ldx, int T, int N, int K, float* dw, float* db,
+                        const float* row_scale, int rows_per_scale, void* stream);
 int dhz_linear_wgrad_multi(const float* dy, int ldy, const float* x, int ldx, int T, int nmat, int nper, int K,
                            float* const* dw, float* const* db, void* stream);
 

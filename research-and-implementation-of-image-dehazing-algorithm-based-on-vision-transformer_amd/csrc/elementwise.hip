@@ -300,8 +300,8 @@ template <typename T>
 __global__ __launch_bounds__(256, DWB_WAVES) void leff_dwconv_bwd_kernel(const T* __restrict__ dz, const T* __restrict__ u,
                                                               const T* __restrict__ tpre, const float* __restrict__ w,
                                                               T* __restrict__ du, float* __restrict__ dw,
-                                                              float* __restrict__ db, int B, int Hres, int Wres, int Ch,
-                                                              int tiles_x, int tiles_y, int wg_per_cg) {
+                                                              float* __restrict__ db, const float* __restrict__ dzscale, int B,
+                                                              int Hres, int Wres, int Ch, int tiles_x, int tiles_y, int wg_per_cg) {
     __shared__ __attribute__((aligned(16))) float ds[HHGT * HWID * CT];    // dt = dz * gelu'(t) with halo
     __shared__ __attribute__((aligned(16))) float us[TH * TW * CT];        // u of the tile: each thread parks ITS OWN loads here
     __shared__ float red[32][CT];                                           // [pos-slot][channel] reduction scratch
@@ -320,6 +320,7 @@ __global__ __launch_bounds__(256, DWB_WAVES) void leff_dwconv_bwd_kernel(const T
         const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, bimg = tile / (tiles_x * tiles_y);
         const int x0 = tx * TW - 1, y0 = ty * TH - 1;
         const size_t ib = (size_t)bimg * Hres * Wres;
+        const float zsc = dzscale ? dzscale[bimg] : 1.f;     // per-image factor of dz (the DropPath scale, folded in here)
         __syncthreads();
         // this thread's u values (interior positions; clamped addresses, masked at the store): in flight across the staging
         float4 uv[NIT];
@@ -354,7 +355,7 @@ __global__ __launch_bounds__(256, DWB_WAVES) void leff_dwconv_bwd_kernel(const T
                 const int pos = (t >> 3) + 32 * (3 * half + i);
                 if (pos < NPOS) {
                     float4 dv = make_float4(0, 0, 0, 0);
-                    if (ok[i]) dv = make_float4(rz[i].x * rt[i].x, rz[i].y * rt[i].y, rz[i].z * rt[i].z, rz[i].w * rt[i].w);
+                    if (ok[i]) dv = make_float4(zsc * rz[i].x * rt[i].x, zsc * rz[i].y * rt[i].y, zsc * rz[i].z * rt[i].z, zsc * rz[i].w * rt[i].w);
                     *reinterpret_cast<float4*>(&ds[pos * CT + c4 * 4]) = dv;
                 }
             }
@@ -693,8 +694,9 @@ extern "C" int dhz_leff_dwconv_fwd(const float* u, const float* w, const float* 
     return dhz_leff_dwconv_fwd_dt(u, w, b, t, z, B, Hres, Wres, Ch, DHZ_F32, stream);
 }
 
-extern "C" int dhz_leff_dwconv_bwd_dt(const void* dz, const void* u, const void* t, const float* w, void* du, float* dw,
-                                      float* db, int B, int Hres, int Wres, int Ch, int dtype, void* stream) {
+extern "C" int dhz_leff_dwconv_bwd_scaled_dt(const void* dz, const void* u, const void* t, const float* w, void* du, float* dw,
+                                             float* db, const float* dz_scale, int B, int Hres, int Wres, int Ch, int dtype,
+                                             void* stream) {
     DHZ_REQUIRE(dz && u && t && w && du && dw && db, "dhz_leff_dwconv_bwd: null pointer");
     DHZ_REQUIRE(B > 0 && Hres > 0 && Wres > 0 && Ch % CT == 0, "dhz_leff_dwconv_bwd: Ch=%d must be a multiple of %d", Ch, CT);
     const int tiles_x = (Wres + TW - 1) / TW, tiles_y = (Hres + TH - 1) / TH;
@@ -704,9 +706,13 @@ extern "C" int dhz_leff_dwconv_bwd_dt(const void* dz, const void* u, const void*
     if (wg_per_cg > ntiles) wg_per_cg = ntiles;
     DT_SWITCH(dtype, "dhz_leff_dwconv_bwd",
               hipLaunchKernelGGL((leff_dwconv_bwd_kernel<T>), dim3(wg_per_cg * ncg), dim3(256), 0, (hipStream_t)stream, (const T*)dz,
-                                 (const T*)u, (const T*)t, w, (T*)du, dw, db, B, Hres, Wres, Ch, tiles_x, tiles_y, wg_per_cg));
+                                 (const T*)u, (const T*)t, w, (T*)du, dw, db, dz_scale, B, Hres, Wres, Ch, tiles_x, tiles_y, wg_per_cg));
     DHZ_CHECK_LAUNCH("dhz_leff_dwconv_bwd");
     return DHZ_OK;
+}
+extern "C" int dhz_leff_dwconv_bwd_dt(const void* dz, const void* u, const void* t, const float* w, void* du, float* dw,
+                                      float* db, int B, int Hres, int Wres, int Ch, int dtype, void* stream) {
+    return dhz_leff_dwconv_bwd_scaled_dt(dz, u, t, w, du, dw, db, nullptr, B, Hres, Wres, Ch, dtype, stream);
 }
 extern "C" int dhz_leff_dwconv_bwd(const float* dz, const float* u, const float* t, const float* w, float* du, float* dw,
                                    float* db, int B, int Hres, int Wres, int Ch, void* stream) {

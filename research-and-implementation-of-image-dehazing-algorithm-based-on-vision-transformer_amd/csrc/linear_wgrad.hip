@@ -25,6 +25,8 @@ struct WgradOut {
     float* dw[MAXMAT];
     float* db[MAXMAT];
     int nper;
+    const float* rs;    // optional row scale of dy: row t is multiplied by rs[t / rps] (DropPath scale of its image); rps % TK == 0
+    int rps;
 };
 
 // WM, WN: 16x16 tiles per wave along N (rows of dW) and K (cols of dW); waves are NWM x 2 (NWM = 2: 256 threads,
@@ -76,7 +78,9 @@ __global__ __launch_bounds__(128 * NWM * TG) void linear_wgrad_kernel(const floa
     for (int i = 0; i < NA; ++i) dbacc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     const bool do_db = (db != nullptr) && (tn == 0);
 
+    int st_loaded = 0;                                 // stage whose rows sit in ra / rb
     auto gload = [&](int st) {
+        st_loaded = st;
         if (WG_ABL & 4) return;
         const size_t tok0 = (size_t)st * TK;
 #pragma unroll
@@ -93,6 +97,11 @@ __global__ __launch_bounds__(128 * NWM * TG) void linear_wgrad_kernel(const floa
         }
     };
     auto swrite = [&](int buf) {
+        if (out.rs) {                                   // a stage (TK tokens) lies inside one image: one wave-uniform factor
+            const float sc = out.rs[(st_loaded * TK) / out.rps];
+#pragma unroll
+            for (int i = 0; i < NA; ++i) ra[i] *= sc;
+        }
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             const int e = tl + GT * i;
@@ -262,6 +271,17 @@ extern "C" int dhz_linear_wgrad(const float* dy, int ldy, const float* x, int ld
     WgradOut out = {};
     out.dw[0] = dw; out.db[0] = db; out.nper = N;
     return wgrad_dispatch("dhz_linear_wgrad", dy, ldy, x, ldx, T, 1, N, K, out, (hipStream_t)stream);
+}
+
+extern "C" int dhz_linear_wgrad_rs(const float* dy, int ldy, const float* x, int ldx, int T, int N, int K, float* dw, float* db,
+                                   const float* row_scale, int rows_per_scale, void* stream) {
+    DHZ_REQUIRE(dy && x && dw, "dhz_linear_wgrad_rs: null pointer");
+    DHZ_REQUIRE(!row_scale || (rows_per_scale > 0 && rows_per_scale % TK == 0 && T % rows_per_scale == 0),
+                "dhz_linear_wgrad_rs: rows_per_scale=%d must be a multiple of %d that divides T=%d", rows_per_scale, TK, T);
+    WgradOut out = {};
+    out.dw[0] = dw; out.db[0] = db; out.nper = N;
+    out.rs = row_scale; out.rps = rows_per_scale;
+    return wgrad_dispatch("dhz_linear_wgrad_rs", dy, ldy, x, ldx, T, 1, N, K, out, (hipStream_t)stream);
 }
 
 extern "C" int dhz_linear_wgrad_multi(const float* dy, int ldy, const float* x, int ldx, int T, int nmat, int nper, int K,

@@ -63,9 +63,11 @@ SIGNATURES = {
     "dhz_reverse_residual_bwd_dt": [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
     "dhz_leff_dwconv_fwd_dt": [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_p],
     "dhz_leff_dwconv_bwd_dt": [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_p],
+    "dhz_leff_dwconv_bwd_scaled_dt": [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_p],
     "dhz_ps_attn_fwd_dt": [c_f, c_f, c_f, c_i, c_p, c_f, c_f, c_f, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_p],
     "dhz_ps_attn_bwd_dt": [c_f, c_f, c_f, c_i, c_f, c_f, c_p, c_f, c_i, c_f, c_f, c_f, c_i, c_f, c_i, c_i, c_i, c_i, c_i, c_p],
     "dhz_linear_wgrad": [c_f, c_i, c_f, c_i, c_i, c_i, c_i, c_f, c_f, c_p],
+    "dhz_linear_wgrad_rs": [c_f, c_i, c_f, c_i, c_i, c_i, c_i, c_f, c_f, c_f, c_i, c_p],
     "dhz_linear_wgrad_multi": [c_f, c_i, c_f, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p],
     "dhz_ln_partition_fwd": [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
     "dhz_ln_partition_bwd": [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_p],

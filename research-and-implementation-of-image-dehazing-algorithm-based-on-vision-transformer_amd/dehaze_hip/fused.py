@@ -25,7 +25,7 @@ LEFF_FUSED_C = (32, 64)     # widths that take the fused forward
 LEFF_FUSED_BWD = False      # True: dhz_leff_fused_bwd instead of the backward kernel chain (any C in 32 / 64 / 128)
 
 
-def _wgrad(dy, off, x, w, b):
+def _wgrad(dy, off, x, w, b, row_scale=None):
     """dW/db of one Linear from dy[:, off:off+N] and x.  In place into .grad when the parameter is a leaf and
     the split-T kernel is the better choice; returns (dw, db) to hand to autograd, or (None, None)."""
     T, K = x.shape
@@ -35,12 +35,12 @@ def _wgrad(dy, off, x, w, b):
     q = 64 if dy.dtype == ops.BF16 else 32
     mine = T % q == 0 and N % q == 0 and K % q == 0         # (the kernel's shape contract; always true on this model)
     if mine and w.is_leaf and w.requires_grad and (b is None or (b.is_leaf and b.requires_grad)):
-        ops._accumulate_param_grads(dy, off, x, [(w, b)])
+        ops._accumulate_param_grads(dy, off, x, [(w, b)], row_scale)
         return None, None
     if mine:
         dw = torch.zeros_like(w, memory_format=torch.contiguous_format)
         db = torch.zeros_like(b) if b is not None else None
-        ops.wgrad_into(dy, off, x, N, dw, db)
+        ops.wgrad_into(dy, off, x, N, dw, db, row_scale)
         return dw, db
     raise RuntimeError(f"dehaze_hip: Linear weight gradient for T={T}, N={N}, K={K}: the HIP kernel needs multiples of 32 "
                        "(there is deliberately no library fallback)")
@@ -358,23 +358,28 @@ class _LeffBranch(Function):
             g_w1, g_b1 = _wgrad(du, 0, xn, w1, b1)
             dx, dgamma, dbeta = _ln_backward(dxn, x, gamma_p, beta_p, gamma, stats, dout, B, L, 1, C, 0, 0)
             return (dx, dgamma, dbeta, g_w1, g_b1, g_wd, g_bd, g_w2, g_b2, None, None, None, None)
-        if dscale is not None:
+        # DropPath scale of the branch output (per image): in fp32 it is folded into the consumers - linear2's weight gradient scales
+        # the rows of dout as it stages them, the depthwise backward scales dz - instead of a scaled copy of dout (one pass over
+        # [T, C] per block less); bf16 keeps the copy
+        fold = dscale is not None and dout.dtype == torch.float32 and L % 32 == 0
+        zscale = dscale if fold else None
+        if dscale is not None and not fold:
             dy = torch.empty((T, C), device=dev, dtype=dout.dtype)
             _lib.call("dhz_reverse_residual_bwd_dt", _p(dout), _p(dscale), _p(dy), B, L, 1, C, 0, 0, ops._dt(dout), _stream())
         else:
             dy = dout.view(T, C)
         dz = ops.gemm_dgrad(dy, w2_)
-        g_w2, g_b2 = _wgrad(dy, 0, z, w2, b2)
+        g_w2, g_b2 = _wgrad(dy, 0, z, w2, b2, (dscale, L) if fold else None)
         du = torch.empty_like(u)
         if gwd is not None and gbd is not None:          # depthwise weight / bias gradients straight into .grad
-            _lib.call("dhz_leff_dwconv_bwd_dt", _p(dz), _p(u), _p(tg), _p(wdc), _p(du), _p(gwd), _p(gbd), B, Hres, Wres, Ch,
-                      ops._dt(u), _stream())
+            _lib.call("dhz_leff_dwconv_bwd_scaled_dt", _p(dz), _p(u), _p(tg), _p(wdc), _p(du), _p(gwd), _p(gbd), _p(zscale), B, Hres,
+                      Wres, Ch, ops._dt(u), _stream())
             _ready(wd, bd)
             g_wd = g_bd = None
         else:
             dwb = torch.zeros((Ch * 10,), **f32)
-            _lib.call("dhz_leff_dwconv_bwd_dt", _p(dz), _p(u), _p(tg), _p(wdc), _p(du), dwb.data_ptr(),
-                      dwb.data_ptr() + 4 * Ch * 9, B, Hres, Wres, Ch, ops._dt(u), _stream())
+            _lib.call("dhz_leff_dwconv_bwd_scaled_dt", _p(dz), _p(u), _p(tg), _p(wdc), _p(du), dwb.data_ptr(),
+                      dwb.data_ptr() + 4 * Ch * 9, _p(zscale), B, Hres, Wres, Ch, ops._dt(u), _stream())
             g_wd, g_bd = dwb[:Ch * 9].view(Ch, 1, 3, 3), dwb[Ch * 9:]
         dxn = ops.gemm_dgrad(du, w1_)
         g_w1, g_b1 = _wgrad(du, 0, xn, w1, b1)

@@ -253,9 +253,10 @@ def shift_mask(Hres, Wres, shift, device):
 GRAD_READY = None
 
 
-def _accumulate_param_grads(dy, ldy_off, x, params):
+def _accumulate_param_grads(dy, ldy_off, x, params, row_scale=None):
     """dW += dy[:, off:off+N]^T x, db += colsum for every (W, b) pair, straight into .grad (zero-init).  Pairs of equal
-    shape (the Q / K / V projections) go through ONE launch that reads x once (dhz_linear_wgrad_multi)."""
+    shape (the Q / K / V projections) go through ONE launch that reads x once (dhz_linear_wgrad_multi).
+    row_scale = (scale[B], rows_per_scale): row t of dy counts as scale[t // rows_per_scale] * dy[t] (fp32, one pair only)."""
     T, K = x.shape
     for W, b in params:
         for p in (W, b):
@@ -265,6 +266,7 @@ def _accumulate_param_grads(dy, ldy_off, x, params):
     N = params[0][0].shape[0]
     same = 1 < len(params) <= 4 and all(W.shape[0] == N for W, _ in params) and \
         len({b is None for _, b in params}) == 1
+    assert row_scale is None or (dy.dtype == torch.float32 and len(params) == 1)
     if dy.dtype == BF16:
         # bf16 dy / x, fp32 accumulation straight into the fp32 .grad buffers; equal-shaped parameters share one launch
         groups = [params] if (same or len(params) == 1) else [[pr] for pr in params]
@@ -286,8 +288,12 @@ def _accumulate_param_grads(dy, ldy_off, x, params):
     else:
         off = ldy_off
         for W, b in params:
-            _lib.call("dhz_linear_wgrad", dy.data_ptr() + 4 * off, dy.stride(0), _p(x), x.stride(0), T, W.shape[0], K,
-                      _p(W.grad), _p(b.grad) if b is not None else None, _stream())
+            if row_scale is not None:
+                _lib.call("dhz_linear_wgrad_rs", dy.data_ptr() + 4 * off, dy.stride(0), _p(x), x.stride(0), T, W.shape[0], K,
+                          _p(W.grad), _p(b.grad) if b is not None else None, _p(row_scale[0]), int(row_scale[1]), _stream())
+            else:
+                _lib.call("dhz_linear_wgrad", dy.data_ptr() + 4 * off, dy.stride(0), _p(x), x.stride(0), T, W.shape[0], K,
+                          _p(W.grad), _p(b.grad) if b is not None else None, _stream())
             off += W.shape[0]
     if GRAD_READY is not None:
         for W, b in params:
@@ -296,9 +302,14 @@ def _accumulate_param_grads(dy, ldy_off, x, params):
                 GRAD_READY(b)
 
 
-def wgrad_into(dy, off, x, N, dw, db):
+def wgrad_into(dy, off, x, N, dw, db, row_scale=None):
     """dw[N,K] += dy[:, off:off+N]^T x, db += column sums (fp32 accumulators) for fp32 or bf16 dy / x."""
     T, K = x.shape
+    if row_scale is not None:
+        assert dy.dtype == torch.float32
+        _lib.call("dhz_linear_wgrad_rs", dy.data_ptr() + 4 * off, dy.stride(0), _p(x), x.stride(0), T, N, K, _p(dw), _p(db),
+                  _p(row_scale[0]), int(row_scale[1]), _stream())
+        return
     if dy.dtype == BF16:
         dws = (ctypes.c_void_p * 1)(dw.data_ptr())
         dbs = (ctypes.c_void_p * 1)(db.data_ptr() if db is not None else None)

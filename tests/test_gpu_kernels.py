@@ -208,6 +208,28 @@ def test_leff_dwconv(dev, ops, Ch, res):
     assert torch.allclose(bd.grad.cpu(), bo.grad, atol=3e-4, rtol=1e-3)
 
 
+def test_leff_dwconv_bwd_scaled_c_abi(dev):
+    """dhz_leff_dwconv_bwd_scaled_dt: a per-image factor on dz (the DropPath scale folded into the kernel) == the plain kernel on a
+    pre-scaled dz (bit-identical up to the order of two multiplications: compared with a tolerance of a few ulp)."""
+    from dehaze_hip import _lib
+    s = torch.cuda.current_stream().cuda_stream
+    B, res, Ch = 4, 16, 64
+    g = torch.Generator().manual_seed(3)
+    u, dz, tp = (torch.randn(B * res * res, Ch, generator=g).to(dev) for _ in range(3))
+    w = (0.3 * torch.randn(Ch, 9, generator=g)).to(dev)
+    sc = torch.tensor([0.0, 1.25, 1.0, 1.111], device=dev)
+    out = []
+    for scaled in (True, False):
+        du = torch.empty_like(u); dw = torch.zeros(Ch * 9, device=dev); db = torch.zeros(Ch, device=dev)
+        dzz = dz if scaled else (dz.view(B, -1, Ch) * sc.view(B, 1, 1)).reshape(-1, Ch).contiguous()
+        _lib.call("dhz_leff_dwconv_bwd_scaled_dt", dzz.data_ptr(), u.data_ptr(), tp.data_ptr(), w.data_ptr(), du.data_ptr(),
+                  dw.data_ptr(), db.data_ptr(), sc.data_ptr() if scaled else None, B, res, res, Ch, 0, s)
+        out.append((du, dw, db))
+    for a, b in zip(*out):
+        assert torch.allclose(a, b, atol=1e-5, rtol=1e-5)
+    assert out[0][0].view(B, -1)[0].abs().max().item() == 0.0          # the dropped image passes no gradient
+
+
 # ----------------------------------------------------------------------------- K10 / K12
 def test_charbonnier(golden, dev, ops):
     g = golden("losses")

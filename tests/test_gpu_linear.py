@@ -63,6 +63,24 @@ def test_packed_qkv_grads(T, C):
     assert torch.allclose(xd.grad.cpu().double(), xr.grad, atol=1e-4, rtol=1e-4)
 
 
+def test_wgrad_row_scale_c_abi():
+    """dhz_linear_wgrad_rs: rows of dy scaled per image on the way in == the plain kernel on a pre-scaled dy."""
+    from dehaze_hip import _lib
+    dev = torch.device("cuda:0")
+    s = torch.cuda.current_stream().cuda_stream
+    B, L, N, K = 4, 256, 96, 64
+    g = torch.Generator().manual_seed(11)
+    dy = torch.randn(B * L, N, generator=g).to(dev); x = torch.randn(B * L, K, generator=g).to(dev)
+    sc = torch.tensor([1.25, 0.0, 1.0, 1.0526316], device=dev)
+    dw = torch.zeros(N, K, device=dev); db = torch.zeros(N, device=dev)
+    _lib.call("dhz_linear_wgrad_rs", dy.data_ptr(), N, x.data_ptr(), K, B * L, N, K, dw.data_ptr(), db.data_ptr(), sc.data_ptr(), L, s)
+    dys = (dy.view(B, L, N) * sc.view(B, 1, 1)).reshape(B * L, N)
+    ref_w = dys.double().t() @ x.double(); ref_b = dys.double().sum(0)
+    assert (dw.double() - ref_w).abs().max().item() < 1e-3 and (db.double() - ref_b).abs().max().item() < 1e-3
+    lib = _lib.load()
+    assert lib.dhz_linear_wgrad_rs(dy.data_ptr(), N, x.data_ptr(), K, B * L, N, K, dw.data_ptr(), db.data_ptr(), sc.data_ptr(), 48, s) == -22
+
+
 def test_wgrad_multi_c_abi():
     """dhz_linear_wgrad_multi through the C-ABI: 4 parameters, no bias gradients, strided dy; and its argument checks."""
     import ctypes
