@@ -60,11 +60,12 @@ int dhz_ps_attn_fwd(const float* q, const float* k, const float* v, int ld, cons
 
 /* Backward of the above (autograd of ATT:287-342; gradient flows through steps 6-12 only).
  * dout: [B_,64,H,d] stride ldo.  dq,dk,dv: [B_,64,H,d] stride ldg (every element written).
- * dbias_part: workspace [dhz_ps_attn_bwd_parts(B_,H), 64, 64] fp32 (written, not accumulated) or
+ * dbias_part: workspace [dhz_ps_attn_bwd_parts_d(B_,H,d), 64, 64] fp32 (written, not accumulated) or
  *             NULL when bias == NULL.  Row p holds the partial bias gradient of head (p % H);
  *             reduce with dhz_bias_table_grad.
  */
-int dhz_ps_attn_bwd_parts(int B_, int H);
+int dhz_ps_attn_bwd_parts(int B_, int H);            /* dhz_dense_attn_bwd */
+int dhz_ps_attn_bwd_parts_d(int B_, int H, int d);   /* dhz_ps_attn_bwd: its persistent workgroups (two per CU) */
 int dhz_ps_attn_bwd(const float* q, const float* k, const float* v, int ld, const float* bias,
                     const float* mask, const uint8_t* rank, const float* dout, int ldo, float* dq,
                     float* dk, float* dv, int ldg, float* dbias_part, int B_, int H, int nW, int d,

@@ -254,10 +254,8 @@ struct BwdSmem {
     float v[NT * DS];      // V        ; later dV staging
     float dor[32 * DS];    // dO[top] rows, row 25 = sum of dO over unselected queries
     float p1[32 * SS];     // scores -> P1 ; later dQ[top] staging (32 x DS)
-    float p2[32 * SS];
-    float ds[32 * SS];     // dP2 -> dS
-    float acc[NT * NT];    // per-workgroup bias-gradient accumulator
-    float dmp[4 * D];
+    float p2[32 * SS];     // P2 ; later dA (gradient w.r.t. the bias-added logits) for the bias-gradient owners
+    float ds[32 * SS];     // dP2 -> dS ; before that (first phase only) the 4 x D partial column sums of dO
     int top[32];
     uint8_t rank[NT];
 };
@@ -279,9 +277,12 @@ __global__ __launch_bounds__(256) void ps_attn_bwd_kernel(
     const int bstep = gridDim.x / H;
     const float scale = rsqrtf((float)D);
 
-    if (HAS_BIAS) {
-        for (int e = t; e < NT * NT / 4; e += 256) reinterpret_cast<float4*>(sm.acc)[e] = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
+    // Bias gradient of this workgroup's window-heads, summed in REGISTERS: thread t owns the 16 elements (row w + 4 i, column lane)
+    // of the 64 x 64 table.  (Round 2: the sum used to live in a 16 KB LDS array - without it the workgroup needs 53 KB (d = 32) /
+    // 78 KB (d = 64) of LDS and three / two workgroups fit a CU instead of two / one.)
+    float accr[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) accr[i] = 0.f;
 
     // The window-heads of this workgroup are processed one after the other, ~9 barrier-separated phases each.  Their
     // inputs (K, V, Q, dO rows and the ranks) are prefetched into registers one window-head ahead - native vectors, so
@@ -342,10 +343,10 @@ __global__ __launch_bounds__(256) void ps_attn_bwd_kernel(
                 dm[0] += __shfl_xor(dm[0], o); dm[1] += __shfl_xor(dm[1], o);
                 dm[2] += __shfl_xor(dm[2], o); dm[3] += __shfl_xor(dm[3], o);
             }
-            if (lane < F) *reinterpret_cast<f32x4*>(&sm.dmp[w * D + lane * 4]) = dm;
+            if (lane < F) *reinterpret_cast<f32x4*>(&sm.ds[w * D + lane * 4]) = dm;
         }
         __syncthreads();
-        if (t < D) sm.dor[NU * DS + t] = sm.dmp[t] + sm.dmp[D + t] + sm.dmp[2 * D + t] + sm.dmp[3 * D + t];
+        if (t < D) sm.dor[NU * DS + t] = sm.ds[t] + sm.ds[D + t] + sm.ds[2 * D + t] + sm.ds[3 * D + t];
 
         // ---- recompute scores of the selected rows: Sr = Q[top] K^T (32 x 64), 8 tiles, 2 per wave
         {
@@ -435,10 +436,9 @@ __global__ __launch_bounds__(256) void ps_attn_bwd_kernel(
 #pragma unroll
             for (int i = 0; i < 8; ++i) { da[i] = p2[i] * (dp[i] - dot2); dot1 += da[i] * p1[i]; }
             dot1 = row8_sum(dot1);
-            if (HAS_BIAS && r < NU) {
-                float* arow = sm.acc + sm.top[r] * NT + c0;
+            if (HAS_BIAS) {                               // dA over the P2 values this thread has just read: picked up by the owners below
 #pragma unroll
-                for (int i = 0; i < 8; ++i) arow[i] += da[i];
+                for (int i = 0; i < 8; ++i) sm.p2[r * SS + c0 + i] = da[i];
             }
 #pragma unroll
             for (int i = 0; i < 8; ++i) sm.ds[r * SS + c0 + i] = p1[i] * (da[i] - dot1) * scale;
@@ -451,6 +451,14 @@ __global__ __launch_bounds__(256) void ps_attn_bwd_kernel(
             }
         }
         __syncthreads();
+
+        if (HAS_BIAS) {                                       // query row `row` was selected as r: its dA row goes to the table row
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int rk = sm.rank[w + 4 * i];            // wave-uniform
+                if (rk < NU) accr[i] += sm.p2[rk * SS + lane];
+            }
+        }
 
         // ---- dQ[top] = dS K (32 x D, K = 64) ; dK = dS^T Q[top] (64 x D, K = 32)
         f32x4 accq[D / 32];
@@ -504,9 +512,9 @@ __global__ __launch_bounds__(256) void ps_attn_bwd_kernel(
     }
 
     if (HAS_BIAS) {
-        __syncthreads();
-        float4* dst = reinterpret_cast<float4*>(dbias_part + (size_t)blockIdx.x * NT * NT);
-        for (int e = t; e < NT * NT / 4; e += 256) dst[e] = reinterpret_cast<const float4*>(sm.acc)[e];
+        float* dst = dbias_part + (size_t)blockIdx.x * NT * NT;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) dst[(w + 4 * i) * NT + lane] = accr[i];
     }
 }
 
@@ -611,14 +619,20 @@ extern "C" int dhz_ps_attn_fwd_dt(const void* q, const void* k, const void* v, i
     return DHZ_EINVAL;
 }
 
-extern "C" int dhz_ps_attn_bwd_parts(int B_, int H) {
+// workgroups of the persistent backward kernel: two per CU.  (At head_dim 64 that is what the LDS allows - 78 KB each since the
+// bias-gradient sum lives in registers, ONE before: config 4 46.0 -> 44.7 ms per step.  At head_dim 32 three would fit (53 KB), but
+// 768 workgroups measured 38.48 ms per step against 38.16 with 512 and 38.95 with 256: more partial tables to reduce, no gain in the
+// kernel.)
+extern "C" int dhz_ps_attn_bwd_parts_d(int B_, int H, int d) {
     if (B_ <= 0 || H <= 0) return 0;
+    (void)d;
     const int cap = 512;
     int per_head = cap / H;
     if (per_head < 1) per_head = 1;
     if (per_head > B_) per_head = B_;
     return per_head * H;
 }
+extern "C" int dhz_ps_attn_bwd_parts(int B_, int H) { return dhz_ps_attn_bwd_parts_d(B_, H, 64); }   // dhz_dense_attn_bwd's count (512 slots)
 
 template <int D, bool HB, typename T>
 static void launch_bwd(int parts, hipStream_t s, const T* q, const T* k, const T* v, int ld,
@@ -641,7 +655,7 @@ static int ps_attn_bwd_t(const T* q, const T* k, const T* v, int ld, const float
     DHZ_REQUIRE(ld % 4 == 0 && ldo % 4 == 0 && ldg % 4 == 0, "dhz_ps_attn_bwd: leading dims must be multiples of 4");
     DHZ_REQUIRE(!mask || (nW > 0 && B_ % nW == 0), "dhz_ps_attn_bwd: B_=%d not a multiple of nW=%d", B_, nW);
     hipStream_t s = (hipStream_t)stream;
-    const int parts = dhz_ps_attn_bwd_parts(B_, H);
+    const int parts = dhz_ps_attn_bwd_parts_d(B_, H, d);
     if (nW <= 0) nW = 1;
     if (d == 32) {
         if (bias) launch_bwd<32, true>(parts, s, q, k, v, ld, bias, mask, rank, dout, ldo, dq, dk, dv, ldg, dbias_part, B_, H, nW);

@@ -21,6 +21,7 @@ SIGNATURES = {
     "dhz_last_error": [],
     "dhz_ps_attn_fwd": [c_f, c_f, c_f, c_i, c_p, c_f, c_f, c_f, c_i, c_p, c_i, c_i, c_i, c_i, c_p],
     "dhz_ps_attn_bwd_parts": [c_i, c_i],
+    "dhz_ps_attn_bwd_parts_d": [c_i, c_i, c_i],
     "dhz_ps_attn_bwd": [c_f, c_f, c_f, c_i, c_f, c_f, c_p, c_f, c_i, c_f, c_f, c_f, c_i, c_f, c_i, c_i, c_i, c_i, c_p],
     "dhz_fused_attn_prepack": [c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_p],
     "dhz_fused_window_attn_fwd": [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_p, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_p,

@@ -165,7 +165,7 @@ class _FusedAttnBranch(Function):
         g_wo, g_bo = _wgrad(daw, 0, cx, wo, bo)
         # (3) attention core
         dqkv = torch.empty_like(qkv)
-        parts = _lib.load().dhz_ps_attn_bwd_parts(B_, H)
+        parts = _lib.load().dhz_ps_attn_bwd_parts_d(B_, H, C // H)
         dpart = torch.empty((parts, NTOK, NTOK), **f32) if bias is not None else None
         nW = mask.shape[0] if mask is not None else 1
         base, gb = qkv.data_ptr(), dqkv.data_ptr()
@@ -253,7 +253,7 @@ class _AttnBranchChain(Function):
         dctx = ops.gemm_dgrad(daw, wo_)
         g_wo, g_bo = _wgrad(daw, 0, cx, wo, bo)
         dqkv = torch.empty_like(qkv)
-        parts = _lib.load().dhz_ps_attn_bwd_parts(B_, H)
+        parts = _lib.load().dhz_ps_attn_bwd_parts_d(B_, H, C // H)
         dpart = torch.empty((parts, NTOK, NTOK), **f32) if bias is not None else None
         nW = mask.shape[0] if mask is not None else 1
         base, gb = qkv.data_ptr(), dqkv.data_ptr()

@@ -163,7 +163,7 @@ class _PSWindowAttention(Function):
         dqkv = torch.empty_like(qkv)
         lib = _lib.load()
         dpart, dtable = None, None
-        parts = lib.dhz_ps_attn_bwd_parts(B_, H)
+        parts = lib.dhz_ps_attn_bwd_parts_d(B_, H, d)
         if bias is not None:
             dpart = torch.empty((parts, NTOK, NTOK), device=qkv.device, dtype=torch.float32)
         base, gb, es = qkv.data_ptr(), dqkv.data_ptr(), qkv.element_size()

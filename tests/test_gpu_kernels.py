@@ -66,7 +66,7 @@ def test_ps_attention_golden(golden, dev, ops, case):
     # backward
     gout = T(g["gout"]).reshape(B_ * N, C).to(dev).contiguous()
     dqkv = torch.empty_like(qkv)
-    parts = _lib.load().dhz_ps_attn_bwd_parts(B_, H)
+    parts = _lib.load().dhz_ps_attn_bwd_parts_d(B_, H, d)
     dpart = torch.empty(parts, 64, 64, device=dev) if use_bias else None
     gb = dqkv.data_ptr()
     _lib.call("dhz_ps_attn_bwd", base, base + 4 * C, base + 8 * C, 3 * C, p(bias), p(mask), p(rank), p(gout), C,

@@ -24,6 +24,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     assert lib.dhz_abi_version() == 1
     assert lib.dhz_ps_attn_bwd_parts(8192, 1) == 512 and lib.dhz_ps_attn_bwd_parts(4, 16) == 64
+    assert lib.dhz_ps_attn_bwd_parts_d(8192, 1, 32) == 512 and lib.dhz_ps_attn_bwd_parts_d(8192, 2, 64) == 512
 
 
 def test_argument_validation_without_gpu():
