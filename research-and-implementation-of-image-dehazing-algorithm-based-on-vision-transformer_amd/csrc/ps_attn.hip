@@ -20,19 +20,23 @@ constexpr int NT = 64;     // tokens per window
 constexpr int NU = 25;     // selected queries / sampled keys
 constexpr int SS = 68;     // row stride of the 64-wide score tiles
 
+#ifndef PSF_WG32
+#define PSF_WG32 3        // four fit (36.3 KB); measured no different from three in the training step (38.15 / 38.14 ms)
+#endif
+#ifndef PSF_WG64
+#define PSF_WG64 3        // config 4: 44.19 ms per step against 44.52 with two
+#endif
+
 template <int D>
 struct FwdSmem {
     static constexpr int DS = D + 4;
-    float q[NT * DS];      // Q, later P (32 x SS)
-    float k[NT * DS];
+    float s[NT * SS];      // Q as staged (64 x DS) -> S (after every wave holds its Q fragments) -> O (32 x DS)
+    float k[NT * DS];      // K -> rank partial counts -> P (32 x SS)
     float v[NT * DS];
-    float s[NT * SS];      // S, later O (32 x DS)
     float m[NT];
-    int part[4 * NT];
     int top[32];
     uint8_t rank[NT];
-    uint8_t idx[NT * NU];
-};
+};                         // 36.3 KB at d = 32 (four workgroups per CU), 52.7 KB at d = 64 (three); round 1 / 2a: 48.6 / 66.6 KB
 
 __device__ __forceinline__ float row8_max(float v) {
     v = fmaxf(v, __shfl_xor(v, 1));
@@ -111,7 +115,6 @@ __global__ __launch_bounds__(256) void ps_attn_fwd_kernel(const T* __restrict__ 
             pv[p] = ld4v(v + g);
         }
     };
-    if (t < NT * NU / 16) reinterpret_cast<uint4*>(sm.idx)[t] = reinterpret_cast<const uint4*>(idx)[t];   // shared by all window-heads
     if ((int)blockIdx.x < nwh) prefetch(blockIdx.x);
 #pragma unroll 1
     for (int wh = blockIdx.x; wh < nwh; wh += gridDim.x) {
@@ -125,7 +128,7 @@ __global__ __launch_bounds__(256) void ps_attn_fwd_kernel(const T* __restrict__ 
 #pragma unroll
         for (int p = 0; p < NR; ++p) {
             const int row = p * RPP + t / F;
-            *reinterpret_cast<f32x4*>(&sm.q[row * DS + c4 * 4]) = pq[p];
+            *reinterpret_cast<f32x4*>(&sm.s[row * DS + c4 * 4]) = pq[p];     // Q parks in the S tile
             *reinterpret_cast<f32x4*>(&sm.k[row * DS + c4 * 4]) = pk[p];
             *reinterpret_cast<f32x4*>(&sm.v[row * DS + c4 * 4]) = pv[p];
         }
@@ -138,7 +141,8 @@ __global__ __launch_bounds__(256) void ps_attn_fwd_kernel(const T* __restrict__ 
         const int i = lane & 15, g = lane >> 4;
         float a[D / 4];
 #pragma unroll
-        for (int s = 0; s < D / 4; ++s) a[s] = sm.q[(16 * w + i) * DS + 4 * s + g];
+        for (int s = 0; s < D / 4; ++s) a[s] = sm.s[(16 * w + i) * DS + 4 * s + g];
+        __syncthreads();                               // every wave holds its Q fragments: the tile is free for S
 #pragma unroll
         for (int tc = 0; tc < 4; ++tc) {
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -155,7 +159,7 @@ __global__ __launch_bounds__(256) void ps_attn_fwd_kernel(const T* __restrict__ 
         const int qi = t >> 2, j = t & 3;
         float mx = -INFINITY, su = 0.f;
         for (int s = j; s < NU; s += 4) {
-            const float val = sm.s[qi * SS + sm.idx[qi * NU + s]];
+            const float val = sm.s[qi * SS + idx[qi * NU + s]];       // the 1.6 KB sample table: L1 / L2 hits
             mx = fmaxf(mx, val);
             su += val;
         }
@@ -176,11 +180,12 @@ __global__ __launch_bounds__(256) void ps_attn_fwd_kernel(const T* __restrict__ 
             const float mj = sm.m[j];
             cnt += (mj > m) || (mj == m && j < qi);
         }
-        sm.part[w * NT + qi] = cnt;
+        reinterpret_cast<int*>(sm.k)[w * NT + qi] = cnt;       // K is dead since S is complete
     }
     __syncthreads();
     if (t < NT) {
-        const int r = sm.part[t] + sm.part[NT + t] + sm.part[2 * NT + t] + sm.part[3 * NT + t];
+        const int* part = reinterpret_cast<const int*>(sm.k);
+        const int r = part[t] + part[NT + t] + part[2 * NT + t] + part[3 * NT + t];
         sm.rank[t] = r < NU ? (uint8_t)r : (uint8_t)255;
         if (r < NU) sm.top[r] = t;
     } else if (t < NT + 32 - NU) {
@@ -188,8 +193,9 @@ __global__ __launch_bounds__(256) void ps_attn_fwd_kernel(const T* __restrict__ 
     }
     __syncthreads();
 
-    // ---- P = softmax(softmax(scale * S[top]) + bias[top] + mask[top])  -> LDS (over the dead Q tile)
-    float* P = sm.q;
+    // ---- P = softmax(softmax(scale * S[top]) + bias[top] + mask[top])  -> LDS (over the dead K tile; the partial counts in its
+    //      first KB were consumed before the barrier above)
+    float* P = sm.k;
     {
         const int r = t >> 3, c0 = (t & 7) * 8;
         float p2[8];
@@ -589,8 +595,8 @@ static int ps_attn_fwd_t(const T* q, const T* k, const T* v, int ld, const uint8
     DHZ_REQUIRE(ld % 4 == 0 && ldo % 4 == 0 && ld >= H * d && ldo >= H * d, "dhz_ps_attn_fwd: bad ld %d/%d", ld, ldo);
     DHZ_REQUIRE(!mask || (nW > 0 && B_ % nW == 0), "dhz_ps_attn_fwd: B_=%d not a multiple of nW=%d", B_, nW);
     hipStream_t s = (hipStream_t)stream;
-    // persistent: as many workgroups as stay resident (LDS: 48.6 KiB at d = 32 -> 3 per CU, 66.6 KiB at d = 64 -> 2 per CU)
-    const int resident = 256 * (d == 32 ? 3 : 2);
+    // persistent workgroups, three per CU (LDS: 36.3 KiB at d = 32, 52.7 KiB at d = 64)
+    const int resident = 256 * (d == 32 ? PSF_WG32 : PSF_WG64);
     const int grid = B_ * H < resident ? B_ * H : resident;
     if (d == 32) {
         allow_smem(reinterpret_cast<const void*>(&ps_attn_fwd_kernel<32, T>), sizeof(FwdSmem<32>));
