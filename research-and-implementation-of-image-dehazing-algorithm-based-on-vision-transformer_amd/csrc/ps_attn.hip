@@ -30,13 +30,15 @@ constexpr int SS = 68;     // row stride of the 64-wide score tiles
 template <int D>
 struct FwdSmem {
     static constexpr int DS = D + 4;
-    float s[NT * SS];      // Q as staged (64 x DS) -> S (after every wave holds its Q fragments) -> O (32 x DS)
-    float k[NT * DS];      // K -> rank partial counts -> P (32 x SS)
+    float s[NT * SS];      // d = 64: Q as staged (64 x DS) -> S (after every wave holds its Q fragments); S -> O (32 x DS)
+    float k[NT * DS];      // K -> rank partial counts; d = 64: -> P (32 x SS)
     float v[NT * DS];
+    float q[D == 32 ? NT * DS : 4];   // d = 32: Q, later P (its own tile: one barrier less per window-head, and three workgroups fit a CU
+                                      // either way; parking Q in the S tile measured 6 % slower there)
     float m[NT];
     int top[32];
     uint8_t rank[NT];
-};                         // 36.3 KB at d = 32 (four workgroups per CU), 52.7 KB at d = 64 (three); round 1 / 2a: 48.6 / 66.6 KB
+};                         // 45.5 KB at d = 32, 52.7 KB at d = 64 (66.6 before Q / P shared tiles): three workgroups per CU
 
 __device__ __forceinline__ float row8_max(float v) {
     v = fmaxf(v, __shfl_xor(v, 1));
@@ -128,7 +130,7 @@ __global__ __launch_bounds__(256) void ps_attn_fwd_kernel(const T* __restrict__ 
 #pragma unroll
         for (int p = 0; p < NR; ++p) {
             const int row = p * RPP + t / F;
-            *reinterpret_cast<f32x4*>(&sm.s[row * DS + c4 * 4]) = pq[p];     // Q parks in the S tile
+            *reinterpret_cast<f32x4*>(&(D == 32 ? sm.q : sm.s)[row * DS + c4 * 4]) = pq[p];     // d = 64: Q parks in the S tile
             *reinterpret_cast<f32x4*>(&sm.k[row * DS + c4 * 4]) = pk[p];
             *reinterpret_cast<f32x4*>(&sm.v[row * DS + c4 * 4]) = pv[p];
         }
@@ -141,8 +143,8 @@ __global__ __launch_bounds__(256) void ps_attn_fwd_kernel(const T* __restrict__ 
         const int i = lane & 15, g = lane >> 4;
         float a[D / 4];
 #pragma unroll
-        for (int s = 0; s < D / 4; ++s) a[s] = sm.s[(16 * w + i) * DS + 4 * s + g];
-        __syncthreads();                               // every wave holds its Q fragments: the tile is free for S
+        for (int s = 0; s < D / 4; ++s) a[s] = (D == 32 ? sm.q : sm.s)[(16 * w + i) * DS + 4 * s + g];
+        if (D != 32) __syncthreads();                  // every wave holds its Q fragments: the tile is free for S
 #pragma unroll
         for (int tc = 0; tc < 4; ++tc) {
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -195,7 +197,7 @@ __global__ __launch_bounds__(256) void ps_attn_fwd_kernel(const T* __restrict__ 
 
     // ---- P = softmax(softmax(scale * S[top]) + bias[top] + mask[top])  -> LDS (over the dead K tile; the partial counts in its
     //      first KB were consumed before the barrier above)
-    float* P = sm.k;
+    float* P = D == 32 ? sm.q : sm.k;
     {
         const int r = t >> 3, c0 = (t & 7) * 8;
         float p2[8];
@@ -262,6 +264,7 @@ struct BwdSmem {
     float p1[32 * SS];     // scores -> P1 ; later dQ[top] staging (32 x DS)
     float p2[32 * SS];     // P2 ; later dA (gradient w.r.t. the bias-added logits) for the bias-gradient owners
     float ds[32 * SS];     // dP2 -> dS ; before that (first phase only) the 4 x D partial column sums of dO
+    float acc[D == 32 ? NT * NT : 4];   // d = 32: per-workgroup bias-gradient accumulator (d = 64 keeps it in registers, see the kernel)
     int top[32];
     uint8_t rank[NT];
 };
@@ -283,12 +286,18 @@ __global__ __launch_bounds__(256) void ps_attn_bwd_kernel(
     const int bstep = gridDim.x / H;
     const float scale = rsqrtf((float)D);
 
-    // Bias gradient of this workgroup's window-heads, summed in REGISTERS: thread t owns the 16 elements (row w + 4 i, column lane)
-    // of the 64 x 64 table.  (Round 2: the sum used to live in a 16 KB LDS array - without it the workgroup needs 53 KB (d = 32) /
-    // 78 KB (d = 64) of LDS and three / two workgroups fit a CU instead of two / one.)
+    // Bias gradient of this workgroup's window-heads.  d = 64: summed in REGISTERS - thread t owns the 16 elements (row w + 4 i,
+    // column lane) of the 64 x 64 table; without the 16 KB LDS array of round 1 the workgroup needs 78 KB and two fit a CU
+    // instead of one.
+    // At d = 32 the LDS accumulator of round 1 stays (two workgroups per CU either way; the register form measured 14 % slower
+    // there: 16 rank tests and up to 16 LDS reads per thread and window-head instead of 8 read-modify-writes in 200 threads).
+    constexpr bool REG_ACC = D == 64;
     float accr[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) accr[i] = 0.f;
+    if (HAS_BIAS && !REG_ACC) {
+        for (int e = t; e < NT * NT / 4; e += 256) reinterpret_cast<float4*>(sm.acc)[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
 
     // The window-heads of this workgroup are processed one after the other, ~9 barrier-separated phases each.  Their
     // inputs (K, V, Q, dO rows and the ranks) are prefetched into registers one window-head ahead - native vectors, so
@@ -442,9 +451,14 @@ __global__ __launch_bounds__(256) void ps_attn_bwd_kernel(
 #pragma unroll
             for (int i = 0; i < 8; ++i) { da[i] = p2[i] * (dp[i] - dot2); dot1 += da[i] * p1[i]; }
             dot1 = row8_sum(dot1);
-            if (HAS_BIAS) {                               // dA over the P2 values this thread has just read: picked up by the owners below
+            if (HAS_BIAS && REG_ACC) {                    // dA over the P2 values this thread has just read: picked up by the owners below
 #pragma unroll
                 for (int i = 0; i < 8; ++i) sm.p2[r * SS + c0 + i] = da[i];
+            }
+            if (HAS_BIAS && !REG_ACC && r < NU) {
+                float* arow = sm.acc + sm.top[r] * NT + c0;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) arow[i] += da[i];
             }
 #pragma unroll
             for (int i = 0; i < 8; ++i) sm.ds[r * SS + c0 + i] = p1[i] * (da[i] - dot1) * scale;
@@ -458,7 +472,7 @@ __global__ __launch_bounds__(256) void ps_attn_bwd_kernel(
         }
         __syncthreads();
 
-        if (HAS_BIAS) {                                       // query row `row` was selected as r: its dA row goes to the table row
+        if (HAS_BIAS && REG_ACC) {                            // query row `row` was selected as r: its dA row goes to the table row
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int rk = sm.rank[w + 4 * i];            // wave-uniform
@@ -517,10 +531,15 @@ __global__ __launch_bounds__(256) void ps_attn_bwd_kernel(
         }
     }
 
-    if (HAS_BIAS) {
+    if (HAS_BIAS && REG_ACC) {
         float* dst = dbias_part + (size_t)blockIdx.x * NT * NT;
 #pragma unroll
         for (int i = 0; i < 16; ++i) dst[(w + 4 * i) * NT + lane] = accr[i];
+    }
+    if (HAS_BIAS && !REG_ACC) {
+        __syncthreads();
+        float4* dst = reinterpret_cast<float4*>(dbias_part + (size_t)blockIdx.x * NT * NT);
+        for (int e = t; e < NT * NT / 4; e += 256) dst[e] = reinterpret_cast<const float4*>(sm.acc)[e];
     }
 }
 
