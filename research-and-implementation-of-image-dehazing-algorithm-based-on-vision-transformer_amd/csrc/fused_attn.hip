@@ -23,6 +23,9 @@
 
 namespace {
 
+#ifndef FUSED_PERSIST_C64
+#define FUSED_PERSIST_C64 0      // C = 64 as persistent workgroups (x of the next window prefetched; weights still streamed from L1 / L2)
+#endif
 #ifndef FUSED_PERSIST_C32
 #define FUSED_PERSIST_C32 1
 #endif
@@ -532,7 +535,7 @@ void launch_fused(hipStream_t s, int nwin, const float* x, const float* gamma, c
                prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
         per_cu = env_wg > 0 ? env_wg : q;
     }
-    int grid = (C == 32 && FUSED_PERSIST_C32) ? ncu * per_cu : nwin;
+    int grid = ((C == 32 && FUSED_PERSIST_C32) || (C == 64 && FUSED_PERSIST_C64)) ? ncu * per_cu : nwin;
     if (grid > nwin) grid = nwin;
     hipLaunchKernelGGL((fused_window_attn_fwd_kernel<C, SAVE>), dim3(grid), dim3(256), smem, s, x, gamma, beta,
                        reinterpret_cast<const float4*>(wqkv_p), bqkv, reinterpret_cast<const float4*>(wo_p), bo, idx,
