@@ -87,6 +87,22 @@ def cpu_baseline(bs=2):
                                            "note": "the reference's own My_model_1.Uformer, config-1 recipe, BASELINE.md section 2"}}
 
 
+def load_pmc_traffic(path, build_id):
+    """HBM bytes per launch from the committed PMC passes (tools/pmc_summary.py: FETCH doubled per the gfx950 correction of
+    MI355X_MICROARCH.md, WRITE exact; separate --pmc runs of this same command).  The file carries the dhz_build_id() of the
+    library the passes ran with; a figure measured on other kernels than the ones loaded now is NOT reported:
+    returns ({}, reason) then, (table, source) otherwise."""
+    try:
+        pmc = json.load(open(path))
+    except Exception as e:
+        return {}, f"no PMC table ({type(e).__name__}): traffic not reported"
+    stamp = (pmc.get("_stamp") or {}).get("build_id")
+    name = os.path.relpath(path, ROOT)
+    if stamp is None or stamp != build_id:
+        return {}, f"{name} was measured on library build {stamp}, the loaded one is {build_id}: traffic not reported"
+    return {k: v for k, v in pmc.items() if not k.startswith("_")}, f"{name} (rocprofv3 --pmc passes of library build {build_id})"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -101,6 +117,7 @@ def main():
     ap.add_argument("--no-cr", action="store_true", help="Charbonnier only (NOT the headline config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--bucket-mb", type=float, default=25.0, help="gradient all-reduce bucket size (N > 1)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -125,7 +142,7 @@ def main():
     import My_model_1 as M1
     import My_CR
     from losses import CharbonnierLoss
-    from dehaze_hip import ops
+    from dehaze_hip import ops, _lib
     from dehaze_hip.train import FlatAdamW, GradReducer, synthetic_batch, train_step
 
     # MIOpen picks the convolution algorithms of the projection / resampling layers by measurement during the warm-up steps,
@@ -136,10 +153,13 @@ def main():
                        token_mlp='leff').to(dev)
     model.train()
     if args.dtype == "bf16":
+        if args.embed_dim % 64:
+            raise SystemExit(f"bench.py --dtype bf16: the bf16 kernels tile channels in 64s; --embed_dim {args.embed_dim} is not a "
+                             "multiple of 64 (BASELINE config 4 is --embed_dim 64 --ps 256 --batch 8)")
         model.act_dtype = torch.bfloat16          # bf16 activations / weight copies, fp32 accumulation and master weights
     opt = FlatAdamW(model, lr=2e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.02)
     opt.zero_grad()
-    reducer = GradReducer(opt) if world > 1 else None
+    reducer = GradReducer(opt, bucket_mb=args.bucket_mb) if world > 1 else None
     char = CharbonnierLoss()
     import warnings
     with warnings.catch_warnings():
@@ -195,12 +215,17 @@ def main():
                        "global_batch": args.batch * world, "parallelism": f"dp{world}", "miopen_find": bool(torch.backends.cudnn.benchmark),
                        "loss_last_step": round(float(loss), 6)},
         }
-        pmc = {}
-        try:    # HBM bytes per launch from the committed PMC passes (tools/pmc_summary.py; FETCH doubled per the
-            # gfx950 correction of MI355X_MICROARCH.md, WRITE exact; separate --pmc runs of this same command)
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-        except Exception:
-            pass
+        if reducer is not None:
+            # the exchange of one step as performed (bucket byte ranges in launch order, single-ring xGMI time): makes a
+            # scaling run diagnosable from its JSON line alone
+            plan = reducer.plan()
+            out["exchange"] = {"backend": backend, "bucket_mb": args.bucket_mb, "payload_bytes": plan["payload_bytes"],
+                               "n_buckets": len(plan["buckets"]), "bucket_bytes": [b["bytes"] for b in plan["buckets"]],
+                               "ring_time_ms_single_link": round(plan["ring_time_ms"], 3),
+                               "measured": "ring time is the plan's figure, not a measurement"}
+        build_id = _lib.load().dhz_build_id().decode()
+        pmc, traffic_source = load_pmc_traffic(os.path.join(ROOT, "profiles", "pmc_traffic.json"), build_id)
+        out["library_build_id"] = build_id
         if timing and timing.get("dhz_linear_bf16"):
             # config 4: the token-Linear GEMMs on v_mfma_f32_16x16x32_bf16 (forward + backward-data launches), against the dense
             # bf16 matrix peak; most of their shapes are HBM-bound at bf16 MFMA rates, so the HBM view is given beside it
@@ -225,8 +250,8 @@ def main():
             out["roofline"] = {"kernel": "fused_window_attn_fwd_kernel<C,SAVE> (dhz_fused_window_attn_fwd), C in {32,64,128}",
                                "bound": "mfma", "achieved": round(tf, 2), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
                                "frac": round(tf / MFMA_F32_PEAK_TF, 4),
-                               "traffic": round(traffic) if traffic else None, "launches": len(ev),
-                               "avg_launch_us": round(1e3 * ms / len(ev), 2),
+                               "traffic": round(traffic) if traffic else None, "traffic_source": traffic_source,
+                               "launches": len(ev), "avg_launch_us": round(1e3 * ms / len(ev), 2),
                                "alg_flops_per_launch": flops // len(ev)}
         if timing and timing.get("dhz_ps_attn_fwd"):
             # the stand-alone ProbSparse core (stages the fused kernel does not cover): HBM-bound, 32 KiB / window-head
@@ -237,7 +262,7 @@ def main():
             traffic = pmc.get("ps_attn_fwd_kernel<32>", {}).get("hbm_bytes_per_launch") if args.dtype == "f32" and args.embed_dim == 32 else None
             entry = {"kernel": "ps_attn_fwd_kernel<d,T> (dhz_ps_attn_fwd)", "bound": "hbm", "achieved": round(gbs, 1),
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
-                     "traffic": round(traffic) if traffic else None, "launches": len(ev),
+                     "traffic": round(traffic) if traffic else None, "traffic_source": traffic_source, "launches": len(ev),
                      "avg_launch_us": round(1e3 * ms / len(ev), 2), "alg_bytes_per_launch": bytes_alg // len(ev)}
             out["roofline" if "roofline" not in out else "roofline_core_unfused"] = entry
         if timing and timing.get("dhz_winograd_conv3x3"):
@@ -253,8 +278,8 @@ def main():
                                         "bound": "mfma", "achieved": round(tf_direct / 2.25, 2), "peak": MFMA_F32_PEAK_TF,
                                         "unit": "TFLOP/s", "frac": round(tf_direct / 2.25 / MFMA_F32_PEAK_TF, 4),
                                         "direct_conv_equivalent_tflops": round(tf_direct, 1),
-                                        "traffic": round(traffic) if traffic else None, "launches": len(ev),
-                                        "avg_launch_us": round(1e3 * ms / len(ev), 2),
+                                        "traffic": round(traffic) if traffic else None, "traffic_source": traffic_source,
+                                        "launches": len(ev), "avg_launch_us": round(1e3 * ms / len(ev), 2),
                                         "alg_flops_per_launch": int(direct / 2.25 / len(ev))}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()

@@ -39,6 +39,9 @@ extern "C" {
 
 int dhz_abi_version(void);
 const char* dhz_last_error(void);
+/* 16 hex digits: content hash of the sources (every .hip file under csrc/, common.h, this header) the loaded library was built from.  The PMC
+ * passes stamp it into profiles/pmc_traffic.json; bench.py reports `roofline.traffic` only when the stamp matches. */
+const char* dhz_build_id(void);
 
 /* ---------------------------------------------------------------------------------------------
  * K3  ProbSparse window attention core.   Replaces ProbAttention.forward  ATT:287-342
@@ -146,20 +149,10 @@ int dhz_conv4s2_wgrad(const float* dy, const float* x, float* dwp, float* db, in
  * w2 [C, 4C], b2 [C]; drop_scale [B] or NULL.  Hres % 8 == 0, Wres % 16 == 0.
  * Training mode - the five save pointers all non-NULL (else all NULL): xn_save [T, C] (norm2 output), stats_save [T, 2]
  * (mean, rstd), u_save [T, 4C] (linear1 output before GELU), tp_save [T, 4C] (gelu'(t), t = dwconv output + bd),
- * z_save [T, 4C] (gelu(t), the input of linear2) - what dhz_leff_fused_bwd and dhz_linear_wgrad consume. */
+ * z_save [T, 4C] (gelu(t), the input of linear2) - what dhz_leff_dwconv_bwd and dhz_linear_wgrad consume. */
 int dhz_leff_fused_fwd(const float* x, const float* gamma, const float* beta, const float* w1, const float* b1,
                        const float* wd, const float* bd, const float* w2, const float* b2, const float* drop_scale,
                        float* out, float* xn_save, float* stats_save, float* u_save, float* tp_save, float* z_save,
-                       int B, int Hres, int Wres, int C, void* stream);
-
-/* Backward-data of the fused LeFF branch (autograd of M1:496-534 from the out-projection side down to norm2's output):
- *     dz = (drop_scale[b] dout) w2;  dt = dz * tp;  du = dwconv3x3^T(dt) * gelu'(u);  dxn = du w1
- * dout [B, HW, C]; u, tp as saved by dhz_leff_fused_fwd.  Written: du [T, 4C] (input of linear1's weight gradient),
- * dxn [T, C] (gradient of norm2's output -> dhz_ln_partition_bwd), dy_save [T, C] = drop_scale[b] dout (input of linear2's
- * weight gradient; may be NULL - pass dout itself to dhz_linear_wgrad when drop_scale is NULL).  ACCUMULATED (fp32 atomics,
- * caller zeroes): dwd [4C, 3, 3], dbd [4C] - the depthwise convolution's weight / bias gradients. */
-int dhz_leff_fused_bwd(const float* dout, const float* drop_scale, const float* u, const float* tp, const float* w1,
-                       const float* wd, const float* w2, float* du, float* dxn, float* dy_save, float* dwd, float* dbd,
                        int B, int Hres, int Wres, int C, void* stream);
 
 /* K2/K4/K5  forward and backward-data GEMMs of every token-major nn.Linear on the path (query/key/value/out

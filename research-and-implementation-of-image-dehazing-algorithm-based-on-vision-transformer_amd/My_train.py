@@ -172,8 +172,19 @@ def main():
         model.train()
         return sum(vals) / len(vals)
 
-    if resumed_rng is not None and utils.load_rng_state(resumed_rng) and is_main:
+    # every rank restores ITS OWN streams (the checkpoint holds one state per rank of the writing run); a rank without an entry
+    # keeps the rank-specific seeds from above
+    if resumed_rng is not None and utils.load_rng_state(resumed_rng, rank) and is_main:
         print("==> generator states restored from the checkpoint (continues the interrupted run's random streams)")
+
+    def all_rng_states():
+        """One generator state per rank (collective: every rank calls it at the same points); rank 0 writes the list."""
+        st = utils.rng_state_dict()
+        if world == 1:
+            return [st]
+        out = [None] * world
+        dist.all_gather_object(out, st)
+        return out
     best_psnr, best_epoch, best_iter = 0, 0, 0
     model.train()
     for epoch in range(start_epoch, opt.nepoch + 1):
@@ -197,11 +208,12 @@ def main():
                       f'{(time.time() - t0) / 60:.1f}', end='', flush=True)
             if (i + 1) % eval_now == 0 and i > 0:
                 val = evaluate()
+                rng_states = all_rng_states()
                 if is_main:
                     if val > best_psnr:
                         best_psnr, best_epoch, best_iter = val, epoch, i
                         torch.save({'epoch': epoch, 'state_dict': {'module.' + k: v for k, v in model.state_dict().items()},
-                                    'optimizer': optimizer.state_dict(), 'rng_state': utils.rng_state_dict()},
+                                    'optimizer': optimizer.state_dict(), 'rng_state': rng_states},
                                    os.path.join(model_dir, "model_best.pth"))
                     line = "[Ep %d it %d/%d\t PSNR: %.4f\t] ----  [best_Ep: %d, best_it: %d, Best_PSNR: %.4f]" % (
                         epoch, i, steps_per_epoch, val, best_epoch, best_iter, best_psnr)
@@ -209,6 +221,7 @@ def main():
                     with open(logname, 'a') as f:
                         f.write(line + '\n')
         scheduler.step()
+        rng_states = all_rng_states()
         if is_main:
             line = "Epoch: {}\tTime: {:.4f}\tLoss: {:.4f}\tLearningRate {:.6f}".format(
                 epoch, time.time() - t0, epoch_loss.item(), scheduler.get_last_lr()[0])
@@ -216,7 +229,7 @@ def main():
             with open(logname, 'a') as f:
                 f.write(line + '\n')
             torch.save({'epoch': epoch, 'state_dict': {'module.' + k: v for k, v in model.state_dict().items()},
-                        'optimizer': optimizer.state_dict(), 'rng_state': utils.rng_state_dict()},
+                        'optimizer': optimizer.state_dict(), 'rng_state': rng_states},
                        os.path.join(model_dir, "epoch_model_{}.pth".format(epoch)))
     if world > 1:
         dist.destroy_process_group()

@@ -1,6 +1,7 @@
 // Error reporting + ABI version of libdehaze_hip.so (see include/dehaze_hip.h).
 #include <stdarg.h>
 #include "common.h"
+#include "build_id.h"
 
 static thread_local char g_err[512] = "";
 
@@ -11,5 +12,18 @@ void dhz_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
+int dhz_num_cus() {
+    static thread_local int cached_dev = -1, cached = 256;          // per thread: no shared mutable state
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    if (dev != cached_dev) {
+        int n = 0;
+        cached = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+        cached_dev = dev;
+    }
+    return cached;
+}
+
 extern "C" const char* dhz_last_error(void) { return g_err; }
 extern "C" int dhz_abi_version(void) { return 1; }
+extern "C" const char* dhz_build_id(void) { return DHZ_BUILD_ID; }

@@ -39,6 +39,9 @@ __device__ __forceinline__ void st1(float* p, float v) { *p = v; }
 __device__ __forceinline__ void st1(bf16s* p, float v) { p->v = f32_to_bf16(v); }
 
 void dhz_set_error(const char* fmt, ...);
+// Compute units of the CURRENT device (256 on MI355X; 256 when no device answers, e.g. argument checks on a GPU-less host).
+// Persistent-grid sizes are "resident workgroups per CU x dhz_num_cus()", never a literal.
+int dhz_num_cus();
 
 #define DHZ_REQUIRE(cond, ...)            \
     do {                                  \

@@ -237,7 +237,8 @@ void launch(const float* A, const float* Wt, const float* bias, float* Y, const 
     constexpr size_t smem = 2 * stage;
     const int tiles_n = N / BN, tiles_m = (M + BM - 1) / BM;
     const int ntiles = tiles_n * tiles_m;
-    const int grid = ntiles < 512 ? ntiles : 512;
+    const int slots = 2 * dhz_num_cus();                          // two resident workgroups per CU
+    const int grid = ntiles < slots ? ntiles : slots;
     if (smem > 48 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_kernel<WM, WN, MODE>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -249,11 +250,12 @@ void dispatch(const float* A, const float* Wt, const float* bias, float* Y, cons
     int wm = 2, wn = 1;
     static const int cand[8][2] = {{4, 4}, {4, 3}, {4, 2}, {2, 4}, {2, 3}, {2, 2}, {4, 1}, {2, 1}};
     long best = -1;
+    const long slots = 2 * dhz_num_cus();
     for (int i = 0; i < 8; ++i) {
         const int a = cand[i][0], b = cand[i][1];
         if (N % (32 * b)) continue;
         const long blocks = (long)((M + 32 * a - 1) / (32 * a)) * (N / (32 * b));
-        if (blocks >= 512) { wm = a; wn = b; break; }
+        if (blocks >= slots) { wm = a; wn = b; break; }
         if (blocks > best) { best = blocks; wm = a; wn = b; }
     }
 #define CASE(a, b) \
@@ -389,7 +391,7 @@ void launch_wgrad(const float* dy, const float* x, float* dw, float* db, const C
     constexpr size_t stage = (size_t)TK * (BM + 16 + BN + 16) * sizeof(float);
     constexpr size_t smem = 2 * stage > (size_t)BM * BN * 4 ? 2 * stage : (size_t)BM * BN * 4;
     const int tiles = (N / BM) * (K / BN);
-    int nsplit = 512 / tiles;
+    int nsplit = 2 * dhz_num_cus() / tiles;
     const int max_split = T / (TK * 4) > 0 ? T / (TK * 4) : 1;
     if (nsplit > max_split) nsplit = max_split;
     if (nsplit < 1) nsplit = 1;

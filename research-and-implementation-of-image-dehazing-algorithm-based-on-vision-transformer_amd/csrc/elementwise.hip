@@ -626,7 +626,8 @@ extern "C" int dhz_ln_partition_bwd_dt(const void* dxw, const void* x, const flo
     // every workgroup ends with 2C same-address atomics (dgamma, dbeta): give each wave >= 8 token groups so that small
     // maps do not pay 1024 workgroups' worth of them
     int grid = (int)(((int64_t)ntok * lpt + 256 * 8 - 1) / (256 * 8));
-    grid = grid < 64 ? 64 : (grid > 512 ? 512 : grid);
+    const int cap = 2 * dhz_num_cus();
+    grid = grid < 64 ? 64 : (grid > cap ? cap : grid);
     hipStream_t s = (hipStream_t)stream;
 #define LAUNCH(V) hipLaunchKernelGGL((ln_partition_bwd_kernel<V, T>), dim3(grid), dim3(256), 0, s, (const T*)dxw, (const T*)x, gamma, stats, (const T*)dres, (T*)dx, dgamma, dbeta, ntok, Hres, Wres, C, shift, lpt, partition)
     DT_SWITCH(dtype, "dhz_ln_partition_bwd",

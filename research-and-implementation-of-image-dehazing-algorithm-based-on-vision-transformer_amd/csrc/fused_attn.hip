@@ -23,11 +23,13 @@
 
 namespace {
 
-#ifndef FUSED_PERSIST_C64
-#define FUSED_PERSIST_C64 0      // C = 64 as persistent workgroups (x of the next window prefetched; weights still streamed from L1 / L2)
-#endif
 #ifndef FUSED_PERSIST_C32
 #define FUSED_PERSIST_C32 1
+#endif
+// Phase skipping for timing diagnostics is a COMPILE-TIME constant of a variant build (tools/abl_fused.sh links copies of the
+// library with -DDHZ_FUSED_ABL=<bit mask>; outputs are then wrong): the product kernel has no such argument and no such branch.
+#ifndef DHZ_FUSED_ABL
+#define DHZ_FUSED_ABL 0
 #endif
 constexpr int NT = 64;
 constexpr int NU = 25;
@@ -81,7 +83,8 @@ __global__ __launch_bounds__(256, C == 128 ? 1 : 2) void fused_window_attn_fwd_k
     const float* __restrict__ bo, const uint8_t* __restrict__ idx, const float* __restrict__ bias,
     const float* __restrict__ mask, const float* __restrict__ dscale, float* __restrict__ out,
     float* __restrict__ xn_save, float* __restrict__ qkv_save, float* __restrict__ ctx_save,
-    float* __restrict__ stats_save, uint8_t* __restrict__ rank_save, int Hres, int Wres, int shift, int nwin, int abl) {
+    float* __restrict__ stats_save, uint8_t* __restrict__ rank_save, int Hres, int Wres, int shift, int nwin) {
+    constexpr int abl = DHZ_FUSED_ABL;
     constexpr int XS = C + 4;
     constexpr int H = C / 32;
     constexpr int CPT = C / 4;            // floats per thread in the token-row phases (4 threads per token)
@@ -505,13 +508,6 @@ void launch_fused(hipStream_t s, int nwin, const float* x, const float* gamma, c
                   const float* bqkv, const float* wo_p, const float* bo, const uint8_t* idx, const float* bias,
                   const float* mask, const float* dscale, float* out, float* xn_save, float* qkv_save, float* ctx_save,
                   float* stats_save, uint8_t* rank_save, int Hres, int Wres, int shift) {
-    // Phase skipping for timing diagnostics exists only in a build with -DDHZ_DIAG (tools/abl_fused.sh compiles its own copy of
-    // the library); the product library has no run-time switch that can change results.
-#ifdef DHZ_DIAG
-    static const int abl = getenv("DHZ_FUSED_ABLATE") ? atoi(getenv("DHZ_FUSED_ABLATE")) : 0;
-#else
-    constexpr int abl = 0;
-#endif
     const size_t smem = sizeof(FusedSmem<C>);
     if (smem > 48 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_window_attn_fwd_kernel<C, SAVE>),
@@ -524,23 +520,22 @@ void launch_fused(hipStream_t s, int nwin, const float* x, const float* gamma, c
 #else
     constexpr int env_wg = 0;
 #endif
-    static int per_cu = 0, ncu = 0;          // queried once per code object (all devices of a node are the same part)
-    if (per_cu == 0) {
-        int q = 0, dev = 0;
-        hipDeviceProp_t prop;
+    // resident workgroups per CU of this instantiation: queried once (thread-safe function-local static initialisation)
+    static const int occ = [&] {
+        int q = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, reinterpret_cast<const void*>(&fused_window_attn_fwd_kernel<C, SAVE>),
                                                          256, smem) != hipSuccess || q < 1)
             q = 2;
-        ncu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
-               prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
-        per_cu = env_wg > 0 ? env_wg : q;
-    }
-    int grid = ((C == 32 && FUSED_PERSIST_C32) || (C == 64 && FUSED_PERSIST_C64)) ? ncu * per_cu : nwin;
+        return q;
+    }();
+    const int per_cu = env_wg > 0 ? env_wg : occ;
+    const int ncu = dhz_num_cus();
+    int grid = (C == 32 && FUSED_PERSIST_C32) ? ncu * per_cu : nwin;
     if (grid > nwin) grid = nwin;
     hipLaunchKernelGGL((fused_window_attn_fwd_kernel<C, SAVE>), dim3(grid), dim3(256), smem, s, x, gamma, beta,
                        reinterpret_cast<const float4*>(wqkv_p), bqkv, reinterpret_cast<const float4*>(wo_p), bo, idx,
                        bias, mask, dscale, out, xn_save, qkv_save, ctx_save, stats_save, rank_save, Hres, Wres, shift,
-                       nwin, abl);
+                       nwin);
 }
 
 }  // namespace

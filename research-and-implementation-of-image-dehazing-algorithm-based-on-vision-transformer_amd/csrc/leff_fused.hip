@@ -1,8 +1,11 @@
-// K5 fused: the whole LeFF branch of a LeWin block (M1:873 + M1:496-534) for C = 32 / 64 / 128 in ONE forward kernel
-// and ONE backward-data kernel, so that the 4C-wide hidden tensors cross HBM only as saves for the backward:
+// K5 fused: the whole LeFF branch of a LeWin block (M1:873 + M1:496-534) for C = 32 / 64 / 128 in ONE forward kernel, so
+// that the 4C-wide hidden tensors cross HBM only as saves for the backward:
 //
 //   forward   out = x + s[b] * ( gelu(dwconv3x3(gelu(LN(x) W1^T + b1)) + bd) W2^T + b2 )
-//   backward  dxn = ( dwconv3x3^T( (s[b] dout W2) * gelu'(t) ) * gelu'(u) ) W1          (+ du, dwd, dbd)
+//
+// (A backward-data twin - dz, dt, the transposed stencil, du, dxn in one persistent kernel - was built and tested in round 2
+// and measured 1.3-1.7x SLOWER than the backward kernel chain at every width; it left the tree in
+// round 3 with its entry point, last present in commit aa2dfe3.)
 //
 // One workgroup owns an 8 x 16 pixel tile of one image.  The LayerNorm-ed tile with its 1-pixel halo (180 tokens, padded
 // to 12 MFMA row tiles) stays in LDS for the whole kernel; the hidden dimension is walked in chunks of HC channels:
@@ -316,308 +319,6 @@ int launch_fwd(const float* x, const float* gamma, const float* beta, const floa
 }
 
 
-// ------------------------------------------------------------------------------------------------ backward-data
-// Persistent workgroups (one per CU) walk the tiles; per tile and hidden chunk:
-//   P1  dz[192 x HC] = dy[192 x C] . W2[:, chunk]          dy = s[b] dout on tile + halo, LDS-resident
-//   P2  dt = dz * gelu'(t) (saved), g = gelu(u)  -> DS, GS in LDS (zero outside the image)
-//   P3  du = dwconv3x3^T(dt) * gelu'(u) -> DU in LDS + global (input of the linear1 weight gradient);
-//       dwd[k] += dt[p] g[p + off(k)], dbd += dt[p]: per-thread partials, folded over the lanes that share a channel quad
-//       and added to a per-workgroup LDS accumulator that is flushed with one atomic per value at the end of the kernel
-//   P4  dxn[128 x C] += DU . W1[chunk, :]
-// Both weight slices are needed K-major for their B fragments (contraction over c in P1, over h in P4), i.e. transposed
-// with respect to their storage: the staging writes scatter the float4 rows into the swizzled images.
-template <int C, int HC, int NW>
-struct BwdCfg {
-    static constexpr int NTHR = 64 * NW;
-    static constexpr int Ch = 4 * C;
-    static constexpr int NCHUNK = Ch / HC;
-    static constexpr int DY_F = NPOS * C;
-    static constexpr int W_F = HC * C;                      // W2T [HC][C] and W1T [C][HC]
-    static constexpr int DS_F = NPOS * HC, DU_F = NINT * HC;
-    static constexpr int ACC_F = Ch * 10;                   // dwd (9) + dbd (1) per hidden channel
-    static constexpr int OFF_W2T = DY_F, OFF_W1T = OFF_W2T + W_F, OFF_DS = OFF_W1T + W_F, OFF_GS = OFF_DS + DS_F,
-                         OFF_DU = OFF_GS + DS_F, OFF_ACC = OFF_DU + DU_F;
-    static constexpr int TOTAL_F = OFF_ACC + ACC_F;
-    static constexpr size_t SMEM = (size_t)TOTAL_F * sizeof(float);
-    static_assert(NINT * (C + 4) <= DY_F, "epilogue staging must fit in the dy image");
-    static_assert(SMEM <= 160 * 1024, "LDS budget");
-};
-
-template <int C, int HC, int NW>
-__global__ __launch_bounds__(64 * NW) void leff_fused_bwd_kernel(
-    const float* __restrict__ dout, const float* __restrict__ scale, const float* __restrict__ u, const float* __restrict__ tp,
-    const float* __restrict__ W1, const float* __restrict__ wd, const float* __restrict__ W2, float* __restrict__ du,
-    float* __restrict__ dxn, float* __restrict__ dy_save, float* __restrict__ dwd, float* __restrict__ dbd, int Hres, int Wres,
-    int tiles_x, int tiles_y, int ntiles) {
-    using Cfg = BwdCfg<C, HC, NW>;
-    constexpr int NTHR = Cfg::NTHR, Ch = Cfg::Ch, NCHUNK = Cfg::NCHUNK;
-    constexpr int NCT1 = HC / 16;
-    static_assert(NW / NCT1 == 4, "P1: four wave groups of three row tiles");
-    constexpr int RT2 = 8 / NW, CT2 = C / 16;
-    constexpr int Q = HC / 4;
-    constexpr int NPS = NTHR / Q;
-    static_assert(NINT % NPS == 0, "P3 pixel loop");
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* const DY = smem;
-    float* const W2T = smem + Cfg::OFF_W2T;
-    float* const W1T = smem + Cfg::OFF_W1T;
-    float* const DS = smem + Cfg::OFF_DS;
-    float* const GS = smem + Cfg::OFF_GS;
-    float* const DU = smem + Cfg::OFF_DU;
-    float* const ACC = smem + Cfg::OFF_ACC;
-
-    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-    const int i16 = lane & 15, g = lane >> 4;
-    const int rt0 = 3 * (w & 3), ct1 = w >> 2;
-    const int c4 = t % Q, ps = t / Q;
-    for (int e = t; e < Cfg::ACC_F; e += NTHR) ACC[e] = 0.f;
-
-    constexpr int NWV = (HC * C / 4 + NTHR - 1) / NTHR;
-    f32x4 rw1[NWV], rw2[NWV];
-    auto wload2 = [&](int hc0) {           // W2[:, chunk]: rows c, HC contiguous floats
-#pragma unroll
-        for (int i = 0; i < NWV; ++i) {
-            const int e = t + NTHR * i;
-            if ((HC * C / 4) % NTHR == 0 || e < HC * C / 4)
-                rw2[i] = *reinterpret_cast<const f32x4*>(W2 + (size_t)(e / Q) * Ch + hc0 + 4 * (e % Q));
-        }
-    };
-    auto wwrite2 = [&]() {                 // -> W2T[h][c]
-#pragma unroll
-        for (int i = 0; i < NWV; ++i) {
-            const int e = t + NTHR * i;
-            if ((HC * C / 4) % NTHR == 0 || e < HC * C / 4) {
-                const int c = e / Q, hq = e % Q;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) W2T[swz<C>(4 * hq + k, c)] = rw2[i][k];
-            }
-        }
-    };
-    auto wload1 = [&](int hc0) {           // W1[chunk, :]: rows h, C contiguous floats
-#pragma unroll
-        for (int i = 0; i < NWV; ++i) {
-            const int e = t + NTHR * i;
-            if ((HC * C / 4) % NTHR == 0 || e < HC * C / 4)
-                rw1[i] = *reinterpret_cast<const f32x4*>(W1 + (size_t)(hc0 + e / (C / 4)) * C + 4 * (e % (C / 4)));
-        }
-    };
-    auto wwrite1 = [&]() {                 // -> W1T[c][h]
-#pragma unroll
-        for (int i = 0; i < NWV; ++i) {
-            const int e = t + NTHR * i;
-            if ((HC * C / 4) % NTHR == 0 || e < HC * C / 4) {
-                const int h = e / (C / 4), cq = e % (C / 4);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) W1T[swz<HC>(4 * cq + k, h)] = rw1[i][k];
-            }
-        }
-    };
-
-#pragma unroll 1
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, bimg = tile / (tiles_x * tiles_y);
-        const int x0 = tx * TW - 1, y0 = ty * TH - 1;
-        const size_t tokbase = (size_t)bimg * Hres * Wres;
-        const float sc = scale ? scale[bimg] : 1.0f;
-        __syncthreads();                    // previous tile's epilogue reads of the staging area / first-tile ACC zeroing
-        wload2(0);
-        // ---- dy = s[b] dout on tile + halo -> DY (zero outside the image)
-        for (int e = t; e < NPOS * (C / 4); e += NTHR) {
-            const int r = e / (C / 4), cq = e % (C / 4);
-            const int hy = r / HWID, hx = r % HWID;
-            const int yy = y0 + hy, xx = x0 + hx;
-            f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (yy >= 0 && yy < Hres && xx >= 0 && xx < Wres) {
-                const size_t tok = tokbase + (size_t)yy * Wres + xx;
-                v = sc * *reinterpret_cast<const f32x4*>(dout + tok * C + 4 * cq);
-                if (dy_save && hy >= 1 && hy <= TH && hx >= 1 && hx <= TW) *reinterpret_cast<f32x4*>(dy_save + tok * C + 4 * cq) = v;
-            }
-            *reinterpret_cast<f32x4*>(&DY[swz<C>(r, 4 * cq)]) = v;
-        }
-        wwrite2();
-        // rows of P1 owned by this lane in the accumulator layout
-        int tokh[3][4];            // clamped in-image token offset of the row
-        unsigned inmask = 0;
-#pragma unroll
-        for (int a = 0; a < 3; ++a)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int r = 16 * (rt0 + a) + 4 * g + j;
-                const int hy = r / HWID, hx = r % HWID;
-                const int yy = y0 + hy, xx = x0 + hx;
-                const bool in = r < NPOS && yy >= 0 && yy < Hres && xx >= 0 && xx < Wres;
-                if (in) inmask |= 1u << (4 * a + j);
-                tokh[a][j] = min(max(yy, 0), Hres - 1) * Wres + min(max(xx, 0), Wres - 1);
-            }
-        f32x4 xacc[RT2][CT2];
-#pragma unroll
-        for (int a = 0; a < RT2; ++a)
-#pragma unroll
-            for (int b = 0; b < CT2; ++b) xacc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-        __syncthreads();
-
-#pragma unroll 1
-        for (int ck = 0; ck < NCHUNK; ++ck) {
-            const int hc0 = ck * HC;
-            const bool more = ck + 1 < NCHUNK;
-            wload1(hc0);
-            if (more) wload2(hc0 + HC);
-            // saved gelu'(t) and u of this lane's P1 rows (accumulator layout), consumed in P2
-            float tpv[3][4], uv[3][4];
-            {
-                const int hcol = hc0 + 16 * ct1 + i16;
-#pragma unroll
-                for (int a = 0; a < 3; ++a)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const size_t o = (tokbase + tokh[a][j]) * Ch + hcol;
-                        tpv[a][j] = tp[o];
-                        uv[a][j] = u[o];
-                    }
-            }
-            // ---- P1: dz = dy . W2[:, chunk]
-            f32x4 acc[3];
-#pragma unroll
-            for (int a = 0; a < 3; ++a) acc[a] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int s = 0; s < C / 16; ++s) {
-                const f32x4 bf = *reinterpret_cast<const f32x4*>(&W2T[swz<C>(16 * ct1 + i16, 16 * s + 4 * g)]);
-                f32x4 af[3];
-#pragma unroll
-                for (int a = 0; a < 3; ++a) af[a] = *reinterpret_cast<const f32x4*>(&DY[swz<C>(16 * (rt0 + a) + i16, 16 * s + 4 * g)]);
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int a = 0; a < 3; ++a) acc[a] = mfma16(af[a][j], bf[j], acc[a]);
-            }
-            // ---- P2: dt = dz gelu'(t), g = gelu(u)
-            {
-                const int hcol = 16 * ct1 + i16;
-#pragma unroll
-                for (int a = 0; a < 3; ++a)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int r = 16 * (rt0 + a) + 4 * g + j;
-                        const bool in = (inmask >> (4 * a + j)) & 1;
-                        if (r < NPOS) {
-                            DS[r * HC + hcol] = in ? acc[a][j] * tpv[a][j] : 0.f;
-                            GS[r * HC + hcol] = in ? gelu_f(uv[a][j]) : 0.f;
-                        }
-                    }
-            }
-            // depthwise taps of this thread's 4 channels (L1/L2-resident): issued here so that the barrier covers their latency
-            f32x4 wkv[9];
-#pragma unroll
-            for (int i = 0; i < 9; ++i) wkv[i] = *reinterpret_cast<const f32x4*>(wd + (size_t)(hc0 + 4 * c4) * 9 + 4 * i);
-            __syncthreads();
-            wwrite1();
-            if (more) wwrite2();
-            // ---- P3: depthwise backward on the interior
-            float dwk[4][9], dbk[4];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                dbk[c] = 0.f;
-#pragma unroll
-                for (int k = 0; k < 9; ++k) dwk[c][k] = 0.f;
-            }
-#pragma unroll 1
-            for (int it = 0; it < NINT / NPS; ++it) {
-                const int p = ps + NPS * it;
-                const int py = p / TW, px = p % TW;
-                const size_t o = (tokbase + (size_t)(y0 + 1 + py) * Wres + (x0 + 1 + px)) * Ch + hc0 + 4 * c4;
-                const f32x4 uc = *reinterpret_cast<const f32x4*>(u + o);          // centre u (L2 hit), used after the taps
-                const f32x4 dtc = *reinterpret_cast<const f32x4*>(&DS[((py + 1) * HWID + px + 1) * HC + 4 * c4]);
-                f32x4 dg = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-                    for (int kx = 0; kx < 3; ++kx) {
-                        const int k = ky * 3 + kx;
-                        const f32x4 dn = *reinterpret_cast<const f32x4*>(&DS[((py + 2 - ky) * HWID + px + 2 - kx) * HC + 4 * c4]);
-                        const f32x4 gn = *reinterpret_cast<const f32x4*>(&GS[((py + ky) * HWID + px + kx) * HC + 4 * c4]);
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) {
-                            dg[c] += wkv[(9 * c + k) >> 2][(9 * c + k) & 3] * dn[c];
-                            dwk[c][k] += dtc[c] * gn[c];
-                        }
-                        if (kx == 2) __builtin_amdgcn_sched_barrier(0);     // keep the 18 LDS reads from being hoisted at once
-                    }
-                f32x4 duv;
-#pragma unroll
-                for (int c = 0; c < 4; ++c) { dbk[c] += dtc[c]; duv[c] = dg[c] * gelu_grad_f(uc[c]); }
-                *reinterpret_cast<f32x4*>(&DU[swz<HC>(p, 4 * c4)]) = duv;
-                *reinterpret_cast<f32x4*>(du + o) = duv;
-            }
-            // fold the partials of the lanes that share this channel quad (lane % Q), one LDS atomic per value and wave
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-#pragma unroll
-                for (int k = 0; k < 10; ++k) {
-                    float v = k < 9 ? dwk[c][k] : dbk[c];
-#pragma unroll
-                    for (int o = Q; o < 64; o <<= 1) v += __shfl_xor(v, o);
-                    if (lane < Q) atomicAdd(&ACC[(hc0 + 4 * c4 + c) * 10 + k], v);
-                }
-            }
-            __syncthreads();
-            // ---- P4: dxn += DU . W1[chunk, :]
-#pragma unroll
-            for (int s = 0; s < HC / 16; ++s) {
-                f32x4 af[RT2], bf[CT2];
-#pragma unroll
-                for (int a = 0; a < RT2; ++a) af[a] = *reinterpret_cast<const f32x4*>(&DU[swz<HC>(16 * (RT2 * w + a) + i16, 16 * s + 4 * g)]);
-#pragma unroll
-                for (int b = 0; b < CT2; ++b) bf[b] = *reinterpret_cast<const f32x4*>(&W1T[swz<HC>(16 * b + i16, 16 * s + 4 * g)]);
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int a = 0; a < RT2; ++a)
-#pragma unroll
-                        for (int b = 0; b < CT2; ++b) xacc[a][b] = mfma16(af[a][j], bf[b][j], xacc[a][b]);
-            }
-        }
-        // ---- tile epilogue: dxn -> LDS (dy image is dead) -> global
-        constexpr int SO = C + 4;
-        float* OS = smem;
-#pragma unroll
-        for (int a = 0; a < RT2; ++a)
-#pragma unroll
-            for (int b = 0; b < CT2; ++b)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) OS[(16 * (RT2 * w + a) + 4 * g + j) * SO + 16 * b + i16] = xacc[a][b][j];
-        __syncthreads();
-        for (int e = t; e < NINT * (C / 4); e += NTHR) {
-            const int p = e / (C / 4), cq = e % (C / 4);
-            const int py = p / TW, px = p % TW;
-            const size_t o = (tokbase + (size_t)(y0 + 1 + py) * Wres + (x0 + 1 + px)) * C + 4 * cq;
-            *reinterpret_cast<f32x4*>(dxn + o) = *reinterpret_cast<const f32x4*>(&OS[p * SO + 4 * cq]);
-        }
-    }
-    // ---- flush the depthwise weight / bias gradients of this workgroup
-    __syncthreads();
-    for (int e = t; e < Cfg::ACC_F; e += NTHR) {
-        const int ch = e / 10, k = e % 10;
-        const float v = ACC[e];
-        if (k < 9) atomicAdd(dwd + ch * 9 + k, v);
-        else atomicAdd(dbd + ch, v);
-    }
-}
-
-template <int C, int HC, int NW>
-int launch_bwd(const float* dout, const float* scale, const float* u, const float* tp, const float* W1, const float* wd,
-               const float* W2, float* du, float* dxn, float* dy_save, float* dwd, float* dbd, int B, int Hres, int Wres,
-               hipStream_t s) {
-    using Cfg = BwdCfg<C, HC, NW>;
-    const int tiles_x = Wres / TW, tiles_y = Hres / TH;
-    const int ntiles = B * tiles_x * tiles_y;
-    auto kern = &leff_fused_bwd_kernel<C, HC, NW>;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::SMEM);
-    const int grid = ntiles < 256 ? ntiles : 256;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(Cfg::NTHR), Cfg::SMEM, s, dout, scale, u, tp, W1, wd, W2, du, dxn, dy_save, dwd, dbd,
-                       Hres, Wres, tiles_x, tiles_y, ntiles);
-    return 0;
-}
-
 }  // namespace
 
 extern "C" int dhz_leff_fused_fwd(const float* x, const float* gamma, const float* beta, const float* w1, const float* b1,
@@ -641,20 +342,5 @@ extern "C" int dhz_leff_fused_fwd(const float* x, const float* gamma, const floa
     else if (C == 64) launch_fwd<64, 32, 8>(x, gamma, beta, w1, b1, wd, bd, w2, b2, drop_scale, out, xn_save, stats_save, u_save, tp_save, z_save, B, Hres, Wres, s);
     else launch_fwd<128, 16, 4>(x, gamma, beta, w1, b1, wd, bd, w2, b2, drop_scale, out, xn_save, stats_save, u_save, tp_save, z_save, B, Hres, Wres, s);
     DHZ_CHECK_LAUNCH("dhz_leff_fused_fwd");
-    return DHZ_OK;
-}
-
-extern "C" int dhz_leff_fused_bwd(const float* dout, const float* drop_scale, const float* u, const float* tp, const float* w1,
-                                  const float* wd, const float* w2, float* du, float* dxn, float* dy_save, float* dwd, float* dbd,
-                                  int B, int Hres, int Wres, int C, void* stream) {
-    DHZ_REQUIRE(dout && u && tp && w1 && wd && w2 && du && dxn && dwd && dbd, "dhz_leff_fused_bwd: null pointer");
-    DHZ_REQUIRE(C == 32 || C == 64 || C == 128, "dhz_leff_fused_bwd: C=%d (supported: 32, 64, 128)", C);
-    DHZ_REQUIRE(B > 0 && Hres > 0 && Wres > 0 && Hres % TH == 0 && Wres % TW == 0,
-                "dhz_leff_fused_bwd: map %dx%d must be a multiple of the %dx%d tile", Hres, Wres, TH, TW);
-    hipStream_t s = (hipStream_t)stream;
-    if (C == 32) launch_bwd<32, 32, 8>(dout, drop_scale, u, tp, w1, wd, w2, du, dxn, dy_save, dwd, dbd, B, Hres, Wres, s);
-    else if (C == 64) launch_bwd<64, 32, 8>(dout, drop_scale, u, tp, w1, wd, w2, du, dxn, dy_save, dwd, dbd, B, Hres, Wres, s);
-    else launch_bwd<128, 16, 4>(dout, drop_scale, u, tp, w1, wd, w2, du, dxn, dy_save, dwd, dbd, B, Hres, Wres, s);
-    DHZ_CHECK_LAUNCH("dhz_leff_fused_bwd");
     return DHZ_OK;
 }

@@ -215,7 +215,8 @@ void launch_gemm(const uint16_t* A, int lda, const uint16_t* B, int ldb, const f
     constexpr size_t smem = 2 * (size_t)(BM * 128 + (BTR ? BK * BN * 2 : BN * 128));
     const int tiles_n = N / BN, tiles_m = (M + BM - 1) / BM;
     const int ntiles = tiles_n * tiles_m;
-    const int grid = ntiles < 512 ? ntiles : 512;
+    const int slots = 2 * dhz_num_cus();                          // two resident workgroups per CU
+    const int grid = ntiles < slots ? ntiles : slots;
     if (smem > 48 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<WM, WN, BTR>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -376,7 +377,7 @@ void launch_wgrad(const uint16_t* dy, int ldy, const uint16_t* x, int ldx, int T
     constexpr size_t stage = (size_t)BK * (FM + FN) * 2;
     constexpr size_t smem = 2 * stage > (size_t)FM * FN * 4 ? 2 * stage : (size_t)FM * FN * 4;
     const int tiles = (N / FM) * (K / FN);
-    int nsplit = 512 / tiles;
+    int nsplit = 2 * dhz_num_cus() / tiles;
     const int max_split = T / (BK * 4) > 0 ? T / (BK * 4) : 1;           // at least 4 stages per workgroup
     if (nsplit > max_split) nsplit = max_split;
     if (nsplit < 1) nsplit = 1;

@@ -217,9 +217,9 @@ void launch(const float* A, int lda, const float* W, int ldw, const float* bias,
     const int ntiles = tiles_n * tiles_m;
     // two workgroups per CU when the LDS allows (it does for every tile shape: <= 66.5 KiB per workgroup)
 #ifdef DHZ_DIAG
-    const int slots = getenv("DHZ_GEMM_SLOTS") ? atoi(getenv("DHZ_GEMM_SLOTS")) : 512;
+    const int slots = getenv("DHZ_GEMM_SLOTS") ? atoi(getenv("DHZ_GEMM_SLOTS")) : 2 * dhz_num_cus();
 #else
-    const int slots = 512;
+    const int slots = 2 * dhz_num_cus();
 #endif
     const int grid = ntiles < slots ? ntiles : slots;
     if (smem > 48 * 1024)
@@ -243,11 +243,12 @@ int dispatch(const char* who, const float* A, int lda, const float* W, int ldw, 
     {
         static const int cand[8][2] = {{4, 4}, {4, 3}, {4, 2}, {2, 4}, {2, 3}, {2, 2}, {4, 1}, {2, 1}};
         long best_blocks = -1;
+        const long slots = 2 * dhz_num_cus();
         for (int i = 0; i < 8; ++i) {
             const int a = cand[i][0], b = cand[i][1];
             if (N % (32 * b)) continue;
             const long blocks = (long)((M + 32 * a - 1) / (32 * a)) * (N / (32 * b));
-            if (blocks >= 512) { wm = a; wn = b; break; }      // two resident workgroups per CU (256 / 384 / 512: 1838 / 1822 / 1809 us over the deep stages)
+            if (blocks >= slots) { wm = a; wn = b; break; }    // two resident workgroups per CU (256 / 384 / 512: 1838 / 1822 / 1809 us over the deep stages)
             if (blocks > best_blocks) { best_blocks = blocks; wm = a; wn = b; }
         }
     }

@@ -208,8 +208,9 @@ int launch(const float* dy, int ldy, const float* x, int ldx, int T, int N, int 
     // Workgroups are dealt in whole rounds over the 256 CUs: the count must not exceed the resident slots (a 257th
     // 512-thread workgroup, or a 513th 256-thread one, runs alone after the others: measured 198 -> 130 us at
     // T=8192, N=1536, K=512 with 12 tiles x 43 splits = 516 workgroups), so the split count is rounded DOWN.
-    int target = env_target > 0 ? env_target : (NWM * TG == 4 ? 256 : 512);   // 2 (1 for 512 threads) workgroups per CU
-    if (2 * smem > 160 * 1024 && target > 256) target = 256;
+    const int ncu = dhz_num_cus();
+    int target = env_target > 0 ? env_target : (NWM * TG == 4 ? ncu : 2 * ncu);   // 2 (1 for 512 threads) workgroups per CU
+    if (2 * smem > 160 * 1024 && target > ncu) target = ncu;
     int nsplit = target / tiles;
     const int max_split = T / (TK * 4 * TG) > 0 ? T / (TK * 4 * TG) : 1;     // at least 4 stages per token group
     if (nsplit > max_split) nsplit = max_split;
@@ -218,7 +219,7 @@ int launch(const float* dy, int ldy, const float* x, int ldx, int T, int N, int 
     // trade splits for stages down to one workgroup per CU (measured: 70 -> 62 us at T=32768, N=512, K=128; 73 -> 64 us at
     // T=131072, N=K=128; the long-slab shapes are untouched)
     if (env_target <= 0 && (T / TK) / nsplit < 16) {
-        int alt = 256 / tiles;
+        int alt = ncu / tiles;
         if (alt < (T / TK) / 16) alt = (T / TK) / 16;
         if (alt >= 1 && alt < nsplit) nsplit = alt;
     }

@@ -651,7 +651,7 @@ extern "C" int dhz_ps_attn_fwd_dt(const void* q, const void* k, const void* v, i
 extern "C" int dhz_ps_attn_bwd_parts_d(int B_, int H, int d) {
     if (B_ <= 0 || H <= 0) return 0;
     (void)d;
-    const int cap = 512;
+    const int cap = 2 * dhz_num_cus();
     int per_head = cap / H;
     if (per_head < 1) per_head = 1;
     if (per_head > B_) per_head = B_;

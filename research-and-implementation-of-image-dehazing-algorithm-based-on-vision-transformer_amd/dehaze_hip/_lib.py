@@ -19,6 +19,7 @@ c_fl = ctypes.c_float
 SIGNATURES = {
     "dhz_abi_version": [],
     "dhz_last_error": [],
+    "dhz_build_id": [],
     "dhz_ps_attn_fwd": [c_f, c_f, c_f, c_i, c_p, c_f, c_f, c_f, c_i, c_p, c_i, c_i, c_i, c_i, c_p],
     "dhz_ps_attn_bwd_parts": [c_i, c_i],
     "dhz_ps_attn_bwd_parts_d": [c_i, c_i, c_i],
@@ -47,7 +48,6 @@ SIGNATURES = {
     "dhz_maxpool2x2_blocked_bwd": [c_f, c_f, c_f, c_i, c_i, c_i, c_p],
     "dhz_layout_blocked8": [c_f, c_f, c_i, c_i, c_i, c_i, c_f, c_i, c_p],
     "dhz_leff_fused_fwd": [c_f] * 16 + [c_i, c_i, c_i, c_i, c_p],
-    "dhz_leff_fused_bwd": [c_f] * 12 + [c_i, c_i, c_i, c_i, c_p],
     "dhz_linear_fwd": [c_f, c_i, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_p],
     "dhz_linear_dgrad": [c_f, c_i, c_f, c_f, c_i, c_i, c_i, c_i, c_p],
     "dhz_input_proj_fwd": [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_fl, c_p],
@@ -80,7 +80,7 @@ SIGNATURES = {
     "dhz_charbonnier_bwd": [c_f, c_f, c_f, c_f, c_f, c_l, c_fl, c_fl, c_i, c_p],
     "dhz_adamw_step": [c_f, c_f, c_f, c_f, c_l, c_fl, c_fl, c_fl, c_fl, c_fl, c_i, c_fl, c_p],
 }
-_RESTYPE = {"dhz_last_error": ctypes.c_char_p}
+_RESTYPE = {"dhz_last_error": ctypes.c_char_p, "dhz_build_id": ctypes.c_char_p}
 
 _lib = None
 

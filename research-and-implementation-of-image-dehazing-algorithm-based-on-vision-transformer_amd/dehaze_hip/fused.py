@@ -16,13 +16,12 @@ SUPPORTED_C = (32, 64, 128)
 ENABLED = True      # set False to force the unfused chain (tests compare the two)
 ATTN_FUSED_C128_MAX_HW = 1024   # C = 128 takes the fused attention forward up to this map size (32 x 32), the chain above
 # Fused LeFF kernels (csrc/leff_fused.hip).  Measured on MI355X (tools/bench_leff.py, bs 32): the fused forward wins at C = 32 / 64
-# (inference 0.76-0.85x of the chain, training 0.87-0.95x) and loses at C = 128; the fused backward-data kernel is correct
-# (tests/test_gpu_leff.py) but 1.5-2x slower than the kernel chain in fp32 - fp32-input MFMA and fp32 VALU instructions share the
-# SIMD's issue (profiles/r02_coexec_micro.txt), so fusing the GELU / depthwise VALU work into the GEMM kernels ADDS its time to the
+# (inference 0.76-0.85x of the chain, training 0.87-0.95x) and loses at C = 128; a fused backward-data kernel (round 2, removed
+# in round 3) was 1.5-2x slower than the kernel chain in fp32 - fp32-input MFMA and fp32 VALU instructions share the SIMD's
+# issue (profiles/r02_coexec_micro.txt), so fusing the GELU / depthwise VALU work into the GEMM kernels ADDS its time to the
 # matrix time instead of hiding it behind HBM traffic as the stand-alone streaming kernels do.
 LEFF_FUSED = True           # False forces the kernel chain everywhere
 LEFF_FUSED_C = (32, 64)     # widths that take the fused forward
-LEFF_FUSED_BWD = False      # True: dhz_leff_fused_bwd instead of the backward kernel chain (any C in 32 / 64 / 128)
 
 
 def _wgrad(dy, off, x, w, b, row_scale=None):
@@ -300,7 +299,6 @@ class _LeffBranch(Function):
         out = torch.empty_like(x)
         tiled = Hres % 8 == 0 and Wres % 16 == 0
         fp32 = x.dtype == torch.float32                      # the fused LeFF kernels are fp32-only
-        ctx.fused_bwd = LEFF_FUSED and LEFF_FUSED_BWD and C in (32, 64, 128) and tiled and fp32
         if LEFF_FUSED and C in LEFF_FUSED_C and tiled and fp32:
             # one kernel: norm2, linear1, GELU, depthwise 3x3, GELU, linear2, DropPath scale, residual (csrc/leff_fused.hip)
             xn = stats = u = tg = z = None
@@ -338,26 +336,6 @@ class _LeffBranch(Function):
         dev = x.device
         f32 = dict(device=dev, dtype=torch.float32)
         gwd, gbd = _grad_buf(wd), _grad_buf(bd)
-        if ctx.fused_bwd:
-            # one kernel from dout down to d(norm2 output): linear2 dgrad, both GELU derivatives, depthwise backward (+ its
-            # weight / bias gradients), linear1 dgrad; the two Linear weight gradients read its du / dy outputs
-            dy = torch.empty((T, C), **f32) if dscale is not None else None
-            du = torch.empty((T, Ch), **f32)
-            dxn = torch.empty((T, C), **f32)
-            inplace = gwd is not None and gbd is not None
-            dwb = None if inplace else torch.zeros((Ch * 10,), **f32)
-            _lib.call("dhz_leff_fused_bwd", _p(dout), _p(dscale), _p(u), _p(tg), _p(w1_), _p(wdc), _p(w2_), _p(du), _p(dxn),
-                      _p(dy), _p(gwd) if inplace else dwb.data_ptr(), _p(gbd) if inplace else dwb.data_ptr() + 4 * Ch * 9,
-                      B, Hres, Wres, C, _stream())
-            if inplace:
-                _ready(wd, bd)
-                g_wd = g_bd = None
-            else:
-                g_wd, g_bd = dwb[:Ch * 9].view(Ch, 1, 3, 3), dwb[Ch * 9:]
-            g_w2, g_b2 = _wgrad(dy if dy is not None else dout.view(T, C), 0, z, w2, b2)
-            g_w1, g_b1 = _wgrad(du, 0, xn, w1, b1)
-            dx, dgamma, dbeta = _ln_backward(dxn, x, gamma_p, beta_p, gamma, stats, dout, B, L, 1, C, 0, 0)
-            return (dx, dgamma, dbeta, g_w1, g_b1, g_wd, g_bd, g_w2, g_b2, None, None, None, None)
         # DropPath scale of the branch output (per image): in fp32 it is folded into the consumers - linear2's weight gradient scales
         # the rows of dout as it stages them, the depthwise backward scales dz - instead of a scaled copy of dout (one pass over
         # [T, C] per block less); bf16 keeps the copy

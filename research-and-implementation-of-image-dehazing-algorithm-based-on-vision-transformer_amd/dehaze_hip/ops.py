@@ -47,7 +47,22 @@ def _dt(t):
 
 # (flat fp32 parameter buffer, its bf16 shadow) when FlatAdamW keeps one (config 4): a weight that is a view of the flat buffer
 # gets the matching view of the shadow - one cast launch per step for all parameters instead of one per Linear and pass.
+# The third element is the flat buffer's autograd version counter at the last cast: parameters written through torch (a loaded
+# checkpoint, a landscape probe; views share the counter) bump it and the next bf16_copy re-casts, so a forward outside
+# train_step never reads stale weights.  (The AdamW kernel writes through raw pointers; FlatAdamW.step refreshes itself.)
 BF16_SHADOW = None
+
+
+def set_bf16_shadow(f32, b16):
+    global BF16_SHADOW
+    BF16_SHADOW = None if f32 is None else [f32, b16, f32._version]
+
+
+def refresh_bf16_shadow():
+    sh = BF16_SHADOW
+    if sh is not None:
+        sh[1].copy_(sh[0])                   # one cast launch for all parameters
+        sh[2] = sh[0]._version
 
 
 def bf16_copy(W):
@@ -56,7 +71,9 @@ def bf16_copy(W):
         return W
     sh = BF16_SHADOW
     if sh is not None and W.is_contiguous():
-        f32, b16 = sh
+        f32, b16, ver = sh
+        if f32._version != ver:
+            refresh_bf16_shadow()
         off = W.data_ptr() - f32.data_ptr()
         if 0 <= off < 4 * f32.numel() and W.untyped_storage().data_ptr() == f32.untyped_storage().data_ptr():
             return b16[off // 4: off // 4 + W.numel()].view(W.shape)
@@ -395,7 +412,7 @@ class _LinearTokens(Function):
                 grads += [dw, db]
             else:
                 raise RuntimeError(f"dehaze_hip: Linear weight gradient for T={T}, N={N}, K={K}: the HIP kernel needs "
-                                   "multiples of 32 (there is deliberately no library fallback)")
+                                   "multiples of 32 in fp32 and of 64 in bf16 (there is deliberately no library fallback)")
             off += N
         return (dx,) + tuple(grads)
 

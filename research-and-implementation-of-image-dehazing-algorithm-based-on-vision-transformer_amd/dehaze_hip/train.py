@@ -117,7 +117,10 @@ class FlatAdamW(torch.optim.Optimizer):
         ops.adamw_step_(f["p"], f["g"], f["m"], f["v"], g["lr"], g["betas"][0], g["betas"][1], g["eps"],
                         g["weight_decay"], self._step, self.grad_scale)
         if "p16" in f:
-            f["p16"].copy_(f["p"])                   # refresh the bf16 shadow the bf16 GEMMs read (one cast launch)
+            if ops.BF16_SHADOW is not None and ops.BF16_SHADOW[0] is f["p"]:
+                ops.refresh_bf16_shadow()            # the bf16 GEMMs read the shadow (one cast launch)
+            else:
+                f["p16"].copy_(f["p"])
 
     def enable_bf16_shadow(self):
         """Keep a bf16 copy of the flat parameter buffer, refreshed after every update, and let ops.bf16_copy hand out views
@@ -126,7 +129,16 @@ class FlatAdamW(torch.optim.Optimizer):
         f = self._flat
         if "p16" not in f:
             f["p16"] = f["p"].to(torch.bfloat16)
-        ops.BF16_SHADOW = (f["p"], f["p16"])
+        ops.set_bf16_shadow(f["p"], f["p16"])
+
+    def __del__(self):
+        # the process-global shadow must not pin the flat buffers of a discarded optimizer
+        try:
+            f = self._flat
+            if f is not None and ops.BF16_SHADOW is not None and ops.BF16_SHADOW[0] is f["p"]:
+                ops.set_bf16_shadow(None, None)
+        except Exception:
+            pass
 
     # -- torch.optim.AdamW-compatible (positional) state
     def state_dict(self):
@@ -295,8 +307,8 @@ def train_step(model, char_loss, cr_loss, optimizer, reducer, input_, target, w_
         if ops.BF16_SHADOW is None or optimizer._flat is None or ops.BF16_SHADOW[0] is not optimizer._flat["p"]:
             optimizer.enable_bf16_shadow()
         else:
-            optimizer._flat["p16"].copy_(optimizer._flat["p"])    # one cast launch: parameters written outside step() (a loaded
-                                                                  # checkpoint, a landscape probe) must reach the bf16 GEMMs too
+            ops.refresh_bf16_shadow()          # one cast launch: parameters written outside step() (a loaded checkpoint, a
+                                               # landscape probe) must reach the bf16 GEMMs too
     standalone = reducer is not None and reducer.opt is None          # torch optimizer + stand-alone reducer (--optimizer adam)
     if standalone:
         reducer.zero_grad()

@@ -296,8 +296,12 @@ class _ContrastTaps(Function):
         a, ps = saved[2:2 + k], saved[2 + k:2 + 2 * k]
         ns = [None] * k if ablation else saved[2 + 2 * k:2 + 3 * k]
         g = torch.empty((k, 2), device=d.device, dtype=torch.float32)          # d loss / d (ap_i, an_i)
-        f32 = lambda t: None if t is None else _p(t.to(torch.float32).contiguous())
-        _lib.call("dhz_contrast_combine_bwd", _p(d), _p(w), k, int(ablation), f32(g_loss), f32(g_ap), f32(g_an), _p(g), _stream())
+        # converted copies stay referenced until the launch is enqueued (a temporary's pointer would dangle when the incoming
+        # gradient is not already a contiguous fp32 scalar)
+        gl, gp, gn = (None if t is None else t.to(torch.float32).contiguous() for t in (g_loss, g_ap, g_an))
+        _lib.call("dhz_contrast_combine_bwd", _p(d), _p(w), k, int(ablation), None if gl is None else _p(gl),
+                  None if gp is None else _p(gp), None if gn is None else _p(gn), _p(g), _stream())
+        del gl, gp, gn
         das = []
         for i in range(k):
             da = torch.empty_like(a[i])

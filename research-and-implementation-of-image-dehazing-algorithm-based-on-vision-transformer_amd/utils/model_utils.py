@@ -66,37 +66,65 @@ def rng_state_dict():
     """State of every generator a training step draws from (python, numpy, torch CPU - the sampled-key tables and the
     epoch permutation - and the current HIP device - DropPath).  The reference's checkpoints hold none of this (TR:296-333:
     epoch, state_dict, optimizer), so a resumed run there re-draws from fresh seeds; My_train.py stores it under the extra
-    key 'rng_state' (ignored by the reference's loaders) and restores it on --resume when present.  Tensors only, so that
-    the file still loads with torch.load's default weights_only=True: the python / numpy states travel as a pickled byte
-    tensor that only set_rng_state() decodes."""
-    import pickle
+    key 'rng_state' (ignored by the reference's loaders) and restores it on --resume when present.  Plain tensors only -
+    the Mersenne-Twister words as int64, the two cached-gaussian fields as float64 - so the file loads under torch.load's
+    default weights_only=True and decoding it executes nothing (no pickle on either side)."""
     import random
     import numpy as np
-    blob = pickle.dumps({"python": random.getstate(), "numpy": np.random.get_state()})
-    st = {"host": torch.frombuffer(bytearray(blob), dtype=torch.uint8).clone(), "torch": torch.get_rng_state()}
+    ver, words, gauss = random.getstate()                      # (3, 625 ints, None | float)
+    name, key, pos, has_gauss, cached = np.random.get_state()   # ('MT19937', uint32[624], int, int, float)
+    assert ver == 3 and name == "MT19937"
+    st = {"python_mt": torch.tensor(words, dtype=torch.int64),
+          "python_gauss": torch.tensor([0.0 if gauss is None else 1.0, 0.0 if gauss is None else float(gauss)],
+                                       dtype=torch.float64),
+          "numpy_mt": torch.tensor(np.asarray(key, dtype=np.int64)),
+          "numpy_aux": torch.tensor([float(pos), float(has_gauss), float(cached)], dtype=torch.float64),
+          "torch": torch.get_rng_state()}
     if torch.cuda.is_available():
         st["cuda"] = torch.cuda.get_rng_state()
     return st
 
 
 def set_rng_state(st):
-    import pickle
+    """Inverse of rng_state_dict(); validates types and sizes and rebuilds the state tuples by hand."""
     import random
     import numpy as np
-    host = pickle.loads(st["host"].cpu().numpy().tobytes())
-    random.setstate(host["python"])
-    np.random.set_state(host["numpy"])
+
+    def vec(key, n, dtype):
+        t = st[key]
+        if not isinstance(t, torch.Tensor) or t.dtype != dtype or t.dim() != 1 or t.numel() != n:
+            raise ValueError(f"rng_state['{key}']: expected a {dtype} tensor of {n} elements")
+        return t.cpu()
+
+    words = vec("python_mt", 625, torch.int64).tolist()
+    pg = vec("python_gauss", 2, torch.float64).tolist()
+    key = vec("numpy_mt", 624, torch.int64).numpy()
+    aux = vec("numpy_aux", 3, torch.float64).tolist()
+    if min(words) < 0 or max(words[:624]) > 0xFFFFFFFF or not 0 <= words[624] <= 624 or key.min() < 0 \
+            or key.max() > 0xFFFFFFFF or not 0 <= int(aux[0]) <= 624:
+        raise ValueError("rng_state: Mersenne-Twister words out of range")
+    random.setstate((3, tuple(int(w) for w in words), pg[1] if pg[0] else None))
+    np.random.set_state(("MT19937", key.astype(np.uint32), int(aux[0]), int(aux[1]), float(aux[2])))
     torch.set_rng_state(st["torch"].cpu())
     if "cuda" in st and torch.cuda.is_available():
         torch.cuda.set_rng_state(st["cuda"].cpu())
 
 
-def load_rng_state(weights):
-    """Restore the generators from a checkpoint written by this My_train.py; False for a reference checkpoint (no such key)."""
+def load_rng_state(weights, rank=0):
+    """Restore the generators from a checkpoint written by this My_train.py; False for a reference checkpoint (no such key).
+    The checkpoint holds one state per rank of the run that wrote it (a list indexed by rank; a bare dict = rank 0 of a
+    single-process run).  A rank the file has no entry for (resumed on more GPUs than it was written with) returns False and
+    keeps the rank-specific seeds My_train.py gave it - every rank restoring rank 0's state would make all of them draw the
+    same crops, MixUp lambdas, DropPath masks and sampled keys."""
     checkpoint = torch.load(weights, map_location="cpu")
     if "rng_state" not in checkpoint:
         return False
-    set_rng_state(checkpoint["rng_state"])
+    st = checkpoint["rng_state"]
+    if isinstance(st, dict):
+        st = [st]
+    if rank >= len(st) or st[rank] is None:
+        return False
+    set_rng_state(st[rank])
     return True
 
 

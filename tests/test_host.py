@@ -169,3 +169,64 @@ def test_flat_buffer_layout_packs_qkv():
     assert ops.cat_rows([u2, v2]).data_ptr() == u2.data_ptr()
     assert ops.cat_rows([u, u2]).data_ptr() not in (u.data_ptr(), u2.data_ptr())
     assert ops.cat_rows([m.query_projection.weight, m.key_projection.weight]).data_ptr() != m.query_projection.weight.data_ptr()
+
+
+def test_rng_state_is_plain_tensors_and_per_rank(tmp_path):
+    """The generator states of a checkpoint decode without pickle (a crafted 'host' blob executed code on --resume),
+    survive torch.load(weights_only=True), are validated, and are restored PER RANK (a multi-rank resume must not hand rank 0's
+    streams to every rank)."""
+    import utils
+    random.seed(5); np.random.seed(6); torch.manual_seed(7)
+    random.gauss(0, 1); np.random.standard_normal()            # populate both cached-gaussian fields
+    st0 = utils.rng_state_dict()
+    assert all(isinstance(v, torch.Tensor) for v in st0.values()) and "host" not in st0
+    want0 = (random.random(), np.random.rand(), np.random.standard_normal(), random.gauss(0, 1), torch.rand(1).item())
+    random.seed(50); np.random.seed(60); torch.manual_seed(70)
+    st1 = utils.rng_state_dict()
+    want1 = (random.random(), np.random.rand(), np.random.standard_normal(), random.gauss(0, 1), torch.rand(1).item())
+    path = str(tmp_path / "ck.pth")
+    torch.save({"epoch": 1, "rng_state": [st0, st1]}, path)
+    torch.load(path, map_location="cpu", weights_only=True)     # nothing but tensors / lists / dicts in the file
+    for rank, want in ((0, want0), (1, want1)):
+        random.seed(999); np.random.seed(999); torch.manual_seed(999)
+        assert utils.load_rng_state(path, rank) is True
+        got = (random.random(), np.random.rand(), np.random.standard_normal(), random.gauss(0, 1), torch.rand(1).item())
+        assert got == want, rank
+    assert utils.load_rng_state(path, 2) is False               # resumed on more ranks than the file was written with
+    torch.save({"epoch": 1, "rng_state": st0}, path)            # single-process layout: a bare dict = rank 0
+    assert utils.load_rng_state(path) is True and utils.load_rng_state(path, 1) is False
+    bad = dict(st0, python_mt=st0["python_mt"][:100])
+    with pytest.raises(ValueError):
+        utils.set_rng_state(bad)
+    bad = dict(st0, numpy_mt=st0["numpy_mt"].clone())
+    bad["numpy_mt"][3] = -1
+    with pytest.raises(ValueError):
+        utils.set_rng_state(bad)
+    with pytest.raises((KeyError, ValueError)):
+        utils.set_rng_state({"host": torch.zeros(8, dtype=torch.uint8), "torch": torch.get_rng_state()})   # the round-2 layout
+
+
+def test_pmc_traffic_is_tied_to_the_loaded_library(tmp_path):
+    """bench.py reports roofline.traffic only when profiles/pmc_traffic.json carries the build id of the library that is loaded
+    (the committed table went stale silently when a kernel changed)."""
+    import importlib.util
+    import json
+    from dehaze_hip import _lib
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    bid = _lib.load().dhz_build_id().decode()
+    assert re.fullmatch(r"[0-9a-f]{16}(-.+)?", bid)
+    table = {"fused_window_attn_fwd_kernel<32, true>": {"launches": 2, "hbm_bytes_per_launch": 1.0e8},
+             "_stamp": {"build_id": bid}}
+    path = str(tmp_path / "pmc.json")
+    json.dump(table, open(path, "w"))
+    pmc, src = bench.load_pmc_traffic(path, bid)
+    assert list(pmc) == ["fused_window_attn_fwd_kernel<32, true>"] and bid in src
+    flipped = bid[:-1] + ("0" if bid[-1] != "0" else "1")
+    table["_stamp"]["build_id"] = flipped
+    json.dump(table, open(path, "w"))
+    pmc, src = bench.load_pmc_traffic(path, bid)
+    assert pmc == {} and "not reported" in src                   # -> every roofline object gets "traffic": null
+    pmc, src = bench.load_pmc_traffic(str(tmp_path / "missing.json"), bid)
+    assert pmc == {} and "not reported" in src

@@ -24,7 +24,7 @@ T=$(ls $O/p_trace/*/*kernel_trace.csv | head -1)
 python tools/prof_summary.py $T --skip 5 --top 70 > $O/${N}_steady_state.txt
 cp $(ls $O/p_trace/*/*kernel_stats.csv | head -1) $O/${N}_kernel_stats.csv
 python tools/pmc_summary.py $(ls $O/p_fetch/*/*counter_collection.csv | head -1) $(ls $O/p_write/*/*counter_collection.csv | head -1) \
-    --json $O/${N}_pmc_traffic.json \
+    --json $O/${N}_pmc_traffic.json --stamp \
     --filter "ps_attn|fused_window|winograd|linear_wgrad|linear_gemm|leff|ln_partition|reverse_residual|charbonnier|adamw|bias_|maxpool|l1_pair|blocked|crop|thin_conv|conv3x3_in3" \
     > $O/${N}_pmc_traffic.txt
 rm -rf $O/p_*
