@@ -22,6 +22,17 @@ constexpr int BK = 32;
 #define DHZ_GEMM_ABL 0           // timing diagnostics (tools/gemm_phases.sh): 1 = no epilogue stores, 2 = no MFMAs, 4 = no global operand loads
 #endif
 
+#ifdef DHZ_GEMM_STAMP      // timing diagnostics only (tools/micro/stamp_gemm.py builds its own copy): s_memtime at the phase boundaries
+__device__ long long* g_stamp = nullptr;
+#define STAMP(slot)                                                                                  \
+    do {                                                                                             \
+        if (g_stamp && blockIdx.x == DHZ_GEMM_STAMP && lane == 0 && nstamp < 40)                     \
+            g_stamp[(w * 40 + nstamp) * 8 + (slot)] = (long long)__builtin_amdgcn_s_memtime();       \
+    } while (0)
+#else
+#define STAMP(slot)
+#endif
+
 template <int WM, int WN, bool WT>
 __global__ __launch_bounds__(256) void linear_gemm_kernel(const float* __restrict__ A, int lda,
                                                           const float* __restrict__ W, int ldw,
@@ -55,11 +66,23 @@ __global__ __launch_bounds__(256) void linear_gemm_kernel(const float* __restric
         return lin;
     };
 
+    // The bias enters as the INITIAL VALUE of the accumulators (exactly the addend of y = x W^T + b), read from an LDS copy of
+    // the whole bias vector: no global load is issued - or waited for - between a tile's epilogue stores and the next tile's
+    // matrix work.  (A bias load at the top of a tile made hipcc wait vmcnt(0) there: on gfx9 stores count in vmcnt, so every
+    // tile began by waiting for the ACKNOWLEDGEMENT of the previous tile's 64 stores - the "matrix phase and store burst add
+    // up" finding of round 2.)
+    float* bsm = smem + 2 * STAGE;
+    for (int i = t; i < N; i += 256) bsm[i] = bias ? bias[i] : 0.f;      // visible after the first barrier below
     f32x4 acc[WM][WN];
+    auto acc_init = [&](int tile) {
+        const float* bp = bsm + (tile % tiles_n) * BN + wn * WN * 16 + i16;
 #pragma unroll
-    for (int a = 0; a < WM; ++a)
+        for (int b = 0; b < WN; ++b) {
+            const float bv = bp[16 * b];
 #pragma unroll
-        for (int b = 0; b < WN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int a = 0; a < WM; ++a) acc[a][b] = f32x4{bv, bv, bv, bv};
+        }
+    };
 
     f32x4 ra[NA], rb[NB];
     // per-tile operand row pointers (recomputed only when the stream moves on to another tile): a stage adds its k offset
@@ -117,21 +140,22 @@ __global__ __launch_bounds__(256) void linear_gemm_kernel(const float* __restric
     gload(0);
     swrite(0);
     __syncthreads();
+    acc_init(tile);
     const int sw = (i16 >> 1) & 7;
     int buf = 0;
+    int nstamp = 0;
+    (void)nstamp;
     while (true) {
         const int ntile = tile_of(ti + 1);
         const int tn = tile % tiles_n, tm = tile / tiles_n;
-        // bias of this tile's columns, in the epilogue's lane layout (loaded here, not in the epilogue: see there)
-        float bvs[WN];
-#pragma unroll
-        for (int b = 0; b < WN; ++b) bvs[b] = bias ? bias[tn * BN + wn * WN * 16 + i16 + 16 * b] : 0.f;
         for (int st = 0; st < nst; ++st) {
             // next stage of the stream: the same tile, or the first stage of this workgroup's next tile
             const bool last = st + 1 == nst;
             const bool more = !last || ntile >= 0;
+            STAMP(0);
             if (!last) gload((st + 1) * BK);
             else if (ntile >= 0) { set_tile(ntile); gload(0); }
+            STAMP(1);
             const float* As = smem + buf * STAGE + (wm * WM * 16 + i16) * BK;
             const float* Bs = smem + buf * STAGE + A_FLOATS;
 #pragma unroll
@@ -159,19 +183,23 @@ __global__ __launch_bounds__(256) void linear_gemm_kernel(const float* __restric
                             if (abl & 2) acc[a][b][j] += af[a][j] + bf[b][j];
                             else acc[a][b] = mfma16(af[a][j], bf[b][j], acc[a][b]);
             }
+            STAMP(2);
             if (more) {
                 swrite(buf ^ 1);
+                STAMP(3);
                 __syncthreads();
                 buf ^= 1;
             }
+            STAMP(4);
+            ++nstamp;
         }
+        STAMP(5);
         // ---- tile epilogue straight from the accumulators; the stores drain behind the next tile's matrix work (its first
         //      stage is already in LDS).  acc[a][b][j] = C[16 a + 4 g + j][16 b + i16]: the 16 lanes of a row write 64 contiguous
         //      bytes, the b sweep completes the lines.
         //      Full tiles (every tile unless T is ragged) store without per-row guards: behind a divergent guard hipcc waits for
         //      vmcnt(0) - i.e. for the acknowledgement of ALL earlier stores - before every guarded group, which serialised the
-        //      epilogue into 16 memory round trips per tile.  The bias values are loaded at the top of the tile for the same
-        //      reason (no load result is waited for between the stores).
+        //      epilogue into 16 memory round trips per tile.
         //      (Swapping the MFMA operands turns a lane's four values into four consecutive features = one 16-byte store: 10-20 %
         //      faster in isolation on outputs of <= 96 features, slower on wide ones, and no gain in the training step - not kept.)
         const bool full = tm * BM + BM <= M;                          // wave-uniform
@@ -185,7 +213,7 @@ __global__ __launch_bounds__(256) void linear_gemm_kernel(const float* __restric
                     for (int j = 0; j < 4; ++j)
 #pragma unroll
                         for (int b = 0; b < WN; ++b)
-                            if (!(abl & 1) || acc[a][0][0] == 12345.678f) y0[(size_t)(16 * a + j) * ldy + 16 * b] = acc[a][b][j] + bvs[b];
+                            if (!(abl & 1) || acc[a][0][0] == 12345.678f) y0[(size_t)(16 * a + j) * ldy + 16 * b] = acc[a][b][j];
             } else {
 #pragma unroll
                 for (int a = 0; a < WM; ++a)
@@ -193,16 +221,15 @@ __global__ __launch_bounds__(256) void linear_gemm_kernel(const float* __restric
                     for (int j = 0; j < 4; ++j)
                         if (m0 + 16 * a + j < M) {
 #pragma unroll
-                            for (int b = 0; b < WN; ++b) y0[(size_t)(16 * a + j) * ldy + 16 * b] = acc[a][b][j] + bvs[b];
+                            for (int b = 0; b < WN; ++b) y0[(size_t)(16 * a + j) * ldy + 16 * b] = acc[a][b][j];
                         }
             }
         }
-#pragma unroll
-        for (int a = 0; a < WM; ++a)
-#pragma unroll
-            for (int b = 0; b < WN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+        STAMP(6);
+        ++nstamp;
         if (ntile < 0) break;
         tile = ntile;
+        acc_init(tile);
         ++ti;
     }
 }
@@ -212,7 +239,7 @@ void launch(const float* A, int lda, const float* W, int ldw, const float* bias,
             hipStream_t s) {
     constexpr int BM = 32 * WM, BN = 32 * WN;
     constexpr size_t stage = (size_t)(BM * BK + (WT ? BN * BK : BK * (BN + 4))) * sizeof(float);
-    constexpr size_t smem = 2 * stage;
+    const size_t smem = 2 * stage + (size_t)N * sizeof(float);       // two operand stages + the bias vector
     const int tiles_n = N / BN, tiles_m = (M + BM - 1) / BM;
     const int ntiles = tiles_n * tiles_m;
     // two workgroups per CU when the LDS allows (it does for every tile shape: <= 66.5 KiB per workgroup)
@@ -235,6 +262,7 @@ int dispatch(const char* who, const float* A, int lda, const float* W, int ldw, 
     DHZ_REQUIRE(A && W && Y, "%s: null pointer", who);
     DHZ_REQUIRE(M > 0 && N > 0 && K > 0 && N % 32 == 0 && K % 32 == 0, "%s: T=%d N=%d K=%d (N, K must be multiples of 32)", who,
                 M, N, K);
+    DHZ_REQUIRE(N <= 16384, "%s: N=%d (at most 16384 output features: the bias vector is staged in LDS)", who, N);
     DHZ_REQUIRE(lda % 4 == 0 && ldy % 4 == 0 && ldw % 4 == 0 && lda >= K && ldy >= N, "%s: bad leading dimensions", who);
     DHZ_REQUIRE((((uintptr_t)A | (uintptr_t)Y) & 15) == 0 && (((uintptr_t)W | (uintptr_t)bias) & 3) == 0,
                 "%s: activations must be 16-byte aligned (weights: 4-byte)", who);
@@ -267,6 +295,12 @@ int dispatch(const char* who, const float* A, int lda, const float* W, int ldw, 
 }
 
 }  // namespace
+
+#ifdef DHZ_GEMM_STAMP
+extern "C" int dhz_debug_stamp(void* p) {
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_stamp), &p, sizeof(p));
+}
+#endif
 
 extern "C" int dhz_linear_fwd(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy, int T, int N, int K,
                               void* stream) {
