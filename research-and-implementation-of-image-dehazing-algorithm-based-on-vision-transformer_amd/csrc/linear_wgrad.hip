@@ -17,6 +17,11 @@ namespace {
 #define WG_ABL 0          // timing diagnostics (tools/variants.sh): 1 no epilogue atomics, 2 no MFMAs, 4 no global loads, 8 no bias sums
 #endif
 constexpr int TK = 32;   // tokens per LDS stage
+// fragment vector width of an operand whose wave tile is W 16 x 16 tiles wide, and the conflict-free LDS row stride for it
+constexpr int frag_vec(int W) { return (W == 4 || W == 2) ? W : 1; }
+constexpr int row_stride(int B, int W) {
+    return B + (frag_vec(W) == 4 ? (B % 64 ? 16 : 0) : frag_vec(W) == 2 ? (B % 64 ? 0 : 32) : 16);
+}
 constexpr int MAXMAT = 4;
 
 // Output side of one launch: the N = nmat * nper rows of dY^T X belong to up to MAXMAT separate parameters of nper rows each
@@ -38,7 +43,15 @@ __global__ __launch_bounds__(128 * NWM * TG) void linear_wgrad_kernel(const floa
     constexpr int GT = 128 * NWM;                      // threads per token group
     constexpr int NTHR = GT * TG;
     constexpr int BM = 16 * WM * NWM, BN = 32 * WN;
-    constexpr int SA = BM + 16, SB = BN + 16;          // LDS row strides (floats): stride % 32 == 16
+    // Fragment reads: both operands are staged "row = token, features along the row", and lane (i16, g) needs, for MFMA k-step s,
+    // the values of token 4 s + g.  With the 16 x 16 tiles a / b of a wave INTERLEAVED over the features (tile a owns rows
+    // WM i + a of dW, tile b columns WN j + b) a lane's WM (WN) values of one token are consecutive: ONE ds_read_b128 / b64
+    // instead of WM (WN) ds_read_b32 - 2 LDS instructions per 16 MFMAs instead of 8 at WM = WN = 4 (the b32 form spent a
+    // quarter of the matrix time issuing LDS reads beside the partner wave's MFMA stream).  Conflict-free row strides: b128
+    // lane groups mix two token rows whose 16-byte slots interleave when the stride is a multiple of 64 floats (no pad); b64
+    // and b32 lane groups want the next row 32 / 16 floats further.  WM = 3 keeps the classic tile-after-tile order.
+    constexpr int VA = frag_vec(WM), VB = frag_vec(WN);
+    constexpr int SA = row_stride(BM, WM), SB = row_stride(BN, WN);
     constexpr int A4 = BM / 4, B4 = BN / 4;            // float4 per staged row
     constexpr int NA = (TK * A4 + GT - 1) / GT, NB = (TK * B4 + GT - 1) / GT;   // float4 per thread per stage
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -131,15 +144,31 @@ __global__ __launch_bounds__(128 * NWM * TG) void linear_wgrad_kernel(const floa
         const bool more = st + TG < st1;
         if (more) gload(st + TG);
         if (st < st1) {
-            const float* A = As(buf) + (wm * WM * 16 + i16);
-            const float* B = Bs(buf) + (wn * WN * 16 + i16);
+            const float* A = As(buf) + (wm * WM * 16 + VA * i16);
+            const float* B = Bs(buf) + (wn * WN * 16 + VB * i16);
 #pragma unroll
             for (int s = 0; s < TK / 4; ++s) {
                 float af[WM], bf[WN];
+                if constexpr (VA == 4) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(&A[(4 * s + g) * SA]);
+                    af[0] = v[0]; af[1] = v[1]; af[2] = v[2]; af[3] = v[3];
+                } else if constexpr (VA == 2) {
+                    const float2 v = *reinterpret_cast<const float2*>(&A[(4 * s + g) * SA]);
+                    af[0] = v.x; af[1] = v.y;
+                } else {
 #pragma unroll
-                for (int a = 0; a < WM; ++a) af[a] = A[(4 * s + g) * SA + 16 * a];
+                    for (int a = 0; a < WM; ++a) af[a] = A[(4 * s + g) * SA + 16 * a];
+                }
+                if constexpr (VB == 4) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(&B[(4 * s + g) * SB]);
+                    bf[0] = v[0]; bf[1] = v[1]; bf[2] = v[2]; bf[3] = v[3];
+                } else if constexpr (VB == 2) {
+                    const float2 v = *reinterpret_cast<const float2*>(&B[(4 * s + g) * SB]);
+                    bf[0] = v.x; bf[1] = v.y;
+                } else {
 #pragma unroll
-                for (int b = 0; b < WN; ++b) bf[b] = B[(4 * s + g) * SB + 16 * b];
+                    for (int b = 0; b < WN; ++b) bf[b] = B[(4 * s + g) * SB + 16 * b];
+                }
 #pragma unroll
                 for (int a = 0; a < WM; ++a)
 #pragma unroll
@@ -164,7 +193,9 @@ __global__ __launch_bounds__(128 * NWM * TG) void linear_wgrad_kernel(const floa
                 for (int b = 0; b < WN; ++b)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        float* c = &Cs[(wm * WM * 16 + a * 16 + 4 * g + j) * BN + wn * WN * 16 + b * 16 + i16];
+                        const int rr = VA > 1 ? VA * (4 * g + j) + a : a * 16 + 4 * g + j;
+                        const int cc = VB > 1 ? VB * i16 + b : b * 16 + i16;
+                        float* c = &Cs[(wm * WM * 16 + rr) * BN + wn * WN * 16 + cc];
                         *c = (r == TG - 1) ? acc[a][b][j] : *c + acc[a][b][j];
                     }
         }
@@ -195,7 +226,7 @@ __global__ __launch_bounds__(128 * NWM * TG) void linear_wgrad_kernel(const floa
 template <int WM, int WN, int NWM = 2, int TG = 1>
 int launch(const float* dy, int ldy, const float* x, int ldx, int T, int N, int K, const WgradOut& out, hipStream_t s) {
     constexpr int BM = 16 * WM * NWM, BN = 32 * WN;
-    constexpr size_t stage = (size_t)TK * (BM + 16 + BN + 16) * sizeof(float);
+    constexpr size_t stage = (size_t)TK * (row_stride(BM, WM) + row_stride(BN, WN)) * sizeof(float);
     constexpr size_t smem = 2 * TG * stage > (size_t)BM * BN * 4 ? 2 * TG * stage : (size_t)BM * BN * 4;
     const int tiles = (N / BM) * (K / BN);
     // Every workgroup ends with BM*BN fp32 atomics (chip-wide ~1.3 TB/s of added bytes): large tiles want
