@@ -62,22 +62,23 @@ __device__ __forceinline__ void ld4(const float* p, float* dst) {
     dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
 }
 
+// 47.4 KB for every C: three workgroups per CU.  (Round 2 kept the LayerNorm output in an LDS tile of its own and P beside K:
+// 48.6 / 73.5 / 107 KB at C = 32 / 64 / 128, i.e. two / two / one workgroup per CU.)
 template <int C>
 struct FusedSmem {
-    static constexpr int XS = C + 4;
-    float xn[NT * XS];         // LN output (rows of wave w are produced and consumed by wave w); later the out-proj staging tile
     float q[NT * HS];          // Q_h, later O_h (32 x HS)
-    float k[NT * HS];
+    float k[NT * HS];          // K_h; dead once S is complete, then P (32 x SS: rows 0..24 selected queries, row 25 = 1/64)
     float v[NT * HS];
-    float s[NT * SS];          // S = Q_h K_h^T
-    float p[32 * SS];          // P (rows 0..24 selected queries, row 25 = 1/64)
+    float s[NT * SS];          // S = Q_h K_h^T; after the last head the out-projection staging tile (rows of wave w are its own)
     float m[NT];               // sparsity measure
+    float vec[6 * C];          // gamma | beta | out-projection bias | Q, K, V biases (loop invariants: in LDS, not in registers,
+                               // and no global load for them inside the window loop)
     int top[4][32];            // per-wave copy of the selected-query list (every wave derives the full ranking itself)
     uint8_t idx[NT * NU];
 };
 
 template <int C, bool SAVE>
-__global__ __launch_bounds__(256, C == 128 ? 1 : 2) void fused_window_attn_fwd_kernel(
+__global__ __launch_bounds__(256, C == 64 ? 3 : (C == 128 ? 1 : 2)) void fused_window_attn_fwd_kernel(
     const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
     const float4* __restrict__ wqkv_p, const float* __restrict__ bqkv, const float4* __restrict__ wo_p,
     const float* __restrict__ bo, const uint8_t* __restrict__ idx, const float* __restrict__ bias,
@@ -85,7 +86,6 @@ __global__ __launch_bounds__(256, C == 128 ? 1 : 2) void fused_window_attn_fwd_k
     float* __restrict__ xn_save, float* __restrict__ qkv_save, float* __restrict__ ctx_save,
     float* __restrict__ stats_save, uint8_t* __restrict__ rank_save, int Hres, int Wres, int shift, int nwin) {
     constexpr int abl = DHZ_FUSED_ABL;
-    constexpr int XS = C + 4;
     constexpr int H = C / 32;
     constexpr int CPT = C / 4;            // floats per thread in the token-row phases (4 threads per token)
     constexpr int KS = C / 4;             // k-steps of the QKV GEMM
@@ -95,7 +95,12 @@ __global__ __launch_bounds__(256, C == 128 ? 1 : 2) void fused_window_attn_fwd_k
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int i16 = lane & 15, g = lane >> 4;
     const int nWw = Wres >> 3, nW = (Hres >> 3) * nWw;
-    const int tl = t >> 2, qd = t & 3;    // token row / channel quarter of this thread in the row phases
+    // token row / channel quarter of this thread in the row phases = the row / k range of its MFMA A fragment: lane (i16, g) of
+    // wave w owns channels g C/4 .. of token 16 w + i16, so the LayerNorm output IS the A fragment of the projections - it never
+    // visits LDS (the four lanes of a token differ in lane bits 4 and 5)
+    const int tl = 16 * w + i16, qd = g;
+    float* const P = sm.k;
+    auto tok4sum = [](float v) -> float { v += __shfl_xor(v, 16); return v + __shfl_xor(v, 32); };
     const float scale = 0.17677669529663687f;      // 1/sqrt(32)
 
     // token this thread's row comes from (and goes back to) for window `win`: cyclic shift folded in
@@ -119,13 +124,12 @@ __global__ __launch_bounds__(256, C == 128 ? 1 : 2) void fused_window_attn_fwd_k
 
     // loop-invariant vectors in registers: nothing inside the window loop waits on a global load except the bias /
     // mask rows (vmcnt is an in-order counter - a waited load also waits for every older load and store)
-    float4 gmr[CPT / 4], btr[CPT / 4], bor[CPT / 4];
-#pragma unroll
-    for (int i = 0; i < CPT / 4; ++i) {
-        gmr[i] = reinterpret_cast<const float4*>(gamma + qd * CPT)[i];
-        btr[i] = reinterpret_cast<const float4*>(beta + qd * CPT)[i];
-        bor[i] = reinterpret_cast<const float4*>(bo + qd * CPT)[i];
-    }
+    for (int i = t; i < 6 * C; i += 256)
+        sm.vec[i] = i < C ? gamma[i] : (i < 2 * C ? beta[i - C] : (i < 3 * C ? bo[i - 2 * C] : bqkv[i - 3 * C]));
+    __syncthreads();
+    const float4* const gmr = reinterpret_cast<const float4*>(sm.vec + qd * CPT);
+    const float4* const btr = reinterpret_cast<const float4*>(sm.vec + C + qd * CPT);
+    const float4* const bor = reinterpret_cast<const float4*>(sm.vec + 2 * C + qd * CPT);
     float4 xv[CPT / 4], xnext[CPT / 4];
     int win = blockIdx.x;
     if (win < nwin) {
@@ -137,12 +141,13 @@ __global__ __launch_bounds__(256, C == 128 ? 1 : 2) void fused_window_attn_fwd_k
     for (; win < nwin; win += gridDim.x) {
         const int bimg = win / nW, wdx = win % nW;
         const size_t src_tok = src_token(win);
-        // ---- 0. LayerNorm of the gathered rows (4 lanes per token)
+        // ---- 0. LayerNorm of the gathered rows (4 lanes per token); xa = this lane's A fragment for every head's projection
+        float xa[KS];
         {
             float s = 0.f;
 #pragma unroll
             for (int i = 0; i < CPT / 4; ++i) s += xv[i].x + xv[i].y + xv[i].z + xv[i].w;
-            s = r4sum(s);
+            s = tok4sum(s);
             const float mean = s * (1.0f / C);
             float var = 0.f;
 #pragma unroll
@@ -150,7 +155,7 @@ __global__ __launch_bounds__(256, C == 128 ? 1 : 2) void fused_window_attn_fwd_k
                 const float a0 = xv[i].x - mean, a1 = xv[i].y - mean, a2 = xv[i].z - mean, a3 = xv[i].w - mean;
                 var += a0 * a0 + a1 * a1 + a2 * a2 + a3 * a3;
             }
-            var = r4sum(var);
+            var = tok4sum(var);
             const float rstd = rsqrtf(var * (1.0f / C) + 1e-5f);
 #pragma unroll
             for (int i = 0; i < CPT / 4; ++i) {
@@ -160,13 +165,11 @@ __global__ __launch_bounds__(256, C == 128 ? 1 : 2) void fused_window_attn_fwd_k
                 y.y = (xv[i].y - mean) * rstd * gm.y + bt.y;
                 y.z = (xv[i].z - mean) * rstd * gm.z + bt.z;
                 y.w = (xv[i].w - mean) * rstd * gm.w + bt.w;
-                *reinterpret_cast<float4*>(&sm.xn[tl * XS + qd * CPT + 4 * i]) = y;
+                xa[4 * i] = y.x; xa[4 * i + 1] = y.y; xa[4 * i + 2] = y.z; xa[4 * i + 3] = y.w;
                 if (SAVE) reinterpret_cast<float4*>(xn_save + ((size_t)win * NT + tl) * C + qd * CPT)[i] = y;
             }
             if (SAVE && qd == 0) *reinterpret_cast<float2*>(stats_save + 2 * src_tok) = make_float2(mean, rstd);
         }
-        // no barrier: wave w normalised exactly the 16 rows (tokens 16w..16w+15) whose A fragments it reads next
-
         f32x4 oacc[C / 16];                    // out-projection accumulators: rows 16w.., all C columns
 #pragma unroll
         for (int i = 0; i < C / 16; ++i) oacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -175,13 +178,11 @@ __global__ __launch_bounds__(256, C == 128 ? 1 : 2) void fused_window_attn_fwd_k
         for (int h = 0; h < H; ++h) {
             // ---- 1. [Q_h | K_h | V_h] = xn W_h^T + b_h : wave w -> rows 16w..16w+15, 6 column tiles, interleaved chains
             if (!(abl & 1)) {
-                float a[KS];
-#pragma unroll
-                for (int s4 = 0; s4 < KS4; ++s4) ld4(&sm.xn[(16 * w + i16) * XS + g * KS + 4 * s4], &a[4 * s4]);
+                const float (&a)[KS] = xa;
                 f32x4 acc[6];
 #pragma unroll
                 for (int j = 0; j < 6; ++j) {
-                    const float bj = bqkv[(j >> 1) * C + 32 * h + 16 * (j & 1) + i16];
+                    const float bj = sm.vec[3 * C + (j >> 1) * C + 32 * h + 16 * (j & 1) + i16];
                     acc[j] = f32x4{bj, bj, bj, bj};
                 }
                 if constexpr (WREG) {
@@ -369,8 +370,8 @@ __global__ __launch_bounds__(256, C == 128 ? 1 : 2) void fused_window_attn_fwd_k
 #pragma unroll
                     for (int i = 0; i < 8; ++i) p2[i] = f;
                 }
-                *reinterpret_cast<float4*>(&sm.p[r * SS + c0]) = make_float4(p2[0], p2[1], p2[2], p2[3]);
-                *reinterpret_cast<float4*>(&sm.p[r * SS + c0 + 4]) = make_float4(p2[4], p2[5], p2[6], p2[7]);
+                *reinterpret_cast<float4*>(&P[r * SS + c0]) = make_float4(p2[0], p2[1], p2[2], p2[3]);
+                *reinterpret_cast<float4*>(&P[r * SS + c0 + 4]) = make_float4(p2[4], p2[5], p2[6], p2[7]);
             }
             // prefetch the next window's rows HERE: younger than every load this window still waits for, so the
             // in-order vmcnt never makes a wait of this window sit out the prefetch's HBM latency
@@ -387,7 +388,7 @@ __global__ __launch_bounds__(256, C == 128 ? 1 : 2) void fused_window_attn_fwd_k
                 f32x4 acc = {0.f, 0.f, 0.f, 0.f};
                 float pa[16];
 #pragma unroll
-                for (int s4 = 0; s4 < 4; ++s4) ld4(&sm.p[(16 * tr + i16) * SS + 16 * g + 4 * s4], &pa[4 * s4]);
+                for (int s4 = 0; s4 < 4; ++s4) ld4(&P[(16 * tr + i16) * SS + 16 * g + 4 * s4], &pa[4 * s4]);
 #pragma unroll
                 for (int s = 0; s < 16; ++s) acc = mfma16(pa[s], sm.v[(16 * g + s) * HS + 16 * tc + i16], acc);
 #pragma unroll
@@ -443,21 +444,31 @@ __global__ __launch_bounds__(256, C == 128 ? 1 : 2) void fused_window_attn_fwd_k
             __syncthreads();                       // O (in the Q tile), K, V, S, P are rewritten by the next head / window
         }
 
-        // ---- 4. epilogue: stage the 64 x C projection through LDS (xn is dead), add bias + shortcut (x is still in
-        //         registers), scatter to token order
-#pragma unroll
-        for (int tn = 0; tn < C / 16; ++tn)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) sm.xn[(16 * w + 4 * g + r) * XS + 16 * tn + i16] = oacc[tn][r];
-        {   // wave-local again: wave w staged rows 16w..16w+15 and reads exactly those (tl = t >> 2)
+        // ---- 4. epilogue: stage the 64 x C projection through the S tile (dead after the last head's barrier; 64 columns at a
+        //         time), add bias + shortcut (x is still in registers), scatter to token order.  Wave-local: wave w stages rows
+        //         16w..16w+15 and reads exactly those (tl = 16 w + i16).
+        {
             const float sc = dscale ? dscale[bimg] : 1.0f;
             float4* op = reinterpret_cast<float4*>(out + src_tok * C + qd * CPT);
+            constexpr int NP = C > 64 ? C / 64 : 1;               // passes of <= 64 columns
+            constexpr int PC = C / NP;                            // columns per pass
 #pragma unroll
-            for (int i = 0; i < CPT / 4; ++i) {
-                const float4 y = *reinterpret_cast<const float4*>(&sm.xn[tl * XS + qd * CPT + 4 * i]);
-                const float4 b4 = bor[i];
-                op[i] = make_float4(xv[i].x + sc * (y.x + b4.x), xv[i].y + sc * (y.y + b4.y), xv[i].z + sc * (y.z + b4.z),
-                                    xv[i].w + sc * (y.w + b4.w));
+            for (int ps = 0; ps < NP; ++ps) {
+#pragma unroll
+                for (int tn = 0; tn < PC / 16; ++tn)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) sm.s[(16 * w + 4 * g + r) * SS + 16 * tn + i16] = oacc[ps * (PC / 16) + tn][r];
+                // channels of this lane: qd CPT .. qd CPT + CPT - 1; in pass ps those inside [ps PC, (ps + 1) PC)
+                if (NP == 1 || (qd * CPT) / PC == ps) {
+                    const int c0 = qd * CPT - ps * PC;
+#pragma unroll
+                    for (int i = 0; i < CPT / 4; ++i) {
+                        const float4 y = *reinterpret_cast<const float4*>(&sm.s[tl * SS + c0 + 4 * i]);
+                        const float4 b4 = bor[i];
+                        op[i] = make_float4(xv[i].x + sc * (y.x + b4.x), xv[i].y + sc * (y.y + b4.y), xv[i].z + sc * (y.z + b4.z),
+                                            xv[i].w + sc * (y.w + b4.w));
+                    }
+                }
             }
         }
         if constexpr (WREG) {
@@ -468,7 +479,7 @@ __global__ __launch_bounds__(256, C == 128 ? 1 : 2) void fused_window_attn_fwd_k
 #pragma unroll
             for (int i = 0; i < CPT / 4; ++i) xv[i] = xp[i];
         }
-        // no barrier: the staging tile is rewritten by this same wave's LayerNorm of the next window
+        // no barrier: the staging rows belong to this wave, and S is next written behind the first barrier of the next window
     }
 }
 
