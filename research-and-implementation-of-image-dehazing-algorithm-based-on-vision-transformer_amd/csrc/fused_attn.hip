@@ -166,9 +166,9 @@ __global__ __launch_bounds__(256, C == 64 ? 3 : (C == 128 ? 1 : 2)) void fused_w
                 y.z = (xv[i].z - mean) * rstd * gm.z + bt.z;
                 y.w = (xv[i].w - mean) * rstd * gm.w + bt.w;
                 xa[4 * i] = y.x; xa[4 * i + 1] = y.y; xa[4 * i + 2] = y.z; xa[4 * i + 3] = y.w;
-                if (SAVE) reinterpret_cast<float4*>(xn_save + ((size_t)win * NT + tl) * C + qd * CPT)[i] = y;
+                if (SAVE && !(abl & 128)) reinterpret_cast<float4*>(xn_save + ((size_t)win * NT + tl) * C + qd * CPT)[i] = y;
             }
-            if (SAVE && qd == 0) *reinterpret_cast<float2*>(stats_save + 2 * src_tok) = make_float2(mean, rstd);
+            if (SAVE && !(abl & 128) && qd == 0) *reinterpret_cast<float2*>(stats_save + 2 * src_tok) = make_float2(mean, rstd);
         }
         f32x4 oacc[C / 16];                    // out-projection accumulators: rows 16w.., all C columns
 #pragma unroll
@@ -228,7 +228,7 @@ __global__ __launch_bounds__(256, C == 64 ? 3 : (C == 128 ? 1 : 2)) void fused_w
                 }
             }
             __syncthreads();
-            if (SAVE) {   // packed QKV rows for the backward kernels: [win*64 + row][3C], head slice 32h..32h+31
+            if (SAVE && !(abl & 128)) {   // packed QKV rows for the backward kernels: [win*64 + row][3C], head slice 32h..32h+31
                 const int row = t >> 2, c8 = (t & 3) * 8;
                 float* dst = qkv_save + ((size_t)win * NT + row) * 3 * C + 32 * h + c8;
                 *reinterpret_cast<float4*>(dst) = *reinterpret_cast<const float4*>(&sm.q[row * HS + c8]);
@@ -431,7 +431,7 @@ __global__ __launch_bounds__(256, C == 64 ? 3 : (C == 128 ? 1 : 2)) void fused_w
                         for (int tn = 0; tn < C / 16; ++tn) oacc[tn] = mfma16(a[4 * s4 + 3], b4[tn][s4].w, oacc[tn]);
                     }
                 }
-                if (SAVE) {
+                if (SAVE && !(abl & 128)) {
                     const int row = t >> 2, c8 = (t & 3) * 8;
                     const int rkr = __shfl(myrank, row);
                     const int rr = rkr < NU ? rkr : NU;

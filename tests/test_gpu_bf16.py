@@ -147,8 +147,9 @@ def test_block_bf16_vs_oracle_fp32_on_rounded_inputs(C, heads, shift):
     """One LeWin block of config 4 (head_dim 64) with bf16 activations against the fp32 CPU oracle given the SAME bf16-rounded
     input and the bf16-rounded weights the GEMMs actually use.  Stated tolerance: every kernel boundary rounds its output
     to bf16 (relative 2^-8 = 3.9e-3), ~10 boundaries in a block -> norm-wise relative error <= 2 % on the block output and
-    <= 4 % on dx, 6 % on parameter gradients (25 % on those that only flow through the selected rows); the top-25 selections can differ at near-ties of the sparsity measure, which shows as a few
-    percent of windows - the norm-wise bound absorbs them."""
+    <= 4 % on dx, 6 % on parameter gradients (15 % on those that only flow through the 25 selected rows of a window: bias table,
+    query / key projections - fewer terms to average the rounding over, and a near-tie of the measure between two bf16-rounded
+    rows can still be broken differently by the accumulation order of the fp32 matrix pipe and of the oracle's matmul)."""
     import My_model_1 as M1
     from oracle import uformer_oracle as O
     dev = torch.device("cuda:0")
@@ -165,7 +166,28 @@ def test_block_bf16_vs_oracle_fp32_on_rounded_inputs(C, heads, shift):
     idx = torch.randint(64, (64, 25))
     P = {"b." + k: v.detach().clone().requires_grad_(v.dtype.is_floating_point) for k, v in blk.state_dict().items()}
     xo = x.clone().requires_grad_()
-    yo = O.lewin_block(xo, P, "b.", heads, win=8, shift=shift, idx=idx, drop_path=0.0, training=True)
+    # The HIP path hands Q, K, V to the attention core ROUNDED to bf16 (the packed QKV buffer is bf16), and the core ranks what it
+    # is given.  The oracle is fed the same rounding at that boundary (straight-through for the gradient), so that both rank the
+    # same numbers: a top-25 set then differs only at a genuine tie, and the selection-path gradients can be held to the same
+    # bound as the others instead of the 25 % a flipped selection needs.
+    real_core = O.prob_attention
+
+    class _RoundBF(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, t):
+            return t.to(BF).float()
+
+        @staticmethod
+        def backward(ctx, g):
+            return g
+
+    def rounded_core(q, k, v, *a, **kw):
+        return real_core(_RoundBF.apply(q), _RoundBF.apply(k), _RoundBF.apply(v), *a, **kw)
+    O.prob_attention = rounded_core
+    try:
+        yo = O.lewin_block(xo, P, "b.", heads, win=8, shift=shift, idx=idx, drop_path=0.0, training=True)
+    finally:
+        O.prob_attention = real_core
     (yo * gout).sum().backward()
     blk.to(dev).train()
     xd = x.to(dev).to(BF).requires_grad_()
@@ -185,8 +207,9 @@ def test_block_bf16_vs_oracle_fp32_on_rounded_inputs(C, heads, shift):
             # gradients that only flow through the 25 selected query rows of each window (bias table, query / key projections)
             # are the quantities most sensitive to a selection flipped at a near-tie: the bf16 rounding of Q and K moves the
             # sparsity measure by ~2^-8 of the scores, the oracle ranks the unrounded ones
+            # (the oracle ranks the same bf16-rounded Q and K, see above; before that alignment these needed 25 %)
             sel = any(k in n for k in ("table", "query_projection", "key_projection"))
-            assert rel(p.grad, go) < (0.25 if sel else 6e-2), (n, rel(p.grad, go))
+            assert rel(p.grad, go) < (0.15 if sel else 6e-2), (n, rel(p.grad, go))
 
 
 def test_config4_train_step_bf16():
@@ -211,3 +234,84 @@ def test_config4_train_step_bf16():
     f, b = losses[torch.float32], losses[BF]
     assert abs(b[0] - f[0]) < 2e-2 * f[0], (b, f)
     assert b[-1] < b[0] and abs(b[-1] - f[-1]) < 5e-2 * f[-1], (b, f)
+
+
+def test_config4_model_bf16_vs_oracle_psnr():
+    """Model level, against the ORACLE (not against this build's fp32 path): the E = 64 model's eval forward with bf16 activations
+    vs the fp32 CPU oracle on the same weights, input and sampled keys.  Stated tolerance: bf16 storage rounds every kernel
+    boundary to 8 significant bits; through the 18 blocks the restored image stays within PSNR >= 35 dB of the fp32 reference
+    image, and its PSNR against the ground truth differs from the reference's by < 0.1 dB (the 0.01 dB contract of the fp32 path
+    does not apply to reduced-precision storage; the reference's own fp16 autocast, TR:224, moves it as much)."""
+    import My_model_1 as M1
+    from oracle import uformer_oracle as O
+    from dehaze_hip.train import synthetic_batch
+    dev = torch.device("cuda:0")
+    torch.manual_seed(1234)
+    model = M1.Uformer(img_size=128, embed_dim=64, win_size=8, token_projection='linear', token_mlp='leff').to(dev).eval()
+    P = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    gt, hazy = synthetic_batch(2, 128, seed=11)
+    torch.manual_seed(77)
+    with torch.no_grad():
+        ref = O.uformer_forward(P, hazy).clamp(0, 1)
+    model.act_dtype = BF
+    torch.manual_seed(77)
+    with torch.no_grad():
+        out = model(hazy.to(dev)).float().clamp(0, 1).cpu()
+
+    def psnr(a, b):
+        return (10 * torch.log10(1.0 / ((a - b) ** 2).mean())).item()
+    assert psnr(out, ref) > 35.0, psnr(out, ref)
+    assert abs(psnr(out, gt) - psnr(ref, gt)) < 0.1, (psnr(out, gt), psnr(ref, gt))
+
+
+def test_config4_full_size_bf16_properties():
+    """BASELINE config 4 AT FULL SIZE and in its dtype (E = 64, 256 x 256 patches, 8 per GPU, bf16 activations), where the CPU
+    oracle is too slow to be the checker - size-independent properties instead: (1) a patch restored inside the batch equals the
+    same patch restored alone to within bf16 rounding of a [0, 1] image: max |difference| <= 2^-6, mean < 1e-3 (this build's own
+    kernels accumulate per token in an order that does not depend on the batch size, but the resampling / projection
+    convolutions of the bf16 path still run on the library, which picks its algorithm by batch size: an fp32 ulp there becomes
+    a bf16 step downstream - measured max 4.4e-3, mean 4.8e-4); (2) the fp32
+    gradient of the 8-patch batch equals the mean of the gradients of its halves (the loss scale differs by a factor of two, which
+    commutes with bf16 rounding; bound 2 % norm-wise, for the same reason as (1)); (3) one finite step that moves the weights."""
+    import My_model_1 as M1
+    from dehaze_hip.train import FlatAdamW, synthetic_batch, train_step
+    from losses import CharbonnierLoss
+    dev = torch.device("cuda:0")
+    torch.manual_seed(1234)
+    model = M1.Uformer(img_size=256, embed_dim=64, win_size=8, token_projection='linear', token_mlp='leff', drop_path_rate=0.).to(dev)
+    model.act_dtype = BF
+    gt, x = synthetic_batch(8, 256, seed=23, device=dev)
+    model.eval()
+    with torch.no_grad():
+        torch.manual_seed(5)
+        y = model(x)
+        for i in (0, 7):
+            torch.manual_seed(5)
+            yi = model(x[i:i + 1])
+            d = (y[i:i + 1].float() - yi.float()).abs()
+            assert d.max().item() <= 2.0 ** -6 and d.mean().item() < 1e-3, (i, d.max().item(), d.mean().item())
+    assert torch.isfinite(y.float()).all() and y.shape == (8, 3, 256, 256)
+    model.train()
+    char = CharbonnierLoss().to(dev)
+    params = [p for _, p in model.live_parameters()]
+
+    def grad_of(sl):
+        for p in params:
+            p.grad = None
+        torch.manual_seed(9)                                  # same sampled keys for every call
+        loss = char(model(x[sl]).float().clamp(0, 1), gt[sl])
+        loss.backward()
+        return torch.cat([p.grad.detach().float().reshape(-1) for p in params]), loss.item()
+    g_full, l_full = grad_of(slice(0, 8))
+    g_a, l_a = grad_of(slice(0, 4))
+    g_b, l_b = grad_of(slice(4, 8))
+    assert abs(l_full - 0.5 * (l_a + l_b)) < 2e-4 * l_full      # (library convolutions by batch size, see above)
+    rel = ((g_full - 0.5 * (g_a + g_b)).norm() / g_full.norm()).item()
+    assert rel < 2e-2, rel
+    for p in params:
+        p.grad = None
+    opt = FlatAdamW(model, lr=2e-4, weight_decay=0.02)
+    before = [p.detach().clone() for p in params[:4]]
+    loss, _, _ = train_step(model, char, None, opt, None, x, gt, w_cr=0.0)
+    assert torch.isfinite(loss) and 0.0 < loss.item() < 1.0
+    assert any(not torch.equal(a, b.detach()) for a, b in zip(before, params[:4]))

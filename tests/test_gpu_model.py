@@ -259,10 +259,11 @@ def test_full_size_gradient_linearity(dev):
     assert err < 2e-4 * g_full.abs().max().item(), (err, g_full.abs().max().item())
 
 
-def test_config4_shape_in_fp32(dev):
-    """BASELINE config 4's SHAPE (E = 64, 256 x 256 patches, 8 per GPU) in fp32 - the build has no bf16 path, so the config's
-    dtype is out of scope, but its sizes (head dimension 64, 1024 windows per patch, channels 64..1024, hidden 4096) must
-    run: batch independence of the eval forward as in the config-2 test, and one finite training step."""
+def test_config4_sizes_on_the_fp32_path(dev):
+    """BASELINE config 4's SIZES (E = 64, 256 x 256 patches, 8 per GPU: head dimension 64, 1024 windows per patch, channels
+    64..1024, hidden 4096) on the fp32 path: batch independence of the eval forward as in the config-2 test, and one finite
+    training step.  The configuration's own dtype, bf16, runs at the same full size in
+    tests/test_gpu_bf16.py::test_config4_full_size_bf16_properties."""
     import My_model_1 as M1
     from dehaze_hip.train import FlatAdamW, train_step
     from losses import CharbonnierLoss
