@@ -125,6 +125,11 @@ int dhz_input_proj_fwd(const float* img, const float* w, const float* bias, floa
                        void* stream);
 int dhz_input_proj_bwd(const float* dy, const float* y, const float* img, float* dw, float* db, int B, int H, int W, int E,
                        float slope, void* stream);
+/* the same with the token tensors (y, dy) stored as `dtype` (DHZ_F32 / DHZ_BF16; image, weights and gradients fp32) */
+int dhz_input_proj_fwd_dt(const float* img, const float* w, const float* bias, void* y, int B, int H, int W, int E, float slope,
+                          int dtype, void* stream);
+int dhz_input_proj_bwd_dt(const void* dy, const void* y, const float* img, float* dw, float* db, int B, int H, int W, int E,
+                          float slope, int dtype, void* stream);
 
 /* K8  Downsample: Conv2d(Cin, Cout, kernel 4, stride 2, padding 1) on the token layout, M1:606-622, as implicit GEMMs on the fp32
  *     matrix pipe (no im2col matrix: a tap of an output pixel is one contiguous run of Cin floats of a token).
@@ -139,6 +144,16 @@ int dhz_conv4s2_fwd(const float* x, const float* wp, const float* bias, float* y
 int dhz_conv4s2_dgrad(const float* dy, const float* wq, float* dx, int B, int H, int W, int Cin, int Cout, void* stream);
 int dhz_conv4s2_wgrad(const float* dy, const float* x, float* dwp, float* db, int B, int H, int W, int Cin, int Cout,
                       void* stream);
+
+/* K8 in bf16 (BASELINE config 4): the same convolution as three token-Linear GEMMs on the bf16 matrix pipe (dhz_linear_fwd_bf16 /
+ *     _dgrad_bf16 / _wgrad_bf16 with wp [Cout, 16*Cin]) over an explicit tap-major patch matrix; in the token layout a tap of an
+ *     output pixel is one contiguous run of Cin bf16, so both helpers are 16-byte-per-lane streaming copies.  Replaces
+ *     aten::convolution / convolution_backward under autocast (MIOpen igemm / CK grouped-conv kernels).
+ *     dhz_im2col_k4s2_bf16: x bf16 [B, H*W, Cin] -> col bf16 [B*(H/2)*(W/2), 16*Cin], col[.][(ky, kx, ci)] = x[2ho+ky-1, 2wo+kx-1, ci]
+ *     dhz_col2im_k4s2_bf16: dx bf16 [B, H*W, Cin] = for every input pixel the fp32 sum of the 4 dcol entries that read it.
+ *     H, W even; Cin a multiple of 8; 16-byte aligned buffers. */
+int dhz_im2col_k4s2_bf16(const void* x, void* col, int B, int H, int W, int Cin, void* stream);
+int dhz_col2im_k4s2_bf16(const void* dcol, void* dx, int B, int H, int W, int Cin, void* stream);
 
 /* K5 fused  The whole LeFF branch of a LeWin block for C = 32, 64, 128 (hidden width 4C), forward, in one kernel:
  *     out = x + drop_scale[b] * linear2(gelu(dwconv3x3(gelu(linear1(norm2(x))))))          replaces M1:873 + M1:496-534
@@ -250,6 +265,12 @@ int dhz_layout_blocked8(const float* src, float* dst, int B, int C, int HW, int 
 int dhz_thin_conv3x3_fwd(const float* x, const float* w, const float* bias, float* y, int B, int H, int W, int C, void* stream);
 int dhz_thin_conv3x3_dgrad(const float* dy, const float* w, float* dx, int B, int H, int W, int C, void* stream);
 int dhz_thin_conv3x3_wgrad(const float* dy, const float* x, float* dw, float* db, int B, int H, int W, int C, void* stream);
+/* the same with the token tensors (x, dx) stored as `dtype` (DHZ_F32 / DHZ_BF16; images, weights and gradients fp32) */
+int dhz_thin_conv3x3_fwd_dt(const void* x, const float* w, const float* bias, float* y, int B, int H, int W, int C, int dtype,
+                            void* stream);
+int dhz_thin_conv3x3_dgrad_dt(const float* dy, const float* w, void* dx, int B, int H, int W, int C, int dtype, void* stream);
+int dhz_thin_conv3x3_wgrad_dt(const float* dy, const void* x, float* dw, float* db, int B, int H, int W, int C, int dtype,
+                              void* stream);
 /*      backward-data of a 3 -> C convolution (the first VGG19 layer, My_CR.py:65) from a channel-blocked gradient
  *      gb[B, C/8, H, W, 8] and that layer's weight w[C, 3, 3, 3]: dx[B, 3, H, W].  C = 64. */
 /*      the same layer forward: y[B, K/8, H, W, 8] (channel-blocked) = max(conv(x[B, 3, H, W], w[K, 3, 3, 3]) + bias, 0 if relu).

@@ -9,9 +9,9 @@ constexpr int TS = 16;               // 16 x 16 pixel tile per workgroup (256 th
 constexpr int HS = TS + 2;
 
 // forward: thread -> (pixel, 4-channel group); the E/4 lanes of a pixel write its E floats as one contiguous run
-template <int E>
+template <int E, typename T>
 __global__ __launch_bounds__(256) void input_proj_fwd_kernel(const float* __restrict__ img, const float* __restrict__ w,
-                                                             const float* __restrict__ bias, float* __restrict__ y, int H, int W,
+                                                             const float* __restrict__ bias, T* __restrict__ y, int H, int W,
                                                              float slope, int tiles_x, int tiles_y) {
     __shared__ float xs[3][HS][HS];
     __shared__ __attribute__((aligned(16))) float ws[27][E];           // [ci*9 + ky*3 + kx][co]
@@ -48,7 +48,7 @@ __global__ __launch_bounds__(256) void input_proj_fwd_kernel(const float* __rest
                 }
         a.x = a.x > 0.f ? a.x : slope * a.x; a.y = a.y > 0.f ? a.y : slope * a.y;
         a.z = a.z > 0.f ? a.z : slope * a.z; a.w = a.w > 0.f ? a.w : slope * a.w;
-        *reinterpret_cast<float4*>(y + ((size_t)b * H * W + (size_t)yy * W + xx) * E + 4 * cq) = a;
+        st4(y + ((size_t)b * H * W + (size_t)yy * W + xx) * E + 4 * cq, a);
     }
 }
 
@@ -58,8 +58,8 @@ __global__ __launch_bounds__(256) void input_proj_fwd_kernel(const float* __rest
 // read straight out of the halo tile,
 // wave w contracts pixels 64 w .. 64 w + 63, accumulators live across the tiles of a persistent workgroup, one cross-wave
 // reduction and one atomic per output and workgroup at the end.
-template <int E>
-__global__ __launch_bounds__(256) void input_proj_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+template <int E, typename T>
+__global__ __launch_bounds__(256) void input_proj_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ y,
                                                              const float* __restrict__ img, float* __restrict__ dw,
                                                              float* __restrict__ db, int H, int W, float slope, int tiles_x,
                                                              int tiles_y, int ntiles) {
@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256) void input_proj_bwd_kernel(const float* __rest
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (yy < H && xx < W) {
                 const size_t o = ((size_t)b * H * W + (size_t)yy * W + xx) * E + 4 * cq;
-                const float4 gq = *reinterpret_cast<const float4*>(dy + o), yv = *reinterpret_cast<const float4*>(y + o);
+                const float4 gq = ld4(dy + o), yv = ld4(y + o);
                 v = make_float4(gq.x * (yv.x > 0.f ? 1.f : slope), gq.y * (yv.y > 0.f ? 1.f : slope), gq.z * (yv.z > 0.f ? 1.f : slope),
                                 gq.w * (yv.w > 0.f ? 1.f : slope));
             }
@@ -135,28 +135,46 @@ __global__ __launch_bounds__(256) void input_proj_bwd_kernel(const float* __rest
 
 }  // namespace
 
-extern "C" int dhz_input_proj_fwd(const float* img, const float* w, const float* bias, float* y, int B, int H, int W, int E,
-                                  float slope, void* stream) {
+#define DT_SWITCH(dtype, who, CALL)                                                      \
+    do {                                                                                 \
+        if ((dtype) == DHZ_F32) { typedef float T; CALL; }                               \
+        else if ((dtype) == DHZ_BF16) { typedef bf16s T; CALL; }                         \
+        else { dhz_set_error("%s: unknown dtype %d", who, (int)(dtype)); return DHZ_EINVAL; } \
+    } while (0)
+
+extern "C" int dhz_input_proj_fwd_dt(const float* img, const float* w, const float* bias, void* y, int B, int H, int W, int E,
+                                     float slope, int dtype, void* stream) {
     DHZ_REQUIRE(img && w && bias && y, "dhz_input_proj_fwd: null pointer");
     DHZ_REQUIRE(B > 0 && H > 0 && W > 0 && (E == 32 || E == 64), "dhz_input_proj_fwd: E=%d (supported: 32, 64)", E);
     const int tiles_x = (W + TS - 1) / TS, tiles_y = (H + TS - 1) / TS;
     hipStream_t s = (hipStream_t)stream;
-    if (E == 32) hipLaunchKernelGGL(input_proj_fwd_kernel<32>, dim3(B * tiles_x * tiles_y), dim3(256), 0, s, img, w, bias, y, H, W, slope, tiles_x, tiles_y);
-    else hipLaunchKernelGGL(input_proj_fwd_kernel<64>, dim3(B * tiles_x * tiles_y), dim3(256), 0, s, img, w, bias, y, H, W, slope, tiles_x, tiles_y);
+#define LAUNCH(EE) hipLaunchKernelGGL((input_proj_fwd_kernel<EE, T>), dim3(B * tiles_x * tiles_y), dim3(256), 0, s, img, w, bias, (T*)y, H, W, slope, tiles_x, tiles_y)
+    DT_SWITCH(dtype, "dhz_input_proj_fwd", if (E == 32) LAUNCH(32); else LAUNCH(64));
+#undef LAUNCH
     DHZ_CHECK_LAUNCH("dhz_input_proj_fwd");
     return DHZ_OK;
 }
-
-extern "C" int dhz_input_proj_bwd(const float* dy, const float* y, const float* img, float* dw, float* db, int B, int H, int W, int E,
+extern "C" int dhz_input_proj_fwd(const float* img, const float* w, const float* bias, float* y, int B, int H, int W, int E,
                                   float slope, void* stream) {
+    return dhz_input_proj_fwd_dt(img, w, bias, y, B, H, W, E, slope, DHZ_F32, stream);
+}
+
+extern "C" int dhz_input_proj_bwd_dt(const void* dy, const void* y, const float* img, float* dw, float* db, int B, int H, int W, int E,
+                                     float slope, int dtype, void* stream) {
     DHZ_REQUIRE(dy && y && img && dw && db, "dhz_input_proj_bwd: null pointer");
     DHZ_REQUIRE(B > 0 && H > 0 && W > 0 && (E == 32 || E == 64), "dhz_input_proj_bwd: E=%d (supported: 32, 64)", E);
     const int tiles_x = (W + TS - 1) / TS, tiles_y = (H + 8 - 1) / 8;
     const int ntiles = B * tiles_x * tiles_y;
-    const int grid = ntiles < 256 ? ntiles : 256;      // every workgroup ends with 28 E same-address atomics: keep them few
+    const int ncu = dhz_num_cus();
+    const int grid = ntiles < ncu ? ntiles : ncu;      // every workgroup ends with 28 E same-address atomics: keep them few
     hipStream_t s = (hipStream_t)stream;
-    if (E == 32) hipLaunchKernelGGL(input_proj_bwd_kernel<32>, dim3(grid), dim3(256), 0, s, dy, y, img, dw, db, H, W, slope, tiles_x, tiles_y, ntiles);
-    else hipLaunchKernelGGL(input_proj_bwd_kernel<64>, dim3(grid), dim3(256), 0, s, dy, y, img, dw, db, H, W, slope, tiles_x, tiles_y, ntiles);
+#define LAUNCH(EE) hipLaunchKernelGGL((input_proj_bwd_kernel<EE, T>), dim3(grid), dim3(256), 0, s, (const T*)dy, (const T*)y, img, dw, db, H, W, slope, tiles_x, tiles_y, ntiles)
+    DT_SWITCH(dtype, "dhz_input_proj_bwd", if (E == 32) LAUNCH(32); else LAUNCH(64));
+#undef LAUNCH
     DHZ_CHECK_LAUNCH("dhz_input_proj_bwd");
     return DHZ_OK;
+}
+extern "C" int dhz_input_proj_bwd(const float* dy, const float* y, const float* img, float* dw, float* db, int B, int H, int W, int E,
+                                  float slope, void* stream) {
+    return dhz_input_proj_bwd_dt(dy, y, img, dw, db, B, H, W, E, slope, DHZ_F32, stream);
 }

@@ -31,8 +31,8 @@ struct ThinSmem {
 
 // stage the 10 x 18 halo tile (zero outside the image) of a token tensor [B, H*W, C] or (BLOCKED) of a channel-blocked
 // NCHW8c map [B, C/8, H, W, 8] (the layout of the VGG feature engine)
-template <int C, bool BLOCKED = false>
-__device__ __forceinline__ void stage_tokens(float* xs, const float* __restrict__ x, int bimg, int ty, int tx, int H, int W) {
+template <int C, bool BLOCKED = false, typename T = float>
+__device__ __forceinline__ void stage_tokens(float* xs, const T* __restrict__ x, int bimg, int ty, int tx, int H, int W) {
     constexpr int XS = C + 4, C4 = C / 4;
     const int t = threadIdx.x;
     const size_t ib = (size_t)bimg * H * W;
@@ -43,7 +43,7 @@ __device__ __forceinline__ void stage_tokens(float* xs, const float* __restrict_
         if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
             const size_t o = BLOCKED ? (((size_t)bimg * (C / 8) + c4 / 2) * H * W + (size_t)yy * W + xx) * 8 + (c4 & 1) * 4
                                      : (ib + (size_t)yy * W + xx) * C + c4 * 4;
-            v = *reinterpret_cast<const f32x4*>(x + o);
+            v = ld4v(x + o);
         }
         *reinterpret_cast<f32x4*>(&xs[pos * XS + c4 * 4]) = v;
     }
@@ -51,8 +51,8 @@ __device__ __forceinline__ void stage_tokens(float* xs, const float* __restrict_
 
 // TRANSPOSED: w is a [C, 3, 3, 3] tensor (a 3 -> C convolution's weight) and the kernel computes that layer's
 // backward-data: y[b, o, p] = sum_{c, ky, kx} w[c][o][2 - ky][2 - kx] x[b, c, p + (ky - 1, kx - 1)]
-template <int C, bool BLOCKED, bool TRANSPOSED>
-__global__ __launch_bounds__(256) void thin_conv_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+template <int C, bool BLOCKED, bool TRANSPOSED, typename T = float>
+__global__ __launch_bounds__(256) void thin_conv_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w,
                                                             const float* __restrict__ bias, float* __restrict__ y, int H,
                                                             int W, int tiles_x, int tiles_y) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void thin_conv_fwd_kernel(const float* __restr
         else { o = e / (9 * C); c = (e / 9) % C; tap = e % 9; }
         sm.w[((c / 4 * 9 + tap) * 3 + o) * 4 + (c & 3)] = w[e];
     }
-    stage_tokens<C, BLOCKED>(sm.x, x, bimg, ty, tx, H, W);
+    stage_tokens<C, BLOCKED, T>(sm.x, x, bimg, ty, tx, H, W);
     __syncthreads();
     const int half = t >> 7, pix = t & 127;
     const int py = pix / TW, px = pix % TW;
@@ -109,9 +109,9 @@ __device__ __forceinline__ void stage_dy(float* ds, const float* __restrict__ dy
 }
 
 // dx[b, p, c] = sum_{o, ky, kx} w[o][c][ky][kx] * dy[b, o, p + (1 - ky, 1 - kx)]
-template <int C>
+template <int C, typename T = float>
 __global__ __launch_bounds__(256) void thin_conv_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ w,
-                                                              float* __restrict__ dx, int H, int W, int tiles_x, int tiles_y) {
+                                                              T* __restrict__ dx, int H, int W, int tiles_x, int tiles_y) {
     __shared__ __attribute__((aligned(16))) float ds[NPOS * 4];
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     const int tx = blockIdx.x % tiles_x, ty = (blockIdx.x / tiles_x) % tiles_y, bimg = blockIdx.x / (tiles_x * tiles_y);
@@ -139,14 +139,14 @@ __global__ __launch_bounds__(256) void thin_conv_dgrad_kernel(const float* __res
                     const f32x4 g = *reinterpret_cast<const f32x4*>(&ds[((py + 2 - ky) * HW_ + px + 2 - kx) * 4]);   // broadcast
                     acc += wr[0][ky * 3 + kx] * g[0] + wr[1][ky * 3 + kx] * g[1] + wr[2][ky * 3 + kx] * g[2];
                 }
-            if (yy < H && xx < W) dx[(ib + (size_t)yy * W + xx) * C + c] = acc;
+            if (yy < H && xx < W) st1(dx + (ib + (size_t)yy * W + xx) * C + c, acc);
         }
     }
 }
 
 // dw[o][c][ky][kx] += sum_p dy[o][p] x[p + (ky - 1, kx - 1)][c] ; db[o] += sum_p dy[o][p]
-template <int C>
-__global__ __launch_bounds__(256) void thin_conv_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+template <int C, typename T = float>
+__global__ __launch_bounds__(256) void thin_conv_wgrad_kernel(const float* __restrict__ dy, const T* __restrict__ x,
                                                               float* __restrict__ dw, float* __restrict__ db, int B, int H,
                                                               int W, int tiles_x, int tiles_y) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(256) void thin_conv_wgrad_kernel(const float* __res
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, bimg = tile / (tiles_x * tiles_y);
         __syncthreads();
-        stage_tokens<C>(sm.x, x, bimg, ty, tx, H, W);
+        stage_tokens<C, false, T>(sm.x, x, bimg, ty, tx, H, W);
         stage_dy(ds, dy, bimg, ty, tx, H, W);
         __syncthreads();
 #pragma unroll 1
@@ -250,55 +250,77 @@ __global__ __launch_bounds__(256) void conv3x3_in3_blocked_kernel(const float* _
     }
 }
 
-template <int C>
-int launch_all(int which, const float* a, const float* b, const float* c, float* d, float* e, int B, int H, int W, hipStream_t s) {
+template <int C, typename T>
+int launch_all(int which, const void* a, const float* b, const float* c, void* d, float* e, int B, int H, int W, hipStream_t s) {
     const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH, ntiles = B * tiles_x * tiles_y;
     const size_t smem = sizeof(ThinSmem<C>);
-    if (which == 0) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&thin_conv_fwd_kernel<C, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        hipLaunchKernelGGL((thin_conv_fwd_kernel<C, false, false>), dim3(ntiles), dim3(256), smem, s, a, b, c, d, H, W, tiles_x, tiles_y);
-    } else if (which == 1) {
-        hipLaunchKernelGGL((thin_conv_dgrad_kernel<C>), dim3(ntiles), dim3(256), 0, s, a, b, d, H, W, tiles_x, tiles_y);
-    } else {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&thin_conv_wgrad_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        const int grid = ntiles < 768 ? ntiles : 768;
-        hipLaunchKernelGGL((thin_conv_wgrad_kernel<C>), dim3(grid), dim3(256), smem, s, a, b, d, e, B, H, W, tiles_x, tiles_y);
+    if (which == 0) {            // a = tokens x (T), b = w, c = bias, d = image y (float)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&thin_conv_fwd_kernel<C, false, false, T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        hipLaunchKernelGGL((thin_conv_fwd_kernel<C, false, false, T>), dim3(ntiles), dim3(256), smem, s, (const T*)a, b, c, (float*)d, H, W, tiles_x, tiles_y);
+    } else if (which == 1) {     // a = image gradient dy (float), b = w, d = token gradient dx (T)
+        hipLaunchKernelGGL((thin_conv_dgrad_kernel<C, T>), dim3(ntiles), dim3(256), 0, s, (const float*)a, b, (T*)d, H, W, tiles_x, tiles_y);
+    } else {                     // a = dy (float), b -> tokens x (T) passed through c's slot: see dispatch
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&thin_conv_wgrad_kernel<C, T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        const int cap = 3 * dhz_num_cus();
+        const int grid = ntiles < cap ? ntiles : cap;
+        hipLaunchKernelGGL((thin_conv_wgrad_kernel<C, T>), dim3(grid), dim3(256), smem, s, (const float*)a, (const T*)c, (float*)d, e, B, H, W, tiles_x, tiles_y);
     }
     return 0;
 }
 
-int dispatch(int which, int C, const float* a, const float* b, const float* c, float* d, float* e, int B, int H, int W, hipStream_t s) {
-    if (C == 64) return launch_all<64>(which, a, b, c, d, e, B, H, W, s);
-    if (C == 128) return launch_all<128>(which, a, b, c, d, e, B, H, W, s);
+// which = 0: (x tokens, w, bias) -> y;  1: (dy, w) -> dx tokens;  2: (dy, x tokens via `c`) -> dw (d), db (e)
+int dispatch(int which, int C, int dtype, const void* a, const float* b, const void* c, void* d, float* e, int B, int H, int W, hipStream_t s) {
+    if (dtype == DHZ_F32) {
+        if (C == 64) return launch_all<64, float>(which, a, b, (const float*)c, d, e, B, H, W, s);
+        if (C == 128) return launch_all<128, float>(which, a, b, (const float*)c, d, e, B, H, W, s);
+    } else if (dtype == DHZ_BF16) {
+        if (C == 64) return launch_all<64, bf16s>(which, a, b, (const float*)c, d, e, B, H, W, s);
+        if (C == 128) return launch_all<128, bf16s>(which, a, b, (const float*)c, d, e, B, H, W, s);
+    }
     return 1;
 }
 
 }  // namespace
 
-extern "C" int dhz_thin_conv3x3_fwd(const float* x, const float* w, const float* bias, float* y, int B, int H, int W, int C,
-                                    void* stream) {
+extern "C" int dhz_thin_conv3x3_fwd_dt(const void* x, const float* w, const float* bias, float* y, int B, int H, int W, int C,
+                                       int dtype, void* stream) {
     DHZ_REQUIRE(x && w && y && B > 0 && H > 0 && W > 0, "dhz_thin_conv3x3_fwd: bad arguments");
     DHZ_REQUIRE(C == 64 || C == 128, "dhz_thin_conv3x3_fwd: C=%d unsupported (64, 128)", C);
-    dispatch(0, C, x, w, bias, y, nullptr, B, H, W, (hipStream_t)stream);
+    DHZ_REQUIRE(dtype == DHZ_F32 || dtype == DHZ_BF16, "dhz_thin_conv3x3_fwd: unknown dtype %d", dtype);
+    dispatch(0, C, dtype, x, w, bias, y, nullptr, B, H, W, (hipStream_t)stream);
     DHZ_CHECK_LAUNCH("dhz_thin_conv3x3_fwd");
     return DHZ_OK;
 }
+extern "C" int dhz_thin_conv3x3_fwd(const float* x, const float* w, const float* bias, float* y, int B, int H, int W, int C,
+                                    void* stream) {
+    return dhz_thin_conv3x3_fwd_dt(x, w, bias, y, B, H, W, C, DHZ_F32, stream);
+}
 
-extern "C" int dhz_thin_conv3x3_dgrad(const float* dy, const float* w, float* dx, int B, int H, int W, int C, void* stream) {
+extern "C" int dhz_thin_conv3x3_dgrad_dt(const float* dy, const float* w, void* dx, int B, int H, int W, int C, int dtype,
+                                         void* stream) {
     DHZ_REQUIRE(dy && w && dx && B > 0 && H > 0 && W > 0, "dhz_thin_conv3x3_dgrad: bad arguments");
     DHZ_REQUIRE(C == 64 || C == 128, "dhz_thin_conv3x3_dgrad: C=%d unsupported (64, 128)", C);
-    dispatch(1, C, dy, w, nullptr, dx, nullptr, B, H, W, (hipStream_t)stream);
+    DHZ_REQUIRE(dtype == DHZ_F32 || dtype == DHZ_BF16, "dhz_thin_conv3x3_dgrad: unknown dtype %d", dtype);
+    dispatch(1, C, dtype, dy, w, nullptr, dx, nullptr, B, H, W, (hipStream_t)stream);
     DHZ_CHECK_LAUNCH("dhz_thin_conv3x3_dgrad");
     return DHZ_OK;
 }
+extern "C" int dhz_thin_conv3x3_dgrad(const float* dy, const float* w, float* dx, int B, int H, int W, int C, void* stream) {
+    return dhz_thin_conv3x3_dgrad_dt(dy, w, dx, B, H, W, C, DHZ_F32, stream);
+}
 
-extern "C" int dhz_thin_conv3x3_wgrad(const float* dy, const float* x, float* dw, float* db, int B, int H, int W, int C,
-                                      void* stream) {
+extern "C" int dhz_thin_conv3x3_wgrad_dt(const float* dy, const void* x, float* dw, float* db, int B, int H, int W, int C,
+                                         int dtype, void* stream) {
     DHZ_REQUIRE(dy && x && dw && B > 0 && H > 0 && W > 0, "dhz_thin_conv3x3_wgrad: bad arguments");
     DHZ_REQUIRE(C == 64 || C == 128, "dhz_thin_conv3x3_wgrad: C=%d unsupported (64, 128)", C);
-    dispatch(2, C, dy, x, nullptr, dw, db, B, H, W, (hipStream_t)stream);
+    DHZ_REQUIRE(dtype == DHZ_F32 || dtype == DHZ_BF16, "dhz_thin_conv3x3_wgrad: unknown dtype %d", dtype);
+    dispatch(2, C, dtype, dy, nullptr, x, dw, db, B, H, W, (hipStream_t)stream);
     DHZ_CHECK_LAUNCH("dhz_thin_conv3x3_wgrad");
     return DHZ_OK;
+}
+extern "C" int dhz_thin_conv3x3_wgrad(const float* dy, const float* x, float* dw, float* db, int B, int H, int W, int C,
+                                      void* stream) {
+    return dhz_thin_conv3x3_wgrad_dt(dy, x, dw, db, B, H, W, C, DHZ_F32, stream);
 }
 
 extern "C" int dhz_thin_conv3x3_dgrad_blocked(const float* gb, const float* w, float* dx, int B, int H, int W, int C,

@@ -55,6 +55,13 @@ SIGNATURES = {
     "dhz_conv4s2_fwd": [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_p],
     "dhz_conv4s2_dgrad": [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_p],
     "dhz_conv4s2_wgrad": [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_p],
+    "dhz_input_proj_fwd_dt": [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_fl, c_i, c_p],
+    "dhz_input_proj_bwd_dt": [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_fl, c_i, c_p],
+    "dhz_thin_conv3x3_fwd_dt": [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_p],
+    "dhz_thin_conv3x3_dgrad_dt": [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_p],
+    "dhz_thin_conv3x3_wgrad_dt": [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_p],
+    "dhz_im2col_k4s2_bf16": [c_f, c_f, c_i, c_i, c_i, c_i, c_p],
+    "dhz_col2im_k4s2_bf16": [c_f, c_f, c_i, c_i, c_i, c_i, c_p],
     "dhz_linear_fwd_bf16": [c_f, c_i, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_p],
     "dhz_linear_dgrad_bf16": [c_f, c_i, c_f, c_f, c_i, c_i, c_i, c_i, c_p],
     "dhz_linear_wgrad_bf16": [c_f, c_i, c_f, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p],

@@ -362,7 +362,11 @@ class Downsample(nn.Module):
         if s_ * s_ == x.shape[1] and ops.conv4s2_supported(x, s_, s_, need_grad) and self.out_channel % 32 == 0:
             # implicit GEMM on the fp32 matrix pipe straight from / to the token layout (csrc/conv_gemm.hip)
             return ops.conv4s2_tokens(x, conv.weight, conv.bias, s_, s_)
-        if x.dtype == torch.bfloat16:       # config 4: library convolution in bf16 (weights cast by autocast, fp32 masters)
+        if (s_ * s_ == x.shape[1] and x.dtype == torch.bfloat16 and ops.conv4s2_bf16_supported(x, s_, s_)
+                and self.out_channel % 64 == 0):
+            # config 4: patch matrix + the bf16-MFMA token-Linear GEMMs (csrc/conv_bf16.hip), fp32 master weights
+            return ops.conv4s2_tokens(x, conv.weight, conv.bias, s_, s_)
+        if x.dtype == torch.bfloat16:       # shapes the kernels do not tile: library convolution in bf16
             with torch.autocast("cuda", dtype=torch.bfloat16):
                 return _map_to_tokens(self.conv(_tokens_to_map(x)))
         return _map_to_tokens(self.conv(_tokens_to_map(x)))
@@ -435,7 +439,8 @@ class InputProj(nn.Module):
         if (x.is_cuda and x.dtype == torch.float32 and self.in_channel == 3 and self.out_channel in (32, 64)
                 and conv.stride == (1, 1) and isinstance(act, nn.LeakyReLU) and not x.requires_grad):
             # convolution + LeakyReLU straight into the token layout (csrc/input_proj.hip)
-            x = ops.input_proj(x, conv.weight, conv.bias, act.negative_slope)
+            # (out_dtype: bf16 tokens straight from the kernel when the model runs BASELINE config 4's storage type)
+            x = ops.input_proj(x, conv.weight, conv.bias, act.negative_slope, getattr(self, "out_dtype", torch.float32))
         else:
             x = _map_to_tokens(self.proj(x.contiguous(memory_format=torch.channels_last)))
         return self.norm(x) if self.norm is not None else x
@@ -455,9 +460,10 @@ class OutputProj(nn.Module):
     def forward(self, x):
         conv = self.proj[0]
         if (x.is_cuda and len(self.proj) == 1 and self.out_channel == 3 and self.in_channel in (64, 128)
-                and conv.stride == (1, 1) and x.dtype == torch.float32):
+                and conv.stride == (1, 1) and x.dtype in (torch.float32, torch.bfloat16)):
             # 3 output channels: nothing for the matrix pipe, the library's implicit GEMM runs at 0.6 TB/s - hand-written
-            # forward / backward-data / weight-gradient kernels on the token layout (csrc/thin_conv.hip)
+            # forward / backward-data / weight-gradient kernels on the token layout (csrc/thin_conv.hip); fp32 or bf16 tokens in,
+            # fp32 image out
             s_ = int(math.sqrt(x.shape[1]))
             x = ops.thin_conv3x3(x, conv.weight, conv.bias, s_, s_)
         elif x.dtype == torch.bfloat16:
@@ -603,8 +609,9 @@ class Uformer(nn.Module):
     def forward(self, x, mask=None):
         self._stage_sample_indices(x.device)
         self._stage_drop_path(x)
+        self.input_proj.out_dtype = self.act_dtype if x.is_cuda else torch.float32
         y = self.pos_drop(self.input_proj(x))
-        if self.act_dtype == torch.bfloat16 and y.is_cuda:
+        if self.act_dtype == torch.bfloat16 and y.is_cuda and y.dtype != torch.bfloat16:
             y = y.to(torch.bfloat16)
         skips = []
         for s in range(4):

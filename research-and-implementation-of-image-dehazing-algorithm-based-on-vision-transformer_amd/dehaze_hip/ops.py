@@ -599,7 +599,7 @@ class _ThinConv(Function):
         assert L == H * W and w.shape == (3, C, 3, 3)
         wc = w.contiguous()
         y = torch.empty((B, 3, H, W), device=x.device, dtype=torch.float32)
-        _lib.call("dhz_thin_conv3x3_fwd", _p(x), _p(wc), _p(b), _p(y), B, H, W, C, _stream())
+        _lib.call("dhz_thin_conv3x3_fwd_dt", _p(x), _p(wc), _p(b), _p(y), B, H, W, C, _dt(x), _stream())
         ctx.save_for_backward(x, wc)
         ctx.params, ctx.geom = (w, b), (B, H, W, C)
         return y
@@ -609,11 +609,11 @@ class _ThinConv(Function):
         x, wc = ctx.saved_tensors
         w, b = ctx.params
         B, H, W, C = ctx.geom
-        dy = dy.contiguous()
+        dy = dy.contiguous().float()
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            _lib.call("dhz_thin_conv3x3_dgrad", _p(dy), _p(wc), _p(dx), B, H, W, C, _stream())
+            _lib.call("dhz_thin_conv3x3_dgrad_dt", _p(dy), _p(wc), _p(dx), B, H, W, C, _dt(x), _stream())
         inplace = w.is_leaf and w.requires_grad and (b is None or (b.is_leaf and b.requires_grad))
         if inplace:
             for p_ in (w, b):
@@ -621,7 +621,8 @@ class _ThinConv(Function):
                     p_.grad = torch.zeros_like(p_, memory_format=torch.contiguous_format)
             inplace = w.grad.is_contiguous()
         if inplace:
-            _lib.call("dhz_thin_conv3x3_wgrad", _p(dy), _p(x), _p(w.grad), _p(b.grad) if b is not None else None, B, H, W, C, _stream())
+            _lib.call("dhz_thin_conv3x3_wgrad_dt", _p(dy), _p(x), _p(w.grad), _p(b.grad) if b is not None else None, B, H, W, C,
+                      _dt(x), _stream())
             if GRAD_READY is not None:
                 GRAD_READY(w)
                 if b is not None:
@@ -629,7 +630,7 @@ class _ThinConv(Function):
             return dx, None, None, None, None
         dw = torch.zeros((3, C, 3, 3), device=x.device, dtype=torch.float32)
         db = torch.zeros(3, device=x.device, dtype=torch.float32) if b is not None else None
-        _lib.call("dhz_thin_conv3x3_wgrad", _p(dy), _p(x), _p(dw), _p(db), B, H, W, C, _stream())
+        _lib.call("dhz_thin_conv3x3_wgrad_dt", _p(dy), _p(x), _p(dw), _p(db), B, H, W, C, _dt(x), _stream())
         return dx, dw, db, None, None
 
 
@@ -702,7 +703,70 @@ class _Conv4s2(Function):
         return dx, gw, gb, None, None
 
 
+class _Conv4s2BF16(Function):
+    """Downsample.conv for bf16 tokens (BASELINE config 4): an explicit tap-major patch matrix (streaming copy in this layout)
+    and the three bf16-MFMA token-Linear GEMMs over it (csrc/conv_bf16.hip); fp32 master weights / gradients."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, H, W):
+        _require_gpu(x, w, b)
+        x = x.contiguous()
+        B, L, Cin = x.shape
+        Cout = w.shape[0]
+        assert L == H * W and tuple(w.shape) == (Cout, Cin, 4, 4) and x.dtype == BF16
+        wp = w.detach().permute(0, 2, 3, 1).reshape(Cout, 16 * Cin).to(BF16)          # [co][(ky, kx, ci)], one cast per pass
+        col = torch.empty((B * (L // 4), 16 * Cin), device=x.device, dtype=BF16)
+        _lib.call("dhz_im2col_k4s2_bf16", _p(x), _p(col), B, H, W, Cin, _stream())
+        y = gemm_fwd(col, wp, b.detach() if b is not None else None)
+        ctx.save_for_backward(col, wp)
+        ctx.params, ctx.geom = (w, b), (B, H, W, Cin, Cout)
+        return y.view(B, L // 4, Cout)
+
+    @staticmethod
+    def backward(ctx, dy):
+        col, wp = ctx.saved_tensors
+        w, b = ctx.params
+        B, H, W, Cin, Cout = ctx.geom
+        dy = dy.contiguous().view(-1, Cout)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dcol = gemm_dgrad(dy, wp)
+            dx = torch.empty((B, H * W, Cin), device=dy.device, dtype=BF16)
+            _lib.call("dhz_col2im_k4s2_bf16", _p(dcol), _p(dx), B, H, W, Cin, _stream())
+        gw = gb = None
+        if w.requires_grad or (b is not None and b.requires_grad):
+            dwp = torch.zeros((Cout, 16 * Cin), device=dy.device, dtype=torch.float32)
+            inplace_b = b is not None and b.is_leaf and b.requires_grad
+            if inplace_b and b.grad is None:
+                b.grad = torch.zeros_like(b)
+            dbv = b.grad if inplace_b else (torch.zeros_like(b) if b is not None else None)
+            wgrad_into(dy, 0, col, Cout, dwp, dbv)
+            dw = dwp.view(Cout, 4, 4, Cin).permute(0, 3, 1, 2)                        # back to [co][ci][ky][kx]
+            if w.is_leaf and w.requires_grad:
+                if w.grad is None:
+                    w.grad = torch.zeros_like(w, memory_format=torch.contiguous_format)
+                w.grad.add_(dw)
+                if GRAD_READY is not None:
+                    GRAD_READY(w)
+            else:
+                gw = dw.contiguous()
+            if inplace_b:
+                if GRAD_READY is not None:
+                    GRAD_READY(b)
+            else:
+                gb = dbv
+        return dx, gw, gb, None, None
+
+
+def conv4s2_bf16_supported(x, H, W):
+    """bf16 tokens, even map, channels in 64s (the bf16 GEMM kernels' tiles), output tokens in 64s."""
+    Cin = x.shape[-1]
+    return x.is_cuda and x.dtype == BF16 and H % 2 == 0 and W % 2 == 0 and Cin % 64 == 0 and (x.shape[0] * (H // 2) * (W // 2)) % 64 == 0
+
+
 def conv4s2_tokens(x, w, b, H, W):
+    if x.dtype == BF16:
+        return _Conv4s2BF16.apply(x, w, b, H, W)
     return _Conv4s2.apply(x, w, b, H, W)
 
 
@@ -711,13 +775,13 @@ class _InputProj(Function):
     """Conv2d(3, E, 3x3, pad 1) + LeakyReLU from the NCHW image into tokens [B, H*W, E] (M1:659-682)."""
 
     @staticmethod
-    def forward(ctx, img, w, b, slope):
+    def forward(ctx, img, w, b, slope, out_dtype=torch.float32):
         _require_gpu(img, w, b)
         img = img.contiguous()
         B, _, H, W = img.shape
         E = w.shape[0]
-        y = torch.empty((B, H * W, E), device=img.device, dtype=torch.float32)
-        _lib.call("dhz_input_proj_fwd", _p(img), _p(w.contiguous()), _p(b), _p(y), B, H, W, E, float(slope), _stream())
+        y = torch.empty((B, H * W, E), device=img.device, dtype=out_dtype)
+        _lib.call("dhz_input_proj_fwd_dt", _p(img), _p(w.contiguous()), _p(b), _p(y), B, H, W, E, float(slope), _dt(y), _stream())
         ctx.save_for_backward(img, y)
         ctx.params, ctx.slope = (w, b), float(slope)
         return y
@@ -738,14 +802,15 @@ class _InputProj(Function):
             inplace = w.grad.is_contiguous()
         gw = w.grad if inplace else torch.zeros_like(w, memory_format=torch.contiguous_format)
         gb = b.grad if inplace else torch.zeros_like(b)
-        _lib.call("dhz_input_proj_bwd", _p(dy.contiguous()), _p(y), _p(img), _p(gw), _p(gb), B, H, W, E, ctx.slope, _stream())
+        _lib.call("dhz_input_proj_bwd_dt", _p(dy.contiguous().to(y.dtype)), _p(y), _p(img), _p(gw), _p(gb), B, H, W, E, ctx.slope, _dt(y),
+                  _stream())
         if inplace:
             if GRAD_READY is not None:
                 GRAD_READY(w)
                 GRAD_READY(b)
-            return None, None, None, None
-        return None, gw, gb, None
+            return None, None, None, None, None
+        return None, gw, gb, None, None
 
 
-def input_proj(img, w, b, slope=0.01):
-    return _InputProj.apply(img, w, b, slope)
+def input_proj(img, w, b, slope=0.01, out_dtype=torch.float32):
+    return _InputProj.apply(img, w, b, slope, out_dtype)

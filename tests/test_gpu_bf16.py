@@ -315,3 +315,80 @@ def test_config4_full_size_bf16_properties():
     loss, _, _ = train_step(model, char, None, opt, None, x, gt, w_cr=0.0)
     assert torch.isfinite(loss) and 0.0 < loss.item() < 1.0
     assert any(not torch.equal(a, b.detach()) for a, b in zip(before, params[:4]))
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 16, 16, 64, 128), (1, 32, 16, 128, 256)])
+def test_downsample_bf16_vs_fp64_conv(B, H, W, Cin, Cout):
+    """Downsample (Conv2d k4 s2 p1, M1:606-622) on bf16 tokens - patch matrix (dhz_im2col_k4s2_bf16), bf16-MFMA GEMMs, dhz_col2im_k4s2_bf16 -
+    against torch's fp64 conv2d on the same bf16-rounded input / weights: output within bf16 rounding (2^-8 relative + accumulation
+    slack), dx within two roundings (dcol is stored in bf16 before the 4-term sum), dw / db (fp32 accumulation) to 1e-3."""
+    import torch.nn.functional as F
+    from dehaze_hip import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(B + H + Cin)
+    x = torch.randn(B, H * W, Cin, generator=g).to(BF)
+    w = (torch.randn(Cout, Cin, 4, 4, generator=g) * 0.05).to(BF).float()
+    b = torch.randn(Cout, generator=g) * 0.1
+    gy = torch.randn(B, (H // 2) * (W // 2), Cout, generator=g).to(BF)
+    x64 = x.double().view(B, H, W, Cin).permute(0, 3, 1, 2).requires_grad_()
+    w64, b64 = w.double().requires_grad_(), b.double().requires_grad_()
+    y64 = F.conv2d(x64, w64, b64, stride=2, padding=1)
+    (y64 * gy.double().view(B, H // 2, W // 2, Cout).permute(0, 3, 1, 2)).sum().backward()
+    ref_y = y64.detach().permute(0, 2, 3, 1).reshape(B, -1, Cout)
+    ref_dx = x64.grad.permute(0, 2, 3, 1).reshape(B, H * W, Cin)
+    xd = x.to(dev).requires_grad_()
+    wd, bd = w.to(dev).requires_grad_(), b.to(dev).requires_grad_()
+    y = ops.conv4s2_tokens(xd, wd, bd, H, W)
+    assert y.dtype == BF and y.shape == (B, (H // 2) * (W // 2), Cout)
+    y.backward(gy.to(dev))
+    err = (y.double().cpu() - ref_y).abs()
+    assert (err <= 1.1 * EPS * ref_y.abs() + 1e-4 * (16 * Cin) ** 0.5).all(), err.max().item()
+    edx = (xd.grad.double().cpu() - ref_dx).abs()
+    assert (edx <= 4 * EPS * ref_dx.abs() + 4 * EPS * ref_dx.abs().max()).all(), edx.max().item()
+    assert torch.allclose(wd.grad.double().cpu(), w64.grad, rtol=1e-3, atol=1e-3 * w64.grad.abs().max().item())
+    assert torch.allclose(bd.grad.double().cpu(), b64.grad, rtol=1e-3, atol=1e-3 * b64.grad.abs().max().item())
+
+
+def test_projections_bf16_tokens_match_fp32_kernels():
+    """InputProj / OutputProj with bf16 token storage: the same arithmetic as the fp32 kernels, rounded once on the token side.
+    InputProj: bf16 output == fp32 output rounded; weight gradients from a bf16 dy / saved bf16 y equal the fp32 kernel's on the
+    same (bf16-representable) values.  OutputProj: fp32 image from bf16 tokens == fp32 kernel on the same values; dx == rounded."""
+    from dehaze_hip import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(5)
+    B, H, W, E = 2, 32, 48, 64
+    img = torch.rand(B, 3, H, W, generator=g).to(dev)
+    w = (torch.randn(E, 3, 3, 3, generator=g) * 0.2).to(dev).requires_grad_()
+    b = (torch.randn(E, generator=g) * 0.1).to(dev).requires_grad_()
+    y32 = ops.input_proj(img, w, b, 0.01)
+    y16 = ops.input_proj(img, w, b, 0.01, BF)
+    assert y16.dtype == BF and torch.equal(y16, y32.to(BF))
+    gy = torch.randn(B, H * W, E, generator=g).to(dev).to(BF)
+    w2, b2 = w.detach().clone().requires_grad_(), b.detach().clone().requires_grad_()
+    y16b = ops.input_proj(img, w2, b2, 0.01, BF)
+    y16b.backward(gy)
+    # fp32 kernel on the same numbers: its saved output must carry the same signs -> feed it the rounded output's pre-image
+    w3, b3 = w.detach().clone().requires_grad_(), b.detach().clone().requires_grad_()
+    y32b = ops.input_proj(img, w3, b3, 0.01)
+    same_sign = ((y32b > 0) == (y16b.float() > 0)).all().item()
+    y32b.backward(gy.float())
+    if same_sign:
+        assert torch.allclose(w2.grad, w3.grad, rtol=1e-4, atol=1e-4 * w3.grad.abs().max().item())
+        assert torch.allclose(b2.grad, b3.grad, rtol=1e-4, atol=1e-4 * b3.grad.abs().max().item())
+    C = 128
+    x = torch.randn(B, H * W, C, generator=g).to(dev).to(BF)
+    wo = (torch.randn(3, C, 3, 3, generator=g) * 0.05).to(dev)
+    bo = (torch.randn(3, generator=g) * 0.1).to(dev)
+    outs = {}
+    for dt in (torch.float32, BF):
+        xx = x.to(dt).requires_grad_()
+        ww, bb = wo.clone().requires_grad_(), bo.clone().requires_grad_()
+        yy = ops.thin_conv3x3(xx, ww, bb, H, W)
+        assert yy.dtype == torch.float32
+        gi = torch.randn(B, 3, H, W, generator=torch.Generator().manual_seed(9)).to(dev)
+        yy.backward(gi)
+        outs[dt] = (yy.detach(), xx.grad, ww.grad, bb.grad)
+    assert torch.equal(outs[BF][0], outs[torch.float32][0])
+    assert outs[BF][1].dtype == BF and torch.equal(outs[BF][1], outs[torch.float32][1].to(BF))
+    assert torch.allclose(outs[BF][2], outs[torch.float32][2], rtol=1e-5, atol=1e-5 * outs[torch.float32][2].abs().max().item())
+    assert torch.allclose(outs[BF][3], outs[torch.float32][3], rtol=1e-5, atol=1e-4)
