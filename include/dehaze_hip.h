@@ -95,6 +95,23 @@ int dhz_fused_window_attn_fwd(const float* x, const float* gamma, const float* b
                               uint8_t* rank_save, int B, int Hres, int Wres, int C, int shift,
                               void* stream);
 
+/* Fused BACKWARD of the same branch at C = 32 (one head): given d(out) it recomputes LayerNorm, Q/K/V, the selected scores, both
+ *     softmaxes and P V per window from x and the 64 selection ranks the forward saved (rank_save of dhz_fused_window_attn_fwd
+ *     called with rank_save ALONE), and produces dx (shortcut included) and every parameter gradient on chip.  Replaces, per block,
+ *     the autograd chain of M1:839-872: dhz_reverse_residual_bwd, two backward-data GEMMs, three weight-gradient launches,
+ *     dhz_ps_attn_bwd, dhz_ln_partition_bwd.
+ *     wqkv_p: the forward's prepack (dhz_fused_attn_prepack); wt [4096]: dhz_fused_attn_bwd_prepack(wq, wk, wv, wo).
+ *     ACCUMULATED with fp32 atomics (caller zeroes): dwq, dwk, dwv, dwo [32, 32]; dbq, dbk, dbv, dbo [32] (each may be NULL);
+ *     dgamma, dbeta [32].  dbias_part [dhz_fused_attn_bwd_parts(nwin)][64][64] (written, not accumulated) iff bias != NULL:
+ *     reduce with dhz_bias_table_grad.  dx [B, Hres*Wres, 32] is written. */
+int dhz_fused_attn_bwd_parts(int nwin);
+int dhz_fused_attn_bwd_prepack(const float* wq, const float* wk, const float* wv, const float* wo, float* wt, int C, void* stream);
+int dhz_fused_window_attn_bwd(const float* x, const float* dout, const float* gamma, const float* beta, const float* wqkv_p,
+                              const float* bqkv, const float* wt, const float* bias, const float* mask, const float* drop_scale,
+                              const uint8_t* rank, float* dx, float* dwq, float* dwk, float* dwv, float* dbq, float* dbk,
+                              float* dbv, float* dwo, float* dbo, float* dgamma, float* dbeta, float* dbias_part, int B, int Hres,
+                              int Wres, int C, int shift, void* stream);
+
 /* K3-dense  Dense window attention of the My_model.Uformer twin.  Replaces WindowAttention.forward
  *     M0:428-492:  out = softmax(scale * q k^T + bias[h] + mask[b % nW]) v   per (window, head).
  *     Same layouts as dhz_ps_attn_fwd (q,k,v [B_,64,H,d] with token stride ld; bias [H,64,64] or NULL;

@@ -77,7 +77,9 @@ struct FusedSmem {
     uint8_t idx[NT * NU];
 };
 
-template <int C, bool SAVE>
+// SAVE: 0 = inference, 1 = every tensor the backward kernel chain consumes, 2 = only the selection ranks (the fused backward of
+// csrc/fused_attn_bwd.hip recomputes the rest)
+template <int C, int SAVE>
 __global__ __launch_bounds__(256, C == 64 ? 3 : (C == 128 ? 1 : 2)) void fused_window_attn_fwd_kernel(
     const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
     const float4* __restrict__ wqkv_p, const float* __restrict__ bqkv, const float4* __restrict__ wo_p,
@@ -166,9 +168,9 @@ __global__ __launch_bounds__(256, C == 64 ? 3 : (C == 128 ? 1 : 2)) void fused_w
                 y.z = (xv[i].z - mean) * rstd * gm.z + bt.z;
                 y.w = (xv[i].w - mean) * rstd * gm.w + bt.w;
                 xa[4 * i] = y.x; xa[4 * i + 1] = y.y; xa[4 * i + 2] = y.z; xa[4 * i + 3] = y.w;
-                if (SAVE && !(abl & 128)) reinterpret_cast<float4*>(xn_save + ((size_t)win * NT + tl) * C + qd * CPT)[i] = y;
+                if (SAVE == 1 && !(abl & 128)) reinterpret_cast<float4*>(xn_save + ((size_t)win * NT + tl) * C + qd * CPT)[i] = y;
             }
-            if (SAVE && !(abl & 128) && qd == 0) *reinterpret_cast<float2*>(stats_save + 2 * src_tok) = make_float2(mean, rstd);
+            if (SAVE == 1 && !(abl & 128) && qd == 0) *reinterpret_cast<float2*>(stats_save + 2 * src_tok) = make_float2(mean, rstd);
         }
         f32x4 oacc[C / 16];                    // out-projection accumulators: rows 16w.., all C columns
 #pragma unroll
@@ -228,7 +230,7 @@ __global__ __launch_bounds__(256, C == 64 ? 3 : (C == 128 ? 1 : 2)) void fused_w
                 }
             }
             __syncthreads();
-            if (SAVE && !(abl & 128)) {   // packed QKV rows for the backward kernels: [win*64 + row][3C], head slice 32h..32h+31
+            if (SAVE == 1 && !(abl & 128)) {   // packed QKV rows for the backward kernels: [win*64 + row][3C], head slice 32h..32h+31
                 const int row = t >> 2, c8 = (t & 3) * 8;
                 float* dst = qkv_save + ((size_t)win * NT + row) * 3 * C + 32 * h + c8;
                 *reinterpret_cast<float4*>(dst) = *reinterpret_cast<const float4*>(&sm.q[row * HS + c8]);
@@ -431,15 +433,16 @@ __global__ __launch_bounds__(256, C == 64 ? 3 : (C == 128 ? 1 : 2)) void fused_w
                         for (int tn = 0; tn < C / 16; ++tn) oacc[tn] = mfma16(a[4 * s4 + 3], b4[tn][s4].w, oacc[tn]);
                     }
                 }
-                if (SAVE && !(abl & 128)) {
+                if (SAVE == 1 && !(abl & 128)) {
                     const int row = t >> 2, c8 = (t & 3) * 8;
                     const int rkr = __shfl(myrank, row);
                     const int rr = rkr < NU ? rkr : NU;
                     float* dst = ctx_save + ((size_t)win * NT + row) * C + 32 * h + c8;
                     *reinterpret_cast<float4*>(dst) = *reinterpret_cast<const float4*>(&O[rr * HS + c8]);
                     *reinterpret_cast<float4*>(dst + 4) = *reinterpret_cast<const float4*>(&O[rr * HS + c8 + 4]);
-                    if (w == 0) rank_save[((size_t)win * H + h) * NT + lane] = myrank < NU ? (uint8_t)myrank : (uint8_t)255;
                 }
+                if (SAVE && !(abl & 128) && w == 0)
+                    rank_save[((size_t)win * H + h) * NT + lane] = myrank < NU ? (uint8_t)myrank : (uint8_t)255;
             }
             __syncthreads();                       // O (in the Q tile), K, V, S, P are rewritten by the next head / window
         }
@@ -514,7 +517,7 @@ __global__ void prepack_weights_kernel(const float* __restrict__ wq, const float
     }
 }
 
-template <int C, bool SAVE>
+template <int C, int SAVE>
 void launch_fused(hipStream_t s, int nwin, const float* x, const float* gamma, const float* beta, const float* wqkv_p,
                   const float* bqkv, const float* wo_p, const float* bo, const uint8_t* idx, const float* bias,
                   const float* mask, const float* dscale, float* out, float* xn_save, float* qkv_save, float* ctx_save,
@@ -571,18 +574,24 @@ extern "C" int dhz_fused_window_attn_fwd(const float* x, const float* gamma, con
     DHZ_REQUIRE(C == 32 || C == 64 || C == 128, "dhz_fused_window_attn_fwd: C=%d unsupported (32, 64, 128)", C);
     DHZ_REQUIRE(B > 0 && Hres % 8 == 0 && Wres % 8 == 0 && Hres >= 8 && Wres >= 8 && shift >= 0 && shift < 8,
                 "dhz_fused_window_attn_fwd: bad geometry %dx%d shift %d", Hres, Wres, shift);
-    const bool save = xn_save || qkv_save || ctx_save || stats_save || rank_save;
-    DHZ_REQUIRE(!save || (xn_save && qkv_save && ctx_save && stats_save && rank_save),
-                "dhz_fused_window_attn_fwd: training mode needs all five save buffers");
+    // three modes: inference (no save pointer), training for the backward kernel chain (all five), training for the fused backward
+    // (rank_save only: everything else is recomputed there)
+    const bool any4 = xn_save || qkv_save || ctx_save || stats_save;
+    const bool all4 = xn_save && qkv_save && ctx_save && stats_save;
+    DHZ_REQUIRE(!any4 || (all4 && rank_save),
+                "dhz_fused_window_attn_fwd: save buffers: none, rank_save alone, or all five");
+    const int save = all4 ? 1 : (rank_save ? 2 : 0);
     DHZ_REQUIRE(!mask || shift > 0, "dhz_fused_window_attn_fwd: a mask is only meaningful for shifted windows");
     hipStream_t s = (hipStream_t)stream;
     const int nwin = B * (Hres / 8) * (Wres / 8);
 #define GO(CC)                                                                                                      \
     do {                                                                                                            \
-        if (save) launch_fused<CC, true>(s, nwin, x, gamma, beta, wqkv_p, bqkv, wo_p, bo, idx, bias, mask, drop_scale, \
-                                         out, xn_save, qkv_save, ctx_save, stats_save, rank_save, Hres, Wres, shift);   \
-        else launch_fused<CC, false>(s, nwin, x, gamma, beta, wqkv_p, bqkv, wo_p, bo, idx, bias, mask, drop_scale, out, \
-                                     nullptr, nullptr, nullptr, nullptr, nullptr, Hres, Wres, shift);                \
+        if (save == 1) launch_fused<CC, 1>(s, nwin, x, gamma, beta, wqkv_p, bqkv, wo_p, bo, idx, bias, mask, drop_scale, \
+                                           out, xn_save, qkv_save, ctx_save, stats_save, rank_save, Hres, Wres, shift);   \
+        else if (save == 2) launch_fused<CC, 2>(s, nwin, x, gamma, beta, wqkv_p, bqkv, wo_p, bo, idx, bias, mask, drop_scale, \
+                                                out, nullptr, nullptr, nullptr, nullptr, rank_save, Hres, Wres, shift);      \
+        else launch_fused<CC, 0>(s, nwin, x, gamma, beta, wqkv_p, bqkv, wo_p, bo, idx, bias, mask, drop_scale, out, \
+                                 nullptr, nullptr, nullptr, nullptr, nullptr, Hres, Wres, shift);                \
     } while (0)
     if (C == 32) GO(32); else if (C == 64) GO(64); else GO(128);
 #undef GO

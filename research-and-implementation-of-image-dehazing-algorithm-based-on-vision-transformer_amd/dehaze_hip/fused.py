@@ -20,6 +20,9 @@ ATTN_FUSED_C128_MAX_HW = 1024   # C = 128 takes the fused attention forward up t
 # in round 3) was 1.5-2x slower than the kernel chain in fp32 - fp32-input MFMA and fp32 VALU instructions share the SIMD's
 # issue (profiles/r02_coexec_micro.txt), so fusing the GELU / depthwise VALU work into the GEMM kernels ADDS its time to the
 # matrix time instead of hiding it behind HBM traffic as the stand-alone streaming kernels do.
+# Fused attention BACKWARD (csrc/fused_attn_bwd.hip, C = 32): the forward then saves only the selection ranks.  A/B against the
+# backward kernel chain: tools/bench_fused.py, profiles/r03_fused_attn_bwd_ab.txt.
+ATTN_FUSED_BWD_C = (32,)
 LEFF_FUSED = True           # False forces the kernel chain everywhere
 LEFF_FUSED_C = (32, 64)     # widths that take the fused forward
 
@@ -123,12 +126,14 @@ class _FusedAttnBranch(Function):
             _lib.call("dhz_bias_gather", _p(table.contiguous()), _p(bias), H, _stream())
         out = torch.empty_like(x)
         train = grad_mode and any(ctx.needs_input_grad)
+        fused_bwd = train and C in ATTN_FUSED_BWD_C and x.dtype == torch.float32
         xn = qkv = cx = stats = rank = None
         if train:
-            xn = torch.empty((T, C), **f32)
-            qkv = torch.empty((T, 3 * C), **f32)
-            cx = torch.empty((T, C), **f32)
-            stats = torch.empty((T, 2), **f32)
+            if not fused_bwd:
+                xn = torch.empty((T, C), **f32)
+                qkv = torch.empty((T, 3 * C), **f32)
+                cx = torch.empty((T, C), **f32)
+                stats = torch.empty((T, 2), **f32)
             rank = torch.empty(((T // NTOK) * H * NTOK,), device=dev, dtype=torch.uint8)
         timing = ops.KERNEL_TIMING.get("dhz_fused_window_attn_fwd") if ops.KERNEL_TIMING is not None else None
         if timing is not None:
@@ -140,14 +145,51 @@ class _FusedAttnBranch(Function):
         if timing is not None:
             e1.record()
             timing.append((e0, e1, T // NTOK, C))
-        if train:
+        ctx.fused_bwd = fused_bwd
+        if fused_bwd:
+            wt = torch.empty(4096, **f32)
+            _lib.call("dhz_fused_attn_bwd_prepack", _p(wq), _p(wk), _p(wv), _p(wo), _p(wt), C, _stream())
+            ctx.save_for_backward(x, gamma, beta, rank, bias, mask, dscale, wqkv_p, bqkv, wt)
+            ctx.params = (wq, bq, wk, bk, wv, bv, wo, bo, gamma, beta, table)
+            ctx.geom = (B, Hres, Wres, C, shift, H)
+        elif train:
             ctx.save_for_backward(x, gamma, stats, xn, qkv, cx, rank, bias, mask, dscale, wq, wk, wv, wo)
             ctx.params = (wq, bq, wk, bk, wv, bv, wo, bo, gamma, beta, table)
             ctx.geom = (B, Hres, Wres, C, shift, H)
         return out
 
     @staticmethod
+    def _backward_fused(ctx, dout):
+        """One kernel from d(out) to dx and every parameter gradient (csrc/fused_attn_bwd.hip)."""
+        x, gamma, beta, rank, bias, mask, dscale, wqkv_p, bqkv, wt = ctx.saved_tensors
+        wq, bq, wk, bk, wv, bv, wo, bo, gamma_p, beta_p, table_p = ctx.params
+        B, Hres, Wres, C, shift, H = ctx.geom
+        dev = x.device
+        f32 = dict(device=dev, dtype=torch.float32)
+        plist = (wq, wk, wv, bq, bk, bv, wo, bo, gamma_p, beta_p)
+        bufs = [_grad_buf(p) if p is not None else None for p in plist]
+        inplace = all(b is not None or p is None for b, p in zip(bufs, plist))
+        if not inplace:
+            bufs = [torch.zeros_like(p, memory_format=torch.contiguous_format) if p is not None else None for p in plist]
+        gwq, gwk, gwv, gbq, gbk, gbv, gwo, gbo, gg, gb = bufs
+        nwin = B * (Hres // 8) * (Wres // 8)
+        parts = _lib.load().dhz_fused_attn_bwd_parts(nwin)
+        dpart = torch.empty((parts, NTOK, NTOK), **f32) if bias is not None else None
+        dx = torch.empty_like(x)
+        _lib.call("dhz_fused_window_attn_bwd", _p(x), _p(dout.contiguous()), _p(gamma), _p(beta), _p(wqkv_p), _p(bqkv), _p(wt),
+                  _p(bias), _p(mask), _p(dscale), _p(rank), _p(dx), _p(gwq), _p(gwk), _p(gwv), _p(gbq), _p(gbk), _p(gbv), _p(gwo),
+                  _p(gbo), _p(gg), _p(gb), _p(dpart), B, Hres, Wres, C, shift, _stream())
+        dtable = _table_backward(dpart, parts, table_p, H, dev) if bias is not None else None
+        if inplace:
+            _ready(*[p for p in plist if p is not None])
+            return (dx, None, None, None, None, None, None, None, None, None, None, dtable,
+                    None, None, None, None, None, None, None, None)
+        return (dx, gg, gb, gwq, gbq, gwk, gbk, gwv, gbv, gwo, gbo, dtable, None, None, None, None, None, None, None, None)
+
+    @staticmethod
     def backward(ctx, dout):
+        if getattr(ctx, "fused_bwd", False):
+            return _FusedAttnBranch._backward_fused(ctx, dout)
         x, gamma, stats, xn, qkv, cx, rank, bias, mask, dscale, wq_, wk_, wv_, wo_ = ctx.saved_tensors
         wq, bq, wk, bk, wv, bv, wo, bo, gamma_p, beta_p, table_p = ctx.params
         B, Hres, Wres, C, shift, H = ctx.geom
@@ -237,7 +279,37 @@ class _AttnBranchChain(Function):
         return out
 
     @staticmethod
+    def _backward_fused(ctx, dout):
+        """One kernel from d(out) to dx and every parameter gradient (csrc/fused_attn_bwd.hip)."""
+        x, gamma, beta, rank, bias, mask, dscale, wqkv_p, bqkv, wt = ctx.saved_tensors
+        wq, bq, wk, bk, wv, bv, wo, bo, gamma_p, beta_p, table_p = ctx.params
+        B, Hres, Wres, C, shift, H = ctx.geom
+        dev = x.device
+        f32 = dict(device=dev, dtype=torch.float32)
+        plist = (wq, wk, wv, bq, bk, bv, wo, bo, gamma_p, beta_p)
+        bufs = [_grad_buf(p) if p is not None else None for p in plist]
+        inplace = all(b is not None or p is None for b, p in zip(bufs, plist))
+        if not inplace:
+            bufs = [torch.zeros_like(p, memory_format=torch.contiguous_format) if p is not None else None for p in plist]
+        gwq, gwk, gwv, gbq, gbk, gbv, gwo, gbo, gg, gb = bufs
+        nwin = B * (Hres // 8) * (Wres // 8)
+        parts = _lib.load().dhz_fused_attn_bwd_parts(nwin)
+        dpart = torch.empty((parts, NTOK, NTOK), **f32) if bias is not None else None
+        dx = torch.empty_like(x)
+        _lib.call("dhz_fused_window_attn_bwd", _p(x), _p(dout.contiguous()), _p(gamma), _p(beta), _p(wqkv_p), _p(bqkv), _p(wt),
+                  _p(bias), _p(mask), _p(dscale), _p(rank), _p(dx), _p(gwq), _p(gwk), _p(gwv), _p(gbq), _p(gbk), _p(gbv), _p(gwo),
+                  _p(gbo), _p(gg), _p(gb), _p(dpart), B, Hres, Wres, C, shift, _stream())
+        dtable = _table_backward(dpart, parts, table_p, H, dev) if bias is not None else None
+        if inplace:
+            _ready(*[p for p in plist if p is not None])
+            return (dx, None, None, None, None, None, None, None, None, None, None, dtable,
+                    None, None, None, None, None, None, None, None)
+        return (dx, gg, gb, gwq, gbq, gwk, gbk, gwv, gbv, gwo, gbo, dtable, None, None, None, None, None, None, None, None)
+
+    @staticmethod
     def backward(ctx, dout):
+        if getattr(ctx, "fused_bwd", False):
+            return _FusedAttnBranch._backward_fused(ctx, dout)
         x, gamma, stats, xn, qkv, cx, rank, bias, mask, dscale, wq_, wk_, wv_, wo_ = ctx.saved_tensors
         wq, bq, wk, bk, wv, bv, wo, bo, gamma_p, beta_p, table_p = ctx.params
         B, Hres, Wres, C, shift, H = ctx.geom
