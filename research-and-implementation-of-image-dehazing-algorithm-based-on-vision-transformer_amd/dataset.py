@@ -39,84 +39,60 @@ def draw_crop_aug(H, W, ps):
     return r, c, random.getrandbits(3)
 
 
-class DataLoaderTrain(Dataset):
-    def __init__(self, rgb_dir, img_options=None, target_transform=None):
+def _chw(path):
+    """One PNG as float32 CHW in [0, 1] (the reference's load_img + permute)."""
+    return torch.from_numpy(np.float32(load_img(path))).permute(2, 0, 1)
+
+
+class _PngFolder(Dataset):
+    """Host-side datasets of the reference's evaluation scripts: item -> decoded tensors + file names.  `pairs` = gt / hazy
+    sub-directories (training, validation), otherwise a HAZY directory only (test).  Attribute names are the reference's."""
+
+    def __init__(self, rgb_dir, pairs=True, target_transform=None):
         super().__init__()
         self.target_transform = target_transform
-        self.clean_filenames, self.noisy_filenames = _pair_files(rgb_dir)
-        self.img_options = img_options
-        self.tar_size = len(self.clean_filenames)
-
-    def __len__(self):
-        return self.tar_size
-
-    def __getitem__(self, index):
-        tar_index = index % self.tar_size
-        clean = torch.from_numpy(np.float32(load_img(self.clean_filenames[tar_index]))).permute(2, 0, 1)
-        noisy = torch.from_numpy(np.float32(load_img(self.noisy_filenames[tar_index]))).permute(2, 0, 1)
-        clean_filename = os.path.split(self.clean_filenames[tar_index])[-1]
-        noisy_filename = os.path.split(self.noisy_filenames[tar_index])[-1]
-        ps = self.img_options['patch_size']
-        r, c, k = draw_crop_aug(clean.shape[1], clean.shape[2], ps)
-        clean = clean[:, r:r + ps, c:c + ps]
-        noisy = noisy[:, r:r + ps, c:c + ps]
-        apply_trans = transforms_aug[k]
-        clean = getattr(augment, apply_trans)(clean)
-        noisy = getattr(augment, apply_trans)(noisy)
-        return clean, noisy, clean_filename, noisy_filename
-
-
-class DataLoaderVal(Dataset):
-    def __init__(self, rgb_dir, target_transform=None):
-        super().__init__()
-        self.target_transform = target_transform
-        self.clean_filenames, self.noisy_filenames = _pair_files(rgb_dir)
-        self.tar_size = len(self.clean_filenames)
-
-    def __len__(self):
-        return self.tar_size
-
-    def __getitem__(self, index):
-        tar_index = index % self.tar_size
-        clean = torch.from_numpy(np.float32(load_img(self.clean_filenames[tar_index]))).permute(2, 0, 1)
-        noisy = torch.from_numpy(np.float32(load_img(self.noisy_filenames[tar_index]))).permute(2, 0, 1)
-        clean_filename = os.path.split(self.clean_filenames[tar_index])[-1]
-        noisy_filename = os.path.split(self.noisy_filenames[tar_index])[-1]
-        return clean, noisy, clean_filename, noisy_filename
-
-
-class DataLoaderTest(Dataset):
-    def __init__(self, rgb_dir, target_transform=None):
-        super().__init__()
-        self.target_transform = target_transform
-        noisy_files = sorted(os.listdir(os.path.join(rgb_dir, 'HAZY')))
-        self.noisy_filenames = [os.path.join(rgb_dir, 'HAZY', x) for x in noisy_files if is_png_file(x)]
+        if pairs:
+            self.clean_filenames, self.noisy_filenames = _pair_files(rgb_dir)
+        else:
+            self.clean_filenames = None
+            self.noisy_filenames = [os.path.join(rgb_dir, 'HAZY', f) for f in sorted(os.listdir(os.path.join(rgb_dir, 'HAZY')))
+                                    if is_png_file(f)]
         self.tar_size = len(self.noisy_filenames)
 
     def __len__(self):
         return self.tar_size
 
+    def _pair(self, index):
+        i = index % self.tar_size
+        cf, nf = self.clean_filenames[i], self.noisy_filenames[i]
+        return _chw(cf), _chw(nf), os.path.basename(cf), os.path.basename(nf)
+
+
+class DataLoaderVal(_PngFolder):                       # dataset.py:82-110: whole image pairs
     def __getitem__(self, index):
-        tar_index = index % self.tar_size
-        noisy = torch.from_numpy(np.float32(load_img(self.noisy_filenames[tar_index]))).permute(2, 0, 1)
-        return noisy, os.path.split(self.noisy_filenames[tar_index])[-1]
+        return self._pair(index)
 
 
-class DataLoaderTestSR(Dataset):
+class DataLoaderTrain(_PngFolder):                     # dataset.py:17-77: random ps x ps crop + one of 8 rotations / flips
+    def __init__(self, rgb_dir, img_options=None, target_transform=None):
+        super().__init__(rgb_dir, True, target_transform)
+        self.img_options = img_options
+
+    def __getitem__(self, index):
+        clean, noisy, cn, nn_ = self._pair(index)
+        ps = self.img_options['patch_size']
+        r, c, k = draw_crop_aug(clean.shape[1], clean.shape[2], ps)        # the reference's draw order (numpy, then random)
+        aug = getattr(augment, transforms_aug[k])
+        return aug(clean[:, r:r + ps, c:c + ps]), aug(noisy[:, r:r + ps, c:c + ps]), cn, nn_
+
+
+class DataLoaderTest(_PngFolder):                      # dataset.py:115-138: hazy images only
     def __init__(self, rgb_dir, target_transform=None):
-        super().__init__()
-        self.target_transform = target_transform
-        LR_files = sorted(os.listdir(os.path.join(rgb_dir)))
-        self.LR_filenames = [os.path.join(rgb_dir, x) for x in LR_files if is_png_file(x)]
-        self.tar_size = len(self.LR_filenames)
-
-    def __len__(self):
-        return self.tar_size
+        super().__init__(rgb_dir, False, target_transform)
 
     def __getitem__(self, index):
-        tar_index = index % self.tar_size
-        LR = torch.from_numpy(np.float32(load_img(self.LR_filenames[tar_index]))).permute(2, 0, 1)
-        return LR, os.path.split(self.LR_filenames[tar_index])[-1]
+        f = self.noisy_filenames[index % self.tar_size]
+        return _chw(f), os.path.basename(f)
 
 
 class PatchStoreHBM:
