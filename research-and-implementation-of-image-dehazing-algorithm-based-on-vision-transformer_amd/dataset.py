@@ -69,6 +69,9 @@ class _PngFolder(Dataset):
 
 
 class DataLoaderVal(_PngFolder):                       # dataset.py:82-110: whole image pairs
+    def __init__(self, rgb_dir, target_transform=None):
+        super().__init__(rgb_dir, True, target_transform)
+
     def __getitem__(self, index):
         return self._pair(index)
 
