@@ -302,6 +302,25 @@ int dhz_thin_conv3x3_dgrad_blocked(const float* gb, const float* w, float* dx, i
 int dhz_l1_pair_fwd(const float* a, const float* p, const float* n, float* sums, int64_t count, void* stream);
 int dhz_l1_pair_bwd(const float* a, const float* p, const float* n, const float* g, float* da, int64_t count, void* stream);
 
+/* K10b the same feature stack for BASELINE config 4 (bf16 feature maps in NHWC / token layout [N, H, W, C]; what torch.autocast
+ *      makes of My_CR.py:65-72's convolutions), csrc/vgg_bf16.hip:
+ *      dhz_vgg_prepack_bf16: filter w[K, C, 3, 3] fp32 -> bf16 [K][9 C] tap-major (transpose = 0) or the backward-data filter
+ *        [C][9 K] with the taps rotated by 180 degrees (transpose = 1).
+ *      dhz_vgg_conv3x3_bf16: y[N, H, W, Cout] = conv3x3(x[N, H, W, Cin], pad 1) as an implicit GEMM on the bf16 matrix pipe
+ *        (fp32 accumulation); forward y = max(. + bias, 0 if relu); backward-data (bias NULL, relu 0, wp the transposed pack)
+ *        y = act > 0 ? . + addend : 0 with act (may be NULL) the saved post-ReLU map at the OUTPUT positions and addend (may be
+ *        NULL; needs act) the gradient reaching that map from its loss tap.  Cin a power of two >= 64, Cout % 64 == 0.
+ *      dhz_maxpool2x2_nhwc_bf16_fwd / _bwd: 2x2 / stride-2 max pooling; the backward routes gy to the first maximum of each
+ *        window of the saved post-ReLU map `act` and applies act > 0.  C % 8 == 0.
+ *      dhz_l1_pair_fwd_bf16 / _bwd_bf16: K11b on bf16 maps (fp32 sums; da in bf16).  count % 8 == 0. */
+int dhz_vgg_prepack_bf16(const float* w, void* out, int K, int C, int transpose, void* stream);
+int dhz_vgg_conv3x3_bf16(const void* x, const void* wp, const float* bias, int relu, const void* act, const void* addend, void* y,
+                         int N, int H, int W, int Cin, int Cout, void* stream);
+int dhz_maxpool2x2_nhwc_bf16_fwd(const void* x, void* y, int N, int H, int W, int C, void* stream);
+int dhz_maxpool2x2_nhwc_bf16_bwd(const void* gy, const void* act, void* gx, int N, int H, int W, int C, void* stream);
+int dhz_l1_pair_fwd_bf16(const void* a, const void* p, const void* n, float* sums, int64_t count, void* stream);
+int dhz_l1_pair_bwd_bf16(const void* a, const void* p, const void* n, const float* g, void* da, int64_t count, void* stream);
+
 /* K11c the scalar side of ContrastLoss.forward (My_CR.py:104-123) over k feature taps: d[i] = (ap_i, an_i) = sums[i] * inv_cnt[i];
  *      out = (sum_i w_i ap_i / (an_i + 1e-7)  [ablation: sum_i w_i ap_i],  sum_i ap_i,  sum_i an_i).  Backward: g[i] = gradient of
  *      (out . (g_loss, g_ap, g_an)) w.r.t. (ap_i, an_i); a NULL upstream gradient counts as zero.  Replaces the [k]-vector

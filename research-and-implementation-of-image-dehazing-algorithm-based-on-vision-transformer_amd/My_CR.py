@@ -78,23 +78,29 @@ class Vgg19(nn.Module):
                 p.requires_grad = False
         self._frozen = not requires_grad
         self._engine = None
+        self.feature_dtype = torch.float32
 
     def engine_for(self, X):
-        """The Winograd-MFMA feature engine (dehaze_hip/vgg.py) when it applies: frozen filters, fp32 on the GPU, maps
-        that stay multiples of 16 down to relu4_4 (H, W multiples of 128); None -> library convolutions."""
+        """The MFMA feature engine (dehaze_hip/vgg.py) when it applies: frozen filters, an fp32 image on the GPU, maps that stay
+        multiples of 16 down to relu4_4 (H, W multiples of 128); None -> library convolutions.  `feature_dtype` selects the
+        Winograd fp32 engine (default) or, for BASELINE config 4, the implicit-GEMM engine with bf16 feature maps - what
+        torch.autocast makes of these convolutions in the reference."""
         if not (self._frozen and X.is_cuda and X.dtype == torch.float32 and X.dim() == 4 and X.shape[1] == 3
                 and X.shape[2] % 128 == 0 and X.shape[3] % 128 == 0 and self.slice1[0].weight.device == X.device):
             return None                      # (filters on another device: let the library path raise torch's own error)
-        if self._engine is None:
-            from dehaze_hip.vgg import VggEngine
-            self._engine = VggEngine([m for m in self.modules() if isinstance(m, nn.Conv2d)])
-        return self._engine
+        bf16 = self.feature_dtype == torch.bfloat16
+        if self._engine is None or self._engine[0] != bf16:
+            from dehaze_hip.vgg import VggEngine, VggEngineBF16
+            self._engine = (bf16, (VggEngineBF16 if bf16 else VggEngine)([m for m in self.modules() if isinstance(m, nn.Conv2d)]))
+        return self._engine[1]
 
     def forward(self, X):
         eng = self.engine_for(X)
         if eng is not None:
             from dehaze_hip import vgg as _v
             taps = _v.vgg_taps(eng, X)
+            if self.feature_dtype == torch.bfloat16:
+                return [t.permute(0, 3, 1, 2) for t in taps]          # NHWC bf16 maps seen as NCHW (autocast's output dtype)
             return [_v.to_plain_tap(t) for t in taps]
         h1 = self.slice1(X)
         h2 = self.slice2(h1)

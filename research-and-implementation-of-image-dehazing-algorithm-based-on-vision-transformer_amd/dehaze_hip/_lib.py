@@ -63,6 +63,12 @@ SIGNATURES = {
     "dhz_thin_conv3x3_fwd_dt": [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_p],
     "dhz_thin_conv3x3_dgrad_dt": [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_p],
     "dhz_thin_conv3x3_wgrad_dt": [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_p],
+    "dhz_vgg_prepack_bf16": [c_f, c_f, c_i, c_i, c_i, c_p],
+    "dhz_vgg_conv3x3_bf16": [c_f, c_f, c_f, c_i, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_p],
+    "dhz_maxpool2x2_nhwc_bf16_fwd": [c_f, c_f, c_i, c_i, c_i, c_i, c_p],
+    "dhz_maxpool2x2_nhwc_bf16_bwd": [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_p],
+    "dhz_l1_pair_fwd_bf16": [c_f, c_f, c_f, c_f, c_l, c_p],
+    "dhz_l1_pair_bwd_bf16": [c_f, c_f, c_f, c_f, c_f, c_l, c_p],
     "dhz_im2col_k4s2_bf16": [c_f, c_f, c_i, c_i, c_i, c_i, c_p],
     "dhz_col2im_k4s2_bf16": [c_f, c_f, c_i, c_i, c_i, c_i, c_p],
     "dhz_linear_fwd_bf16": [c_f, c_i, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_p],

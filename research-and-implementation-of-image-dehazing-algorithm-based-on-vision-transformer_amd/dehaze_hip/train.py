@@ -309,6 +309,9 @@ def train_step(model, char_loss, cr_loss, optimizer, reducer, input_, target, w_
         else:
             ops.refresh_bf16_shadow()          # one cast launch: parameters written outside step() (a loaded checkpoint, a
                                                # landscape probe) must reach the bf16 GEMMs too
+    if cr_loss is not None and hasattr(cr_loss, "vgg") and hasattr(cr_loss.vgg, "feature_dtype"):
+        # config 4: the frozen feature stack follows the model's activation type (autocast covers the loss in the reference)
+        cr_loss.vgg.feature_dtype = getattr(model, "act_dtype", None) or torch.float32
     standalone = reducer is not None and reducer.opt is None          # torch optimizer + stand-alone reducer (--optimizer adam)
     if standalone:
         reducer.zero_grad()

@@ -202,9 +202,153 @@ class _VggTaps(Function):
         return None, gx
 
 
+# ------------------------------------------------------------------------------------------------ bf16 feature maps
+class VggEngineBF16:
+    """The same stack for BASELINE config 4: feature maps in bf16, NHWC ([N, H, W, C]), every 64+-channel convolution an implicit
+    GEMM on the bf16 matrix pipe (csrc/vgg_bf16.hip), conv 0 on the input-projection kernel (3 -> 64, bias + ReLU, bf16 tokens out)
+    and its backward-data on the output-projection kernel (64 -> 3 from bf16 tokens) with the rotated filter.  The tap features
+    leave in NHWC - the L1 means do not care about element order as long as a / p / n agree."""
+
+    dtype = torch.bfloat16
+
+    def __init__(self, convs):
+        self.convs = convs
+        self._packed = {}
+
+    def packed(self, i, device):
+        wt = self.convs[i].weight
+        key = (i, str(device), wt.data_ptr(), wt._version)
+        hit = self._packed.get(i)
+        if hit is None or hit[0] != key:
+            w = wt.detach().float().contiguous()
+            K, C = w.shape[0], w.shape[1]
+            if i == 0:
+                # backward-data of conv 0 as a thin 64 -> 3 convolution: filter [3][64][3][3], taps rotated
+                hit = (key, w, w.flip(2, 3).transpose(0, 1).contiguous())
+            else:
+                wf = torch.empty(K * 9 * C, device=device, dtype=torch.bfloat16)
+                wb = torch.empty(K * 9 * C, device=device, dtype=torch.bfloat16)
+                _lib.call("dhz_vgg_prepack_bf16", _p(w), _p(wf), K, C, 0, _stream())
+                _lib.call("dhz_vgg_prepack_bf16", _p(w), _p(wb), K, C, 1, _stream())
+                hit = (key, wf, wb)
+            self._packed[i] = hit
+        return hit[1], hit[2]
+
+    @staticmethod
+    def _timing_begin():
+        timing = ops.KERNEL_TIMING.get("dhz_vgg_conv3x3_bf16") if ops.KERNEL_TIMING is not None else None
+        if timing is None:
+            return None
+        e0 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        return timing, e0
+
+    def conv(self, i, x):
+        N, H, W, C = x.shape
+        K = CONVS[i][1]
+        wf, _ = self.packed(i, x.device)
+        y = torch.empty((N, H, W, K), device=x.device, dtype=torch.bfloat16)
+        ev = self._timing_begin()
+        _lib.call("dhz_vgg_conv3x3_bf16", _p(x), _p(wf), _p(self.convs[i].bias), 1, None, None, _p(y), N, H, W, C, K, _stream())
+        _timing_end(ev, N, H, W, C, K)
+        return y
+
+    def conv_dgrad(self, i, g, below_act=None, addend=None):
+        """as VggEngine.conv_dgrad, on NHWC bf16 maps"""
+        g = g.contiguous()                     # (a tap gradient may arrive as a permuted view of an NCHW tensor)
+        N, H, W, K = g.shape
+        C = CONVS[i][0]
+        _, wb = self.packed(i, g.device)
+        dx = torch.empty((N, H, W, C), device=g.device, dtype=torch.bfloat16)
+        ev = self._timing_begin()
+        _lib.call("dhz_vgg_conv3x3_bf16", _p(g), _p(wb), None, 0, _p(below_act) if below_act is not None else None,
+                  _p(addend.contiguous()) if addend is not None else None, _p(dx), N, H, W, K, C, _stream())
+        _timing_end(ev, N, H, W, K, C)
+        return dx
+
+    @staticmethod
+    def pool_fwd(x):
+        N, H, W, C = x.shape
+        y = torch.empty((N, H // 2, W // 2, C), device=x.device, dtype=torch.bfloat16)
+        _lib.call("dhz_maxpool2x2_nhwc_bf16_fwd", _p(x), _p(y), N, H, W, C, _stream())
+        return y
+
+    @staticmethod
+    def pool_bwd_relu(g, act):
+        N, H, W, C = act.shape
+        gx = torch.empty_like(act)
+        _lib.call("dhz_maxpool2x2_nhwc_bf16_bwd", _p(g.contiguous()), _p(act), _p(gx), N, H, W, C, _stream())
+        return gx
+
+    def forward_taps(self, x, save=None):
+        """x: [N,3,H,W] NCHW fp32.  Returns the 5 tap features [N,H,W,C] bf16."""
+        c0 = self.convs[0]
+        xc = x.contiguous().float()
+        N, _, H, W = xc.shape
+        w0, _ = self.packed(0, x.device)
+        cur = torch.empty((N, H, W, 64), device=x.device, dtype=torch.bfloat16)
+        # LeakyReLU with slope 0 = the ReLU behind conv 0
+        _lib.call("dhz_input_proj_fwd_dt", _p(xc), _p(w0), _p(c0.bias), _p(cur), N, H, W, 64, 0.0, 1, _stream())
+        acts = {0: cur}
+        taps = [cur]
+        for i in range(1, 13):
+            cur = self.conv(i, cur)
+            acts[i] = cur
+            if i in TAPS:
+                taps.append(cur)
+            if i in POOL_AFTER:
+                cur = self.pool_fwd(cur)
+        if save is not None:
+            save.update(x=xc, acts=acts)
+        return taps
+
+    def backward_taps(self, saved, grads):
+        """gradient w.r.t. the image from the gradients of the five taps (None where a tap received none)"""
+        acts = saved["acts"]
+        g1, g2, g3, g4, g5 = grads
+        tap_grad = {0: g1, 2: g2, 4: g3, 8: g4}
+        G = g5 * (acts[12] > 0) if g5 is not None else None
+        for i in range(12, 0, -1):
+            below = i - 1
+            tg = tap_grad.get(below)
+            if G is None:
+                if tg is not None:
+                    G = tg * (acts[below] > 0)
+                continue
+            if below in POOL_AFTER:
+                G = self.pool_bwd_relu(self.conv_dgrad(i, G), acts[below])
+            else:
+                G = self.conv_dgrad(i, G, below_act=acts[below], addend=tg)
+        if G is None:
+            return None
+        x0 = saved["x"]
+        N, _, H, W = x0.shape
+        _, w0r = self.packed(0, x0.device)
+        gx = torch.empty_like(x0)
+        _lib.call("dhz_thin_conv3x3_fwd_dt", _p(G.contiguous()), _p(w0r), None, _p(gx), N, H, W, 64, 1, _stream())
+        return gx
+
+
+class _VggTapsBF16(Function):
+    @staticmethod
+    def forward(ctx, engine, x):
+        saved = {}
+        with torch.no_grad():
+            taps = engine.forward_taps(x, save=saved)
+        ctx.engine, ctx.saved, ctx.xdtype = engine, saved, x.dtype
+        return tuple(taps)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        with torch.no_grad():
+            gx = ctx.engine.backward_taps(ctx.saved, grads)
+        ctx.saved = None
+        return None, (gx.to(ctx.xdtype) if gx is not None else None)
+
+
 def vgg_taps(engine, x):
     if torch.is_grad_enabled() and x.requires_grad:
-        return list(_VggTaps.apply(engine, x))
+        return list((_VggTapsBF16 if isinstance(engine, VggEngineBF16) else _VggTaps).apply(engine, x))
     with torch.no_grad():
         return engine.forward_taps(x)
 
@@ -224,6 +368,11 @@ def to_plain_tap(t):
     return _ToPlain.apply(t) if t.dim() == 5 else t
 
 
+def _sfx(t):
+    """entry-point suffix for the storage type of a feature map (the fp32 and the bf16 L1 kernels)"""
+    return "_bf16" if t.dtype == torch.bfloat16 else ""
+
+
 class _L1Pair(Function):
     """(mean|a - p|, mean|a - n|) of one feature tap in one pass; gradient w.r.t. a only (p, n carry none, My_CR.py:102)."""
 
@@ -232,7 +381,7 @@ class _L1Pair(Function):
         a, p = a.contiguous(), p.contiguous()
         n = n.contiguous() if n is not None else None
         sums = torch.zeros(2, device=a.device, dtype=torch.float32)
-        _lib.call("dhz_l1_pair_fwd", _p(a), _p(p), _p(n) if n is not None else None, _p(sums), a.numel(), _stream())
+        _lib.call("dhz_l1_pair_fwd" + _sfx(a), _p(a), _p(p), _p(n) if n is not None else None, _p(sums), a.numel(), _stream())
         ctx.save_for_backward(a, p, n) if n is not None else ctx.save_for_backward(a, p)
         ctx.has_n = n is not None
         return sums / a.numel()
@@ -243,7 +392,8 @@ class _L1Pair(Function):
         a, p = saved[0], saved[1]
         n = saved[2] if ctx.has_n else None
         da = torch.empty_like(a)
-        _lib.call("dhz_l1_pair_bwd", _p(a), _p(p), _p(n) if n is not None else None, _p(g.contiguous()), _p(da), a.numel(), _stream())
+        _lib.call("dhz_l1_pair_bwd" + _sfx(a), _p(a), _p(p), _p(n) if n is not None else None, _p(g.contiguous()), _p(da),
+                  a.numel(), _stream())
         return da, None, None
 
 
@@ -276,7 +426,7 @@ class _ContrastTaps(Function):
         for i in range(k):
             p = feats[k + i][:B].contiguous()
             n = None if ablation else feats[k + i][B:].contiguous()
-            _lib.call("dhz_l1_pair_fwd", _p(a[i]), _p(p), _p(n) if n is not None else None, sums.data_ptr() + 8 * i,
+            _lib.call("dhz_l1_pair_fwd" + _sfx(a[i]), _p(a[i]), _p(p), _p(n) if n is not None else None, sums.data_ptr() + 8 * i,
                       a[i].numel(), _stream())
             ps.append(p)
             ns.append(n)
@@ -305,7 +455,7 @@ class _ContrastTaps(Function):
         das = []
         for i in range(k):
             da = torch.empty_like(a[i])
-            _lib.call("dhz_l1_pair_bwd", _p(a[i]), _p(ps[i]), _p(ns[i]) if ns[i] is not None else None, g.data_ptr() + 8 * i,
+            _lib.call("dhz_l1_pair_bwd" + _sfx(a[i]), _p(a[i]), _p(ps[i]), _p(ns[i]) if ns[i] is not None else None, g.data_ptr() + 8 * i,
                       _p(da), a[i].numel(), _stream())
             das.append(da)
         return (None, None, None) + tuple(das) + (None,) * k
