@@ -151,12 +151,15 @@ __global__ __launch_bounds__(256) void ln_partition_bwd_kernel(const T* __restri
         }
     };
     const int stride = nwaves * tpw;
-    for (int base = wave_global * tpw; base < ntok; base += 2 * stride) {
-        Group A, Bg;
-        load(base, A);
-        load(base + stride, Bg);          // past the end: ok = false, nothing loaded or stored
-        compute(A);
-        compute(Bg);
+    // (bf16 storage halves the bytes per load: four groups per trip keep the same bytes in flight; VPL <= 2 there keeps the
+    // register budget)
+    constexpr int NG = (sizeof(T) == 2 && VPL <= 2) ? 4 : 2;
+    for (int base = wave_global * tpw; base < ntok; base += NG * stride) {
+        Group G[NG];
+#pragma unroll
+        for (int i = 0; i < NG; ++i) load(base + i * stride, G[i]);          // past the end: ok = false, nothing loaded or stored
+#pragma unroll
+        for (int i = 0; i < NG; ++i) compute(G[i]);
     }
     // reduce dgamma/dbeta: lanes with equal li inside the wave, then waves through LDS, then one atomic per channel
 #pragma unroll

@@ -283,7 +283,7 @@ class LeWinTransformerBlock(nn.Module):
             attn_mask = attn_mask + sm if attn_mask is not None else sm
         idx, self._staged_idx = self._staged_idx, None
 
-        if self.attn.variant == "probsparse" and self.win_size == 8 and C == 32 * self.num_heads and mask is None:
+        if self.attn.variant == "probsparse" and self.win_size == 8 and C in (32 * self.num_heads, 64 * self.num_heads) and mask is None:
             # attention branch as ONE autograd node: the fused kernel (LN, roll, partition, QKV, ProbSparse core,
             # out-proj, residual) where it wins, the kernel chain elsewhere; hand-sequenced backward in both cases
             import options
