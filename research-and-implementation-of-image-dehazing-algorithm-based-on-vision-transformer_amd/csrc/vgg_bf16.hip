@@ -36,7 +36,7 @@ __device__ __forceinline__ f32x4 unpack4(uint2 r) {
 
 // persistent workgroups over [BM = 32 WM pixels] x [BN = 32 WN output channels] tiles; 4 waves as 2 x 2, wave tile 16 WM x 16 WN
 template <int WM, int WN>
-__global__ __launch_bounds__(256) void conv3_bf16_kernel(const uint16_t* __restrict__ X, const uint16_t* __restrict__ Wp,
+__global__ __launch_bounds__(256, 2) void conv3_bf16_kernel(const uint16_t* __restrict__ X, const uint16_t* __restrict__ Wp,
                                                          const float* __restrict__ bias, int relu,
                                                          const uint16_t* __restrict__ act, const uint16_t* __restrict__ addend,
                                                          uint16_t* __restrict__ Y, int M, int H, int W, int lgC, int Cout,
@@ -64,7 +64,12 @@ __global__ __launch_bounds__(256) void conv3_bf16_kernel(const uint16_t* __restr
 #pragma unroll
         for (int b = 0; b < WN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    u32x4 ra[NA], rb[NB];
+    // Operand staging runs TWO stages ahead of the matrix pipe through two register sets: stage s + 2 is requested at the top of
+    // stage s and written to LDS at the end of stage s + 1, so a request has two stages of MFMAs (of both resident workgroups)
+    // to come back from L2 / HBM - one stage of look-ahead left the pipe waiting on every stage.  The request stream
+    // is its own cursor over (tile, stage) and runs across tile boundaries; past the end of this workgroup's tiles it keeps
+    // re-requesting its last position (unconditional loads keep the compiler's vmcnt accounting exact).
+    u32x4 ra[2][NA], rb[2][NB];
     const uint16_t* pa[NA];
     int pyx[NA];                                                 // (row << 16) | column of the pixel whose chunk this thread stages
     const uint16_t* pb[NB];
@@ -85,7 +90,7 @@ __global__ __launch_bounds__(256) void conv3_bf16_kernel(const uint16_t* __restr
             pb[i] = Wp + (size_t)(n0 + (e >> 3)) * K + 8 * (e & 7);
         }
     };
-    auto gload = [&](int k0) {
+    auto gload = [&](int k0, u32x4 (&A)[NA], u32x4 (&B)[NB]) {
         const int tap = k0 >> lgC, c0 = k0 & (Cin - 1);
         const int dy = ((tap * 11) >> 5) - 1, dx = tap - 3 * (dy + 1) - 1;
         const int off = ((dy * W + dx) << lgC) + c0;             // elements; negative for the taps above / left
@@ -94,89 +99,99 @@ __global__ __launch_bounds__(256) void conv3_bf16_kernel(const uint16_t* __restr
             const int py = pyx[i] >> 16, px = pyx[i] & 0xffff;
             const bool ok = (unsigned)(py + dy) < (unsigned)H && (unsigned)(px + dx) < (unsigned)W;
             const u32x4 v = *reinterpret_cast<const u32x4*>(ok ? pa[i] + off : pa[i]);
-            ra[i] = ok ? v : u32x4{0u, 0u, 0u, 0u};
+            A[i] = ok ? v : u32x4{0u, 0u, 0u, 0u};
         }
 #pragma unroll
-        for (int i = 0; i < NB; ++i) rb[i] = *reinterpret_cast<const u32x4*>(pb[i] + k0);
+        for (int i = 0; i < NB; ++i) B[i] = *reinterpret_cast<const u32x4*>(pb[i] + k0);
     };
-    auto swrite = [&](int buf) {
+    auto swrite = [&](int buf, const u32x4 (&A)[NA], const u32x4 (&B)[NB]) {
         unsigned char* As = smem + buf * STAGE;
         unsigned char* Bs = As + A_BYTES;
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             const int e = t + 256 * i;
-            *reinterpret_cast<u32x4*>(As + off_row(e >> 3, e & 7)) = ra[i];
+            *reinterpret_cast<u32x4*>(As + off_row(e >> 3, e & 7)) = A[i];
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             const int e = t + 256 * i;
-            *reinterpret_cast<u32x4*>(Bs + off_row(e >> 3, e & 7)) = rb[i];
+            *reinterpret_cast<u32x4*>(Bs + off_row(e >> 3, e & 7)) = B[i];
         }
     };
 
-    int ti = 0, tile = tile_of(0);
+    int tile = tile_of(0);
     if (tile < 0) return;
+    const int mytiles = (ntiles - (int)blockIdx.x + grid - 1) / grid;
+    const int total = mytiles * nst;                             // stages of this workgroup over all its tiles
+    int l_ti = 0, l_st = 0;                                      // request cursor
     set_tile(tile);
-    gload(0);
-    swrite(0);
+    auto request = [&](u32x4 (&A)[NA], u32x4 (&B)[NB]) {
+        gload(l_st * BK, A, B);
+        if (++l_st == nst) {
+            const int nt = tile_of(l_ti + 1);
+            if (nt >= 0) { ++l_ti; l_st = 0; set_tile(nt); }
+            else l_st = nst - 1;                                 // end of the stream: stay on a valid position
+        }
+    };
+    request(ra[0], rb[0]);
+    request(ra[1], rb[1]);
+    swrite(0, ra[0], rb[0]);
     __syncthreads();
     const int sw = (i16 >> 1) & 7;
-    int buf = 0;
-    while (true) {
-        const int ntile = tile_of(ti + 1);
-        const int tn = tile % tiles_n, tm = tile / tiles_n;
-        f32x4 bv[WN];                                            // bias of this tile's channels in the epilogue's lane layout
+    int buf = 0, st = 0, ti = 0;
+    // one stage: request stage gs + 2 into the set stage gs came from, multiply stage gs, stage gs + 1 into the other LDS buffer
+    auto stage = [&](int gs, u32x4 (&Aq)[NA], u32x4 (&Bq)[NB], const u32x4 (&Aw)[NA], const u32x4 (&Bw)[NB]) {
+        request(Aq, Bq);
+        const unsigned char* As = smem + buf * STAGE;
+        const unsigned char* Bs = As + A_BYTES;
 #pragma unroll
-        for (int b = 0; b < WN; ++b)
+        for (int s = 0; s < 2; ++s) {
+            s16x8 af[WM], bf[WN];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) bv[b][j] = bias ? bias[tn * BN + wn * WN * 16 + 4 * g + 16 * b + j] : 0.f;
-        for (int st = 0; st < nst; ++st) {
-            const bool last = st + 1 == nst;
-            const bool more = !last || ntile >= 0;
-            if (!last) gload((st + 1) * BK);
-            else if (ntile >= 0) { set_tile(ntile); gload(0); }
-            const unsigned char* As = smem + buf * STAGE;
-            const unsigned char* Bs = As + A_BYTES;
+            for (int a = 0; a < WM; ++a)
+                af[a] = *reinterpret_cast<const s16x8*>(As + (wm * WM * 16 + a * 16 + i16) * 128 + 16 * ((4 * s + g) ^ sw));
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                s16x8 af[WM], bf[WN];
+            for (int b = 0; b < WN; ++b)
+                bf[b] = *reinterpret_cast<const s16x8*>(Bs + ((wn * WN + b) * 16 + i16) * 128 + 16 * ((4 * s + g) ^ sw));
 #pragma unroll
-                for (int a = 0; a < WM; ++a)
-                    af[a] = *reinterpret_cast<const s16x8*>(As + (wm * WM * 16 + a * 16 + i16) * 128 + 16 * ((4 * s + g) ^ sw));
+            for (int a = 0; a < WM; ++a)
 #pragma unroll
-                for (int b = 0; b < WN; ++b)
-                    bf[b] = *reinterpret_cast<const s16x8*>(Bs + ((wn * WN + b) * 16 + i16) * 128 + 16 * ((4 * s + g) ^ sw));
-#pragma unroll
-                for (int a = 0; a < WM; ++a)
-#pragma unroll
-                    for (int b = 0; b < WN; ++b) acc[a][b] = mfma_bf16(bf[b], af[a], acc[a][b]);     // D = C^T block (epilogue)
-            }
-            if (more) {
-                swrite(buf ^ 1);
-                __syncthreads();
-                buf ^= 1;
-            }
+                for (int b = 0; b < WN; ++b) acc[a][b] = mfma_bf16(bf[b], af[a], acc[a][b]);     // D = C^T block (epilogue)
         }
+        if (gs + 1 < total) {
+            swrite(buf ^ 1, Aw, Bw);
+            __syncthreads();
+            buf ^= 1;
+        }
+        if (++st < nst) return;
+        st = 0;
         {   // acc[a][b][j] = C[pixel 16 a + i16][channel 16 b + 4 g + j]: four consecutive channels of one pixel per lane
+            const int tn = tile % tiles_n, tm = tile / tiles_n;
             const int m0 = tm * BM + wm * WM * 16 + i16, n0 = tn * BN + wn * WN * 16 + 4 * g;
             const size_t o0 = (size_t)m0 * Cout + n0;
+            f32x4 bv[WN];                                        // bias in the lane layout (loaded here: 16 registers less held
+#pragma unroll                                                   // through the stages; one wait per tile of >= 9 stages)
+            for (int b = 0; b < WN; ++b)
+                bv[b] = bias ? *reinterpret_cast<const f32x4*>(bias + n0 + 16 * b) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int a = 0; a < WM; ++a) {
-                if (m0 + 16 * a >= M) continue;
+                if (m0 + 16 * a < M) {
 #pragma unroll
-                for (int b = 0; b < WN; ++b) {
-                    const size_t o = o0 + (size_t)(16 * a) * Cout + 16 * b;
-                    f32x4 v = acc[a][b] + bv[b];
-                    if (relu) v = f32x4{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
-                    if (act) {
-                        if (addend) v += unpack4(*reinterpret_cast<const uint2*>(addend + o));
-                        const f32x4 m = unpack4(*reinterpret_cast<const uint2*>(act + o));
-                        v = f32x4{m[0] > 0.f ? v[0] : 0.f, m[1] > 0.f ? v[1] : 0.f, m[2] > 0.f ? v[2] : 0.f, m[3] > 0.f ? v[3] : 0.f};
+                    for (int b = 0; b < WN; ++b) {
+                        const size_t o = o0 + (size_t)(16 * a) * Cout + 16 * b;
+                        f32x4 v = acc[a][b] + bv[b];
+                        if (relu) v = f32x4{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
+                        if (act) {
+                            if (addend) v += unpack4(*reinterpret_cast<const uint2*>(addend + o));
+                            const f32x4 m = unpack4(*reinterpret_cast<const uint2*>(act + o));
+                            v = f32x4{m[0] > 0.f ? v[0] : 0.f, m[1] > 0.f ? v[1] : 0.f, m[2] > 0.f ? v[2] : 0.f,
+                                      m[3] > 0.f ? v[3] : 0.f};
+                        }
+                        uint2 r;
+                        r.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+                        r.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+                        *reinterpret_cast<uint2*>(Y + o) = r;
                     }
-                    uint2 r;
-                    r.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
-                    r.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
-                    *reinterpret_cast<uint2*>(Y + o) = r;
                 }
             }
 #pragma unroll
@@ -184,9 +199,14 @@ __global__ __launch_bounds__(256) void conv3_bf16_kernel(const uint16_t* __restr
 #pragma unroll
                 for (int b = 0; b < WN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        if (ntile < 0) break;
-        tile = ntile;
         ++ti;
+        const int nt = tile_of(ti);
+        if (nt >= 0) tile = nt;
+    };
+    for (int gs = 0; gs < total; gs += 2) {
+        stage(gs, ra[0], rb[0], ra[1], rb[1]);
+        if (gs + 1 >= total) break;
+        stage(gs + 1, ra[1], rb[1], ra[0], rb[0]);
     }
 }
 
