@@ -3,16 +3,19 @@
 //
 // The library serves this "thin" convolution (3 output channels) with implicit-GEMM kernels built for wide outputs:
 // 235 us forward and 340 us backward at B = 32, 128 x 128, C = 64 - 0.6 TB/s on a problem whose whole traffic is the
-// 134 MB token tensor.  With 3 output channels there is nothing for the matrix pipe to do (N = 3 pads to 16), so these
-// are VALU kernels shaped by the data movement:
-//   forward : one workgroup = 8 x 16 output pixels; the 10 x 18 halo tile of tokens goes to LDS once (row stride C + 4:
-//             a lane <-> pixel b128 read is conflict-free); lane <-> pixel, wave pair <-> half of the channels, the
-//             27*C weights are broadcast reads of an LDS copy in (channel quad, tap, output) order; the two channel
-//             halves meet in LDS; 3 coalesced row stores.
-//   dgrad   : lane <-> channel (the token row is the contiguous axis of the output), the 27 weights of the lane's channel
+// 134 MB token tensor.  Round 1-2 ran it as VALU kernels (lane <-> pixel, weights as LDS broadcasts): 128 / 150 us, bound by
+// the four LDS reads per 12 FMAs.  Round 3: the matrix pipe after all, by splitting the 3 x 3 window off the contraction:
+//   forward : Z[q][(o, tap)] = sum_c x[q][c] w[o][c][tap] is a plain GEMM over the 10 x 18 HALO positions q of an 8 x 16
+//             output tile (K = C contiguous in the token row, N = 27 -> 32: two 16-column blocks of v_mfma_f32_16x16x4_f32),
+//             and y[o][p] = sum_tap Z[p + off(tap)][(o, tap)] is a 9-term gather of that 180 x 32 matrix from LDS.  1.4 x
+//             the FLOPs of the direct form (halo positions), all of them on the matrix pipe.
+//   wgrad   : dW^T[c][(o, tap)] = sum_q x[q][c] G[q][(o, tap)] with G[q][(o, tap)] = dy[o][q - off(tap)] (zero outside the
+//             tile's own output pixels) - a GEMM with the halo positions as the contraction (K = 180 = 45 MFMA steps); G is
+//             built in LDS from the 3 x 128 dy values of the tile.  Persistent workgroups, accumulators in registers over all
+//             tiles, one atomic per (o, c, tap) per workgroup at the end.
+//   dgrad   : (VALU) lane <-> channel (the token row is the contiguous axis of the output), the 27 weights of the lane's channel
 //             live in registers, the 3-channel gradient tile is read as LDS broadcasts.
-//   wgrad   : persistent workgroups, lane <-> channel, 27 accumulators per lane over all pixels of the workgroup's tiles,
-//             the token halo tile in LDS, dy broadcast; one atomic per (output, channel, tap) per workgroup at the end.
+// Channels are processed in chunks of 64 (C = 128: two passes over the tile) so two workgroups fit a CU's LDS.
 #include "common.h"
 
 namespace {
@@ -21,79 +24,135 @@ constexpr int TW = 16, TH = 8;                 // output pixels per workgroup
 constexpr int HW_ = TW + 2, HH_ = TH + 2;      // halo tile
 constexpr int NPOS = HH_ * HW_;                // 180
 
-template <int C>
-struct ThinSmem {
-    static constexpr int XS = C + 4;
-    float x[NPOS * XS];                        // token halo tile
-    float w[27 * C];                           // forward: [c/4][tap][o][4]
-    float part[2][3][TH * TW];                 // forward: per channel-half partial sums
+constexpr int CC = 64;                         // channel chunk
+constexpr int XS = CC + 4;                     // row stride of the token halo tile (floats): b128 row reads conflict-free
+constexpr int ZS = 36;                         // row stride of Z (forward)
+constexpr int GS = 33;                         // row stride of G (wgrad)
+constexpr int NRB = (NPOS + 15) / 16;          // 12 row blocks of 16 halo positions (the last one runs 12 rows past the tile)
+
+struct ThinFwdSmem {
+    float x[NPOS * XS];                        // token halo tile of one channel chunk (rows 180 .. 191 of the last block: whatever
+    float z[NRB * 16 * ZS];                    // follows - their Z rows are never read);  Z, and before the MFMAs the weights
+};
+struct ThinWgradSmem {
+    float x[NPOS * XS];
+    float g[NPOS * GS];
+    float dy[3 * TH * TW];
+    float red[4];
 };
 
-// stage the 10 x 18 halo tile (zero outside the image) of a token tensor [B, H*W, C] or (BLOCKED) of a channel-blocked
-// NCHW8c map [B, C/8, H, W, 8] (the layout of the VGG feature engine)
+// stage channels [cb, cb + 64) of the 10 x 18 halo tile (zero outside the image) of a token tensor [B, H*W, C] or (BLOCKED) of a
+// channel-blocked NCHW8c map [B, C/8, H, W, 8] (the layout of the fp32 VGG feature engine)
+// All requests of a thread are issued before the first LDS write (clamped addresses + select instead of a divergent guard): as a
+// loop of (load, write) pairs the tile cost one global round trip per iteration - 12 of them.
 template <int C, bool BLOCKED = false, typename T = float>
-__device__ __forceinline__ void stage_tokens(float* xs, const T* __restrict__ x, int bimg, int ty, int tx, int H, int W) {
-    constexpr int XS = C + 4, C4 = C / 4;
+__device__ __forceinline__ void stage_tokens(float* xs, const T* __restrict__ x, int bimg, int ty, int tx, int H, int W, int cb) {
+    constexpr int C4 = CC / 4;
+    constexpr int NIT = (NPOS * C4 + 255) / 256;
     const int t = threadIdx.x;
     const size_t ib = (size_t)bimg * H * W;
-    for (int e = t; e < NPOS * C4; e += 256) {
+    f32x4 v[NIT];
+    bool ok[NIT];
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+        const int e = min(t + 256 * i, NPOS * C4 - 1);
         const int pos = BLOCKED ? e % NPOS : e / C4, c4 = BLOCKED ? e / NPOS : e % C4;     // consecutive lanes walk the contiguous axis
         const int yy = ty * TH - 1 + pos / HW_, xx = tx * TW - 1 + pos % HW_;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
-            const size_t o = BLOCKED ? (((size_t)bimg * (C / 8) + c4 / 2) * H * W + (size_t)yy * W + xx) * 8 + (c4 & 1) * 4
-                                     : (ib + (size_t)yy * W + xx) * C + c4 * 4;
-            v = ld4v(x + o);
+        ok[i] = yy >= 0 && yy < H && xx >= 0 && xx < W;
+        const int yc = min(max(yy, 0), H - 1), xc = min(max(xx, 0), W - 1);
+        const int c = cb + c4 * 4;
+        const size_t o = BLOCKED ? (((size_t)bimg * (C / 8) + c / 8) * H * W + (size_t)yc * W + xc) * 8 + (c & 7)
+                                 : (ib + (size_t)yc * W + xc) * C + c;
+        v[i] = ld4v(x + o);
+    }
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+        const int e = t + 256 * i;
+        if (e < NPOS * C4) {
+            const int pos = BLOCKED ? e % NPOS : e / C4, c4 = BLOCKED ? e / NPOS : e % C4;
+            *reinterpret_cast<f32x4*>(&xs[pos * XS + c4 * 4]) = ok[i] ? v[i] : f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        *reinterpret_cast<f32x4*>(&xs[pos * XS + c4 * 4]) = v;
     }
 }
 
 // TRANSPOSED: w is a [C, 3, 3, 3] tensor (a 3 -> C convolution's weight) and the kernel computes that layer's
 // backward-data: y[b, o, p] = sum_{c, ky, kx} w[c][o][2 - ky][2 - kx] x[b, c, p + (ky - 1, kx - 1)]
 template <int C, bool BLOCKED, bool TRANSPOSED, typename T = float>
-__global__ __launch_bounds__(256) void thin_conv_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w,
-                                                            const float* __restrict__ bias, float* __restrict__ y, int H,
-                                                            int W, int tiles_x, int tiles_y) {
+__global__ __launch_bounds__(256, 2) void thin_conv_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w,
+                                                               const float* __restrict__ bias, float* __restrict__ y, int H,
+                                                               int W, int tiles_x, int tiles_y) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    ThinSmem<C>& sm = *reinterpret_cast<ThinSmem<C>*>(smem_raw);
-    constexpr int XS = C + 4, CH = C / 2;
-    const int t = threadIdx.x;
+    ThinFwdSmem& sm = *reinterpret_cast<ThinFwdSmem*>(smem_raw);
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int i16 = lane & 15, g = lane >> 4;
     const int tx = blockIdx.x % tiles_x, ty = (blockIdx.x / tiles_x) % tiles_y, bimg = blockIdx.x / (tiles_x * tiles_y);
-    // weights -> LDS in (channel quad, tap, output, channel % 4) order: w[o][c][tap] -> sm.w[((c/4 * 9 + tap) * 3 + o) * 4 + c%4]
-    for (int e = t; e < 27 * C; e += 256) {
-        int o, c, tap;
-        if (TRANSPOSED) { c = e / 27; o = (e / 9) % 3; tap = 8 - e % 9; }      // w[c][o][ky][kx] acts at tap (2-ky, 2-kx)
-        else { o = e / (9 * C); c = (e / 9) % C; tap = e % 9; }
-        sm.w[((c / 4 * 9 + tap) * 3 + o) * 4 + (c & 3)] = w[e];
-    }
-    stage_tokens<C, BLOCKED, T>(sm.x, x, bimg, ty, tx, H, W);
-    __syncthreads();
-    const int half = t >> 7, pix = t & 127;
-    const int py = pix / TW, px = pix % TW;
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
-    const float* xb = sm.x + (py * HW_ + px) * XS + half * CH;
-    const float* wb = sm.w + (half * (CH / 4)) * 9 * 12;
-#pragma unroll 2
-    for (int c4 = 0; c4 < CH / 4; ++c4) {
+    // weights -> LDS as wl[c][n = o * 9 + tap] (32 columns, 27 used) with coalesced reads of w; the slot is Z's
+    float* wl = sm.z;
+    static_assert(C * 32 <= NRB * 16 * ZS, "weight staging must fit the Z slot");
+    {
+        constexpr int NW = (27 * C + 255) / 256;
+        float wv_[NW];
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const f32x4 xv = *reinterpret_cast<const f32x4*>(xb + ((tap / 3) * HW_ + tap % 3) * XS + c4 * 4);
-            const f32x4 w0 = *reinterpret_cast<const f32x4*>(wb + (c4 * 9 + tap) * 12);         // broadcast reads
-            const f32x4 w1 = *reinterpret_cast<const f32x4*>(wb + (c4 * 9 + tap) * 12 + 4);
-            const f32x4 w2 = *reinterpret_cast<const f32x4*>(wb + (c4 * 9 + tap) * 12 + 8);
-            a0 += xv[0] * w0[0] + xv[1] * w0[1] + xv[2] * w0[2] + xv[3] * w0[3];
-            a1 += xv[0] * w1[0] + xv[1] * w1[1] + xv[2] * w1[2] + xv[3] * w1[3];
-            a2 += xv[0] * w2[0] + xv[1] * w2[1] + xv[2] * w2[2] + xv[3] * w2[3];
+        for (int i = 0; i < NW; ++i) wv_[i] = w[min(t + 256 * i, 27 * C - 1)];
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+            const int e = t + 256 * i;
+            if (e < 27 * C) {
+                int o, c, tap;
+                if (TRANSPOSED) { c = e / 27; o = (e / 9) % 3; tap = 8 - e % 9; }      // w[c][o][ky][kx] acts at tap (2-ky, 2-kx)
+                else { o = e / (9 * C); c = (e / 9) % C; tap = e % 9; }
+                wl[c * 32 + o * 9 + tap] = wv_[i];
+            }
         }
     }
-    sm.part[half][0][pix] = a0; sm.part[half][1][pix] = a1; sm.part[half][2][pix] = a2;
+    for (int e = t; e < 5 * C; e += 256) wl[(e / 5) * 32 + 27 + e % 5] = 0.f;
+    // Z^T block = W^T (rows n) . X^T (columns q): the accumulator of lane (q = i16) holds n = 4 g .. 4 g + 3 -> one b128 store
+    // into Z[q][.].  Wave wv owns row blocks 3 wv .. 3 wv + 2 (halo positions) x both column blocks.
+    f32x4 acc[3][2];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) acc[r][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int cb = 0; cb < C; cb += CC) {
+        if (cb) __syncthreads();                                              // the previous chunk's tile is still being read
+        stage_tokens<C, BLOCKED, T>(sm.x, x, bimg, ty, tx, H, W, cb);
+        __syncthreads();
+        // contraction order inside a 16-channel group: MFMA step j of group s4 takes channel 16 s4 + 4 g + j from lane group g,
+        // so a lane's four steps read ONE b128 of its token row (any order of the contraction is as good as another)
+#pragma unroll
+        for (int s4 = 0; s4 < CC / 16; ++s4) {
+            float wr[4][2];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb) wr[j][nb] = wl[(cb + 16 * s4 + 4 * g + j) * 32 + 16 * nb + i16];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                const f32x4 xv = *reinterpret_cast<const f32x4*>(&sm.x[(16 * (3 * wv + r) + i16) * XS + 16 * s4 + 4 * g]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int nb = 0; nb < 2; ++nb)
+                        acc[r][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[j][nb], xv[j], acc[r][nb], 0, 0, 0);
+            }
+        }
+    }
+    __syncthreads();                                                          // weights (in Z's slot) no longer needed
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+            *reinterpret_cast<f32x4*>(&sm.z[(16 * (3 * wv + r) + i16) * ZS + 16 * nb + 4 * g]) = acc[r][nb];
     __syncthreads();
     for (int e = t; e < 3 * TH * TW; e += 256) {
         const int o = e / (TH * TW), p = e % (TH * TW);
-        const int yy = ty * TH + p / TW, xx = tx * TW + p % TW;
-        if (yy < H && xx < W)
-            y[(((size_t)bimg * 3 + o) * H + yy) * W + xx] = sm.part[0][o][p] + sm.part[1][o][p] + (bias ? bias[o] : 0.f);
+        const int py = p / TW, px = p % TW;
+        const int yy = ty * TH + py, xx = tx * TW + px;
+        float a = bias ? bias[o] : 0.f;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) a += sm.z[((py + tap / 3) * HW_ + px + tap % 3) * ZS + o * 9 + tap];
+        if (yy < H && xx < W) y[(((size_t)bimg * 3 + o) * H + yy) * W + xx] = a;
     }
 }
 
@@ -146,60 +205,87 @@ __global__ __launch_bounds__(256) void thin_conv_dgrad_kernel(const float* __res
 
 // dw[o][c][ky][kx] += sum_p dy[o][p] x[p + (ky - 1, kx - 1)][c] ; db[o] += sum_p dy[o][p]
 template <int C, typename T = float>
-__global__ __launch_bounds__(256) void thin_conv_wgrad_kernel(const float* __restrict__ dy, const T* __restrict__ x,
-                                                              float* __restrict__ dw, float* __restrict__ db, int B, int H,
-                                                              int W, int tiles_x, int tiles_y) {
+__global__ __launch_bounds__(256, 2) void thin_conv_wgrad_kernel(const float* __restrict__ dy, const T* __restrict__ x,
+                                                                 float* __restrict__ dw, float* __restrict__ db, int B, int H,
+                                                                 int W, int tiles_x, int tiles_y) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    ThinSmem<C>& sm = *reinterpret_cast<ThinSmem<C>*>(smem_raw);
-    constexpr int XS = C + 4;
-    float* ds = sm.w;                                        // dy tile [NPOS][4] (the weight slot is free here)
+    ThinWgradSmem& sm = *reinterpret_cast<ThinWgradSmem*>(smem_raw);
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-    constexpr int NCB = C / 64;
-    float acc[NCB][3][9];
-    float accb[3] = {0.f, 0.f, 0.f};
+    const int i16 = lane & 15, g = lane >> 4;
+    constexpr int NCH = C / CC;
+    // dW^T block [16 channels 16 (4 ch + wv) ..][16 columns of (o, tap)]: A = x^T (row c = i16, step q = g), B = G (column n = i16)
+    f32x4 acc[NCH][2];
 #pragma unroll
-    for (int j = 0; j < NCB; ++j)
+    for (int ch = 0; ch < NCH; ++ch)
 #pragma unroll
-        for (int o = 0; o < 3; ++o)
-#pragma unroll
-            for (int k = 0; k < 9; ++k) acc[j][o][k] = 0.f;
+        for (int nb = 0; nb < 2; ++nb) acc[ch][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float accb0 = 0.f, accb1 = 0.f;                                           // db: dy sums of output t / 128, and (t < 128) of output 2
+    for (int e = t; e < NPOS * GS; e += 256) sm.g[e] = 0.f;                   // columns 27 .. 32 stay zero
     const int ntiles = B * tiles_x * tiles_y;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, bimg = tile / (tiles_x * tiles_y);
+        __syncthreads();                                                      // previous tile's reads done
+        for (int e = t; e < 3 * TH * TW; e += 256) {
+            const int o = e / (TH * TW), p = e % (TH * TW);
+            const int yy = ty * TH + p / TW, xx = tx * TW + p % TW;
+            const float v = (yy < H && xx < W) ? dy[(((size_t)bimg * 3 + o) * H + yy) * W + xx] : 0.f;
+            sm.dy[e] = v;
+            if (e < 256) accb0 += v; else accb1 += v;
+        }
+        stage_tokens<C, false, T>(sm.x, x, bimg, ty, tx, H, W, 0);
         __syncthreads();
-        stage_tokens<C, false, T>(sm.x, x, bimg, ty, tx, H, W);
-        stage_dy(ds, dy, bimg, ty, tx, H, W);
+        // G[q][(o, tap)] = dy[o][q - (ky, kx)] in tile coordinates (q: halo position, its origin one pixel up / left)
+        for (int e = t; e < NPOS * 3; e += 256) {                             // one (halo position, output) per trip: 9 taps
+            const int q = e % NPOS, o = e / NPOS;
+            const int qy = q / HW_, qx = q % HW_;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int py = qy - tap / 3, px = qx - tap % 3;
+                const bool in = (unsigned)py < (unsigned)TH && (unsigned)px < (unsigned)TW;
+                sm.g[q * GS + o * 9 + tap] = in ? sm.dy[o * TH * TW + (in ? py * TW + px : 0)] : 0.f;
+            }
+        }
         __syncthreads();
-#pragma unroll 1
-        for (int i = 0; i < TH * TW / 4; ++i) {
-            const int pix = wv * (TH * TW / 4) + i;
-            const int py = pix / TW, px = pix % TW;
-            if (ty * TH + py >= H || tx * TW + px >= W) continue;
-            const f32x4 g = *reinterpret_cast<const f32x4*>(&ds[((py + 1) * HW_ + px + 1) * 4]);    // broadcast
-            if (lane == 0) { accb[0] += g[0]; accb[1] += g[1]; accb[2] += g[2]; }
 #pragma unroll
-            for (int j = 0; j < NCB; ++j)
-#pragma unroll
-                for (int k = 0; k < 9; ++k) {
-                    const float xv = sm.x[((py + k / 3) * HW_ + px + k % 3) * XS + 64 * j + lane];
-                    acc[j][0][k] += g[0] * xv; acc[j][1][k] += g[1] * xv; acc[j][2][k] += g[2] * xv;
-                }
+        for (int ch = 0; ch < NCH; ++ch) {
+            if (ch) {
+                __syncthreads();
+                stage_tokens<C, false, T>(sm.x, x, bimg, ty, tx, H, W, ch * CC);
+                __syncthreads();
+            }
+#pragma unroll 5
+            for (int ks = 0; ks < NPOS / 4; ++ks) {
+                const int q = 4 * ks + g;
+                const float xv = sm.x[q * XS + 16 * wv + i16];
+                const float g0 = sm.g[q * GS + i16], g1 = sm.g[q * GS + 16 + i16];
+                acc[ch][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv, g0, acc[ch][0], 0, 0, 0);
+                acc[ch][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv, g1, acc[ch][1], 0, 0, 0);
+            }
         }
     }
-    // 4 waves hold partial sums of the same (o, c, k): fold through LDS, then one atomic each
-    __syncthreads();
-    float* red = sm.x;                                       // [4 waves][27 * C]
+    // acc[ch][nb][r] = dW^T[c = 64 ch + 16 wv + 4 g + r][n = 16 nb + i16]
 #pragma unroll
-    for (int j = 0; j < NCB; ++j)
+    for (int ch = 0; ch < NCH; ++ch)
 #pragma unroll
-        for (int o = 0; o < 3; ++o)
+        for (int nb = 0; nb < 2; ++nb) {
+            const int n = 16 * nb + i16;
+            if (n < 27) {
 #pragma unroll
-            for (int k = 0; k < 9; ++k) red[wv * 27 * C + (o * C + 64 * j + lane) * 9 + k] = acc[j][o][k];
-    if (lane == 0) { red[4 * 27 * C + wv * 4 + 0] = accb[0]; red[4 * 27 * C + wv * 4 + 1] = accb[1]; red[4 * 27 * C + wv * 4 + 2] = accb[2]; }
-    __syncthreads();
-    for (int e = t; e < 27 * C; e += 256)
-        atomicAdd(dw + e, red[e] + red[27 * C + e] + red[2 * 27 * C + e] + red[3 * 27 * C + e]);
-    if (db && t < 3) atomicAdd(db + t, red[4 * 27 * C + t] + red[4 * 27 * C + 4 + t] + red[4 * 27 * C + 8 + t] + red[4 * 27 * C + 12 + t]);
+                for (int r = 0; r < 4; ++r) {
+                    const int c = CC * ch + 16 * wv + 4 * g + r;
+                    atomicAdd(dw + ((n / 9) * C + c) * 9 + n % 9, acc[ch][nb][r]);
+                }
+            }
+        }
+    if (db) {
+        __syncthreads();
+        if (t < 4) sm.red[t] = 0.f;
+        __syncthreads();
+        atomicAdd(&sm.red[t >> 7], accb0);
+        if (t < 128) atomicAdd(&sm.red[2], accb1);
+        __syncthreads();
+        if (t < 3) atomicAdd(db + t, sm.red[t]);
+    }
 }
 
 // First VGG19 layer (My_CR.py:65, features[0..1]): Conv2d(3 -> 64, 3x3, pad 1) + bias + ReLU from an NCHW image
@@ -253,15 +339,16 @@ __global__ __launch_bounds__(256) void conv3x3_in3_blocked_kernel(const float* _
 template <int C, typename T>
 int launch_all(int which, const void* a, const float* b, const float* c, void* d, float* e, int B, int H, int W, hipStream_t s) {
     const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH, ntiles = B * tiles_x * tiles_y;
-    const size_t smem = sizeof(ThinSmem<C>);
-    if (which == 0) {            // a = tokens x (T), b = w, c = bias, d = image y (float)
+    if (which == 0) {
+        const size_t smem = sizeof(ThinFwdSmem);            // a = tokens x (T), b = w, c = bias, d = image y (float)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&thin_conv_fwd_kernel<C, false, false, T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         hipLaunchKernelGGL((thin_conv_fwd_kernel<C, false, false, T>), dim3(ntiles), dim3(256), smem, s, (const T*)a, b, c, (float*)d, H, W, tiles_x, tiles_y);
     } else if (which == 1) {     // a = image gradient dy (float), b = w, d = token gradient dx (T)
         hipLaunchKernelGGL((thin_conv_dgrad_kernel<C, T>), dim3(ntiles), dim3(256), 0, s, (const float*)a, b, (T*)d, H, W, tiles_x, tiles_y);
     } else {                     // a = dy (float), b -> tokens x (T) passed through c's slot: see dispatch
+        const size_t smem = sizeof(ThinWgradSmem);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&thin_conv_wgrad_kernel<C, T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        const int cap = 3 * dhz_num_cus();
+        const int cap = 2 * dhz_num_cus();                   // two resident workgroups per CU (LDS)
         const int grid = ntiles < cap ? ntiles : cap;
         hipLaunchKernelGGL((thin_conv_wgrad_kernel<C, T>), dim3(grid), dim3(256), smem, s, (const float*)a, (const T*)c, (float*)d, e, B, H, W, tiles_x, tiles_y);
     }
@@ -328,7 +415,7 @@ extern "C" int dhz_thin_conv3x3_dgrad_blocked(const float* gb, const float* w, f
     DHZ_REQUIRE(gb && w && dx && B > 0 && H > 0 && W > 0, "dhz_thin_conv3x3_dgrad_blocked: bad arguments");
     DHZ_REQUIRE(C == 64, "dhz_thin_conv3x3_dgrad_blocked: C=%d unsupported (64)", C);
     const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH, ntiles = B * tiles_x * tiles_y;
-    const size_t smem = sizeof(ThinSmem<64>);
+    const size_t smem = sizeof(ThinFwdSmem);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&thin_conv_fwd_kernel<64, true, true>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     hipLaunchKernelGGL((thin_conv_fwd_kernel<64, true, true>), dim3(ntiles), dim3(256), smem, (hipStream_t)stream, gb, w, nullptr,
