@@ -401,6 +401,10 @@ int dhz_charbonnier_bwd(const float* x, const float* y, const float* gscale, con
  *      grad_scale multiplies g first (1/world_size after a sum all-reduce). */
 int dhz_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
                    float beta2, float eps, float wd, int step, float grad_scale, void* stream);
+/*      the same, also writing the updated parameters as bf16 to p16[n] (may be NULL): the weight copy the bf16 GEMMs of BASELINE
+ *      config 4 read, produced in the optimizer's own pass instead of a separate cast of the whole buffer */
+int dhz_adamw_step_shadow(float* p, const float* g, float* m, float* v, void* p16, int64_t n, float lr, float beta1,
+                          float beta2, float eps, float wd, int step, float grad_scale, void* stream);
 
 #ifdef __cplusplus
 }

@@ -8,8 +8,16 @@
 namespace {
 
 // ------------------------------------------------------------------------------------------------ K1
+// first column of quad v of lane li: quads interleaved over the lanes, or (WIDE: bf16 storage) PAIRS of adjacent quads per lane -
+// 16 bytes of bf16 per lane and access as in fp32, and half the lanes (hence half the per-lane index / shuffle work) per token:
+// at C = 64 the bf16 kernels were instruction-bound at 2.8 TB/s where the fp32 ones stream at 5.9
+template <bool WIDE>
+__device__ __forceinline__ int quad_col(int li, int v, int lpt) {
+    return WIDE ? 8 * (li + (v >> 1) * lpt) + 4 * (v & 1) : 4 * (li + v * lpt);
+}
+
 // One token = C floats.  LPT lanes cooperate on a token (C/4 float4, up to 4 per lane).
-template <int VPL, typename T>   // float4 per lane; T = storage type of x / xw
+template <int VPL, typename T, bool WIDE = false>   // float4 per lane; T = storage type of x / xw
 __global__ __launch_bounds__(256) void ln_partition_fwd_kernel(const T* __restrict__ x,
                                                                const float* __restrict__ gamma,
                                                                const float* __restrict__ beta, T* __restrict__ xw,
@@ -25,8 +33,8 @@ __global__ __launch_bounds__(256) void ln_partition_fwd_kernel(const T* __restri
     float4 gm[VPL], bt[VPL];
 #pragma unroll
     for (int v = 0; v < VPL; ++v) {
-        gm[v] = reinterpret_cast<const float4*>(gamma)[li + v * lpt];
-        bt[v] = reinterpret_cast<const float4*>(beta)[li + v * lpt];
+        gm[v] = *reinterpret_cast<const float4*>(gamma + quad_col<WIDE>(li, v, lpt));
+        bt[v] = *reinterpret_cast<const float4*>(beta + quad_col<WIDE>(li, v, lpt));
     }
     for (int base = wave_global * tpw; base < ntok; base += nwaves * tpw) {
         const int tok = base + sub;
@@ -35,7 +43,7 @@ __global__ __launch_bounds__(256) void ln_partition_fwd_kernel(const T* __restri
         float s = 0.f;
 #pragma unroll
         for (int v = 0; v < VPL; ++v) {
-            xv[v] = ok ? ld4(x + (size_t)tok * C + 4 * (li + v * lpt)) : make_float4(0, 0, 0, 0);
+            xv[v] = ok ? ld4(x + (size_t)tok * C + quad_col<WIDE>(li, v, lpt)) : make_float4(0, 0, 0, 0);
             s += xv[v].x + xv[v].y + xv[v].z + xv[v].w;
         }
         for (int o = 1; o < lpt; o <<= 1) s += __shfl_xor(s, o);
@@ -58,14 +66,14 @@ __global__ __launch_bounds__(256) void ln_partition_fwd_kernel(const T* __restri
                 y.y = (xv[v].y - mean) * rstd * gm[v].y + bt[v].y;
                 y.z = (xv[v].z - mean) * rstd * gm[v].z + bt[v].z;
                 y.w = (xv[v].w - mean) * rstd * gm[v].w + bt[v].w;
-                st4(xw + dst * C + 4 * (li + v * lpt), y);
+                st4(xw + dst * C + quad_col<WIDE>(li, v, lpt), y);
             }
             if (li == 0 && stats) *reinterpret_cast<float2*>(stats + 2 * (size_t)tok) = make_float2(mean, rstd);
         }
     }
 }
 
-template <int VPL, typename T>
+template <int VPL, typename T, bool WIDE = false>
 __global__ __launch_bounds__(256) void ln_partition_bwd_kernel(const T* __restrict__ dxw,
                                                                const T* __restrict__ x,
                                                                const float* __restrict__ gamma,
@@ -87,7 +95,7 @@ __global__ __launch_bounds__(256) void ln_partition_bwd_kernel(const T* __restri
     float4 gm[VPL], dg[VPL], db[VPL];
 #pragma unroll
     for (int v = 0; v < VPL; ++v) {
-        gm[v] = reinterpret_cast<const float4*>(gamma)[li + v * lpt];
+        gm[v] = *reinterpret_cast<const float4*>(gamma + quad_col<WIDE>(li, v, lpt));
         dg[v] = make_float4(0, 0, 0, 0);
         db[v] = make_float4(0, 0, 0, 0);
     }
@@ -108,9 +116,9 @@ __global__ __launch_bounds__(256) void ln_partition_bwd_kernel(const T* __restri
             const size_t src = partition ? (size_t)bimg * HW + window_slot(p / Wres, p % Wres, Hres, Wres, shift) : (size_t)G.tok;
 #pragma unroll
             for (int v = 0; v < VPL; ++v) {
-                G.xh[v] = ld4(x + (size_t)G.tok * C + 4 * (li + v * lpt));
-                G.dy[v] = ld4(dxw + src * C + 4 * (li + v * lpt));
-                if (dres) G.rs[v] = ld4(dres + (size_t)G.tok * C + 4 * (li + v * lpt));
+                G.xh[v] = ld4(x + (size_t)G.tok * C + quad_col<WIDE>(li, v, lpt));
+                G.dy[v] = ld4(dxw + src * C + quad_col<WIDE>(li, v, lpt));
+                if (dres) G.rs[v] = ld4(dres + (size_t)G.tok * C + quad_col<WIDE>(li, v, lpt));
             }
             const float2 st = *reinterpret_cast<const float2*>(stats + 2 * (size_t)G.tok);
             G.mean = st.x; G.rstd = st.y;
@@ -146,7 +154,7 @@ __global__ __launch_bounds__(256) void ln_partition_bwd_kernel(const T* __restri
                 r.z = rstd * (G.dy[v].z - s1 - G.xh[v].z * s2);
                 r.w = rstd * (G.dy[v].w - s1 - G.xh[v].w * s2);
                 if (dres) { r.x += G.rs[v].x; r.y += G.rs[v].y; r.z += G.rs[v].z; r.w += G.rs[v].w; }
-                st4(dx + (size_t)G.tok * C + 4 * (li + v * lpt), r);
+                st4(dx + (size_t)G.tok * C + quad_col<WIDE>(li, v, lpt), r);
             }
         }
     };
@@ -171,7 +179,7 @@ __global__ __launch_bounds__(256) void ln_partition_bwd_kernel(const T* __restri
             db[v].z += __shfl_xor(db[v].z, o); db[v].w += __shfl_xor(db[v].w, o);
         }
         if (sub == 0) {
-            const int c = 4 * (li + v * lpt);
+            const int c = quad_col<WIDE>(li, v, lpt);
             atomicAdd(&red[c + 0], dg[v].x); atomicAdd(&red[c + 1], dg[v].y);
             atomicAdd(&red[c + 2], dg[v].z); atomicAdd(&red[c + 3], dg[v].w);
             atomicAdd(&red[C + c + 0], db[v].x); atomicAdd(&red[C + c + 1], db[v].y);
@@ -542,7 +550,8 @@ __global__ __launch_bounds__(64) void contrast_combine_bwd_kernel(const float* _
 
 // ------------------------------------------------------------------------------------------------ K12
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
-                                                    float* __restrict__ m, float* __restrict__ v, int64_t n, float lr,
+                                                    float* __restrict__ m, float* __restrict__ v,
+                                                    uint16_t* __restrict__ p16, int64_t n, float lr,
                                                     float b1, float b2, float eps, float wd, float step_size,
                                                     float bc2_sqrt, float gscale) {
     const int64_t n4 = n >> 2;
@@ -559,10 +568,14 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
         const float4 gv = reinterpret_cast<const float4*>(g)[e];
         upd(pv.x, gv.x, mv.x, vv.x); upd(pv.y, gv.y, mv.y, vv.y); upd(pv.z, gv.z, mv.z, vv.z); upd(pv.w, gv.w, mv.w, vv.w);
         reinterpret_cast<float4*>(p)[e] = pv; reinterpret_cast<float4*>(m)[e] = mv; reinterpret_cast<float4*>(v)[e] = vv;
+        if (p16) st4(reinterpret_cast<bf16s*>(p16) + 4 * e, pv);          // the bf16 GEMMs' copy of the weights, in the same pass
     }
     // tail
     const int64_t e = (n4 << 2) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e < n) upd(p[e], g[e], m[e], v[e]);
+    if (e < n) {
+        upd(p[e], g[e], m[e], v[e]);
+        if (p16) p16[e] = f32_to_bf16(p[e]);
+    }
 }
 
 inline int grid_for(int64_t work_items, int per_block = 256, int cap = 256 * 8) {
@@ -586,6 +599,16 @@ static int ln_geometry(int C, int* lpt, int* vpl) {
     return (*vpl >= 1 && *vpl <= 4) ? 0 : -1;
 }
 
+// bf16 storage, 8 channels per lane: lanes per token and quads per lane (2 or 4), or -1 when C does not split that way
+static int wide_geometry(int C, int* lpt, int* vpl) {
+    if (C % 8 != 0) return -1;
+    int l, v;
+    if (ln_geometry(C / 2, &l, &v) != 0 || 2 * v > 4) return -1;
+    *lpt = l;
+    *vpl = 2 * v;
+    return 0;
+}
+
 // Each token-tensor op exists as dhz_<op>_dt(..., dtype, stream) with dtype = DHZ_F32 / DHZ_BF16 (the storage type of the token
 // tensors; parameters, statistics and parameter gradients are always fp32) and as the fp32 entry point dhz_<op>.
 #define DT_SWITCH(dtype, who, CALL)                                                      \
@@ -603,8 +626,17 @@ extern "C" int dhz_ln_partition_fwd_dt(const void* x, const float* gamma, const 
     int lpt, vpl;
     DHZ_REQUIRE(ln_geometry(C, &lpt, &vpl) == 0, "dhz_ln_partition_fwd: unsupported C=%d", C);
     const int ntok = B * Hres * Wres;
-    const int grid = grid_for((int64_t)ntok * lpt);
     hipStream_t s = (hipStream_t)stream;
+    int lpw, vpw;
+    if (dtype == DHZ_BF16 && wide_geometry(C, &lpw, &vpw) == 0) {            // bf16: 8 channels (16 bytes) per lane
+        const int grid = grid_for((int64_t)ntok * lpw);
+#define LAUNCHW(V) hipLaunchKernelGGL((ln_partition_fwd_kernel<V, bf16s, true>), dim3(grid), dim3(256), 0, s, (const bf16s*)x, gamma, beta, (bf16s*)xw, stats, ntok, Hres, Wres, C, shift, lpw, partition)
+        if (vpw == 2) LAUNCHW(2); else LAUNCHW(4);
+#undef LAUNCHW
+        DHZ_CHECK_LAUNCH("dhz_ln_partition_fwd");
+        return DHZ_OK;
+    }
+    const int grid = grid_for((int64_t)ntok * lpt);
 #define LAUNCH(V) hipLaunchKernelGGL((ln_partition_fwd_kernel<V, T>), dim3(grid), dim3(256), 0, s, (const T*)x, gamma, beta, (T*)xw, stats, ntok, Hres, Wres, C, shift, lpt, partition)
     DT_SWITCH(dtype, "dhz_ln_partition_fwd",
               switch (vpl) { case 1: LAUNCH(1); break; case 2: LAUNCH(2); break; case 3: LAUNCH(3); break; default: LAUNCH(4); });
@@ -628,10 +660,20 @@ extern "C" int dhz_ln_partition_bwd_dt(const void* dxw, const void* x, const flo
     const int ntok = B * Hres * Wres;
     // every workgroup ends with 2C same-address atomics (dgamma, dbeta): give each wave >= 8 token groups so that small
     // maps do not pay 1024 workgroups' worth of them
+    int lpw, vpw;
+    const bool wide = dtype == DHZ_BF16 && wide_geometry(C, &lpw, &vpw) == 0;   // bf16: 8 channels (16 bytes) per lane
+    if (wide) lpt = lpw;
     int grid = (int)(((int64_t)ntok * lpt + 256 * 8 - 1) / (256 * 8));
     const int cap = 2 * dhz_num_cus();
     grid = grid < 64 ? 64 : (grid > cap ? cap : grid);
     hipStream_t s = (hipStream_t)stream;
+    if (wide) {
+#define LAUNCHW(V) hipLaunchKernelGGL((ln_partition_bwd_kernel<V, bf16s, true>), dim3(grid), dim3(256), 0, s, (const bf16s*)dxw, (const bf16s*)x, gamma, stats, (const bf16s*)dres, (bf16s*)dx, dgamma, dbeta, ntok, Hres, Wres, C, shift, lpt, partition)
+        if (vpw == 2) LAUNCHW(2); else LAUNCHW(4);
+#undef LAUNCHW
+        DHZ_CHECK_LAUNCH("dhz_ln_partition_bwd");
+        return DHZ_OK;
+    }
 #define LAUNCH(V) hipLaunchKernelGGL((ln_partition_bwd_kernel<V, T>), dim3(grid), dim3(256), 0, s, (const T*)dxw, (const T*)x, gamma, stats, (const T*)dres, (T*)dx, dgamma, dbeta, ntok, Hres, Wres, C, shift, lpt, partition)
     DT_SWITCH(dtype, "dhz_ln_partition_bwd",
               switch (vpl) { case 1: LAUNCH(1); break; case 2: LAUNCH(2); break; case 3: LAUNCH(3); break; default: LAUNCH(4); });
@@ -741,17 +783,22 @@ extern "C" int dhz_charbonnier_bwd(const float* x, const float* y, const float* 
     return DHZ_OK;
 }
 
-extern "C" int dhz_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
-                              float eps, float wd, int step, float grad_scale, void* stream) {
+extern "C" int dhz_adamw_step_shadow(float* p, const float* g, float* m, float* v, void* p16, int64_t n, float lr, float beta1,
+                                     float beta2, float eps, float wd, int step, float grad_scale, void* stream) {
     DHZ_REQUIRE(p && g && m && v && n > 0 && step >= 1, "dhz_adamw_step: bad arguments");
+    DHZ_REQUIRE(((uintptr_t)p16 & 7) == 0, "dhz_adamw_step: the bf16 shadow must be 8-byte aligned");
     const double bc1 = 1.0 - pow((double)beta1, (double)step);
     const double bc2 = 1.0 - pow((double)beta2, (double)step);
     const float step_size = (float)((double)lr / bc1);
     const float bc2_sqrt = (float)sqrt(bc2);
-    hipLaunchKernelGGL(adamw_kernel, dim3(grid_for((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr,
-                       beta1, beta2, eps, wd, step_size, bc2_sqrt, grad_scale);
+    hipLaunchKernelGGL(adamw_kernel, dim3(grid_for((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (uint16_t*)p16, n,
+                       lr, beta1, beta2, eps, wd, step_size, bc2_sqrt, grad_scale);
     DHZ_CHECK_LAUNCH("dhz_adamw_step");
     return DHZ_OK;
+}
+extern "C" int dhz_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                              float eps, float wd, int step, float grad_scale, void* stream) {
+    return dhz_adamw_step_shadow(p, g, m, v, nullptr, n, lr, beta1, beta2, eps, wd, step, grad_scale, stream);
 }
 
 extern "C" int dhz_contrast_combine_fwd(const float* sums, const float* inv_cnt, const float* w, int k, int ablation, float* d,

@@ -95,6 +95,7 @@ SIGNATURES = {
     "dhz_charbonnier_fwd": [c_f, c_f, c_f, c_f, c_l, c_fl, c_i, c_p],
     "dhz_charbonnier_bwd": [c_f, c_f, c_f, c_f, c_f, c_l, c_fl, c_fl, c_i, c_p],
     "dhz_adamw_step": [c_f, c_f, c_f, c_f, c_l, c_fl, c_fl, c_fl, c_fl, c_fl, c_i, c_fl, c_p],
+    "dhz_adamw_step_shadow": [c_f, c_f, c_f, c_f, c_f, c_l, c_fl, c_fl, c_fl, c_fl, c_fl, c_i, c_fl, c_p],
 }
 _RESTYPE = {"dhz_last_error": ctypes.c_char_p, "dhz_build_id": ctypes.c_char_p}
 

@@ -58,10 +58,12 @@ def set_bf16_shadow(f32, b16):
     BF16_SHADOW = None if f32 is None else [f32, b16, f32._version]
 
 
-def refresh_bf16_shadow():
+def refresh_bf16_shadow(cast=True):
+    """cast=False: the shadow was just written by the optimizer kernel itself - only record the version"""
     sh = BF16_SHADOW
     if sh is not None:
-        sh[1].copy_(sh[0])                   # one cast launch for all parameters
+        if cast:
+            sh[1].copy_(sh[0])               # one cast launch for all parameters
         sh[2] = sh[0]._version
 
 
@@ -578,11 +580,13 @@ def charbonnier(x, y, eps=1e-3):
 
 
 # ----------------------------------------------------------------------------- K12
-def adamw_step_(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
-    """In-place AdamW over flat fp32 buffers (torch.optim.AdamW semantics, TR:90-92)."""
+def adamw_step_(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0, p16=None):
+    """In-place AdamW over flat fp32 buffers (torch.optim.AdamW semantics, TR:90-92); p16: optional bf16 buffer that receives
+    the updated parameters in the same pass (the weight copy of the bf16 GEMMs)."""
     _require_gpu(p, g, m, v)
     assert p.is_contiguous() and g.is_contiguous() and m.is_contiguous() and v.is_contiguous()
-    _lib.call("dhz_adamw_step", _p(p), _p(g), _p(m), _p(v), p.numel(), float(lr), float(beta1), float(beta2),
+    assert p16 is None or (p16.dtype == BF16 and p16.is_contiguous() and p16.numel() == p.numel())
+    _lib.call("dhz_adamw_step_shadow", _p(p), _p(g), _p(m), _p(v), _p(p16), p.numel(), float(lr), float(beta1), float(beta2),
               float(eps), float(weight_decay), int(step), float(grad_scale), _stream())
 
 

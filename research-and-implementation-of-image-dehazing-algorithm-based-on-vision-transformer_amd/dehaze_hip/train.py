@@ -114,13 +114,24 @@ class FlatAdamW(torch.optim.Optimizer):
         g = self.param_groups[0]
         self._step += 1
         f = self._flat
+        shadowed = "p16" in f
         ops.adamw_step_(f["p"], f["g"], f["m"], f["v"], g["lr"], g["betas"][0], g["betas"][1], g["eps"],
-                        g["weight_decay"], self._step, self.grad_scale)
-        if "p16" in f:
-            if ops.BF16_SHADOW is not None and ops.BF16_SHADOW[0] is f["p"]:
-                ops.refresh_bf16_shadow()            # the bf16 GEMMs read the shadow (one cast launch)
-            else:
-                f["p16"].copy_(f["p"])
+                        g["weight_decay"], self._step, self.grad_scale, p16=f["p16"] if shadowed else None)
+        if shadowed and ops.BF16_SHADOW is not None and ops.BF16_SHADOW[0] is f["p"]:
+            ops.refresh_bf16_shadow(cast=False)  # the kernel wrote the bf16 copy in its own pass
+            self._pver = self._param_versions()
+
+    def _param_versions(self):
+        """sum of the version counters of the parameters (views of the flat buffer with counters of their own): changes when
+        anything but the optimizer kernel writes a parameter in place (a loaded checkpoint, a landscape probe)"""
+        return sum(p._version for p in self._live) + self._flat["p"]._version
+
+    def sync_bf16_shadow(self):
+        """Start-of-step check of train_step: re-cast the shadow only if a parameter was written since the last update."""
+        v = self._param_versions()
+        if getattr(self, "_pver", None) != v:
+            ops.refresh_bf16_shadow()
+            self._pver = self._param_versions()
 
     def enable_bf16_shadow(self):
         """Keep a bf16 copy of the flat parameter buffer, refreshed after every update, and let ops.bf16_copy hand out views
@@ -307,8 +318,8 @@ def train_step(model, char_loss, cr_loss, optimizer, reducer, input_, target, w_
         if ops.BF16_SHADOW is None or optimizer._flat is None or ops.BF16_SHADOW[0] is not optimizer._flat["p"]:
             optimizer.enable_bf16_shadow()
         else:
-            ops.refresh_bf16_shadow()          # one cast launch: parameters written outside step() (a loaded checkpoint, a
-                                               # landscape probe) must reach the bf16 GEMMs too
+            optimizer.sync_bf16_shadow()       # parameters written outside step() (a loaded checkpoint, a landscape probe)
+                                               # must reach the bf16 GEMMs too: one cast launch, only when that happened
     if cr_loss is not None and hasattr(cr_loss, "vgg") and hasattr(cr_loss.vgg, "feature_dtype"):
         # config 4: the frozen feature stack follows the model's activation type (autocast covers the loss in the reference)
         cr_loss.vgg.feature_dtype = getattr(model, "act_dtype", None) or torch.float32

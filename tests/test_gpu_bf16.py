@@ -96,11 +96,16 @@ def test_streaming_kernels_bf16_equal_fp32_kernels_on_rounded_inputs():
     xf = xb.detach().float().requires_grad_()
     yb = ops.ln_partition(xb, gm_b, bt_b, H, W, shift)
     yf = ops.ln_partition(xf, gm_f, bt_f, H, W, shift)
-    assert yb.dtype == BF and torch.equal(yb, yf.to(BF))
+    # (the bf16 LayerNorm kernels give a lane 8 channels instead of 4, so their row sums add up in another order than the fp32
+    # kernels': equal up to one bf16 step on a few elements whose fp32 value sits on a rounding boundary)
+    def one_step(a, b):
+        d = (a.float() - b.float()).abs()
+        return (a != b).float().mean().item() < 2e-3 and bool((d <= 2.0 ** -7 * torch.maximum(a.float().abs(), b.float().abs())).all())
+    assert yb.dtype == BF and one_step(yb, yf.to(BF))
     gb = gout.to(BF)
     yb.backward(gb)
     yf.backward(gb.float())
-    assert torch.equal(xb.grad, xf.grad.to(BF))
+    assert one_step(xb.grad, xf.grad.to(BF))
     assert torch.allclose(gm_b.grad, gm_f.grad, rtol=1e-4, atol=1e-4) and torch.allclose(bt_b.grad, bt_f.grad, rtol=1e-4, atol=1e-4)
     # window reverse + un-roll + residual with a DropPath vector
     sc = torch.tensor([1.0 / 0.9, 0.0], device=dev)
@@ -392,3 +397,40 @@ def test_projections_bf16_tokens_match_fp32_kernels():
     assert outs[BF][1].dtype == BF and torch.equal(outs[BF][1], outs[torch.float32][1].to(BF))
     assert torch.allclose(outs[BF][2], outs[torch.float32][2], rtol=1e-5, atol=1e-5 * outs[torch.float32][2].abs().max().item())
     assert torch.allclose(outs[BF][3], outs[torch.float32][3], rtol=1e-5, atol=1e-4)
+
+
+def test_bf16_shadow_written_by_optimizer_and_resynced_after_outside_writes():
+    """The bf16 weight copy the GEMMs read: (a) the AdamW kernel writes it in its own pass - bit-equal to a cast of the updated
+    parameters, no separate cast launch; (b) a parameter written in place by anything else (a loaded checkpoint, a landscape
+    probe) reaches the shadow at the start of the next train_step; (c) without such a write the start-of-step check does nothing."""
+    import My_model_1 as M1
+    from dehaze_hip import ops
+    from dehaze_hip.train import FlatAdamW, synthetic_batch, train_step
+    from losses import CharbonnierLoss
+    dev = torch.device("cuda:0")
+    torch.manual_seed(3)
+    model = M1.Uformer(img_size=128, embed_dim=64, win_size=8, token_projection='linear', token_mlp='leff',
+                       drop_path_rate=0.).to(dev).train()
+    model.act_dtype = BF
+    opt = FlatAdamW(model, lr=2e-4, weight_decay=0.02)
+    gt, hazy = synthetic_batch(1, 128, seed=3, device=dev)
+    train_step(model, CharbonnierLoss(), None, opt, None, hazy, gt, 1.0, 0.0)
+    f = opt._flat
+    assert ops.BF16_SHADOW is not None and ops.BF16_SHADOW[0] is f["p"]
+    assert torch.equal(f["p16"], f["p"].to(BF))                                    # (a)
+    p = next(model.parameters())
+    with torch.no_grad():
+        p.add_(0.5)                                                                # (b) an outside write
+    assert not torch.equal(f["p16"], f["p"].to(BF))
+    seen = []
+    orig = ops.refresh_bf16_shadow
+    ops.refresh_bf16_shadow = lambda cast=True: (seen.append(cast), orig(cast))[1]
+    try:
+        opt.sync_bf16_shadow()
+        assert seen == [True] and torch.equal(f["p16"], f["p"].to(BF))
+        seen.clear()
+        train_step(model, CharbonnierLoss(), None, opt, None, hazy, gt, 1.0, 0.0)  # (c) nothing written outside: no cast launch
+        assert seen == [False], seen
+        assert torch.equal(f["p16"], f["p"].to(BF))
+    finally:
+        ops.refresh_bf16_shadow = orig
