@@ -1,0 +1,460 @@
+// EXPERIMENT (off by default, never the headline): the fp32 token-Linear GEMMs with a contraction of 128 or more on the bf16
+// matrix pipe by operand splitting.  Every fp32 operand is cut, on its way into LDS, into two bf16 pieces
+//     x = hi + lo + r,   hi = bf16(x),  lo = bf16(x - hi),   |r| <= 2^-17 |x|
+// and a product is taken as  a.b ~ a_hi b_hi + a_hi b_lo + a_lo b_hi  (three v_mfma_f32_16x16x32_bf16 with fp32 accumulation;
+// the dropped a_lo b_lo and the r terms are <= 2^-16 relative per product).  The result is NOT fp32 arithmetic - about 16
+// mantissa bits per product instead of 24 - which is why the path sits behind an explicit switch (dehaze_hip.ops.SPLIT_BF16,
+// bench.py --split-bf16), is reported as its own bench object with its dtype stated, and BASELINE configs[1] stays on the fp32 pipe
+// (csrc/linear_gemm.hip).  What it buys: the bf16 pipe has 16 x the rate of v_mfma_f32_16x16x4_f32, so three passes plus the
+// split arithmetic cost about a third of the fp32 matrix time and these GEMMs fall back to their HBM time.
+//     forward        y[T,N]  = x[T,K]  . W[N,K]^T + b      both operands contraction-contiguous
+//     backward-data  dx[T,K] = dy[T,N] . W[N,K]            W's rows are the contraction: transpose reads of the bf16 images
+// LDS images and fragment reads are those of csrc/linear_bf16.hip (one hi and one lo image per operand); operands and results stay
+// fp32 in HBM.
+#include "common.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int BK = 64;
+
+__device__ __forceinline__ f32x4 mfma_bf16(s16x8 a, s16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ int off_row(int row, int ch) { return row * 128 + 16 * (ch ^ ((row >> 1) & 7)); }
+template <int F>
+__device__ __forceinline__ int off_tr(int row, int ch) {
+    if (F == 128) return row * 256 + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3)));
+    return row * 128 + 16 * (ch ^ ((row & 2) | ((row & 8) >> 1)));
+}
+template <int F>
+__device__ __forceinline__ s16x8 tr_frag(const unsigned char* img, int r0, int cb, int lane) {
+    const int m = lane & 15, q = m >> 2, p = m & 3;
+    typedef s16x4 __attribute__((address_space(3))) * lds_ptr;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(img + off_tr<F>(r0 + q, 2 * cb + (p >> 1)) + 8 * (p & 1)));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(img + off_tr<F>(r0 + 4 + q, 2 * cb + (p >> 1)) + 8 * (p & 1)));
+    return s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+
+// eight fp32 values -> their bf16 heads and the bf16 of what the heads leave
+__device__ __forceinline__ void split8(const f32x4 a, const f32x4 b, u32x4& hi, u32x4& lo) {
+    const float x[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    uint32_t h[8], l[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        h[i] = f32_to_bf16(x[i]);
+        l[i] = f32_to_bf16(x[i] - __uint_as_float(h[i] << 16));
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        hi[i] = h[2 * i] | (h[2 * i + 1] << 16);
+        lo[i] = l[2 * i] | (l[2 * i + 1] << 16);
+    }
+}
+
+// C[M,NF] = A[M,KC] . op(B) (+ bias).  BTR = false: B is [NF][KC] (forward); true: B is [KC][NF] (backward-data).
+template <int WM, int WN, bool BTR>
+__global__ __launch_bounds__(256, 2) void gemm_split_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B,
+                                                            int ldb, const float* __restrict__ bias, float* __restrict__ C, int ldc,
+                                                            int M, int NF, int KC, int tiles_n, int ntiles) {
+    constexpr int BM = 32 * WM, BN = 32 * WN;
+    constexpr int A_BYTES = BM * 128;
+    constexpr int B_BYTES = BTR ? BK * BN * 2 : BN * 128;
+    constexpr int NA = WM, NB = WN;                              // 8-element chunks per thread per stage
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* const Ah = smem;
+    unsigned char* const Al = Ah + A_BYTES;
+    unsigned char* const Bh = Al + A_BYTES;
+    unsigned char* const Bl = Bh + B_BYTES;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int i16 = lane & 15, g = lane >> 4;
+    const int wm = w >> 1, wn = w & 1;
+    const int nst = KC / BK;
+    const int grid = gridDim.x;
+    auto tile_of = [&](int i) -> int {
+        const int lin = blockIdx.x + i * grid;
+        if (lin >= ntiles) return -1;
+        if ((grid & 7) == 0 && (ntiles & 7) == 0) return (lin & 7) * (ntiles >> 3) + (lin >> 3);
+        return lin;
+    };
+    f32x4 acc[WM][WN];
+#pragma unroll
+    for (int a = 0; a < WM; ++a)
+#pragma unroll
+        for (int b = 0; b < WN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    f32x4 ra[NA][2], rb[NB][2];
+    const float* pa[NA];
+    const float* pb[NB];
+    auto set_tile = [&](int tile) {
+        const int tn = tile % tiles_n, tm = tile / tiles_n;
+        const int m0 = tm * BM, n0 = tn * BN;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int e = t + 256 * i;
+            pa[i] = A + (size_t)min(m0 + (e >> 3), M - 1) * lda + 8 * (e & 7);
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int e = t + 256 * i;
+            if (BTR) pb[i] = B + (size_t)(e / (BN / 8)) * ldb + n0 + 8 * (e % (BN / 8));
+            else pb[i] = B + (size_t)(n0 + (e >> 3)) * ldb + 8 * (e & 7);
+        }
+    };
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            ra[i][0] = *reinterpret_cast<const f32x4*>(pa[i] + k0);
+            ra[i][1] = *reinterpret_cast<const f32x4*>(pa[i] + k0 + 4);
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const float* p = pb[i] + (BTR ? (size_t)k0 * ldb : (size_t)k0);
+            rb[i][0] = *reinterpret_cast<const f32x4*>(p);
+            rb[i][1] = *reinterpret_cast<const f32x4*>(p + 4);
+        }
+    };
+    auto swrite = [&]() {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int e = t + 256 * i;
+            u32x4 hi, lo;
+            split8(ra[i][0], ra[i][1], hi, lo);
+            const int o = off_row(e >> 3, e & 7);
+            *reinterpret_cast<u32x4*>(Ah + o) = hi;
+            *reinterpret_cast<u32x4*>(Al + o) = lo;
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int e = t + 256 * i;
+            u32x4 hi, lo;
+            split8(rb[i][0], rb[i][1], hi, lo);
+            const int o = BTR ? off_tr<BN>(e / (BN / 8), e % (BN / 8)) : off_row(e >> 3, e & 7);
+            *reinterpret_cast<u32x4*>(Bh + o) = hi;
+            *reinterpret_cast<u32x4*>(Bl + o) = lo;
+        }
+    };
+
+    int ti = 0, tile = tile_of(0);
+    if (tile < 0) return;
+    set_tile(tile);
+    gload(0);
+    swrite();
+    __syncthreads();
+    const int sw = (i16 >> 1) & 7;
+    while (true) {
+        const int ntile = tile_of(ti + 1);
+        const int tn = tile % tiles_n, tm = tile / tiles_n;
+        for (int st = 0; st < nst; ++st) {
+            const bool last = st + 1 == nst;
+            const bool more = !last || ntile >= 0;
+            if (!last) gload((st + 1) * BK);
+            else if (ntile >= 0) { set_tile(ntile); gload(0); }
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                s16x8 ah[WM], al[WM], bh[WN], bl[WN];
+#pragma unroll
+                for (int a = 0; a < WM; ++a) {
+                    const int o = (wm * WM * 16 + a * 16 + i16) * 128 + 16 * ((4 * s + g) ^ sw);
+                    ah[a] = *reinterpret_cast<const s16x8*>(Ah + o);
+                    al[a] = *reinterpret_cast<const s16x8*>(Al + o);
+                }
+#pragma unroll
+                for (int b = 0; b < WN; ++b) {
+                    if (BTR) {
+                        bh[b] = tr_frag<BN>(Bh, 32 * s + 8 * g, wn * WN + b, lane);
+                        bl[b] = tr_frag<BN>(Bl, 32 * s + 8 * g, wn * WN + b, lane);
+                    } else {
+                        const int o = ((wn * WN + b) * 16 + i16) * 128 + 16 * ((4 * s + g) ^ sw);
+                        bh[b] = *reinterpret_cast<const s16x8*>(Bh + o);
+                        bl[b] = *reinterpret_cast<const s16x8*>(Bl + o);
+                    }
+                }
+#pragma unroll
+                for (int a = 0; a < WM; ++a)
+#pragma unroll
+                    for (int b = 0; b < WN; ++b) {                           // D = C^T block (epilogue); small terms first
+                        acc[a][b] = mfma_bf16(bl[b], ah[a], acc[a][b]);
+                        acc[a][b] = mfma_bf16(bh[b], al[a], acc[a][b]);
+                        acc[a][b] = mfma_bf16(bh[b], ah[a], acc[a][b]);
+                    }
+            }
+            if (more) {
+                __syncthreads();                                         // every wave is done with this stage's images
+                swrite();
+                __syncthreads();
+            }
+        }
+        {   // acc[a][b][j] = C[token 16 a + i16][feature 16 b + 4 g + j]: one 16-byte store per block and lane
+            const int m0 = tm * BM + wm * WM * 16 + i16, n0 = tn * BN + wn * WN * 16 + 4 * g;
+            float* c0 = C + (size_t)m0 * ldc + n0;
+#pragma unroll
+            for (int a = 0; a < WM; ++a) {
+                if (m0 + 16 * a < M) {
+#pragma unroll
+                    for (int b = 0; b < WN; ++b) {
+                        f32x4 v = acc[a][b];
+                        if (bias) v += *reinterpret_cast<const f32x4*>(bias + n0 + 16 * b);
+                        *reinterpret_cast<f32x4*>(c0 + (size_t)(16 * a) * ldc + 16 * b) = v;
+                    }
+                }
+            }
+#pragma unroll
+            for (int a = 0; a < WM; ++a)
+#pragma unroll
+                for (int b = 0; b < WN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        if (ntile < 0) break;
+        tile = ntile;
+        ++ti;
+    }
+}
+
+template <int WM, int WN, bool BTR>
+void launch_split(const float* A, int lda, const float* B, int ldb, const float* bias, float* C, int ldc, int M, int NF, int KC,
+                  hipStream_t s) {
+    constexpr int BM = 32 * WM, BN = 32 * WN;
+    constexpr size_t smem = 2 * (size_t)(BM * 128) + 2 * (size_t)(BTR ? BK * BN * 2 : BN * 128);
+    const int tiles_n = NF / BN, tiles_m = (M + BM - 1) / BM;
+    const int ntiles = tiles_n * tiles_m;
+    const int slots = 2 * dhz_num_cus();
+    const int grid = ntiles < slots ? ntiles : slots;
+    if (smem > 48 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_split_kernel<WM, WN, BTR>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipLaunchKernelGGL((gemm_split_kernel<WM, WN, BTR>), dim3(grid), dim3(256), smem, s, A, lda, B, ldb, bias, C, ldc, M, NF, KC,
+                       tiles_n, ntiles);
+}
+
+template <bool BTR>
+int dispatch_split(const char* who, const float* A, int lda, const float* B, int ldb, const float* bias, float* C, int ldc, int M,
+                   int NF, int KC, hipStream_t s) {
+    DHZ_REQUIRE(A && B && C, "%s: null pointer", who);
+    DHZ_REQUIRE(M > 0 && NF > 0 && KC > 0 && NF % 64 == 0 && KC % 64 == 0, "%s: T=%d features=%d contraction=%d (multiples of 64)", who,
+                M, NF, KC);
+    DHZ_REQUIRE(lda % 4 == 0 && ldb % 4 == 0 && ldc % 4 == 0 && ldc >= NF && lda >= KC, "%s: bad leading dimensions", who);
+    DHZ_REQUIRE((((uintptr_t)A | (uintptr_t)B | (uintptr_t)C | (uintptr_t)bias) & 15) == 0, "%s: operands must be 16-byte aligned", who);
+    const int wn = NF % 128 == 0 ? 4 : 2;
+    const long blocks128 = (long)((M + 127) / 128) * (NF / (32 * wn));
+    const int wm = blocks128 >= dhz_num_cus() ? 4 : 2;
+#define CASE(a, b) \
+    if (wm == a && wn == b) launch_split<a, b, BTR>(A, lda, B, ldb, bias, C, ldc, M, NF, KC, s);
+    CASE(4, 4) CASE(4, 2) CASE(2, 4) CASE(2, 2)
+#undef CASE
+    DHZ_CHECK_LAUNCH(who);
+    return DHZ_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ weight gradient
+//     dW[N,K] += dy^T[N,T] . x[T,K],  db[N] += column sums of dy        (contraction over token rows: both operands by transpose
+// reads of their hi / lo images; split over T, fp32 atomics; db from the fp32 values, i.e. exact).  Row t of dy may carry a factor
+// row_scale[t / rows_per_scale] (the per-image DropPath scale of dhz_linear_wgrad_rs), applied before the split.
+constexpr int MAXMAT = 4;
+struct WgradOut {
+    float* dw[MAXMAT];
+    float* db[MAXMAT];
+    int nper;
+};
+
+template <int WM, int WN>
+__global__ __launch_bounds__(256, 2) void wgrad_split_kernel(const float* __restrict__ dy, int ldy, const float* __restrict__ x,
+                                                             int ldx, int T, int N, int K, WgradOut out, int nsplit,
+                                                             const float* __restrict__ row_scale, int rows_per_scale) {
+    constexpr int FM = 32 * WM, FN = 32 * WN;
+    constexpr int A_BYTES = BK * FM * 2, B_BYTES = BK * FN * 2;
+    constexpr int NA = BK * (FM / 8) / 256, NB = BK * (FN / 8) / 256;       // 8-element chunks per thread per stage (2 or 4)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* const Ah = smem;
+    unsigned char* const Al = Ah + A_BYTES;
+    unsigned char* const Bh = Al + A_BYTES;
+    unsigned char* const Bl = Bh + B_BYTES;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int i16 = lane & 15, g = lane >> 4;
+    const int wm = w >> 1, wn = w & 1;
+    const int tiles_n = K / FN;
+    int bid = blockIdx.x;
+    const int split = bid % nsplit; bid /= nsplit;
+    const int tn = bid % tiles_n, tm = bid / tiles_n;
+    const int n0 = tm * FM, k0 = tn * FN;
+    const int mat = n0 / out.nper, nloc = n0 - mat * out.nper;
+    float* __restrict__ const dw = out.dw[mat];
+    float* __restrict__ const db = out.db[mat];
+    const int nst = T / BK;
+    const int st0 = (int)((long long)nst * split / nsplit), st1 = (int)((long long)nst * (split + 1) / nsplit);
+
+    f32x4 acc[WM][WN];
+#pragma unroll
+    for (int a = 0; a < WM; ++a)
+#pragma unroll
+        for (int b = 0; b < WN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 ra[NA][2], rb[NB][2];
+    float rs[NA];
+    float dbacc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};     // column sums of this thread's 8 dy columns (chunk t % (FM/8))
+    const bool do_db = (db != nullptr) && (tn == 0);
+
+    auto gload = [&](int st) {
+        const size_t tok0 = (size_t)st * BK;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int e = t + 256 * i;
+            const size_t tok = tok0 + e / (FM / 8);
+            const float* p = dy + tok * ldy + n0 + 8 * (e % (FM / 8));
+            ra[i][0] = *reinterpret_cast<const f32x4*>(p);
+            ra[i][1] = *reinterpret_cast<const f32x4*>(p + 4);
+            rs[i] = row_scale ? row_scale[tok / rows_per_scale] : 1.f;
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int e = t + 256 * i;
+            const float* p = x + (tok0 + e / (FN / 8)) * ldx + k0 + 8 * (e % (FN / 8));
+            rb[i][0] = *reinterpret_cast<const f32x4*>(p);
+            rb[i][1] = *reinterpret_cast<const f32x4*>(p + 4);
+        }
+    };
+    auto swrite = [&]() {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int e = t + 256 * i;
+            const f32x4 v0 = ra[i][0] * rs[i], v1 = ra[i][1] * rs[i];
+            u32x4 hi, lo;
+            split8(v0, v1, hi, lo);
+            const int o = off_tr<FM>(e / (FM / 8), e % (FM / 8));
+            *reinterpret_cast<u32x4*>(Ah + o) = hi;
+            *reinterpret_cast<u32x4*>(Al + o) = lo;
+            if (do_db) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) { dbacc[c] += v0[c]; dbacc[4 + c] += v1[c]; }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int e = t + 256 * i;
+            u32x4 hi, lo;
+            split8(rb[i][0], rb[i][1], hi, lo);
+            const int o = off_tr<FN>(e / (FN / 8), e % (FN / 8));
+            *reinterpret_cast<u32x4*>(Bh + o) = hi;
+            *reinterpret_cast<u32x4*>(Bl + o) = lo;
+        }
+    };
+
+    if (st0 < st1) {
+        gload(st0);
+        swrite();
+    }
+    __syncthreads();
+    for (int st = st0; st < st1; ++st) {
+        const bool more = st + 1 < st1;
+        if (more) gload(st + 1);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            s16x8 ah[WM], al[WM], bh[WN], bl[WN];
+#pragma unroll
+            for (int a = 0; a < WM; ++a) {
+                ah[a] = tr_frag<FM>(Ah, 32 * s + 8 * g, wm * WM + a, lane);
+                al[a] = tr_frag<FM>(Al, 32 * s + 8 * g, wm * WM + a, lane);
+            }
+#pragma unroll
+            for (int b = 0; b < WN; ++b) {
+                bh[b] = tr_frag<FN>(Bh, 32 * s + 8 * g, wn * WN + b, lane);
+                bl[b] = tr_frag<FN>(Bl, 32 * s + 8 * g, wn * WN + b, lane);
+            }
+#pragma unroll
+            for (int a = 0; a < WM; ++a)
+#pragma unroll
+                for (int b = 0; b < WN; ++b) {
+                    acc[a][b] = mfma_bf16(al[a], bh[b], acc[a][b]);
+                    acc[a][b] = mfma_bf16(ah[a], bl[b], acc[a][b]);
+                    acc[a][b] = mfma_bf16(ah[a], bh[b], acc[a][b]);
+                }
+        }
+        __syncthreads();
+        if (more) {
+            swrite();
+            __syncthreads();
+        }
+    }
+    // ---- epilogue: tile -> LDS (row-major FM x FN fp32) -> full-line fp32 atomics
+    float* Cs = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int a = 0; a < WM; ++a)
+#pragma unroll
+        for (int b = 0; b < WN; ++b)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) Cs[(wm * WM * 16 + a * 16 + 4 * g + j) * FN + wn * WN * 16 + b * 16 + i16] = acc[a][b][j];
+    __syncthreads();
+    for (int e = t; e < FM * FN; e += 256) atomicAdd(dw + (size_t)(nloc + e / FN) * K + k0 + e % FN, Cs[e]);
+    if (do_db) {
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(smem);          // [256 / (FM/8)][FM]
+        constexpr int CPR = FM / 8;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) red[(t / CPR) * FM + 8 * (t % CPR) + c] = dbacc[c];
+        __syncthreads();
+        if (t < FM) {
+            float tot = 0.f;
+            for (int r = 0; r < 256 / CPR; ++r) tot += red[r * FM + t];
+            atomicAdd(db + nloc + t, tot);
+        }
+    }
+}
+
+template <int WM, int WN>
+void launch_wgrad_split(const float* dy, int ldy, const float* x, int ldx, int T, int N, int K, const WgradOut& out,
+                        const float* row_scale, int rows_per_scale, hipStream_t s) {
+    constexpr int FM = 32 * WM, FN = 32 * WN;
+    constexpr size_t stage = (size_t)BK * (FM + FN) * 2 * 2;                 // hi and lo images of both operands
+    constexpr size_t smem = stage > (size_t)FM * FN * 4 ? stage : (size_t)FM * FN * 4;
+    const int tiles = (N / FM) * (K / FN);
+    int nsplit = 2 * dhz_num_cus() / tiles;
+    const int max_split = T / (BK * 4) > 0 ? T / (BK * 4) : 1;           // at least 4 stages per workgroup
+    if (nsplit > max_split) nsplit = max_split;
+    if (nsplit < 1) nsplit = 1;
+    if (smem > 48 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_split_kernel<WM, WN>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)smem);
+    hipLaunchKernelGGL((wgrad_split_kernel<WM, WN>), dim3(tiles * nsplit), dim3(256), smem, s, dy, ldy, x, ldx, T, N, K, out, nsplit,
+                       row_scale, rows_per_scale);
+}
+
+}  // namespace
+
+extern "C" int dhz_linear_fwd_split(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy, int T, int N, int K,
+                                    void* stream) {
+    return dispatch_split<false>("dhz_linear_fwd_split", x, ldx, w, K, bias, y, ldy, T, N, K, (hipStream_t)stream);
+}
+
+extern "C" int dhz_linear_dgrad_split(const float* dy, int ldy, const float* w, float* dx, int ldx, int T, int N, int K, void* stream) {
+    return dispatch_split<true>("dhz_linear_dgrad_split", dy, ldy, w, K, nullptr, dx, ldx, T, K, N, (hipStream_t)stream);
+}
+
+extern "C" int dhz_linear_wgrad_split(const float* dy, int ldy, const float* x, int ldx, int T, int nmat, int nper, int K,
+                                      float* const* dw, float* const* db, const float* row_scale, int rows_per_scale, void* stream) {
+    const char* who = "dhz_linear_wgrad_split";
+    DHZ_REQUIRE(dy && x && dw, "%s: null pointer", who);
+    DHZ_REQUIRE(nmat >= 1 && nmat <= MAXMAT, "%s: nmat=%d must be 1..%d", who, nmat, MAXMAT);
+    DHZ_REQUIRE(T > 0 && T % BK == 0, "%s: T=%d must be a multiple of %d", who, T, BK);
+    DHZ_REQUIRE(nper % 64 == 0 && K % 64 == 0 && nper > 0 && K > 0, "%s: N=%d K=%d must be multiples of 64", who, nper, K);
+    const int N = nmat * nper;
+    DHZ_REQUIRE(ldy % 4 == 0 && ldx % 4 == 0 && ldy >= N && ldx >= K, "%s: bad leading dims", who);
+    DHZ_REQUIRE((((uintptr_t)dy | (uintptr_t)x) & 15) == 0, "%s: operands must be 16-byte aligned", who);
+    DHZ_REQUIRE(!row_scale || (rows_per_scale > 0 && T % rows_per_scale == 0), "%s: rows_per_scale=%d must divide T", who, rows_per_scale);
+    WgradOut out = {};
+    for (int i = 0; i < nmat; ++i) {
+        DHZ_REQUIRE(dw[i], "%s: null dw[%d]", who, i);
+        out.dw[i] = dw[i];
+        out.db[i] = db ? db[i] : nullptr;
+    }
+    out.nper = nper;
+    const int wm = nper % 128 == 0 ? 4 : 2, wn = K % 128 == 0 ? 4 : 2;
+    hipStream_t s = (hipStream_t)stream;
+#define CASE(a, b) \
+    if (wm == a && wn == b) launch_wgrad_split<a, b>(dy, ldy, x, ldx, T, N, K, out, row_scale, rows_per_scale > 0 ? rows_per_scale : 1, s);
+    CASE(4, 4) CASE(4, 2) CASE(2, 4) CASE(2, 2)
+#undef CASE
+    DHZ_CHECK_LAUNCH(who);
+    return DHZ_OK;
+}

@@ -8,6 +8,8 @@ fallback path.
 """
 import ctypes
 
+import os
+
 import torch
 from torch.autograd import Function
 
@@ -51,6 +53,11 @@ def _dt(t):
 # checkpoint, a landscape probe; views share the counter) bump it and the next bf16_copy re-casts, so a forward outside
 # train_step never reads stale weights.  (The AdamW kernel writes through raw pointers; FlatAdamW.step refreshes itself.)
 BF16_SHADOW = None
+
+# EXPERIMENT, off by default: fp32 token-Linear GEMMs with a contraction >= 128 on the bf16 matrix pipe by operand splitting
+# (hi + lo bf16 pieces, three MFMA passes, ~16 mantissa bits per product; csrc/linear_split.hip).  Not fp32 arithmetic: the
+# headline configuration never sets it; bench.py --split-bf16 reports it as a separate object.
+SPLIT_BF16 = bool(int(os.environ.get("DHZ_SPLIT_BF16", "0")))
 
 
 def set_bf16_shadow(f32, b16):
@@ -113,6 +120,8 @@ def gemm_fwd(x, W, b=None):
         ev = _timed("dhz_linear_bf16")
         _lib.call("dhz_linear_fwd_bf16", _p(x), x.stride(0), _p(Wb), _p(b), _p(y), N, T, N, K, _stream())
         _timed_end(ev, 2.0 * T * N * K)
+    elif SPLIT_BF16 and K >= 128 and K % 64 == 0 and N % 64 == 0:
+        _lib.call("dhz_linear_fwd_split", _p(x), x.stride(0), _p(W), _p(b), _p(y), N, T, N, K, _stream())
     else:
         _lib.call("dhz_linear_fwd", _p(x), x.stride(0), _p(W), _p(b), _p(y), N, T, N, K, _stream())
     return y
@@ -131,6 +140,8 @@ def gemm_dgrad(dy, W):
         ev = _timed("dhz_linear_bf16")
         _lib.call("dhz_linear_dgrad_bf16", _p(dy), dy.stride(0), _p(Wb), _p(dx), K, T, N, K, _stream())
         _timed_end(ev, 2.0 * T * N * K)
+    elif SPLIT_BF16 and N >= 128 and N % 64 == 0 and K % 64 == 0:
+        _lib.call("dhz_linear_dgrad_split", _p(dy), dy.stride(0), _p(W), _p(dx), K, T, N, K, _stream())
     else:
         _lib.call("dhz_linear_dgrad", _p(dy), dy.stride(0), _p(W), _p(dx), K, T, N, K, _stream())
     return dx
@@ -298,6 +309,20 @@ def _accumulate_param_grads(dy, ldy_off, x, params, row_scale=None):
             _lib.call("dhz_linear_wgrad_bf16", dy.data_ptr() + 2 * off, dy.stride(0), _p(x), x.stride(0), T, n, Ng, K,
                       ctypes.cast(dws, ctypes.c_void_p), ctypes.cast(dbs, ctypes.c_void_p), _stream())
             off += n * Ng
+    elif SPLIT_BF16 and T % 64 == 0 and K % 64 == 0 and all(W.shape[0] % 64 == 0 for W, _ in params):
+        # EXPERIMENT (off by default): contraction over T on the bf16 pipe with split operands (csrc/linear_split.hip)
+        groups = [params] if (same or len(params) == 1) else [[pr] for pr in params]
+        off = ldy_off
+        for grp in groups:
+            n = len(grp)
+            Ng = grp[0][0].shape[0]
+            dws = (ctypes.c_void_p * n)(*[W.grad.data_ptr() for W, _ in grp])
+            dbs = (ctypes.c_void_p * n)(*[(b.grad.data_ptr() if b is not None else None) for _, b in grp])
+            _lib.call("dhz_linear_wgrad_split", dy.data_ptr() + 4 * off, dy.stride(0), _p(x), x.stride(0), T, n, Ng, K,
+                      ctypes.cast(dws, ctypes.c_void_p), ctypes.cast(dbs, ctypes.c_void_p),
+                      _p(row_scale[0]) if row_scale is not None else None, int(row_scale[1]) if row_scale is not None else 0,
+                      _stream())
+            off += n * Ng
     elif same:
         n = len(params)
         dws = (ctypes.c_void_p * n)(*[W.grad.data_ptr() for W, _ in params])
@@ -324,6 +349,13 @@ def _accumulate_param_grads(dy, ldy_off, x, params, row_scale=None):
 def wgrad_into(dy, off, x, N, dw, db, row_scale=None):
     """dw[N,K] += dy[:, off:off+N]^T x, db += column sums (fp32 accumulators) for fp32 or bf16 dy / x."""
     T, K = x.shape
+    if SPLIT_BF16 and dy.dtype == torch.float32 and T % 64 == 0 and K % 64 == 0 and N % 64 == 0:
+        dws = (ctypes.c_void_p * 1)(dw.data_ptr())
+        dbs = (ctypes.c_void_p * 1)(db.data_ptr() if db is not None else None)
+        _lib.call("dhz_linear_wgrad_split", dy.data_ptr() + 4 * off, dy.stride(0), _p(x), x.stride(0), T, 1, N, K,
+                  ctypes.cast(dws, ctypes.c_void_p), ctypes.cast(dbs, ctypes.c_void_p),
+                  _p(row_scale[0]) if row_scale is not None else None, int(row_scale[1]) if row_scale is not None else 0, _stream())
+        return
     if row_scale is not None:
         assert dy.dtype == torch.float32
         _lib.call("dhz_linear_wgrad_rs", dy.data_ptr() + 4 * off, dy.stride(0), _p(x), x.stride(0), T, N, K, _p(dw), _p(db),
