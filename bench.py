@@ -200,7 +200,7 @@ def main():
     timing = None
     if not args.no_kernel_timing and rank == 0:
         ops.KERNEL_TIMING = {"dhz_ps_attn_fwd": [], "dhz_fused_window_attn_fwd": [], "dhz_winograd_conv3x3": [],
-                             "dhz_linear_bf16": []}
+                             "dhz_linear_bf16": [], "dhz_vgg_conv3x3_bf16": []}
     if not args.no_kernel_timing:
         for _ in range(min(args.steps, 5)):
             step()                                # every rank runs it (the step holds a collective)
@@ -273,6 +273,17 @@ def main():
                                "achieved": round(tf, 1), "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s",
                                "frac": round(tf / MFMA_BF16_PEAK_TF, 4), "traffic": None, "launches": len(ev),
                                "avg_launch_us": round(1e3 * ms / len(ev), 2), "alg_flops_per_launch": int(flops / len(ev))}
+        if timing and timing.get("dhz_vgg_conv3x3_bf16"):
+            # config 4: the VGG19 convolutions of the contrastive loss as implicit GEMMs on the bf16 matrix pipe (direct-convolution
+            # FLOPs, nothing skipped); LDS bandwidth caps this tiling near 0.5 of the dense peak
+            ev = timing["dhz_vgg_conv3x3_bf16"]
+            ms = sum(a.elapsed_time(b_) for a, b_, _ in ev)
+            flops = sum(f for _, _, f in ev)
+            tf = flops / (ms * 1e-3) / 1e12
+            out["roofline_conv_bf16"] = {"kernel": "conv3_bf16_kernel<WM,WN> (dhz_vgg_conv3x3_bf16)", "bound": "mfma",
+                                         "achieved": round(tf, 1), "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s",
+                                         "frac": round(tf / MFMA_BF16_PEAK_TF, 4), "traffic": None, "launches": len(ev),
+                                         "avg_launch_us": round(1e3 * ms / len(ev), 2), "alg_flops_per_launch": int(flops / len(ev))}
         if timing and timing.get("dhz_fused_window_attn_fwd"):
             # the window-attention kernel of the north star: LN + QKV + ProbSparse core + out-proj + residual, fused.
             # algorithmic FLOPs per window = 2*64*(4C^2 + 75C) (four CxC projections + 3x(25x64x32) core)
