@@ -201,14 +201,16 @@ int dhz_linear_dgrad(const float* dy, int ldy, const float* w, float* dx, int ld
 /* EXPERIMENT, off by default (dehaze_hip.ops.SPLIT_BF16 / bench.py --split-bf16; BASELINE configs[1] never takes it): the same two
  *     GEMMs with fp32 operands and results in HBM but the products on the bf16 matrix pipe, each operand split on its way into LDS
  *     into bf16 head + bf16 remainder and a.b taken as a_hi b_hi + a_hi b_lo + a_lo b_hi (~16 mantissa bits per product, fp32
- *     accumulation) - csrc/linear_split.hip.  N % 64 == 0, K % 64 == 0. */
+ *     accumulation) - csrc/linear_split.hip.  terms = 3: as described; terms = 6: three pieces per operand (all 24 mantissa bits)
+ *     and the six products down to 2^-16 - the error class of an fp32 GEMM at 6/16 of its matrix time.  N % 64 == 0, K % 64 == 0. */
 int dhz_linear_fwd_split(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy, int T, int N, int K,
-                         void* stream);
-int dhz_linear_dgrad_split(const float* dy, int ldy, const float* w, float* dx, int ldx, int T, int N, int K, void* stream);
+                         int terms, void* stream);
+int dhz_linear_dgrad_split(const float* dy, int ldy, const float* w, float* dx, int ldx, int T, int N, int K, int terms,
+                           void* stream);
 /*     ... and the weight gradient (contract of dhz_linear_wgrad_multi + the row scale of dhz_linear_wgrad_rs: row_scale may be NULL;
  *     dw / db HOST arrays of nmat device pointers; ACCUMULATED; db exact fp32 column sums).  T % 64 == 0, nper % 64 == 0, K % 64 == 0. */
 int dhz_linear_wgrad_split(const float* dy, int ldy, const float* x, int ldx, int T, int nmat, int nper, int K, float* const* dw,
-                           float* const* db, const float* row_scale, int rows_per_scale, void* stream);
+                           float* const* db, const float* row_scale, int rows_per_scale, int terms, void* stream);
 
 /* bf16 forms of the three token-Linear GEMMs (BASELINE config 4: bf16 activations and bf16 weight copies, fp32 accumulation on
  *     v_mfma_f32_16x16x32_bf16; biases and all parameter gradients stay fp32).  Same contracts as dhz_linear_fwd / _dgrad /

@@ -9,6 +9,10 @@
 // split arithmetic cost about a third of the fp32 matrix time and these GEMMs fall back to their HBM time.
 //     forward        y[T,N]  = x[T,K]  . W[N,K]^T + b      both operands contraction-contiguous
 //     backward-data  dx[T,K] = dy[T,N] . W[N,K]            W's rows are the contraction: transpose reads of the bf16 images
+// SIX = true is the 6-term form: three pieces per operand (hi + mid + lo = all 24 mantissa bits, exactly) and the six products
+// down to 2^-16 (hh, hm, mh, hl, lh, mm); the dropped ml, lm, ll terms are <= 2^-24 relative - the size of ONE fp32 rounding - so
+// the result is in the error class of an fp32 GEMM (not bit-identical: other grouping of the sums) at 6 / 16 of the fp32 pipe's
+// matrix time.
 // LDS images and fragment reads are those of csrc/linear_bf16.hip (one hi and one lo image per operand); operands and results stay
 // fp32 in HBM.
 #include "common.h"
@@ -56,8 +60,27 @@ __device__ __forceinline__ void split8(const f32x4 a, const f32x4 b, u32x4& hi, 
     }
 }
 
+// ... and into three pieces (the third holds what two bf16 leave: together all 24 bits)
+__device__ __forceinline__ void split8x3(const f32x4 a, const f32x4 b, u32x4& hi, u32x4& mid, u32x4& lo) {
+    const float x[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    uint32_t h[8], m[8], l[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        h[i] = f32_to_bf16(x[i]);
+        const float r1 = x[i] - __uint_as_float(h[i] << 16);
+        m[i] = f32_to_bf16(r1);
+        l[i] = f32_to_bf16(r1 - __uint_as_float(m[i] << 16));
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        hi[i] = h[2 * i] | (h[2 * i + 1] << 16);
+        mid[i] = m[2 * i] | (m[2 * i + 1] << 16);
+        lo[i] = l[2 * i] | (l[2 * i + 1] << 16);
+    }
+}
+
 // C[M,NF] = A[M,KC] . op(B) (+ bias).  BTR = false: B is [NF][KC] (forward); true: B is [KC][NF] (backward-data).
-template <int WM, int WN, bool BTR>
+template <int WM, int WN, bool BTR, bool SIX>
 __global__ __launch_bounds__(256, 2) void gemm_split_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B,
                                                             int ldb, const float* __restrict__ bias, float* __restrict__ C, int ldc,
                                                             int M, int NF, int KC, int tiles_n, int ntiles) {
@@ -66,10 +89,13 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(const float* __restr
     constexpr int B_BYTES = BTR ? BK * BN * 2 : BN * 128;
     constexpr int NA = WM, NB = WN;                              // 8-element chunks per thread per stage
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* const Ah = smem;
-    unsigned char* const Al = Ah + A_BYTES;
-    unsigned char* const Bh = Al + A_BYTES;
-    unsigned char* const Bl = Bh + B_BYTES;
+    constexpr int NP = SIX ? 3 : 2;                              // pieces (LDS images) per operand; piece NP - 1 is the smallest
+    unsigned char* const Ah = smem;                              // A images: hi, (mid,) lo
+    unsigned char* const Bh = smem + NP * A_BYTES;               // B images
+    unsigned char* const Al = Ah + (NP - 1) * A_BYTES;
+    unsigned char* const Bl = Bh + (NP - 1) * B_BYTES;
+    unsigned char* const Am = Ah + A_BYTES;                      // (SIX only)
+    unsigned char* const Bm = Bh + B_BYTES;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int i16 = lane & 15, g = lane >> 4;
     const int wm = w >> 1, wn = w & 1;
@@ -122,19 +148,23 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(const float* __restr
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             const int e = t + 256 * i;
-            u32x4 hi, lo;
-            split8(ra[i][0], ra[i][1], hi, lo);
+            u32x4 hi, mid, lo;
+            if (SIX) split8x3(ra[i][0], ra[i][1], hi, mid, lo);
+            else split8(ra[i][0], ra[i][1], hi, lo);
             const int o = off_row(e >> 3, e & 7);
             *reinterpret_cast<u32x4*>(Ah + o) = hi;
+            if (SIX) *reinterpret_cast<u32x4*>(Am + o) = mid;
             *reinterpret_cast<u32x4*>(Al + o) = lo;
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             const int e = t + 256 * i;
-            u32x4 hi, lo;
-            split8(rb[i][0], rb[i][1], hi, lo);
+            u32x4 hi, mid, lo;
+            if (SIX) split8x3(rb[i][0], rb[i][1], hi, mid, lo);
+            else split8(rb[i][0], rb[i][1], hi, lo);
             const int o = BTR ? off_tr<BN>(e / (BN / 8), e % (BN / 8)) : off_row(e >> 3, e & 7);
             *reinterpret_cast<u32x4*>(Bh + o) = hi;
+            if (SIX) *reinterpret_cast<u32x4*>(Bm + o) = mid;
             *reinterpret_cast<u32x4*>(Bl + o) = lo;
         }
     };
@@ -156,21 +186,24 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(const float* __restr
             else if (ntile >= 0) { set_tile(ntile); gload(0); }
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                s16x8 ah[WM], al[WM], bh[WN], bl[WN];
+                s16x8 ah[WM], am[SIX ? WM : 1], al[WM], bh[WN], bm[SIX ? WN : 1], bl[WN];
 #pragma unroll
                 for (int a = 0; a < WM; ++a) {
                     const int o = (wm * WM * 16 + a * 16 + i16) * 128 + 16 * ((4 * s + g) ^ sw);
                     ah[a] = *reinterpret_cast<const s16x8*>(Ah + o);
+                    if (SIX) am[a] = *reinterpret_cast<const s16x8*>(Am + o);
                     al[a] = *reinterpret_cast<const s16x8*>(Al + o);
                 }
 #pragma unroll
                 for (int b = 0; b < WN; ++b) {
                     if (BTR) {
                         bh[b] = tr_frag<BN>(Bh, 32 * s + 8 * g, wn * WN + b, lane);
+                        if (SIX) bm[b] = tr_frag<BN>(Bm, 32 * s + 8 * g, wn * WN + b, lane);
                         bl[b] = tr_frag<BN>(Bl, 32 * s + 8 * g, wn * WN + b, lane);
                     } else {
                         const int o = ((wn * WN + b) * 16 + i16) * 128 + 16 * ((4 * s + g) ^ sw);
                         bh[b] = *reinterpret_cast<const s16x8*>(Bh + o);
+                        if (SIX) bm[b] = *reinterpret_cast<const s16x8*>(Bm + o);
                         bl[b] = *reinterpret_cast<const s16x8*>(Bl + o);
                     }
                 }
@@ -180,6 +213,11 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(const float* __restr
                     for (int b = 0; b < WN; ++b) {                           // D = C^T block (epilogue); small terms first
                         acc[a][b] = mfma_bf16(bl[b], ah[a], acc[a][b]);
                         acc[a][b] = mfma_bf16(bh[b], al[a], acc[a][b]);
+                        if (SIX) {
+                            acc[a][b] = mfma_bf16(bm[b], am[a], acc[a][b]);
+                            acc[a][b] = mfma_bf16(bm[b], ah[a], acc[a][b]);
+                            acc[a][b] = mfma_bf16(bh[b], am[a], acc[a][b]);
+                        }
                         acc[a][b] = mfma_bf16(bh[b], ah[a], acc[a][b]);
                     }
             }
@@ -214,35 +252,40 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(const float* __restr
     }
 }
 
-template <int WM, int WN, bool BTR>
+template <int WM, int WN, bool BTR, bool SIX>
 void launch_split(const float* A, int lda, const float* B, int ldb, const float* bias, float* C, int ldc, int M, int NF, int KC,
                   hipStream_t s) {
     constexpr int BM = 32 * WM, BN = 32 * WN;
-    constexpr size_t smem = 2 * (size_t)(BM * 128) + 2 * (size_t)(BTR ? BK * BN * 2 : BN * 128);
+    constexpr size_t smem = (SIX ? 3 : 2) * ((size_t)(BM * 128) + (size_t)(BTR ? BK * BN * 2 : BN * 128));
     const int tiles_n = NF / BN, tiles_m = (M + BM - 1) / BM;
     const int ntiles = tiles_n * tiles_m;
     const int slots = 2 * dhz_num_cus();
     const int grid = ntiles < slots ? ntiles : slots;
     if (smem > 48 * 1024)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_split_kernel<WM, WN, BTR>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_split_kernel<WM, WN, BTR, SIX>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    hipLaunchKernelGGL((gemm_split_kernel<WM, WN, BTR>), dim3(grid), dim3(256), smem, s, A, lda, B, ldb, bias, C, ldc, M, NF, KC,
+    hipLaunchKernelGGL((gemm_split_kernel<WM, WN, BTR, SIX>), dim3(grid), dim3(256), smem, s, A, lda, B, ldb, bias, C, ldc, M, NF, KC,
                        tiles_n, ntiles);
 }
 
 template <bool BTR>
 int dispatch_split(const char* who, const float* A, int lda, const float* B, int ldb, const float* bias, float* C, int ldc, int M,
-                   int NF, int KC, hipStream_t s) {
+                   int NF, int KC, int terms, hipStream_t s) {
+    DHZ_REQUIRE(terms == 3 || terms == 6, "%s: terms=%d (3 or 6)", who, terms);
     DHZ_REQUIRE(A && B && C, "%s: null pointer", who);
     DHZ_REQUIRE(M > 0 && NF > 0 && KC > 0 && NF % 64 == 0 && KC % 64 == 0, "%s: T=%d features=%d contraction=%d (multiples of 64)", who,
                 M, NF, KC);
     DHZ_REQUIRE(lda % 4 == 0 && ldb % 4 == 0 && ldc % 4 == 0 && ldc >= NF && lda >= KC, "%s: bad leading dimensions", who);
     DHZ_REQUIRE((((uintptr_t)A | (uintptr_t)B | (uintptr_t)C | (uintptr_t)bias) & 15) == 0, "%s: operands must be 16-byte aligned", who);
-    const int wn = NF % 128 == 0 ? 4 : 2;
+    // six-term form: three LDS images per operand - 64-column tiles keep two workgroups per CU (72 KB)
+    const int wn = (NF % 128 == 0 && terms == 3) ? 4 : 2;
     const long blocks128 = (long)((M + 127) / 128) * (NF / (32 * wn));
     const int wm = blocks128 >= dhz_num_cus() ? 4 : 2;
 #define CASE(a, b) \
-    if (wm == a && wn == b) launch_split<a, b, BTR>(A, lda, B, ldb, bias, C, ldc, M, NF, KC, s);
+    if (wm == a && wn == b) {                                                                              \
+        if (terms == 3) launch_split<a, b, BTR, false>(A, lda, B, ldb, bias, C, ldc, M, NF, KC, s);        \
+        else launch_split<a, b, BTR, true>(A, lda, B, ldb, bias, C, ldc, M, NF, KC, s);                    \
+    }
     CASE(4, 4) CASE(4, 2) CASE(2, 4) CASE(2, 2)
 #undef CASE
     DHZ_CHECK_LAUNCH(who);
@@ -260,7 +303,7 @@ struct WgradOut {
     int nper;
 };
 
-template <int WM, int WN>
+template <int WM, int WN, bool SIX>
 __global__ __launch_bounds__(256, 2) void wgrad_split_kernel(const float* __restrict__ dy, int ldy, const float* __restrict__ x,
                                                              int ldx, int T, int N, int K, WgradOut out, int nsplit,
                                                              const float* __restrict__ row_scale, int rows_per_scale) {
@@ -268,10 +311,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_split_kernel(const float* __rest
     constexpr int A_BYTES = BK * FM * 2, B_BYTES = BK * FN * 2;
     constexpr int NA = BK * (FM / 8) / 256, NB = BK * (FN / 8) / 256;       // 8-element chunks per thread per stage (2 or 4)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int NP = SIX ? 3 : 2;
     unsigned char* const Ah = smem;
-    unsigned char* const Al = Ah + A_BYTES;
-    unsigned char* const Bh = Al + A_BYTES;
-    unsigned char* const Bl = Bh + B_BYTES;
+    unsigned char* const Bh = smem + NP * A_BYTES;
+    unsigned char* const Al = Ah + (NP - 1) * A_BYTES;
+    unsigned char* const Bl = Bh + (NP - 1) * B_BYTES;
+    unsigned char* const Am = Ah + A_BYTES;                      // (SIX only)
+    unsigned char* const Bm = Bh + B_BYTES;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int i16 = lane & 15, g = lane >> 4;
     const int wm = w >> 1, wn = w & 1;
@@ -320,10 +366,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_split_kernel(const float* __rest
         for (int i = 0; i < NA; ++i) {
             const int e = t + 256 * i;
             const f32x4 v0 = ra[i][0] * rs[i], v1 = ra[i][1] * rs[i];
-            u32x4 hi, lo;
-            split8(v0, v1, hi, lo);
+            u32x4 hi, mid, lo;
+            if (SIX) split8x3(v0, v1, hi, mid, lo);
+            else split8(v0, v1, hi, lo);
             const int o = off_tr<FM>(e / (FM / 8), e % (FM / 8));
             *reinterpret_cast<u32x4*>(Ah + o) = hi;
+            if (SIX) *reinterpret_cast<u32x4*>(Am + o) = mid;
             *reinterpret_cast<u32x4*>(Al + o) = lo;
             if (do_db) {
 #pragma unroll
@@ -333,10 +381,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_split_kernel(const float* __rest
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             const int e = t + 256 * i;
-            u32x4 hi, lo;
-            split8(rb[i][0], rb[i][1], hi, lo);
+            u32x4 hi, mid, lo;
+            if (SIX) split8x3(rb[i][0], rb[i][1], hi, mid, lo);
+            else split8(rb[i][0], rb[i][1], hi, lo);
             const int o = off_tr<FN>(e / (FN / 8), e % (FN / 8));
             *reinterpret_cast<u32x4*>(Bh + o) = hi;
+            if (SIX) *reinterpret_cast<u32x4*>(Bm + o) = mid;
             *reinterpret_cast<u32x4*>(Bl + o) = lo;
         }
     };
@@ -351,15 +401,17 @@ __global__ __launch_bounds__(256, 2) void wgrad_split_kernel(const float* __rest
         if (more) gload(st + 1);
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            s16x8 ah[WM], al[WM], bh[WN], bl[WN];
+            s16x8 ah[WM], am[SIX ? WM : 1], al[WM], bh[WN], bm[SIX ? WN : 1], bl[WN];
 #pragma unroll
             for (int a = 0; a < WM; ++a) {
                 ah[a] = tr_frag<FM>(Ah, 32 * s + 8 * g, wm * WM + a, lane);
+                if (SIX) am[a] = tr_frag<FM>(Am, 32 * s + 8 * g, wm * WM + a, lane);
                 al[a] = tr_frag<FM>(Al, 32 * s + 8 * g, wm * WM + a, lane);
             }
 #pragma unroll
             for (int b = 0; b < WN; ++b) {
                 bh[b] = tr_frag<FN>(Bh, 32 * s + 8 * g, wn * WN + b, lane);
+                if (SIX) bm[b] = tr_frag<FN>(Bm, 32 * s + 8 * g, wn * WN + b, lane);
                 bl[b] = tr_frag<FN>(Bl, 32 * s + 8 * g, wn * WN + b, lane);
             }
 #pragma unroll
@@ -368,6 +420,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_split_kernel(const float* __rest
                 for (int b = 0; b < WN; ++b) {
                     acc[a][b] = mfma_bf16(al[a], bh[b], acc[a][b]);
                     acc[a][b] = mfma_bf16(ah[a], bl[b], acc[a][b]);
+                    if (SIX) {
+                        acc[a][b] = mfma_bf16(am[a], bm[b], acc[a][b]);
+                        acc[a][b] = mfma_bf16(am[a], bh[b], acc[a][b]);
+                        acc[a][b] = mfma_bf16(ah[a], bm[b], acc[a][b]);
+                    }
                     acc[a][b] = mfma_bf16(ah[a], bh[b], acc[a][b]);
                 }
         }
@@ -402,11 +459,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_split_kernel(const float* __rest
     }
 }
 
-template <int WM, int WN>
+template <int WM, int WN, bool SIX>
 void launch_wgrad_split(const float* dy, int ldy, const float* x, int ldx, int T, int N, int K, const WgradOut& out,
                         const float* row_scale, int rows_per_scale, hipStream_t s) {
     constexpr int FM = 32 * WM, FN = 32 * WN;
-    constexpr size_t stage = (size_t)BK * (FM + FN) * 2 * 2;                 // hi and lo images of both operands
+    constexpr size_t stage = (size_t)BK * (FM + FN) * 2 * (SIX ? 3 : 2);     // hi, (mid,) lo images of both operands
     constexpr size_t smem = stage > (size_t)FM * FN * 4 ? stage : (size_t)FM * FN * 4;
     const int tiles = (N / FM) * (K / FN);
     int nsplit = 2 * dhz_num_cus() / tiles;
@@ -414,26 +471,29 @@ void launch_wgrad_split(const float* dy, int ldy, const float* x, int ldx, int T
     if (nsplit > max_split) nsplit = max_split;
     if (nsplit < 1) nsplit = 1;
     if (smem > 48 * 1024)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_split_kernel<WM, WN>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_split_kernel<WM, WN, SIX>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)smem);
-    hipLaunchKernelGGL((wgrad_split_kernel<WM, WN>), dim3(tiles * nsplit), dim3(256), smem, s, dy, ldy, x, ldx, T, N, K, out, nsplit,
+    hipLaunchKernelGGL((wgrad_split_kernel<WM, WN, SIX>), dim3(tiles * nsplit), dim3(256), smem, s, dy, ldy, x, ldx, T, N, K, out, nsplit,
                        row_scale, rows_per_scale);
 }
 
 }  // namespace
 
 extern "C" int dhz_linear_fwd_split(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy, int T, int N, int K,
-                                    void* stream) {
-    return dispatch_split<false>("dhz_linear_fwd_split", x, ldx, w, K, bias, y, ldy, T, N, K, (hipStream_t)stream);
+                                    int terms, void* stream) {
+    return dispatch_split<false>("dhz_linear_fwd_split", x, ldx, w, K, bias, y, ldy, T, N, K, terms, (hipStream_t)stream);
 }
 
-extern "C" int dhz_linear_dgrad_split(const float* dy, int ldy, const float* w, float* dx, int ldx, int T, int N, int K, void* stream) {
-    return dispatch_split<true>("dhz_linear_dgrad_split", dy, ldy, w, K, nullptr, dx, ldx, T, K, N, (hipStream_t)stream);
+extern "C" int dhz_linear_dgrad_split(const float* dy, int ldy, const float* w, float* dx, int ldx, int T, int N, int K, int terms,
+                                      void* stream) {
+    return dispatch_split<true>("dhz_linear_dgrad_split", dy, ldy, w, K, nullptr, dx, ldx, T, K, N, terms, (hipStream_t)stream);
 }
 
 extern "C" int dhz_linear_wgrad_split(const float* dy, int ldy, const float* x, int ldx, int T, int nmat, int nper, int K,
-                                      float* const* dw, float* const* db, const float* row_scale, int rows_per_scale, void* stream) {
+                                      float* const* dw, float* const* db, const float* row_scale, int rows_per_scale, int terms,
+                                      void* stream) {
     const char* who = "dhz_linear_wgrad_split";
+    DHZ_REQUIRE(terms == 3 || terms == 6, "%s: terms=%d (3 or 6)", who, terms);
     DHZ_REQUIRE(dy && x && dw, "%s: null pointer", who);
     DHZ_REQUIRE(nmat >= 1 && nmat <= MAXMAT, "%s: nmat=%d must be 1..%d", who, nmat, MAXMAT);
     DHZ_REQUIRE(T > 0 && T % BK == 0, "%s: T=%d must be a multiple of %d", who, T, BK);
@@ -449,10 +509,15 @@ extern "C" int dhz_linear_wgrad_split(const float* dy, int ldy, const float* x, 
         out.db[i] = db ? db[i] : nullptr;
     }
     out.nper = nper;
-    const int wm = nper % 128 == 0 ? 4 : 2, wn = K % 128 == 0 ? 4 : 2;
+    // six-term form: three images per operand - a 128 x 64 tile keeps the stage at 72 KB (two workgroups per CU)
+    const int wm = nper % 128 == 0 ? 4 : 2, wn = (K % 128 == 0 && !(terms == 6 && wm == 4)) ? 4 : 2;
     hipStream_t s = (hipStream_t)stream;
+    const int rps = rows_per_scale > 0 ? rows_per_scale : 1;
 #define CASE(a, b) \
-    if (wm == a && wn == b) launch_wgrad_split<a, b>(dy, ldy, x, ldx, T, N, K, out, row_scale, rows_per_scale > 0 ? rows_per_scale : 1, s);
+    if (wm == a && wn == b) {                                                                                  \
+        if (terms == 3) launch_wgrad_split<a, b, false>(dy, ldy, x, ldx, T, N, K, out, row_scale, rps, s);     \
+        else launch_wgrad_split<a, b, true>(dy, ldy, x, ldx, T, N, K, out, row_scale, rps, s);                 \
+    }
     CASE(4, 4) CASE(4, 2) CASE(2, 4) CASE(2, 2)
 #undef CASE
     DHZ_CHECK_LAUNCH(who);

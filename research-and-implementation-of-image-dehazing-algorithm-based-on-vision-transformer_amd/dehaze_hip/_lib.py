@@ -71,9 +71,9 @@ SIGNATURES = {
     "dhz_l1_pair_bwd_bf16": [c_f, c_f, c_f, c_f, c_f, c_l, c_p],
     "dhz_im2col_k4s2_bf16": [c_f, c_f, c_i, c_i, c_i, c_i, c_p],
     "dhz_col2im_k4s2_bf16": [c_f, c_f, c_i, c_i, c_i, c_i, c_p],
-    "dhz_linear_fwd_split": [c_f, c_i, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_p],
-    "dhz_linear_dgrad_split": [c_f, c_i, c_f, c_f, c_i, c_i, c_i, c_i, c_p],
-    "dhz_linear_wgrad_split": [c_f, c_i, c_f, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_f, c_i, c_p],
+    "dhz_linear_fwd_split": [c_f, c_i, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_p],
+    "dhz_linear_dgrad_split": [c_f, c_i, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_p],
+    "dhz_linear_wgrad_split": [c_f, c_i, c_f, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_f, c_i, c_i, c_p],
     "dhz_linear_fwd_bf16": [c_f, c_i, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_p],
     "dhz_linear_dgrad_bf16": [c_f, c_i, c_f, c_f, c_i, c_i, c_i, c_i, c_p],
     "dhz_linear_wgrad_bf16": [c_f, c_i, c_f, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p],

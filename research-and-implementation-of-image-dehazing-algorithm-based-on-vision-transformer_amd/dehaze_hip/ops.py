@@ -57,7 +57,9 @@ BF16_SHADOW = None
 # EXPERIMENT, off by default: fp32 token-Linear GEMMs with a contraction >= 128 on the bf16 matrix pipe by operand splitting
 # (hi + lo bf16 pieces, three MFMA passes, ~16 mantissa bits per product; csrc/linear_split.hip).  Not fp32 arithmetic: the
 # headline configuration never sets it; bench.py --split-bf16 reports it as a separate object.
-SPLIT_BF16 = bool(int(os.environ.get("DHZ_SPLIT_BF16", "0")))
+# 0 = off; 3 = hi / lo pieces, three products (~16 mantissa bits per product); 6 = hi / mid / lo pieces, six products (the error
+# class of an fp32 GEMM).  DHZ_SPLIT_BF16=1 means 3.
+SPLIT_BF16 = {0: 0, 1: 3, 3: 3, 6: 6}[int(os.environ.get("DHZ_SPLIT_BF16", "0"))]
 
 
 def set_bf16_shadow(f32, b16):
@@ -87,6 +89,11 @@ def bf16_copy(W):
         if 0 <= off < 4 * f32.numel() and W.untyped_storage().data_ptr() == f32.untyped_storage().data_ptr():
             return b16[off // 4: off // 4 + W.numel()].view(W.shape)
     return W.detach().to(BF16)
+
+
+def _terms():
+    """3 or 6 for the split kernels (True counts as 3)"""
+    return 6 if SPLIT_BF16 == 6 else 3
 
 
 def _timed(name):
@@ -121,7 +128,7 @@ def gemm_fwd(x, W, b=None):
         _lib.call("dhz_linear_fwd_bf16", _p(x), x.stride(0), _p(Wb), _p(b), _p(y), N, T, N, K, _stream())
         _timed_end(ev, 2.0 * T * N * K)
     elif SPLIT_BF16 and K >= 128 and K % 64 == 0 and N % 64 == 0:
-        _lib.call("dhz_linear_fwd_split", _p(x), x.stride(0), _p(W), _p(b), _p(y), N, T, N, K, _stream())
+        _lib.call("dhz_linear_fwd_split", _p(x), x.stride(0), _p(W), _p(b), _p(y), N, T, N, K, _terms(), _stream())
     else:
         _lib.call("dhz_linear_fwd", _p(x), x.stride(0), _p(W), _p(b), _p(y), N, T, N, K, _stream())
     return y
@@ -141,7 +148,7 @@ def gemm_dgrad(dy, W):
         _lib.call("dhz_linear_dgrad_bf16", _p(dy), dy.stride(0), _p(Wb), _p(dx), K, T, N, K, _stream())
         _timed_end(ev, 2.0 * T * N * K)
     elif SPLIT_BF16 and N >= 128 and N % 64 == 0 and K % 64 == 0:
-        _lib.call("dhz_linear_dgrad_split", _p(dy), dy.stride(0), _p(W), _p(dx), K, T, N, K, _stream())
+        _lib.call("dhz_linear_dgrad_split", _p(dy), dy.stride(0), _p(W), _p(dx), K, T, N, K, _terms(), _stream())
     else:
         _lib.call("dhz_linear_dgrad", _p(dy), dy.stride(0), _p(W), _p(dx), K, T, N, K, _stream())
     return dx
@@ -321,7 +328,7 @@ def _accumulate_param_grads(dy, ldy_off, x, params, row_scale=None):
             _lib.call("dhz_linear_wgrad_split", dy.data_ptr() + 4 * off, dy.stride(0), _p(x), x.stride(0), T, n, Ng, K,
                       ctypes.cast(dws, ctypes.c_void_p), ctypes.cast(dbs, ctypes.c_void_p),
                       _p(row_scale[0]) if row_scale is not None else None, int(row_scale[1]) if row_scale is not None else 0,
-                      _stream())
+                      _terms(), _stream())
             off += n * Ng
     elif same:
         n = len(params)
@@ -354,7 +361,8 @@ def wgrad_into(dy, off, x, N, dw, db, row_scale=None):
         dbs = (ctypes.c_void_p * 1)(db.data_ptr() if db is not None else None)
         _lib.call("dhz_linear_wgrad_split", dy.data_ptr() + 4 * off, dy.stride(0), _p(x), x.stride(0), T, 1, N, K,
                   ctypes.cast(dws, ctypes.c_void_p), ctypes.cast(dbs, ctypes.c_void_p),
-                  _p(row_scale[0]) if row_scale is not None else None, int(row_scale[1]) if row_scale is not None else 0, _stream())
+                  _p(row_scale[0]) if row_scale is not None else None, int(row_scale[1]) if row_scale is not None else 0, _terms(),
+                  _stream())
         return
     if row_scale is not None:
         assert dy.dtype == torch.float32

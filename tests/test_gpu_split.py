@@ -8,9 +8,15 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
+# elementwise bound against float64, relative to sum_k |a_k||b_k|: three terms drop 2^-16-class products; six terms drop only
+# 2^-24-class ones and are left with fp32 accumulation error - the class of the fp32 kernel itself
+BOUND = {3: 2.0 ** -15, 6: 2.0 ** -21}
+
+
+@pytest.mark.parametrize("terms", [3, 6])
 @pytest.mark.parametrize("T,K,N", [(4096, 128, 128), (1000, 256, 64), (777, 128, 512), (32768, 256, 64), (64, 1024, 256),
                                    (5000, 192, 64)])
-def test_split_gemm_forward_and_dgrad_vs_fp64(T, K, N):
+def test_split_gemm_forward_and_dgrad_vs_fp64(T, K, N, terms):
     from dehaze_hip import _lib
     dev = torch.device("cuda:0")
     s = torch.cuda.current_stream().cuda_stream
@@ -19,23 +25,24 @@ def test_split_gemm_forward_and_dgrad_vs_fp64(T, K, N):
     w = (torch.randn(N, K, generator=g) / K ** 0.5).to(dev)
     b = torch.randn(N, generator=g).to(dev)
     y = torch.empty(T, N, device=dev)
-    _lib.call("dhz_linear_fwd_split", x.data_ptr(), K, w.data_ptr(), b.data_ptr(), y.data_ptr(), N, T, N, K, s)
+    _lib.call("dhz_linear_fwd_split", x.data_ptr(), K, w.data_ptr(), b.data_ptr(), y.data_ptr(), N, T, N, K, terms, s)
     ref = x.double() @ w.double().t() + b.double()
     mag = x.double().abs() @ w.double().abs().t() + b.double().abs()
     err = (y.double() - ref).abs()
-    assert (err <= 2.0 ** -15 * mag).all(), (err / mag).max().item()
+    assert (err <= BOUND[terms] * mag).all(), (err / mag).max().item()
     y32 = torch.empty(T, N, device=dev)
     _lib.call("dhz_linear_fwd", x.data_ptr(), K, w.data_ptr(), b.data_ptr(), y32.data_ptr(), N, T, N, K, s)
     e32 = (y32.double() - ref).abs().max().item()
-    assert err.max().item() < 2000 * max(e32, 1e-7)                    # same algorithmic result, bounded loss of precision
+    # three terms: bounded loss of precision; six terms: within a small factor of the fp32 kernel's own error
+    assert err.max().item() < (2000 if terms == 3 else 4) * max(e32, 1e-7), (err.max().item(), e32)
     # backward-data: dx[T,K] = dy[T,N] . w[N,K] needs a contraction (N) of a multiple of 64
     dy = torch.randn(T, N, generator=g).to(dev)
     dx = torch.empty(T, K, device=dev)
-    _lib.call("dhz_linear_dgrad_split", dy.data_ptr(), N, w.data_ptr(), dx.data_ptr(), K, T, N, K, s)
+    _lib.call("dhz_linear_dgrad_split", dy.data_ptr(), N, w.data_ptr(), dx.data_ptr(), K, T, N, K, terms, s)
     ref = dy.double() @ w.double()
     mag = dy.double().abs() @ w.double().abs()
     err = (dx.double() - ref).abs()
-    assert (err <= 2.0 ** -15 * mag).all(), (err / mag).max().item()
+    assert (err <= BOUND[terms] * mag).all(), (err / mag).max().item()
 
 
 def test_split_switch_is_off_by_default_and_routes_k128():
@@ -51,9 +58,9 @@ def test_split_switch_is_off_by_default_and_routes_k128():
     _lib.call = lambda name, *a: (calls.append(name), orig(name, *a))[1]
     old = ops.SPLIT_BF16
     try:
-        ops.SPLIT_BF16 = False
+        ops.SPLIT_BF16 = 0
         y0 = ops.gemm_fwd(x, w)
-        ops.SPLIT_BF16 = True
+        ops.SPLIT_BF16 = 3
         y1 = ops.gemm_fwd(x, w)
         y2 = ops.gemm_fwd(x[:, :64].contiguous(), w[:, :64].contiguous())      # K = 64: stays on the fp32 pipe
     finally:
@@ -63,9 +70,10 @@ def test_split_switch_is_off_by_default_and_routes_k128():
     assert torch.allclose(y0, y1, atol=1e-3, rtol=1e-3) and y2.shape == (512, 64)
 
 
+@pytest.mark.parametrize("terms", [3, 6])
 @pytest.mark.parametrize("T,nmat,nper,K,scaled", [(4096, 1, 128, 64, False), (2048, 3, 64, 64, False), (8192, 1, 64, 256, True),
                                                   (1024, 1, 512, 128, False), (4096, 3, 128, 128, False)])
-def test_split_wgrad_vs_fp64(T, nmat, nper, K, scaled):
+def test_split_wgrad_vs_fp64(T, nmat, nper, K, scaled, terms):
     import ctypes
     from dehaze_hip import _lib
     dev = torch.device("cuda:0")
@@ -81,17 +89,18 @@ def test_split_wgrad_vs_fp64(T, nmat, nper, K, scaled):
     pw = (ctypes.c_void_p * nmat)(*[t.data_ptr() for t in dws])
     pb = (ctypes.c_void_p * nmat)(*[t.data_ptr() for t in dbs])
     _lib.call("dhz_linear_wgrad_split", dy.data_ptr(), N, x.data_ptr(), K, T, nmat, nper, K, ctypes.cast(pw, ctypes.c_void_p),
-              ctypes.cast(pb, ctypes.c_void_p), rs.data_ptr() if scaled else None, rps if scaled else 0, s)
+              ctypes.cast(pb, ctypes.c_void_p), rs.data_ptr() if scaled else None, rps if scaled else 0, terms, s)
     d64 = dy.double() * (rs.double().repeat_interleave(rps)[:, None] if scaled else 1.0)
     ref = d64.t() @ x.double()
     mag = d64.abs().t() @ x.double().abs()
     got = torch.cat(dws, 0).double()
     err = (got - ref).abs()
-    assert (err <= 2.0 ** -15 * mag + 1e-6).all(), (err / mag).max().item()
+    assert (err <= BOUND[terms] * mag + 1e-6).all(), (err / mag).max().item()
     assert torch.allclose(torch.cat(dbs, 0).double(), d64.sum(0), rtol=1e-5, atol=1e-3 * T ** 0.5)
 
 
-def test_split_model_step_close_to_fp32_step():
+@pytest.mark.parametrize("terms", [3, 6])
+def test_split_model_step_close_to_fp32_step(terms):
     """the whole model forward / backward with the switch on against the fp32 pipe on the same weights, batch and sampled keys:
     output PSNR, loss, parameter-gradient direction.  (The golden / oracle model tests of tests/test_gpu_model.py also pass under
     DHZ_SPLIT_BF16=1 at their fp32 tolerances - DESIGN.md section 4c; the kernel-level fp32 tolerances of tests/test_gpu_linear.py
@@ -111,7 +120,7 @@ def test_split_model_step_close_to_fp32_step():
     old = ops.SPLIT_BF16
     try:
         for flag in (False, True):
-            ops.SPLIT_BF16 = flag
+            ops.SPLIT_BF16 = terms if flag else 0
             model.zero_grad(set_to_none=True)
             torch.manual_seed(99)                                   # the same sampled keys
             out = model(hazy)
@@ -125,6 +134,6 @@ def test_split_model_step_close_to_fp32_step():
     psnr = 10 * math.log10(1.0 / max(mse, 1e-30))
     cos = torch.nn.functional.cosine_similarity(g0.double(), g1.double(), dim=0).item()
     rel = ((g0 - g1).norm() / g0.norm()).item()
-    print("split vs fp32: PSNR %.1f dB, loss %.7f vs %.7f, grad cos %.8f rel %.2e" % (psnr, l0, l1, cos, rel))
-    # measured: PSNR 132 dB, equal loss to 7 digits, gradient relative difference 1.4e-6
+    print("split(%d) vs fp32: PSNR %.1f dB, loss %.7f vs %.7f, grad cos %.8f rel %.2e" % (terms, psnr, l0, l1, cos, rel))
+    # measured (three terms): PSNR 132 dB, equal loss to 7 digits, gradient relative difference 1.4e-6
     assert psnr > 100 and abs(l0 - l1) < 1e-5 * abs(l0) and cos > 0.999999 and rel < 1e-4, (psnr, l0, l1, cos, rel)

@@ -19,7 +19,7 @@ def timeit(fn, n=20):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) * 1e3 / n
 tot = [0.0, 0.0, 0.0, 0.0]
-print(f"{'T':>7} {'K':>5} {'N':>5} | fwd fp32  split | dgrad fp32  split   (us)")
+print(f"{'T':>7} {'K':>5} {'N':>5} | fwd fp32  split3 split6 | dgrad fp32  split3 split6   (us)")
 for T, K, N in shapes:
     x = torch.randn(T, K, device=dev); w = torch.randn(N, K, device=dev) / K ** 0.5; b = torch.randn(N, device=dev)
     y = torch.empty(T, N, device=dev); dx = torch.empty(T, K, device=dev)
@@ -27,7 +27,9 @@ for T, K, N in shapes:
     ok_f = K >= 128 and K % 64 == 0 and N % 64 == 0
     ok_d = N >= 128 and N % 64 == 0 and K % 64 == 0
     r.append(timeit(lambda: _lib.call("dhz_linear_fwd", x.data_ptr(), K, w.data_ptr(), b.data_ptr(), y.data_ptr(), N, T, N, K, s)))
-    r.append(timeit(lambda: _lib.call("dhz_linear_fwd_split", x.data_ptr(), K, w.data_ptr(), b.data_ptr(), y.data_ptr(), N, T, N, K, s)) if ok_f else float('nan'))
+    for terms in (3, 6):
+        r.append(timeit(lambda: _lib.call("dhz_linear_fwd_split", x.data_ptr(), K, w.data_ptr(), b.data_ptr(), y.data_ptr(), N, T, N, K, terms, s)) if ok_f else float('nan'))
     r.append(timeit(lambda: _lib.call("dhz_linear_dgrad", y.data_ptr(), N, w.data_ptr(), dx.data_ptr(), K, T, N, K, s)))
-    r.append(timeit(lambda: _lib.call("dhz_linear_dgrad_split", y.data_ptr(), N, w.data_ptr(), dx.data_ptr(), K, T, N, K, s)) if ok_d else float('nan'))
-    print(f"{T:7d} {K:5d} {N:5d} | {r[0]:8.1f} {r[1]:6.1f} | {r[2]:10.1f} {r[3]:6.1f}")
+    for terms in (3, 6):
+        r.append(timeit(lambda: _lib.call("dhz_linear_dgrad_split", y.data_ptr(), N, w.data_ptr(), dx.data_ptr(), K, T, N, K, terms, s)) if ok_d else float('nan'))
+    print(f"{T:7d} {K:5d} {N:5d} | {r[0]:8.1f} {r[1]:6.1f} {r[2]:6.1f} | {r[3]:10.1f} {r[4]:6.1f} {r[5]:6.1f}")
