@@ -60,22 +60,25 @@ __device__ __forceinline__ void split8(const f32x4 a, const f32x4 b, u32x4& hi, 
     }
 }
 
-// ... and into three pieces (the third holds what two bf16 leave: together all 24 bits)
+// ... and into three pieces by TRUNCATION: a bf16 is the top 16 bits of the fp32 pattern, so each piece takes the next eight
+// significant bits of what is left (x - hi and r - mid are exact) and three pieces hold all 24.  Per pair of elements: two masks
+// and one packed subtraction per level, one v_perm_b32 per piece to pack the two top halves - 4.5 VALU instructions per element.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pack_top(float x1, float x0) {              // (x1 & 0xffff0000) | (x0 >> 16)
+    return __builtin_amdgcn_perm(__float_as_uint(x1), __float_as_uint(x0), 0x07060302u);
+}
+__device__ __forceinline__ f32x2 top16(f32x2 v) {
+    return f32x2{__uint_as_float(__float_as_uint(v[0]) & 0xffff0000u), __uint_as_float(__float_as_uint(v[1]) & 0xffff0000u)};
+}
 __device__ __forceinline__ void split8x3(const f32x4 a, const f32x4 b, u32x4& hi, u32x4& mid, u32x4& lo) {
-    const float x[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
-    uint32_t h[8], m[8], l[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        h[i] = f32_to_bf16(x[i]);
-        const float r1 = x[i] - __uint_as_float(h[i] << 16);
-        m[i] = f32_to_bf16(r1);
-        l[i] = f32_to_bf16(r1 - __uint_as_float(m[i] << 16));
-    }
+    const f32x2 x[4] = {{a[0], a[1]}, {a[2], a[3]}, {b[0], b[1]}, {b[2], b[3]}};
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        hi[i] = h[2 * i] | (h[2 * i + 1] << 16);
-        mid[i] = m[2 * i] | (m[2 * i + 1] << 16);
-        lo[i] = l[2 * i] | (l[2 * i + 1] << 16);
+        const f32x2 r1 = x[i] - top16(x[i]);
+        const f32x2 r2 = r1 - top16(r1);
+        hi[i] = pack_top(x[i][1], x[i][0]);
+        mid[i] = pack_top(r1[1], r1[0]);
+        lo[i] = pack_top(r2[1], r2[0]);
     }
 }
 
@@ -278,7 +281,7 @@ int dispatch_split(const char* who, const float* A, int lda, const float* B, int
     DHZ_REQUIRE(lda % 4 == 0 && ldb % 4 == 0 && ldc % 4 == 0 && ldc >= NF && lda >= KC, "%s: bad leading dimensions", who);
     DHZ_REQUIRE((((uintptr_t)A | (uintptr_t)B | (uintptr_t)C | (uintptr_t)bias) & 15) == 0, "%s: operands must be 16-byte aligned", who);
     // six-term form: three LDS images per operand - 64-column tiles keep two workgroups per CU (72 KB)
-    const int wn = (NF % 128 == 0 && terms == 3) ? 4 : 2;
+    const int wn = (NF % 128 == 0 && terms == 3) ? 4 : 2;      // (128-column tiles at 96 KB / one workgroup per CU: slower, measured)
     const long blocks128 = (long)((M + 127) / 128) * (NF / (32 * wn));
     const int wm = blocks128 >= dhz_num_cus() ? 4 : 2;
 #define CASE(a, b) \
