@@ -6,6 +6,7 @@ dhz_linear_fwd / dhz_linear_dgrad / dhz_linear_wgrad).  What still runs on vendo
 (the 8x8 last VGG layer on MIOpen; the library convolutions of the bf16 mode).  CPU tensors are rejected - there is no
 fallback path.
 """
+import collections
 import ctypes
 
 import os
@@ -26,8 +27,18 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+# The last tensors whose device pointers were handed to a launch: a pointer argument is often taken from a temporary
+# (`_p(g.contiguous())`, `_p(w.to(dtype))`), which Python drops as soon as `_p` returns - before the launch is even enqueued.
+# Stream order makes a later reuse of that block by the same stream harmless, but not a reuse from another stream (the
+# reducer's, a loader's).  Keeping the most recent ones referenced closes the whole class; 64 covers the longest argument list.
+_RECENT = collections.deque(maxlen=64)
+
+
 def _p(t):
-    return None if t is None else t.data_ptr()
+    if t is None:
+        return None
+    _RECENT.append(t)
+    return t.data_ptr()
 
 
 def _require_gpu(*tensors):

@@ -230,3 +230,25 @@ def test_pmc_traffic_is_tied_to_the_loaded_library(tmp_path):
     assert pmc == {} and "not reported" in src                   # -> every roofline object gets "traffic": null
     pmc, src = bench.load_pmc_traffic(str(tmp_path / "missing.json"), bid)
     assert pmc == {} and "not reported" in src
+
+
+def test_pointer_arguments_keep_their_tensors_alive():
+    """ops._p hands a raw device pointer to a launch; a temporary (`_p(g.contiguous())`) must not be freed the moment _p returns:
+    the most recent pointer-argument tensors stay referenced (longer than the longest argument list)."""
+    import gc
+    import weakref
+    import torch
+    from dehaze_hip import ops
+    t = torch.arange(12.0).view(3, 4).t()                 # non-contiguous: .contiguous() makes a temporary
+    tmp = t.contiguous()
+    ref = weakref.ref(tmp)
+    ptr = ops._p(tmp)
+    del tmp
+    gc.collect()
+    assert ref() is not None and ref().data_ptr() == ptr  # still alive although no caller holds it
+    keep = [torch.zeros(1) for _ in range(ops._RECENT.maxlen)]
+    for k in keep:
+        ops._p(k)
+    gc.collect()
+    assert ref() is None                                  # and released once enough launches have gone by
+    assert ops._p(None) is None and ops._RECENT.maxlen >= 32
