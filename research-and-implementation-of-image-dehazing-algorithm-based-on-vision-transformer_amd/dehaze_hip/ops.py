@@ -71,6 +71,7 @@ BF16_SHADOW = None
 # 0 = off; 3 = hi / lo pieces, three products (~16 mantissa bits per product); 6 = hi / mid / lo pieces, six products (the error
 # class of an fp32 GEMM).  DHZ_SPLIT_BF16=1 means 3.
 SPLIT_BF16 = {0: 0, 1: 3, 3: 3, 6: 6}[int(os.environ.get("DHZ_SPLIT_BF16", "0"))]
+SPLIT_MIN_K = int(os.environ.get("DHZ_SPLIT_MIN_K", "128"))      # smallest contraction the forward / backward-data GEMMs split
 
 
 def set_bf16_shadow(f32, b16):
@@ -138,7 +139,7 @@ def gemm_fwd(x, W, b=None):
         ev = _timed("dhz_linear_bf16")
         _lib.call("dhz_linear_fwd_bf16", _p(x), x.stride(0), _p(Wb), _p(b), _p(y), N, T, N, K, _stream())
         _timed_end(ev, 2.0 * T * N * K)
-    elif SPLIT_BF16 and K >= 128 and K % 64 == 0 and N % 64 == 0:
+    elif SPLIT_BF16 and K >= SPLIT_MIN_K and K % 64 == 0 and N % 64 == 0:
         _lib.call("dhz_linear_fwd_split", _p(x), x.stride(0), _p(W), _p(b), _p(y), N, T, N, K, _terms(), _stream())
     else:
         _lib.call("dhz_linear_fwd", _p(x), x.stride(0), _p(W), _p(b), _p(y), N, T, N, K, _stream())
@@ -158,7 +159,7 @@ def gemm_dgrad(dy, W):
         ev = _timed("dhz_linear_bf16")
         _lib.call("dhz_linear_dgrad_bf16", _p(dy), dy.stride(0), _p(Wb), _p(dx), K, T, N, K, _stream())
         _timed_end(ev, 2.0 * T * N * K)
-    elif SPLIT_BF16 and N >= 128 and N % 64 == 0 and K % 64 == 0:
+    elif SPLIT_BF16 and N >= SPLIT_MIN_K and N % 64 == 0 and K % 64 == 0:
         _lib.call("dhz_linear_dgrad_split", _p(dy), dy.stride(0), _p(W), _p(dx), K, T, N, K, _terms(), _stream())
     else:
         _lib.call("dhz_linear_dgrad", _p(dy), dy.stride(0), _p(W), _p(dx), K, T, N, K, _stream())
