@@ -45,34 +45,50 @@ struct ThinWgradSmem {
 // channel-blocked NCHW8c map [B, C/8, H, W, 8] (the layout of the fp32 VGG feature engine)
 // All requests of a thread are issued before the first LDS write (clamped addresses + select instead of a divergent guard): as a
 // loop of (load, write) pairs the tile cost one global round trip per iteration - 12 of them.
+constexpr int TOK_NIT = (NPOS * (CC / 4) + 255) / 256;           // 16-byte requests per thread per (tile, channel chunk): 12
+struct TokRegs {
+    f32x4 v[TOK_NIT];
+    unsigned ok;                                                 // bit i: request i lies inside the image
+};
 template <int C, bool BLOCKED = false, typename T = float>
-__device__ __forceinline__ void stage_tokens(float* xs, const T* __restrict__ x, int bimg, int ty, int tx, int H, int W, int cb) {
+__device__ __forceinline__ void fetch_tokens(TokRegs& r, const T* __restrict__ x, int bimg, int ty, int tx, int H, int W, int cb) {
     constexpr int C4 = CC / 4;
-    constexpr int NIT = (NPOS * C4 + 255) / 256;
     const int t = threadIdx.x;
     const size_t ib = (size_t)bimg * H * W;
-    f32x4 v[NIT];
-    bool ok[NIT];
+    r.ok = 0u;
 #pragma unroll
-    for (int i = 0; i < NIT; ++i) {
+    for (int i = 0; i < TOK_NIT; ++i) {
         const int e = min(t + 256 * i, NPOS * C4 - 1);
         const int pos = BLOCKED ? e % NPOS : e / C4, c4 = BLOCKED ? e / NPOS : e % C4;     // consecutive lanes walk the contiguous axis
         const int yy = ty * TH - 1 + pos / HW_, xx = tx * TW - 1 + pos % HW_;
-        ok[i] = yy >= 0 && yy < H && xx >= 0 && xx < W;
+        if (yy >= 0 && yy < H && xx >= 0 && xx < W) r.ok |= 1u << i;
         const int yc = min(max(yy, 0), H - 1), xc = min(max(xx, 0), W - 1);
         const int c = cb + c4 * 4;
         const size_t o = BLOCKED ? (((size_t)bimg * (C / 8) + c / 8) * H * W + (size_t)yc * W + xc) * 8 + (c & 7)
                                  : (ib + (size_t)yc * W + xc) * C + c;
-        v[i] = ld4v(x + o);
+        r.v[i] = ld4v(x + o);
     }
+}
+template <bool BLOCKED = false>
+__device__ __forceinline__ void put_tokens(float* xs, const TokRegs& r) {
+    constexpr int C4 = CC / 4;
+    const int t = threadIdx.x;
 #pragma unroll
-    for (int i = 0; i < NIT; ++i) {
+    for (int i = 0; i < TOK_NIT; ++i) {
         const int e = t + 256 * i;
         if (e < NPOS * C4) {
             const int pos = BLOCKED ? e % NPOS : e / C4, c4 = BLOCKED ? e / NPOS : e % C4;
-            *reinterpret_cast<f32x4*>(&xs[pos * XS + c4 * 4]) = ok[i] ? v[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+            *reinterpret_cast<f32x4*>(&xs[pos * XS + c4 * 4]) = ((r.ok >> i) & 1u) ? r.v[i] : f32x4{0.f, 0.f, 0.f, 0.f};
         }
     }
+}
+// All requests of a thread are issued before the first LDS write (clamped addresses + select instead of a divergent guard): as a
+// loop of (load, write) pairs the tile cost one global round trip per iteration - 12 of them.
+template <int C, bool BLOCKED = false, typename T = float>
+__device__ __forceinline__ void stage_tokens(float* xs, const T* __restrict__ x, int bimg, int ty, int tx, int H, int W, int cb) {
+    TokRegs r;
+    fetch_tokens<C, BLOCKED, T>(r, x, bimg, ty, tx, H, W, cb);
+    put_tokens<BLOCKED>(xs, r);
 }
 
 // TRANSPOSED: w is a [C, 3, 3, 3] tensor (a 3 -> C convolution's weight) and the kernel computes that layer's
@@ -80,13 +96,14 @@ __device__ __forceinline__ void stage_tokens(float* xs, const T* __restrict__ x,
 template <int C, bool BLOCKED, bool TRANSPOSED, typename T = float>
 __global__ __launch_bounds__(256, 2) void thin_conv_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w,
                                                                const float* __restrict__ bias, float* __restrict__ y, int H,
-                                                               int W, int tiles_x, int tiles_y) {
+                                                               int W, int tiles_x, int tiles_y, int ntiles) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     ThinFwdSmem& sm = *reinterpret_cast<ThinFwdSmem*>(smem_raw);
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     const int i16 = lane & 15, g = lane >> 4;
-    const int tx = blockIdx.x % tiles_x, ty = (blockIdx.x / tiles_x) % tiles_y, bimg = blockIdx.x / (tiles_x * tiles_y);
-    // weights -> LDS as wl[c][n = o * 9 + tap] (32 columns, 27 used) with coalesced reads of w; the slot is Z's
+    constexpr int NCH = C / CC;
+    // Persistent workgroups.  The weights go through LDS once (coalesced reads of w, re-ordered to wl[c][n = o * 9 + tap], 32
+    // columns, 27 used; the slot is Z's) into registers in the MFMA operand layout and stay there for all tiles.
     float* wl = sm.z;
     static_assert(C * 32 <= NRB * 16 * ZS, "weight staging must fit the Z slot");
     {
@@ -106,53 +123,79 @@ __global__ __launch_bounds__(256, 2) void thin_conv_fwd_kernel(const T* __restri
         }
     }
     for (int e = t; e < 5 * C; e += 256) wl[(e / 5) * 32 + 27 + e % 5] = 0.f;
+    __syncthreads();
+    // contraction order inside a 16-channel group: MFMA step j of group s4 takes channel 16 s4 + 4 g + j from lane group g, so a
+    // lane's four steps read ONE b128 of its token row (any order of the contraction is as good as another)
+    float wr[C / 16][4][2];
+#pragma unroll
+    for (int s4 = 0; s4 < C / 16; ++s4)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) wr[s4][j][nb] = wl[(16 * s4 + 4 * g + j) * 32 + 16 * nb + i16];
+    const float b0 = bias ? bias[0] : 0.f, b1 = bias ? bias[1] : 0.f, b2 = bias ? bias[2] : 0.f;
+    __syncthreads();                                                          // the slot becomes Z
+
     // Z^T block = W^T (rows n) . X^T (columns q): the accumulator of lane (q = i16) holds n = 4 g .. 4 g + 3 -> one b128 store
     // into Z[q][.].  Wave wv owns row blocks 3 wv .. 3 wv + 2 (halo positions) x both column blocks.
-    f32x4 acc[3][2];
-#pragma unroll
-    for (int r = 0; r < 3; ++r)
-#pragma unroll
-        for (int nb = 0; nb < 2; ++nb) acc[r][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll 1
-    for (int cb = 0; cb < C; cb += CC) {
-        if (cb) __syncthreads();                                              // the previous chunk's tile is still being read
-        stage_tokens<C, BLOCKED, T>(sm.x, x, bimg, ty, tx, H, W, cb);
-        __syncthreads();
-        // contraction order inside a 16-channel group: MFMA step j of group s4 takes channel 16 s4 + 4 g + j from lane group g,
-        // so a lane's four steps read ONE b128 of its token row (any order of the contraction is as good as another)
-#pragma unroll
-        for (int s4 = 0; s4 < CC / 16; ++s4) {
-            float wr[4][2];
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int nb = 0; nb < 2; ++nb) wr[j][nb] = wl[(cb + 16 * s4 + 4 * g + j) * 32 + 16 * nb + i16];
-#pragma unroll
-            for (int r = 0; r < 3; ++r) {
-                const f32x4 xv = *reinterpret_cast<const f32x4*>(&sm.x[(16 * (3 * wv + r) + i16) * XS + 16 * s4 + 4 * g]);
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int nb = 0; nb < 2; ++nb)
-                        acc[r][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[j][nb], xv[j], acc[r][nb], 0, 0, 0);
-            }
-        }
+    // The token requests of step s + 1 (next channel chunk, or the next tile's first) are in flight while step s multiplies,
+    // gathers and stores - before that, every tile paid one exposed global round trip with two workgroups per CU to hide it.
+    TokRegs regs;
+    int tile = blockIdx.x;
+    auto coords = [&](int tl, int& tx, int& ty, int& bimg) { tx = tl % tiles_x; ty = (tl / tiles_x) % tiles_y; bimg = tl / (tiles_x * tiles_y); };
+    {
+        int tx, ty, bimg;
+        coords(tile, tx, ty, bimg);
+        fetch_tokens<C, BLOCKED, T>(regs, x, bimg, ty, tx, H, W, 0);
     }
-    __syncthreads();                                                          // weights (in Z's slot) no longer needed
+    for (; tile < ntiles; tile += gridDim.x) {
+        int tx, ty, bimg;
+        coords(tile, tx, ty, bimg);
+        f32x4 acc[3][2];
 #pragma unroll
-    for (int r = 0; r < 3; ++r)
+        for (int r = 0; r < 3; ++r)
 #pragma unroll
-        for (int nb = 0; nb < 2; ++nb)
-            *reinterpret_cast<f32x4*>(&sm.z[(16 * (3 * wv + r) + i16) * ZS + 16 * nb + 4 * g]) = acc[r][nb];
-    __syncthreads();
-    for (int e = t; e < 3 * TH * TW; e += 256) {
-        const int o = e / (TH * TW), p = e % (TH * TW);
-        const int py = p / TW, px = p % TW;
-        const int yy = ty * TH + py, xx = tx * TW + px;
-        float a = bias ? bias[o] : 0.f;
+            for (int nb = 0; nb < 2; ++nb) acc[r][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) a += sm.z[((py + tap / 3) * HW_ + px + tap % 3) * ZS + o * 9 + tap];
-        if (yy < H && xx < W) y[(((size_t)bimg * 3 + o) * H + yy) * W + xx] = a;
+        for (int ch = 0; ch < NCH; ++ch) {
+            put_tokens<BLOCKED>(sm.x, regs);
+            __syncthreads();
+            if (ch + 1 < NCH) fetch_tokens<C, BLOCKED, T>(regs, x, bimg, ty, tx, H, W, (ch + 1) * CC);
+            else if (tile + (int)gridDim.x < ntiles) {
+                int nx, ny, nb_;
+                coords(tile + gridDim.x, nx, ny, nb_);
+                fetch_tokens<C, BLOCKED, T>(regs, x, nb_, ny, nx, H, W, 0);
+            }
+#pragma unroll
+            for (int s4 = 0; s4 < CC / 16; ++s4) {
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    const f32x4 xv = *reinterpret_cast<const f32x4*>(&sm.x[(16 * (3 * wv + r) + i16) * XS + 16 * s4 + 4 * g]);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int nb = 0; nb < 2; ++nb)
+                            acc[r][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[ch * (CC / 16) + s4][j][nb], xv[j], acc[r][nb], 0, 0, 0);
+                }
+            }
+            if (ch + 1 < NCH) __syncthreads();                                // this chunk's tile is read; the next one may land
+        }
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+                *reinterpret_cast<f32x4*>(&sm.z[(16 * (3 * wv + r) + i16) * ZS + 16 * nb + 4 * g]) = acc[r][nb];
+        __syncthreads();                                                      // Z complete; also: every wave is done with sm.x
+        for (int e = t; e < 3 * TH * TW; e += 256) {
+            const int o = e / (TH * TW), p = e % (TH * TW);
+            const int py = p / TW, px = p % TW;
+            const int yy = ty * TH + py, xx = tx * TW + px;
+            float a = o == 0 ? b0 : (o == 1 ? b1 : b2);
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) a += sm.z[((py + tap / 3) * HW_ + px + tap % 3) * ZS + o * 9 + tap];
+            if (yy < H && xx < W) y[(((size_t)bimg * 3 + o) * H + yy) * W + xx] = a;
+        }
+        // (the next tile's Z stores come after its own put + barrier: the gather above is finished by then)
     }
 }
 
@@ -222,18 +265,46 @@ __global__ __launch_bounds__(256, 2) void thin_conv_wgrad_kernel(const float* __
     float accb0 = 0.f, accb1 = 0.f;                                           // db: dy sums of output t / 128, and (t < 128) of output 2
     for (int e = t; e < NPOS * GS; e += 256) sm.g[e] = 0.f;                   // columns 27 .. 32 stay zero
     const int ntiles = B * tiles_x * tiles_y;
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, bimg = tile / (tiles_x * tiles_y);
-        __syncthreads();                                                      // previous tile's reads done
-        for (int e = t; e < 3 * TH * TW; e += 256) {
+    // the token requests (and the 3 x 128 dy values) of the next step - next channel chunk, or the next tile - are in flight while
+    // this one multiplies
+    TokRegs regs;
+    float dyr[2];
+    auto coords = [&](int tl, int& tx, int& ty, int& bimg) { tx = tl % tiles_x; ty = (tl / tiles_x) % tiles_y; bimg = tl / (tiles_x * tiles_y); };
+    auto fetch_dy = [&](int tl) {
+        int tx, ty, bimg;
+        coords(tl, tx, ty, bimg);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int e = min(t + 256 * i, 3 * TH * TW - 1);
             const int o = e / (TH * TW), p = e % (TH * TW);
             const int yy = ty * TH + p / TW, xx = tx * TW + p % TW;
-            const float v = (yy < H && xx < W) ? dy[(((size_t)bimg * 3 + o) * H + yy) * W + xx] : 0.f;
-            sm.dy[e] = v;
-            if (e < 256) accb0 += v; else accb1 += v;
+            const float v = dy[(((size_t)bimg * 3 + o) * H + min(yy, H - 1)) * W + min(xx, W - 1)];
+            dyr[i] = (yy < H && xx < W) ? v : 0.f;
         }
-        stage_tokens<C, false, T>(sm.x, x, bimg, ty, tx, H, W, 0);
+    };
+    if ((int)blockIdx.x < ntiles) {
+        int tx, ty, bimg;
+        coords(blockIdx.x, tx, ty, bimg);
+        fetch_tokens<C, false, T>(regs, x, bimg, ty, tx, H, W, 0);
+        fetch_dy(blockIdx.x);
+    }
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        int tx, ty, bimg;
+        coords(tile, tx, ty, bimg);
+        const bool has_next = tile + (int)gridDim.x < ntiles;
+        __syncthreads();                                                      // previous tile's reads done
+        sm.dy[t] = dyr[0];
+        accb0 += dyr[0];
+        if (t < 3 * TH * TW - 256) { sm.dy[t + 256] = dyr[1]; accb1 += dyr[1]; }
+        put_tokens<false>(sm.x, regs);
         __syncthreads();
+        if (NCH > 1) fetch_tokens<C, false, T>(regs, x, bimg, ty, tx, H, W, CC);
+        else if (has_next) {
+            int nx, ny, nb_;
+            coords(tile + gridDim.x, nx, ny, nb_);
+            fetch_tokens<C, false, T>(regs, x, nb_, ny, nx, H, W, 0);
+            fetch_dy(tile + gridDim.x);
+        }
         // G[q][(o, tap)] = dy[o][q - (ky, kx)] in tile coordinates (q: halo position, its origin one pixel up / left)
         for (int e = t; e < NPOS * 3; e += 256) {                             // one (halo position, output) per trip: 9 taps
             const int q = e % NPOS, o = e / NPOS;
@@ -250,8 +321,15 @@ __global__ __launch_bounds__(256, 2) void thin_conv_wgrad_kernel(const float* __
         for (int ch = 0; ch < NCH; ++ch) {
             if (ch) {
                 __syncthreads();
-                stage_tokens<C, false, T>(sm.x, x, bimg, ty, tx, H, W, ch * CC);
+                put_tokens<false>(sm.x, regs);
                 __syncthreads();
+                if (ch + 1 < NCH) fetch_tokens<C, false, T>(regs, x, bimg, ty, tx, H, W, (ch + 1) * CC);
+                else if (has_next) {
+                    int nx, ny, nb_;
+                    coords(tile + gridDim.x, nx, ny, nb_);
+                    fetch_tokens<C, false, T>(regs, x, nb_, ny, nx, H, W, 0);
+                    fetch_dy(tile + gridDim.x);
+                }
             }
 #pragma unroll 5
             for (int ks = 0; ks < NPOS / 4; ++ks) {
@@ -342,7 +420,8 @@ int launch_all(int which, const void* a, const float* b, const float* c, void* d
     if (which == 0) {
         const size_t smem = sizeof(ThinFwdSmem);            // a = tokens x (T), b = w, c = bias, d = image y (float)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&thin_conv_fwd_kernel<C, false, false, T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        hipLaunchKernelGGL((thin_conv_fwd_kernel<C, false, false, T>), dim3(ntiles), dim3(256), smem, s, (const T*)a, b, c, (float*)d, H, W, tiles_x, tiles_y);
+        const int cap = 2 * dhz_num_cus();                   // two resident workgroups per CU (LDS), persistent over tiles
+        hipLaunchKernelGGL((thin_conv_fwd_kernel<C, false, false, T>), dim3(ntiles < cap ? ntiles : cap), dim3(256), smem, s, (const T*)a, b, c, (float*)d, H, W, tiles_x, tiles_y, ntiles);
     } else if (which == 1) {     // a = image gradient dy (float), b = w, d = token gradient dx (T)
         hipLaunchKernelGGL((thin_conv_dgrad_kernel<C, T>), dim3(ntiles), dim3(256), 0, s, (const float*)a, b, (T*)d, H, W, tiles_x, tiles_y);
     } else {                     // a = dy (float), b -> tokens x (T) passed through c's slot: see dispatch
@@ -418,8 +497,9 @@ extern "C" int dhz_thin_conv3x3_dgrad_blocked(const float* gb, const float* w, f
     const size_t smem = sizeof(ThinFwdSmem);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&thin_conv_fwd_kernel<64, true, true>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    hipLaunchKernelGGL((thin_conv_fwd_kernel<64, true, true>), dim3(ntiles), dim3(256), smem, (hipStream_t)stream, gb, w, nullptr,
-                       dx, H, W, tiles_x, tiles_y);
+    const int cap = 2 * dhz_num_cus();
+    hipLaunchKernelGGL((thin_conv_fwd_kernel<64, true, true>), dim3(ntiles < cap ? ntiles : cap), dim3(256), smem, (hipStream_t)stream, gb,
+                       w, nullptr, dx, H, W, tiles_x, tiles_y, ntiles);
     DHZ_CHECK_LAUNCH("dhz_thin_conv3x3_dgrad_blocked");
     return DHZ_OK;
 }
