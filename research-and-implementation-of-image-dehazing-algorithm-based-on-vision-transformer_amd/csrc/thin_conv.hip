@@ -18,6 +18,10 @@
 // Channels are processed in chunks of 64 (C = 128: two passes over the tile) so two workgroups fit a CU's LDS.
 #include "common.h"
 
+#ifndef TW_ABL
+#define TW_ABL 0        // timing diagnostics of the weight-gradient kernel (tools/variants.sh): 1 no MFMA loop, 2 no G build, 4 no token fetch / put, 8 no atomics
+#endif
+
 namespace {
 
 constexpr int TW = 16, TH = 8;                 // output pixels per workgroup
@@ -296,9 +300,9 @@ __global__ __launch_bounds__(256, 2) void thin_conv_wgrad_kernel(const float* __
         sm.dy[t] = dyr[0];
         accb0 += dyr[0];
         if (t < 3 * TH * TW - 256) { sm.dy[t + 256] = dyr[1]; accb1 += dyr[1]; }
-        put_tokens<false>(sm.x, regs);
+        if (!(TW_ABL & 4)) put_tokens<false>(sm.x, regs);
         __syncthreads();
-        if (NCH > 1) fetch_tokens<C, false, T>(regs, x, bimg, ty, tx, H, W, CC);
+        if (TW_ABL & 4) {} else if (NCH > 1) fetch_tokens<C, false, T>(regs, x, bimg, ty, tx, H, W, CC);
         else if (has_next) {
             int nx, ny, nb_;
             coords(tile + gridDim.x, nx, ny, nb_);
@@ -306,14 +310,20 @@ __global__ __launch_bounds__(256, 2) void thin_conv_wgrad_kernel(const float* __
             fetch_dy(tile + gridDim.x);
         }
         // G[q][(o, tap)] = dy[o][q - (ky, kx)] in tile coordinates (q: halo position, its origin one pixel up / left)
-        for (int e = t; e < NPOS * 3; e += 256) {                             // one (halo position, output) per trip: 9 taps
-            const int q = e % NPOS, o = e / NPOS;
-            const int qy = q / HW_, qx = q % HW_;
+        // (no loop with a back edge between a fetch and its put: hipcc drains vmcnt in front of one, which would wait for the
+        // prefetch right here)
 #pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
-                const int py = qy - tap / 3, px = qx - tap % 3;
-                const bool in = (unsigned)py < (unsigned)TH && (unsigned)px < (unsigned)TW;
-                sm.g[q * GS + o * 9 + tap] = in ? sm.dy[o * TH * TW + (in ? py * TW + px : 0)] : 0.f;
+        for (int it = 0; it < (NPOS * 3 + 255) / 256; ++it) {                 // one (halo position, output) per trip: 9 taps
+            const int e = t + 256 * it;
+            if (e < NPOS * 3 && !(TW_ABL & 2)) {
+                const int q = e % NPOS, o = e / NPOS;
+                const int qy = q / HW_, qx = q % HW_;
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) {
+                    const int py = qy - tap / 3, px = qx - tap % 3;
+                    const bool in = (unsigned)py < (unsigned)TH && (unsigned)px < (unsigned)TW;
+                    sm.g[q * GS + o * 9 + tap] = in ? sm.dy[o * TH * TW + (in ? py * TW + px : 0)] : 0.f;
+                }
             }
         }
         __syncthreads();
@@ -331,8 +341,8 @@ __global__ __launch_bounds__(256, 2) void thin_conv_wgrad_kernel(const float* __
                     fetch_dy(tile + gridDim.x);
                 }
             }
-#pragma unroll 5
-            for (int ks = 0; ks < NPOS / 4; ++ks) {
+#pragma unroll
+            for (int ks = 0; ks < ((TW_ABL & 1) ? 1 : NPOS / 4); ++ks) {
                 const int q = 4 * ks + g;
                 const float xv = sm.x[q * XS + 16 * wv + i16];
                 const float g0 = sm.g[q * GS + i16], g1 = sm.g[q * GS + 16 + i16];
@@ -347,7 +357,7 @@ __global__ __launch_bounds__(256, 2) void thin_conv_wgrad_kernel(const float* __
 #pragma unroll
         for (int nb = 0; nb < 2; ++nb) {
             const int n = 16 * nb + i16;
-            if (n < 27) {
+            if (n < 27 && !(TW_ABL & 8)) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int c = CC * ch + 16 * wv + 4 * g + r;
