@@ -84,3 +84,23 @@ def test_bench_bf16_contract_line():
     assert d["dtype"] == "bf16" and d["metric"] == "train patches/sec (128x128, embed_dim=64)" and d["config"]["global_batch"] == 2
     ro = d["roofline"]
     assert "bf16" in ro["kernel"] and ro["peak"] == 2500.0 and ro["unit"] == "TFLOP/s" and 0 < ro["frac"] < 1 and ro["launches"] > 0
+
+
+def test_bench_split_experiment_is_a_separate_object_and_never_the_headline():
+    """bench.py --split-bf16: the headline is measured on the fp32 pipe even with DHZ_SPLIT_BF16 set in the environment (no
+    experiment object, no change of dtype without the flag); with the flag the experiment is a separate object that states its
+    arithmetic and is marked not-headline."""
+    env = dict(os.environ, DHZ_SPLIT_BF16="3")
+    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "2", "--batch", "4",
+            "--no-cpu-baseline", "--no-kernel-timing"]
+    r0 = subprocess.run(base, capture_output=True, text=True, timeout=800, cwd=ROOT, env=env)
+    assert r0.returncode == 0, r0.stderr[-2000:]
+    d0 = json.loads([ln for ln in r0.stdout.splitlines() if ln.startswith("{")][0])
+    assert "experiment_split_bf16" not in d0 and d0["dtype"] == "f32"
+    r1 = subprocess.run(base + ["--split-bf16", "6"], capture_output=True, text=True, timeout=800, cwd=ROOT, env=env)
+    assert r1.returncode == 0, r1.stderr[-2000:]
+    d1 = json.loads([ln for ln in r1.stdout.splitlines() if ln.startswith("{")][0])
+    ex = d1["experiment_split_bf16"]
+    assert d1["dtype"] == "f32" and ex["headline"] is False and ex["terms"] == 6 and "bf16 MFMA" in ex["dtype"] and ex["value"] > 0
+    # same seed, same batch, same three steps on the fp32 pipe: the headline loss does not depend on the flag
+    assert abs(d0["config"]["loss_last_step"] - d1["config"]["loss_last_step"]) < 1e-4 * abs(d0["config"]["loss_last_step"])
