@@ -70,7 +70,14 @@ BF16_SHADOW = None
 # headline configuration never sets it; bench.py --split-bf16 reports it as a separate object.
 # 0 = off; 3 = hi / lo pieces, three products (~16 mantissa bits per product); 6 = hi / mid / lo pieces, six products (the error
 # class of an fp32 GEMM).  DHZ_SPLIT_BF16=1 means 3.
-SPLIT_BF16 = {0: 0, 1: 3, 3: 3, 6: 6}[int(os.environ.get("DHZ_SPLIT_BF16", "0"))]
+def _split_terms(v):
+    try:
+        return {0: 0, 1: 3, 3: 3, 6: 6}[int(v)]
+    except (KeyError, ValueError):
+        raise ValueError(f"DHZ_SPLIT_BF16={v!r}: expected 0 (off), 3 (or 1) or 6") from None
+
+
+SPLIT_BF16 = _split_terms(os.environ.get("DHZ_SPLIT_BF16", "0"))
 SPLIT_MIN_K = int(os.environ.get("DHZ_SPLIT_MIN_K", "128"))      # smallest contraction the forward / backward-data GEMMs split
 
 

@@ -252,3 +252,12 @@ def test_pointer_arguments_keep_their_tensors_alive():
     gc.collect()
     assert ref() is None                                  # and released once enough launches have gone by
     assert ops._p(None) is None and ops._RECENT.maxlen >= 32
+
+
+def test_split_switch_values():
+    from dehaze_hip import ops
+    assert [ops._split_terms(v) for v in ("0", "1", "3", "6", 6)] == [0, 3, 3, 6, 6]
+    import pytest
+    for bad in ("2", "x", "-1"):
+        with pytest.raises(ValueError, match="DHZ_SPLIT_BF16"):
+            ops._split_terms(bad)
