@@ -2,8 +2,9 @@
 
 PyTorch is plumbing here: it owns device memory (caching allocator), the current HIP stream and the
 autograd tape; the ops below run hand-written gfx950 kernels through ctypes (the token-Linear GEMMs included:
-dhz_linear_fwd / dhz_linear_dgrad / dhz_linear_wgrad).  What still runs on vendor libraries is listed in DESIGN.md §4
-(the 8x8 last VGG layer on MIOpen; the library convolutions of the bf16 mode).  CPU tensors are rejected - there is no
+dhz_linear_fwd / dhz_linear_dgrad / dhz_linear_wgrad).  No vendor compute kernel is left in the fp32 or the bf16 training
+step; the library is reached only for shapes the kernels do not tile (e.g. the last VGG layer on 24 x 24 maps of 384 x 384
+patches, Downsample / projections of unusual channel counts - DESIGN.md section 2).  CPU tensors are rejected - there is no
 fallback path.
 """
 import collections
