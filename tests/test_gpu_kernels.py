@@ -272,7 +272,9 @@ def test_adamw(dev, ops):
     assert torch.allclose(m.cpu(), opt.state[pr]["exp_avg"], atol=1e-7, rtol=1e-5)   # torch uses lerp for m
 
 
-@pytest.mark.parametrize("B,H,W,C", [(2, 24, 40, 64), (1, 16, 16, 128), (3, 9, 21, 64)])
+# the last two: more 8 x 16 tiles (640, 1152) than persistent workgroups (2 per CU), so workgroups walk several tiles with the
+# next one prefetched; C = 128 = two channel chunks per tile
+@pytest.mark.parametrize("B,H,W,C", [(2, 24, 40, 64), (1, 16, 16, 128), (3, 9, 21, 64), (5, 128, 128, 64), (9, 128, 128, 128)])
 def test_thin_conv3x3_vs_torch(B, H, W, C):
     """Output projection kernels (C -> 3, 3x3, pad 1; ragged tiles included) vs conv2d in float64: forward, backward-data and
     the in-place weight / bias gradients."""
@@ -293,5 +295,6 @@ def test_thin_conv3x3_vs_torch(B, H, W, C):
     assert torch.allclose(y.cpu(), ref.float(), atol=2e-5, rtol=1e-4), (y.cpu() - ref.float()).abs().max()
     y.backward(gy.to(dev))
     assert torch.allclose(xd.grad.cpu(), x64.grad.float().reshape(B, H * W, C), atol=2e-5, rtol=1e-4)
-    assert torch.allclose(wd.grad.cpu(), w64.grad.float(), atol=2e-4, rtol=1e-4), (wd.grad.cpu() - w64.grad.float()).abs().max()
-    assert torch.allclose(bd.grad.cpu(), b64.grad.float(), atol=2e-4, rtol=1e-4)
+    scale = max(1.0, (B * H * W / 1000.0) ** 0.5)            # sums over B H W terms of O(1): fp32 accumulation error grows with sqrt
+    assert torch.allclose(wd.grad.cpu(), w64.grad.float(), atol=2e-4 * scale, rtol=1e-4), (wd.grad.cpu() - w64.grad.float()).abs().max()
+    assert torch.allclose(bd.grad.cpu(), b64.grad.float(), atol=2e-4 * scale, rtol=1e-4)

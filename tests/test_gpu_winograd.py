@@ -209,3 +209,20 @@ def test_first_vgg_layer_kernel(B, H, W):
               torch.cuda.current_stream().cuda_stream)
     ref = torch.relu(F.conv2d(x.double(), w.double(), b.double(), padding=1)).float()
     assert torch.allclose(V.to_plain(yb), ref, atol=2e-5, rtol=1e-4), (V.to_plain(yb) - ref).abs().max()
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 16, 32), (1, 13, 21), (5, 128, 128)])
+def test_first_vgg_layer_backward_data_from_blocked_gradient(B, H, W):
+    """dhz_thin_conv3x3_dgrad_blocked (first VGG layer's backward-data, 64 -> 3, straight from the channel-blocked gradient;
+    matrix-pipe kernel with persistent workgroups - the last shape has more tiles than workgroups) vs conv_transpose2d."""
+    from dehaze_hip import _lib
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(H + B)
+    G = torch.randn(B, 64, H, W, generator=g).to(dev)
+    w = (torch.randn(64, 3, 3, 3, generator=g) * 0.3).to(dev)
+    gb = _blocked(G)
+    dx = torch.empty(B, 3, H, W, device=dev)
+    _lib.call("dhz_thin_conv3x3_dgrad_blocked", gb.data_ptr(), w.data_ptr(), dx.data_ptr(), B, H, W, 64,
+              torch.cuda.current_stream().cuda_stream)
+    ref = F.conv_transpose2d(G.double(), w.double(), padding=1).float()
+    assert torch.allclose(dx, ref, atol=1e-4, rtol=1e-4), (dx - ref).abs().max()
