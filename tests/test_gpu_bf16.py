@@ -434,3 +434,22 @@ def test_bf16_shadow_written_by_optimizer_and_resynced_after_outside_writes():
         assert torch.equal(f["p16"], f["p"].to(BF))
     finally:
         ops.refresh_bf16_shadow = orig
+
+
+@pytest.mark.parametrize("n", [1003, 4096, 7])
+def test_adamw_shadow_equals_cast_of_updated_parameters(n):
+    """dhz_adamw_step_shadow: the bf16 copy written in the optimizer's pass == a cast of the updated fp32 parameters (vector body
+    and scalar tail), and the fp32 update == dhz_adamw_step's."""
+    from dehaze_hip import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(n)
+    p = torch.randn(n, generator=g).to(dev)
+    gr = torch.randn(n, generator=g).to(dev)
+    m = torch.zeros(n, device=dev); v = torch.zeros(n, device=dev)
+    p2, m2, v2 = p.clone(), m.clone(), v.clone()
+    p16 = torch.zeros(n, device=dev, dtype=BF)
+    for step in (1, 2, 3):
+        ops.adamw_step_(p, gr, m, v, 2e-4, 0.9, 0.999, 1e-8, 0.02, step, 1.0, p16=p16)
+        ops.adamw_step_(p2, gr, m2, v2, 2e-4, 0.9, 0.999, 1e-8, 0.02, step, 1.0)
+    assert torch.equal(p, p2) and torch.equal(m, m2) and torch.equal(v, v2)
+    assert torch.equal(p16, p.to(BF))
