@@ -34,6 +34,14 @@ __device__ __forceinline__ f32x4 mfma_bf16(s16x8 a, s16x8 b, f32x4 c) {
 }
 // byte offset of 16-byte chunk ch of row `row` in a K-contiguous image (128-B rows)
 __device__ __forceinline__ int off_row(int row, int ch) { return row * 128 + 16 * (ch ^ ((row >> 1) & 7)); }
+// The same for the feature-major B image of the forward / backward-data kernels, whose rows are read in the order
+//     fragment block b, fragment row r  <->  tile feature 32 (b >> 1) + 8 (r >> 2) + 4 (b & 1) + (r & 3)
+// (a lane then owns 8 CONSECUTIVE features per pair of blocks and the four lanes of a token 32: 16-byte stores in 64-byte runs
+// instead of 8-byte stores in 32-byte runs; any assignment of features to MFMA columns is as good as another).  The 16 rows of a
+// fragment are base + 8 q + p (q, p in 0..3): the key (2 q + (p >> 1)) keeps them on distinct chunk positions in pairs, as
+// (row >> 1) & 7 does for 16 consecutive rows.
+__device__ __forceinline__ int off_rowp(int row, int ch) { return row * 128 + 16 * (ch ^ ((((row >> 3) & 3) << 1) | ((row >> 1) & 1))); }
+__device__ __forceinline__ int perm_row(int b, int r) { return 32 * (b >> 1) + 8 * (r >> 2) + 4 * (b & 1) + (r & 3); }
 // byte offset of 16-byte chunk ch of contraction row `row` in a contraction-major image with F features per row
 template <int F>
 __device__ __forceinline__ int off_tr(int row, int ch) {
@@ -116,8 +124,16 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const uint16_t* __restri
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             const int e = t + 256 * i;
-            if (BTR) *reinterpret_cast<u32x4*>(Bs + off_tr<BN>(e / (BN / 8), e % (BN / 8))) = rb[i];
-            else *reinterpret_cast<u32x4*>(Bs + off_row(e >> 3, e & 7)) = rb[i];
+            if (BTR) {
+                // feature chunk fc = 4 B + q of contraction row kr: its two 4-feature halves belong to fragment blocks 2 B and 2 B + 1
+                // (physical columns 32 B + 4 q + p and 32 B + 16 + 4 q + p): two 8-byte writes
+                const int kr = e / (BN / 8), fc = e % (BN / 8);
+                const int B2 = fc >> 2, q = fc & 3;
+                unsigned char* d0 = Bs + off_tr<BN>(kr, 4 * B2 + (q >> 1)) + 8 * (q & 1);
+                unsigned char* d1 = Bs + off_tr<BN>(kr, 4 * B2 + 2 + (q >> 1)) + 8 * (q & 1);
+                *reinterpret_cast<uint2*>(d0) = uint2{rb[i][0], rb[i][1]};
+                *reinterpret_cast<uint2*>(d1) = uint2{rb[i][2], rb[i][3]};
+            } else *reinterpret_cast<u32x4*>(Bs + off_rowp(e >> 3, e & 7)) = rb[i];
         }
     };
 
@@ -136,7 +152,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const uint16_t* __restri
 #pragma unroll
         for (int b = 0; b < WN; ++b)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) bv[b][j] = bias ? bias[tn * BN + wn * WN * 16 + 4 * g + 16 * b + j] : 0.f;
+            for (int j = 0; j < 4; ++j) bv[b][j] = bias ? bias[tn * BN + wn * WN * 16 + perm_row(b, 4 * g + j)] : 0.f;
         for (int st = 0; st < nst; ++st) {
             const bool last = st + 1 == nst;
             const bool more = !last || ntile >= 0;
@@ -153,7 +169,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const uint16_t* __restri
 #pragma unroll
                 for (int b = 0; b < WN; ++b) {
                     if (BTR) bf[b] = tr_frag<BN>(Bs, 32 * s + 8 * g, wn * WN + b, lane);
-                    else bf[b] = *reinterpret_cast<const s16x8*>(Bs + ((wn * WN + b) * 16 + i16) * 128 + 16 * ((4 * s + g) ^ sw));
+                    else bf[b] = *reinterpret_cast<const s16x8*>(Bs + off_rowp(wn * WN * 16 + perm_row(b, i16), 4 * s + g));
                 }
 #pragma unroll
                 for (int a = 0; a < WM; ++a)
@@ -170,31 +186,34 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const uint16_t* __restri
             }
         }
         {   // epilogue from the accumulators.  The MFMAs take the B (feature) fragment as their first operand, so a 16 x 16 block
-            // arrives transposed: acc[a][b][j] = C[token 16 a + i16][feature 16 b + 4 g + j] - a lane owns four CONSECUTIVE features
-            // of one token and stores them as one 8-byte vector (2-byte scalar stores in the untransposed form: 4 x the store
-            // instructions).  Full tiles store without per-row guards and the bias was loaded at the top of the tile: behind a
-            // divergent guard or a load hipcc waits for vmcnt(0), i.e. for the acknowledgement of all earlier stores.
-            const int m0 = tm * BM + wm * WM * 16 + i16, n0 = tn * BN + wn * WN * 16 + 4 * g;
+            // arrives transposed: acc[a][b][j] = C[token 16 a + i16][feature perm_row(b, 4 g + j)] - with the permuted feature order a
+            // lane owns the 8 consecutive features 32 h + 8 g .. + 7 in blocks 2 h, 2 h + 1 and stores them as ONE 16-byte vector; the
+            // four lanes of a token cover 64 contiguous bytes per store (8-byte stores of 32-byte pieces ran the wide outputs at
+            // 3.7 TB/s stores-only, 40 - 50 % behind the tuned library on them).  Full tiles store without per-row guards and the
+            // bias was loaded at the top of the tile: behind a divergent guard or a load hipcc waits for vmcnt(0).
+            const int m0 = tm * BM + wm * WM * 16 + i16, n0 = tn * BN + wn * WN * 16 + 8 * g;
             uint16_t* c0 = C + (size_t)m0 * ldc + n0;
-            auto pack = [&](int a, int b) {
-                const f32x4 v = acc[a][b] + bv[b];
-                uint2 r;
-                r.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
-                r.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+            auto pack = [&](int a, int h) {
+                const f32x4 v0 = acc[a][2 * h] + bv[2 * h], v1 = acc[a][2 * h + 1] + bv[2 * h + 1];
+                u32x4 r;
+                r[0] = (uint32_t)f32_to_bf16(v0[0]) | ((uint32_t)f32_to_bf16(v0[1]) << 16);
+                r[1] = (uint32_t)f32_to_bf16(v0[2]) | ((uint32_t)f32_to_bf16(v0[3]) << 16);
+                r[2] = (uint32_t)f32_to_bf16(v1[0]) | ((uint32_t)f32_to_bf16(v1[1]) << 16);
+                r[3] = (uint32_t)f32_to_bf16(v1[2]) | ((uint32_t)f32_to_bf16(v1[3]) << 16);
                 return r;
             };
             if (tm * BM + BM <= M) {                                     // wave-uniform
 #pragma unroll
                 for (int a = 0; a < WM; ++a)
 #pragma unroll
-                    for (int b = 0; b < WN; ++b)
-                        if (!(BF_ABL & 1) || acc[a][0][0] == 12345.678f) *reinterpret_cast<uint2*>(c0 + (size_t)(16 * a) * ldc + 16 * b) = pack(a, b);
+                    for (int h = 0; h < WN / 2; ++h)
+                        if (!(BF_ABL & 1) || acc[a][0][0] == 12345.678f) *reinterpret_cast<u32x4*>(c0 + (size_t)(16 * a) * ldc + 32 * h) = pack(a, h);
             } else {
 #pragma unroll
                 for (int a = 0; a < WM; ++a)
                     if (m0 + 16 * a < M) {
 #pragma unroll
-                        for (int b = 0; b < WN; ++b) *reinterpret_cast<uint2*>(c0 + (size_t)(16 * a) * ldc + 16 * b) = pack(a, b);
+                        for (int h = 0; h < WN / 2; ++h) *reinterpret_cast<u32x4*>(c0 + (size_t)(16 * a) * ldc + 32 * h) = pack(a, h);
                     }
             }
 #pragma unroll
@@ -230,8 +249,8 @@ int dispatch_gemm(const char* who, const uint16_t* A, int lda, const uint16_t* B
     DHZ_REQUIRE(A && B && C, "%s: null pointer", who);
     DHZ_REQUIRE(M > 0 && N > 0 && K > 0 && N % 64 == 0 && K % 64 == 0, "%s: T=%d N=%d K=%d (N, K must be multiples of 64)", who, M, N,
                 K);
-    DHZ_REQUIRE(lda % 8 == 0 && ldb % 8 == 0 && ldc % 4 == 0 && ldc >= N && lda >= K, "%s: bad leading dimensions", who);
-    DHZ_REQUIRE((((uintptr_t)A | (uintptr_t)B) & 15) == 0 && ((uintptr_t)C & 7) == 0, "%s: operands must be 16-byte aligned (output: 8)", who);
+    DHZ_REQUIRE(lda % 8 == 0 && ldb % 8 == 0 && ldc % 8 == 0 && ldc >= N && lda >= K, "%s: bad leading dimensions", who);
+    DHZ_REQUIRE((((uintptr_t)A | (uintptr_t)B | (uintptr_t)C) & 15) == 0, "%s: operands must be 16-byte aligned", who);
     const int wn = N % 128 == 0 ? 4 : 2;
     const long blocks128 = (long)((M + 127) / 128) * (N / (32 * wn));
     const int wm = blocks128 >= 256 ? 4 : 2;
