@@ -28,10 +28,13 @@ __device__ __forceinline__ f32x4 mfma_bf16(s16x8 a, s16x8 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 __device__ __forceinline__ int off_row(int row, int ch) { return row * 128 + 16 * (ch ^ ((row >> 1) & 7)); }
+// the filter (B) image is read in the row order of csrc/linear_bf16.hip::perm_row, so that a lane owns 8 consecutive output channels
+// per pair of fragment blocks (16-byte stores / mask / addend loads in 64-byte runs); its swizzle key follows that order
+__device__ __forceinline__ int off_rowp(int row, int ch) { return row * 128 + 16 * (ch ^ ((((row >> 3) & 3) << 1) | ((row >> 1) & 1))); }
+__device__ __forceinline__ int perm_row(int b, int r) { return 32 * (b >> 1) + 8 * (r >> 2) + 4 * (b & 1) + (r & 3); }
 
-__device__ __forceinline__ f32x4 unpack4(uint2 r) {
-    return f32x4{__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u), __uint_as_float(r.y << 16),
-                 __uint_as_float(r.y & 0xffff0000u)};
+__device__ __forceinline__ f32x4 unpack4(uint32_t x, uint32_t y) {
+    return f32x4{__uint_as_float(x << 16), __uint_as_float(x & 0xffff0000u), __uint_as_float(y << 16), __uint_as_float(y & 0xffff0000u)};
 }
 
 // persistent workgroups over [BM = 32 WM pixels] x [BN = 32 WN output channels] tiles; 4 waves as 2 x 2, wave tile 16 WM x 16 WN
@@ -115,7 +118,7 @@ __global__ __launch_bounds__(256, 2) void conv3_bf16_kernel(const uint16_t* __re
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             const int e = t + 256 * i;
-            *reinterpret_cast<u32x4*>(Bs + off_row(e >> 3, e & 7)) = B[i];
+            *reinterpret_cast<u32x4*>(Bs + off_rowp(e >> 3, e & 7)) = B[i];
         }
     };
 
@@ -152,7 +155,7 @@ __global__ __launch_bounds__(256, 2) void conv3_bf16_kernel(const uint16_t* __re
                 af[a] = *reinterpret_cast<const s16x8*>(As + (wm * WM * 16 + a * 16 + i16) * 128 + 16 * ((4 * s + g) ^ sw));
 #pragma unroll
             for (int b = 0; b < WN; ++b)
-                bf[b] = *reinterpret_cast<const s16x8*>(Bs + ((wn * WN + b) * 16 + i16) * 128 + 16 * ((4 * s + g) ^ sw));
+                bf[b] = *reinterpret_cast<const s16x8*>(Bs + off_rowp(wn * WN * 16 + perm_row(b, i16), 4 * s + g));
 #pragma unroll
             for (int a = 0; a < WM; ++a)
 #pragma unroll
@@ -165,32 +168,43 @@ __global__ __launch_bounds__(256, 2) void conv3_bf16_kernel(const uint16_t* __re
         }
         if (++st < nst) return;
         st = 0;
-        {   // acc[a][b][j] = C[pixel 16 a + i16][channel 16 b + 4 g + j]: four consecutive channels of one pixel per lane
+        {   // acc[a][b][j] = C[pixel 16 a + i16][channel perm_row(b, 4 g + j)]: blocks 2 h, 2 h + 1 of a lane are the 8 consecutive
+            // channels 32 h + 8 g .. + 7 of one pixel - one 16-byte store (and mask / addend load) per pair
             const int tn = tile % tiles_n, tm = tile / tiles_n;
-            const int m0 = tm * BM + wm * WM * 16 + i16, n0 = tn * BN + wn * WN * 16 + 4 * g;
+            const int m0 = tm * BM + wm * WM * 16 + i16, n0 = tn * BN + wn * WN * 16 + 8 * g;
             const size_t o0 = (size_t)m0 * Cout + n0;
             f32x4 bv[WN];                                        // bias in the lane layout (loaded here: 16 registers less held
 #pragma unroll                                                   // through the stages; one wait per tile of >= 9 stages)
             for (int b = 0; b < WN; ++b)
-                bv[b] = bias ? *reinterpret_cast<const f32x4*>(bias + n0 + 16 * b) : f32x4{0.f, 0.f, 0.f, 0.f};
+                bv[b] = bias ? *reinterpret_cast<const f32x4*>(bias + n0 + 32 * (b >> 1) + 4 * (b & 1)) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int a = 0; a < WM; ++a) {
                 if (m0 + 16 * a < M) {
 #pragma unroll
-                    for (int b = 0; b < WN; ++b) {
-                        const size_t o = o0 + (size_t)(16 * a) * Cout + 16 * b;
-                        f32x4 v = acc[a][b] + bv[b];
-                        if (relu) v = f32x4{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
-                        if (act) {
-                            if (addend) v += unpack4(*reinterpret_cast<const uint2*>(addend + o));
-                            const f32x4 m = unpack4(*reinterpret_cast<const uint2*>(act + o));
-                            v = f32x4{m[0] > 0.f ? v[0] : 0.f, m[1] > 0.f ? v[1] : 0.f, m[2] > 0.f ? v[2] : 0.f,
-                                      m[3] > 0.f ? v[3] : 0.f};
+                    for (int h = 0; h < WN / 2; ++h) {
+                        const size_t o = o0 + (size_t)(16 * a) * Cout + 32 * h;
+                        f32x4 v0 = acc[a][2 * h] + bv[2 * h], v1 = acc[a][2 * h + 1] + bv[2 * h + 1];
+                        if (relu) {
+                            v0 = f32x4{fmaxf(v0[0], 0.f), fmaxf(v0[1], 0.f), fmaxf(v0[2], 0.f), fmaxf(v0[3], 0.f)};
+                            v1 = f32x4{fmaxf(v1[0], 0.f), fmaxf(v1[1], 0.f), fmaxf(v1[2], 0.f), fmaxf(v1[3], 0.f)};
                         }
-                        uint2 r;
-                        r.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
-                        r.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
-                        *reinterpret_cast<uint2*>(Y + o) = r;
+                        if (act) {
+                            if (addend) {
+                                const u32x4 ad = *reinterpret_cast<const u32x4*>(addend + o);
+                                v0 += unpack4(ad[0], ad[1]);
+                                v1 += unpack4(ad[2], ad[3]);
+                            }
+                            const u32x4 mk = *reinterpret_cast<const u32x4*>(act + o);
+                            const f32x4 m0v = unpack4(mk[0], mk[1]), m1v = unpack4(mk[2], mk[3]);
+                            v0 = f32x4{m0v[0] > 0.f ? v0[0] : 0.f, m0v[1] > 0.f ? v0[1] : 0.f, m0v[2] > 0.f ? v0[2] : 0.f, m0v[3] > 0.f ? v0[3] : 0.f};
+                            v1 = f32x4{m1v[0] > 0.f ? v1[0] : 0.f, m1v[1] > 0.f ? v1[1] : 0.f, m1v[2] > 0.f ? v1[2] : 0.f, m1v[3] > 0.f ? v1[3] : 0.f};
+                        }
+                        u32x4 r;
+                        r[0] = (uint32_t)f32_to_bf16(v0[0]) | ((uint32_t)f32_to_bf16(v0[1]) << 16);
+                        r[1] = (uint32_t)f32_to_bf16(v0[2]) | ((uint32_t)f32_to_bf16(v0[3]) << 16);
+                        r[2] = (uint32_t)f32_to_bf16(v1[0]) | ((uint32_t)f32_to_bf16(v1[1]) << 16);
+                        r[3] = (uint32_t)f32_to_bf16(v1[2]) | ((uint32_t)f32_to_bf16(v1[3]) << 16);
+                        *reinterpret_cast<u32x4*>(Y + o) = r;
                     }
                 }
             }
@@ -394,8 +408,8 @@ extern "C" int dhz_vgg_conv3x3_bf16(const void* x, const void* wp, const float* 
                 "dhz_vgg_conv3x3_bf16: Cin=%d (power of two >= 64) Cout=%d (multiple of 64)", Cin, Cout);
     DHZ_REQUIRE(act || !addend, "dhz_vgg_conv3x3_bf16: addend without act");
     DHZ_REQUIRE((long long)N * H * W < (1ll << 31) / 2, "dhz_vgg_conv3x3_bf16: too many pixels");
-    DHZ_REQUIRE((((uintptr_t)x | (uintptr_t)wp) & 15) == 0 && (((uintptr_t)y | (uintptr_t)act | (uintptr_t)addend) & 7) == 0,
-                "dhz_vgg_conv3x3_bf16: operands must be 16-byte aligned (maps of the epilogue: 8)");
+    DHZ_REQUIRE((((uintptr_t)x | (uintptr_t)wp | (uintptr_t)y | (uintptr_t)act | (uintptr_t)addend) & 15) == 0,
+                "dhz_vgg_conv3x3_bf16: operands must be 16-byte aligned");
     int lgC = 0;
     while ((1 << lgC) < Cin) ++lgC;
     const int M = N * H * W;
