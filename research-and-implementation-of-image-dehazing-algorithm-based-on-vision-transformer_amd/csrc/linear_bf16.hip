@@ -17,7 +17,7 @@
 #include "common.h"
 
 #ifndef BF_ABL
-#define BF_ABL 0        // timing diagnostics (tools/variants.sh): 1 no epilogue stores, 2 no MFMAs, 4 no global operand loads
+#define BF_ABL 0        // timing diagnostics (tools/variants.sh): 1 no epilogue stores, 2 no MFMAs, 4 no global operand loads, 8 weight gradient: no atomics
 #endif
 
 namespace {
@@ -373,7 +373,16 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const uint16_t* __restr
 #pragma unroll
             for (int j = 0; j < 4; ++j) Cs[(wm * WM * 16 + a * 16 + 4 * g + j) * FN + wn * WN * 16 + b * 16 + i16] = acc[a][b][j];
     __syncthreads();
-    for (int e = t; e < FM * FN; e += 256) atomicAdd(dw + (size_t)(nloc + e / FN) * K + k0 + e % FN, Cs[e]);
+    // (each of a tile's nsplit workgroups starts its walk over the FM x FN addresses at another row: they finish together, and
+    // queueing on the same cache lines was a quarter of the kernel)
+    if (!(BF_ABL & 8)) {
+        const int rot = (int)(((unsigned)split * 2654435761u) % (unsigned)FM) * FN;
+        for (int i = t; i < FM * FN; i += 256) {
+            int e = i + rot;
+            if (e >= FM * FN) e -= FM * FN;
+            atomicAdd(dw + (size_t)(nloc + e / FN) * K + k0 + e % FN, Cs[e]);
+        }
+    }
     if (do_db) {
         // thread t always staged chunk (t % (FM/8)) of rows (t / (FM/8)) + k * 256 / (FM/8): fold the 256 / (FM/8) row groups
         __syncthreads();

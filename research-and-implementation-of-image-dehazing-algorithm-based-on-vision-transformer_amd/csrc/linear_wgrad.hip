@@ -201,7 +201,12 @@ __global__ __launch_bounds__(128 * NWM * TG) void linear_wgrad_kernel(const floa
         }
         __syncthreads();
     }
-    for (int e = t; e < BM * BN; e += NTHR) {
+    // the nsplit workgroups of a tile finish together and add into the SAME BM x BN addresses: each starts its walk at another
+    // row of the tile, so that at any moment they hit different cache lines instead of queueing on one
+    const int rot = (int)(((unsigned)split * 2654435761u) % (unsigned)BM) * BN;
+    for (int i = t; i < BM * BN; i += NTHR) {
+        int e = i + rot;
+        if (e >= BM * BN) e -= BM * BN;
         const int r = e / BN, c = e % BN;
         if (!(WG_ABL & 1) || Cs[e] == 12345.678f) atomicAdd(dw + (size_t)(nloc + r) * K + k0 + c, Cs[e]);
     }
