@@ -101,6 +101,31 @@ __device__ __forceinline__ void gelu_both(float x, float& g, float& gp) {
     g = x * cdf;
     gp = cdf + x * (0.39894228040143267794f * e);
 }
+// Four values at once, written on vectors so that the multiply / add chain compiles to packed fp32 instructions
+// (v_pk_mul_f32 / v_pk_fma_f32: two values per issue slot; reciprocal, exponential and the sign transfer stay per value): ~15
+// issue-slot equivalents per value instead of ~23 - the GELU evaluations are what bounds the depthwise stage in bf16 storage
+// (config 4) and a fifth of the fused LeFF kernel.  Same formula as gelu_both; the two constants of the rational argument and
+// of the exponent are pre-multiplied, so results agree with it to an fp32 rounding, not bit for bit.
+__device__ __forceinline__ void gelu_both4(const f32x4 x, f32x4& g, f32x4& gp) {
+    f32x4 ax, t, e, sg;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ax[i] = fabsf(x[i]);
+    const f32x4 den = 1.0f + (0.3275911f * 0.70710678118654752440f) * ax;
+    const f32x4 ex = (x * x) * (-0.5f * 1.44269504088896340736f);          // exp(-x^2/2) = 2^(x^2 * -0.5 log2 e)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        t[i] = __builtin_amdgcn_rcpf(den[i]);
+        e[i] = __builtin_amdgcn_exp2f(ex[i]);
+    }
+    const f32x4 poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    const f32x4 erf_abs = 1.0f - poly * e;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) sg[i] = copysignf(erf_abs[i], x[i]);
+    const f32x4 cdf = 0.5f + 0.5f * sg;
+    g = x * cdf;
+    gp = cdf + x * (0.39894228040143267794f * e);
+}
+__device__ __forceinline__ f32x4 gelu_f4(const f32x4 x) { f32x4 g, gp; gelu_both4(x, g, gp); return g; }
 __device__ __forceinline__ float gelu_f(float x) { float g, gp; gelu_both(x, g, gp); return g; }
 __device__ __forceinline__ float gelu_grad_f(float x) { float g, gp; gelu_both(x, g, gp); return gp; }
 

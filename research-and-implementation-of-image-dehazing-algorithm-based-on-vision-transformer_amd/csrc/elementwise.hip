@@ -267,7 +267,10 @@ __global__ __launch_bounds__(256) void leff_dwconv_fwd_kernel(const T* __restric
             const int pos = (t >> 3) + 32 * i;
             if (pos < NPOS) {
                 float4 val = make_float4(0, 0, 0, 0);
-                if (ok[i]) val = make_float4(gelu_f(ru[i].x), gelu_f(ru[i].y), gelu_f(ru[i].z), gelu_f(ru[i].w));
+                if (ok[i]) {
+                    const f32x4 gv = gelu_f4(f32x4{ru[i].x, ru[i].y, ru[i].z, ru[i].w});
+                    val = make_float4(gv[0], gv[1], gv[2], gv[3]);
+                }
                 *reinterpret_cast<float4*>(&g[pos * CT + c4 * 4]) = val;
             }
         }
@@ -294,7 +297,12 @@ __global__ __launch_bounds__(256) void leff_dwconv_fwd_kernel(const T* __restric
             }
         const size_t o = ((size_t)bimg * Hres * Wres + (size_t)yy * Wres + xx) * Ch + ch0;
         float4 zz, zp;
-        gelu_both(acc.x, zz.x, zp.x); gelu_both(acc.y, zz.y, zp.y); gelu_both(acc.z, zz.z, zp.z); gelu_both(acc.w, zz.w, zp.w);
+        {
+            f32x4 zv, pv;
+            gelu_both4(f32x4{acc.x, acc.y, acc.z, acc.w}, zv, pv);
+            zz = make_float4(zv[0], zv[1], zv[2], zv[3]);
+            zp = make_float4(pv[0], pv[1], pv[2], pv[3]);
+        }
         if (tpre) st4(tpre + o, zp);      // saved for backward: gelu'(t), not t itself
         st4(z + o, zz);
     }
@@ -390,8 +398,10 @@ __global__ __launch_bounds__(256, DWB_WAVES) void leff_dwconv_bwd_kernel(const T
             float4 gc, gp;                                               // gelu(u), gelu'(u) of this position
             if (DW_ABL & 8) { gc = uc; gp = uc; }
             else {
-                gelu_both(uc.x, gc.x, gp.x); gelu_both(uc.y, gc.y, gp.y);
-                gelu_both(uc.z, gc.z, gp.z); gelu_both(uc.w, gc.w, gp.w);
+                f32x4 gv, pv;
+                gelu_both4(f32x4{uc.x, uc.y, uc.z, uc.w}, gv, pv);
+                gc = make_float4(gv[0], gv[1], gv[2], gv[3]);
+                gp = make_float4(pv[0], pv[1], pv[2], pv[3]);
             }
             float4 dg = make_float4(0, 0, 0, 0);
 #pragma unroll

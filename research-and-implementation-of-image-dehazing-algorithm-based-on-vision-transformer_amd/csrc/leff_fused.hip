@@ -223,15 +223,17 @@ __global__ __launch_bounds__(64 * NW) void leff_fused_fwd_kernel(
         {
             const int hcol = 16 * ct1 + i16;
 #pragma unroll
-            for (int a = 0; a < 3; ++a)
+            for (int a = 0; a < 3; ++a) {
+                const f32x4 uv = acc[a] + b1v;
+                const f32x4 gq = gelu_f4(uv);                                            // four rows of this column at once (packed math)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int r = 16 * (rt0 + a) + 4 * g + j;
-                    const float u = acc[a][j] + b1v;
-                    if (train && tokoff[a][j] >= 0) US[tokoff[a][j] * HC + hcol] = u;     // -> P3 stores it with z and gelu'(t)
-                    const float gv = ((inmask >> (4 * a + j)) & 1) ? gelu_f(u) : 0.f;
+                    if (train && tokoff[a][j] >= 0) US[tokoff[a][j] * HC + hcol] = uv[j];     // -> P3 stores it with z and gelu'(t)
+                    const float gv = ((inmask >> (4 * a + j)) & 1) ? gq[j] : 0.f;
                     if (r < NPOS) GS[r * HC + hcol] = gv;
                 }
+            }
         }
         __syncthreads();
         wwrite2();
@@ -253,8 +255,7 @@ __global__ __launch_bounds__(64 * NW) void leff_fused_fwd_kernel(
                     for (int c = 0; c < 4; ++c) tacc[c] += wkv[(9 * c + k) >> 2][(9 * c + k) & 3] * gv[c];
                 }
             f32x4 zz, zp;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) { float a_, b_; gelu_both(tacc[c], a_, b_); zz[c] = a_; zp[c] = b_; }
+            gelu_both4(tacc, zz, zp);
             *reinterpret_cast<f32x4*>(&ZS[swz<HC>(p, 4 * c4)]) = zz;
             if (train) {
                 const size_t o = (tokbase + (size_t)(y0 + 1 + py) * Wres + (x0 + 1 + px)) * Ch + hc0 + 4 * c4;
