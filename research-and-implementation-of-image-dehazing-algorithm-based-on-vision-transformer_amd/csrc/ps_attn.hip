@@ -27,6 +27,27 @@ constexpr int SS = 68;     // row stride of the 64-wide score tiles
 #define PSF_WG64 3        // config 4: 44.19 ms per step against 44.52 with two
 #endif
 
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint32_t pack_top16(float x1, float x0) {           // bf16(x1) : bf16(x0) of bf16-representable values
+    return __builtin_amdgcn_perm(__float_as_uint(x1), __float_as_uint(x0), 0x07060302u);
+}
+// 16 x 16 tile of A . B^T over a contraction of 64 for two row-major fp32 LDS tiles that hold bf16-representable values (bf16
+// storage: Q, K, V, dO rows): the products on v_mfma_f32_16x16x32_bf16, exact, fp32 accumulation.  Rows that hold other fp32
+// values (the summed dO row of the mean(V) path) are TRUNCATED to bf16 - only where the result is not used.
+__device__ __forceinline__ bf16x8_t frag_bf16(const float* row, int half, int g) {
+    const f32x4 lo = *reinterpret_cast<const f32x4*>(row + 32 * half + 8 * g);
+    const f32x4 hi = *reinterpret_cast<const f32x4*>(row + 32 * half + 8 * g + 4);
+    u32x4_t r;
+    r[0] = pack_top16(lo[1], lo[0]); r[1] = pack_top16(lo[3], lo[2]);
+    r[2] = pack_top16(hi[1], hi[0]); r[3] = pack_top16(hi[3], hi[2]);
+    return __builtin_bit_cast(bf16x8_t, r);
+}
+__device__ __forceinline__ f32x4 tile_mma_bf16_k64(const float* A, int lda, const float* B, int ldb, int i16, int g, f32x4 acc) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_bf16(A + i16 * lda, 0, g), frag_bf16(B + i16 * ldb, 0, g), acc, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_bf16(A + i16 * lda, 1, g), frag_bf16(B + i16 * ldb, 1, g), acc, 0, 0, 0);
+}
+
 template <int D>
 struct FwdSmem {
     static constexpr int DS = D + 4;
@@ -139,7 +160,23 @@ __global__ __launch_bounds__(256) void ps_attn_fwd_kernel(const T* __restrict__ 
     __syncthreads();
 
     // ---- S = Q K^T : wave w owns rows 16w..16w+15, all 64 columns (4 tiles)
-    {
+    if constexpr (sizeof(T) == 2 && D == 64) {
+        // bf16 storage: the fp32 values in the tiles ARE bf16 values, so the same products run on v_mfma_f32_16x16x32_bf16 (16 x
+        // the rate of the fp32 pipe; exact products, fp32 accumulation - only the order of the sums differs): the fragment of a
+        // lane is 8 consecutive channels of its row, packed from the top halves of the fp32 words
+        const int i = lane & 15, g = lane >> 4;
+        auto frag = [&](const float* row, int half) { return frag_bf16(row, half, g); };
+        const bf16x8_t qa0 = frag(&sm.s[(16 * w + i) * DS], 0), qa1 = frag(&sm.s[(16 * w + i) * DS], 1);
+        __syncthreads();                               // every wave holds its Q fragments: the tile is free for S
+#pragma unroll
+        for (int tc = 0; tc < 4; ++tc) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa0, frag(&sm.k[(16 * tc + i) * DS], 0), acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa1, frag(&sm.k[(16 * tc + i) * DS], 1), acc, 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sm.s[(16 * w + 4 * g + j) * SS + 16 * tc + i] = acc[j];
+        }
+    } else {
         const int i = lane & 15, g = lane >> 4;
         float a[D / 4];
 #pragma unroll
@@ -370,7 +407,8 @@ __global__ __launch_bounds__(256) void ps_attn_bwd_kernel(
             for (int ii = 0; ii < 2; ++ii) {
                 const int tc = (w >> 1) + 2 * ii;
                 f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-                acc = tile_mma<D / 4>(sm.qr + 16 * tr * DS, DS, 1, sm.k + 16 * tc * DS, DS, 1, acc);
+                if constexpr (sizeof(T) == 2 && D == 64) acc = tile_mma_bf16_k64(sm.qr + 16 * tr * DS, DS, sm.k + 16 * tc * DS, DS, i16, g, acc);
+                else acc = tile_mma<D / 4>(sm.qr + 16 * tr * DS, DS, 1, sm.k + 16 * tc * DS, DS, 1, acc);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) sm.p1[(16 * tr + 4 * g + j) * SS + 16 * tc + i16] = acc[j];
             }
@@ -417,7 +455,10 @@ __global__ __launch_bounds__(256) void ps_attn_bwd_kernel(
                 const int tc = (w >> 1) + 2 * ii;
                 f32x4 acc = {0.f, 0.f, 0.f, 0.f};
                 // A(i=r, k=e) = dOr[16tr + r][e] ; B(k=e, j=n) = V[16tc + n][e]
-                accp[ii] = tile_mma<D / 4>(sm.dor + 16 * tr * DS, DS, 1, sm.v + 16 * tc * DS, DS, 1, acc);
+                // (bf16 storage: row 25 of dOr - the fp32 sum of the unselected queries' dO - is truncated here; its dP2 row only meets
+                // P1 = 0 below)
+                if constexpr (sizeof(T) == 2 && D == 64) accp[ii] = tile_mma_bf16_k64(sm.dor + 16 * tr * DS, DS, sm.v + 16 * tc * DS, DS, i16, g, acc);
+                else accp[ii] = tile_mma<D / 4>(sm.dor + 16 * tr * DS, DS, 1, sm.v + 16 * tc * DS, DS, 1, acc);
             }
         }
         __syncthreads();   // all reads of V done -> V tile becomes the dV staging buffer

@@ -139,11 +139,13 @@ def test_streaming_kernels_bf16_equal_fp32_kernels_on_rounded_inputs():
     qb = qkv.to(dev).to(BF).requires_grad_()
     qf = qb.detach().float().requires_grad_()
     cb, cf = ops.ps_window_attention(qb, tb_, idx, mask, heads, d), ops.ps_window_attention(qf, tf_, idx, mask, heads, d)
-    assert cb.dtype == BF and torch.equal(cb, cf.to(BF))                      # same selection, same context
+    # (with bf16 storage the products of two stored tensors - Q K^T, dO V^T - run on the bf16 matrix pipe: exact products, another
+    # order of the fp32 sums than the fp32 kernel's: equal up to one bf16 step on a few elements)
+    assert cb.dtype == BF and one_step(cb, cf.to(BF))                         # same selection, same context
     gc = torch.randn(B * H * W, Cq, generator=g).to(dev).to(BF)
     cb.backward(gc)
     cf.backward(gc.float())
-    assert torch.equal(qb.grad, qf.grad.to(BF))
+    assert one_step(qb.grad, qf.grad.to(BF))
     assert torch.allclose(tb_.grad, tf_.grad, rtol=1e-4, atol=1e-4)
 
 
