@@ -274,7 +274,7 @@ def test_adamw(dev, ops):
 
 # the last two: more 8 x 16 tiles (640, 1152) than persistent workgroups (2 per CU), so workgroups walk several tiles with the
 # next one prefetched; C = 128 = two channel chunks per tile
-@pytest.mark.parametrize("B,H,W,C", [(2, 24, 40, 64), (1, 16, 16, 128), (3, 9, 21, 64), (5, 128, 128, 64), (9, 128, 128, 128)])
+@pytest.mark.parametrize("B,H,W,C", [(2, 24, 40, 64), (1, 16, 16, 128), (3, 9, 21, 64), (5, 128, 128, 64), (9, 128, 128, 128), (7, 100, 90, 64)])
 def test_thin_conv3x3_vs_torch(B, H, W, C):
     """Output projection kernels (C -> 3, 3x3, pad 1; ragged tiles included) vs conv2d in float64: forward, backward-data and
     the in-place weight / bias gradients."""
