@@ -323,7 +323,6 @@ __global__ __launch_bounds__(256, DWB_WAVES) void leff_dwconv_bwd_kernel(const T
                                                               int Hres, int Wres, int Ch, int tiles_x, int tiles_y, int wg_per_cg) {
     __shared__ __attribute__((aligned(16))) float ds[HHGT * HWID * CT];    // dt = dz * gelu'(t) with halo
     __shared__ __attribute__((aligned(16))) float us[TH * TW * CT];        // u of the tile: each thread parks ITS OWN loads here
-    __shared__ float red[32][CT];                                           // [pos-slot][channel] reduction scratch
     const int t = threadIdx.x;
     const int cg = blockIdx.x % (Ch / CT);
     const int wslot = blockIdx.x / (Ch / CT);
@@ -419,19 +418,29 @@ __global__ __launch_bounds__(256, DWB_WAVES) void leff_dwconv_bwd_kernel(const T
             st4(du + o, make_float4(dg.x * gp.x, dg.y * gp.y, dg.z * gp.z, dg.w * gp.w));
         }
     }
-    // reduce the 32 position-slots (t>>3) that share a channel quad, one quantity at a time
+    // reduce the 32 position-slots (t >> 3) that share a channel quad: five quantities per round through the dead dt tile
+    // ([5][32 slots][CT]: two rounds, four barriers - ten rounds of one quantity with a serial 32-term sum by 32 threads each
+    // cost 7 - 11 us per launch)
     const int ps = t >> 3;
-    for (int kk = 0; kk < 10; ++kk) {
+    float* red5 = ds;
+    static_assert(HHGT * HWID * CT >= 5 * 32 * CT, "reduction scratch must fit the dt tile");
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
         __syncthreads();
 #pragma unroll
-        for (int c = 0; c < 4; ++c) red[ps][c4 * 4 + c] = (kk < 9) ? dwk[c][kk] : dbk[c];
-        __syncthreads();
-        if (t < CT) {
-            float s = 0.f;
+        for (int q = 0; q < 5; ++q) {
+            const int kk = 5 * half + q;
 #pragma unroll
-            for (int p = 0; p < 32; ++p) s += red[p][t];
-            if (kk < 9) atomicAdd(dw + (cg * CT + t) * 9 + kk, s);
-            else atomicAdd(db + cg * CT + t, s);
+            for (int c = 0; c < 4; ++c) red5[(q * 32 + ps) * CT + c4 * 4 + c] = (kk < 9) ? dwk[c][kk] : dbk[c];
+        }
+        __syncthreads();
+        if (t < 5 * CT) {
+            const int q = t / CT, c = t % CT, kk = 5 * half + q;
+            float sum = 0.f;
+#pragma unroll
+            for (int p = 0; p < 32; ++p) sum += red5[(q * 32 + p) * CT + c];
+            if (kk < 9) atomicAdd(dw + (cg * CT + c) * 9 + kk, sum);
+            else atomicAdd(db + cg * CT + c, sum);
         }
     }
 }
