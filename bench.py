@@ -118,10 +118,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--bucket-mb", type=float, default=25.0, help="gradient all-reduce bucket size (N > 1)")
-    ap.add_argument("--split-bf16", type=int, nargs="?", const=3, default=0, choices=[0, 3, 6],
-                    help="EXPERIMENT: after the fp32 measurement, time the same step with the K >= 128 token-Linear GEMMs / weight "
-                         "gradients as three bf16 MFMA passes over split operands (csrc/linear_split.hip); reported as the separate "
-                         "object experiment_split_bf16 - never the headline value")
+    ap.add_argument("--no-fp32-pipe", action="store_true",
+                    help="skip the second measurement of the same step on the fp32 matrix pipe (the `fp32_pipe` object)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -175,8 +173,10 @@ def main():
     def step():
         return train_step(model, char, cr, opt, reducer, input_, target, 1.0, 0.0 if args.no_cr else 1.0)
 
-    # the headline is measured on the fp32 matrix pipe whatever the environment says (DHZ_SPLIT_BF16 is an experiment switch)
-    ops.SPLIT_BF16 = 0
+    # The headline runs the product's DEFAULT arithmetic (dehaze_hip.ops.SPLIT_BF16 = 6 unless the environment overrides it): fp32
+    # storage and accumulation, the products of the GEMM-shaped kernels as six bf16 MFMA passes over operands cut into three bf16
+    # pieces (dropped terms <= 2^-24 relative).  The same step on the fp32 matrix pipe is timed after it as `fp32_pipe`.
+    headline_terms = ops.SPLIT_BF16 if args.dtype == "f32" else 0
 
     for _ in range(args.warmup):
         step()
@@ -207,10 +207,10 @@ def main():
         torch.cuda.synchronize()
     timing = ops.KERNEL_TIMING
     ops.KERNEL_TIMING = None
-    split_exp = None
-    if args.split_bf16 and args.dtype == "f32":
-        # EXPERIMENT pass, after everything the headline line is made of: same model / optimizer state / batch, the switch on
-        ops.SPLIT_BF16 = args.split_bf16
+    fp32_pipe = None
+    if headline_terms and not args.no_fp32_pipe:
+        # the same model / optimizer state / batch with every product on the fp32 matrix pipe (v_mfma_f32_16x16x4_f32)
+        ops.SPLIT_BF16 = 0
         for _ in range(min(args.warmup, 5)):
             step()
         if world > 1:
@@ -223,23 +223,16 @@ def main():
         if world > 1:
             dist.barrier()
         el = time.perf_counter() - t1
-        ops.SPLIT_BF16 = 0
+        ops.SPLIT_BF16 = headline_terms
         if world > 1:
             tm = torch.tensor([el], device=dev, dtype=torch.float64)
             dist.all_reduce(tm, op=dist.ReduceOp.MAX)
             el = tm.item()
-        split_exp = {"value": round(args.batch * world * args.steps / el, 3), "unit": "patches/s",
+        fp32_pipe = {"value": round(args.batch * world * args.steps / el, 3), "unit": "patches/s",
                      "ms_per_step": round(1e3 * el / args.steps, 3), "steps": args.steps,
-                     "terms": args.split_bf16,
-                     "dtype": "fp32 storage and accumulation; products of the token-Linear GEMMs with a contraction >= 128 and of "
-                              "all 64-aligned weight gradients as " + (
-                                  "3 x bf16 MFMA over operands split into bf16 head + remainder (~16 mantissa bits per product) - NOT "
-                                  "fp32 arithmetic" if args.split_bf16 == 3 else
-                                  "6 x bf16 MFMA over operands split into three bf16 pieces (all 24 mantissa bits; dropped terms <= 2^-24 "
-                                  "relative: the error class of an fp32 GEMM, not bit-identical to one)"),
-                     "headline": False, "loss_last_step": round(float(loss_s), 6),
-                     "note": "csrc/linear_split.hip; kernel-level fp32 tolerance tests (tests/test_gpu_linear.py) fail under the "
-                             "switch by design, model-level / golden / oracle parity tests pass (DESIGN.md section 4c)"}
+                     "arithmetic": "every product on the fp32 matrix pipe (v_mfma_f32_16x16x4_f32); same process, model, optimizer "
+                                   "state and batch as the headline, measured after it",
+                     "loss_last_step": round(float(loss_s), 6)}
     if rank == 0:
         total = args.batch * world * args.steps
         out = {
@@ -255,6 +248,12 @@ def main():
                        "global_batch": args.batch * world, "parallelism": f"dp{world}", "miopen_find": bool(torch.backends.cudnn.benchmark),
                        "loss_last_step": round(float(loss), 6)},
         }
+        if args.dtype == "f32":
+            out["config"]["arithmetic"] = (
+                "fp32 storage/accumulate; products 6xbf16 MFMA, dropped <= 2^-24" if headline_terms == 6 else
+                "fp32 storage/accumulate; products on the fp32 matrix pipe" if headline_terms == 0 else
+                "EXPERIMENT (not a product setting): fp32 storage/accumulate; products 3xbf16 MFMA (~16 mantissa bits per product)")
+            out["config"]["split_terms"] = headline_terms
         if reducer is not None:
             # the exchange of one step as performed (bucket byte ranges in launch order, single-ring xGMI time): makes a
             # scaling run diagnosable from its JSON line alone
@@ -332,8 +331,8 @@ def main():
                                         "traffic": round(traffic) if traffic else None, "traffic_source": traffic_source,
                                         "launches": len(ev), "avg_launch_us": round(1e3 * ms / len(ev), 2),
                                         "alg_flops_per_launch": int(direct / 2.25 / len(ev))}
-        if split_exp is not None:
-            out["experiment_split_bf16"] = split_exp
+        if fp32_pipe is not None:
+            out["fp32_pipe"] = fp32_pipe
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

@@ -66,19 +66,23 @@ def _dt(t):
 # train_step never reads stale weights.  (The AdamW kernel writes through raw pointers; FlatAdamW.step refreshes itself.)
 BF16_SHADOW = None
 
-# EXPERIMENT, off by default: fp32 token-Linear GEMMs with a contraction >= 128 on the bf16 matrix pipe by operand splitting
-# (hi + lo bf16 pieces, three MFMA passes, ~16 mantissa bits per product; csrc/linear_split.hip).  Not fp32 arithmetic: the
-# headline configuration never sets it; bench.py --split-bf16 reports it as a separate object.
-# 0 = off; 3 = hi / lo pieces, three products (~16 mantissa bits per product); 6 = hi / mid / lo pieces, six products (the error
-# class of an fp32 GEMM).  DHZ_SPLIT_BF16=1 means 3.
+# Which matrix pipe takes the PRODUCTS of the fp32 path's GEMM-shaped kernels (storage, accumulation, bias / statistics stay fp32):
+#   6 (default) - the bf16 pipe by operand splitting into three bf16 pieces (hi + mid + lo = all 24 mantissa bits, exactly) and the
+#                 six products down to 2^-16 (hh, hm, mh, hl, lh, mm); what is dropped (ml, lm, ll) is <= 2^-24 relative - the size of
+#                 ONE fp32 rounding, i.e. the error class of an fp32 FMA chain (csrc/linear_split.hip; every kernel-level fp32
+#                 tolerance of tests/ holds under it).  6 / 16 of the fp32 pipe's matrix time.
+#   0           - the fp32 matrix pipe itself (v_mfma_f32_16x16x4_f32, csrc/linear_gemm.hip / linear_wgrad.hip): bench.py times the
+#                 same step on it as `fp32_pipe` beside the headline.
+#   3           - EXPERIMENT, never a product setting: hi / lo pieces, three products (~16 mantissa bits per product).
+# DHZ_SPLIT_BF16 in the environment overrides the default (1 means 3).
 def _split_terms(v):
     try:
         return {0: 0, 1: 3, 3: 3, 6: 6}[int(v)]
     except (KeyError, ValueError):
-        raise ValueError(f"DHZ_SPLIT_BF16={v!r}: expected 0 (off), 3 (or 1) or 6") from None
+        raise ValueError(f"DHZ_SPLIT_BF16={v!r}: expected 0 (fp32 matrix pipe), 6 (default: six-term bf16 split) or 3 (or 1; experiment)") from None
 
 
-SPLIT_BF16 = _split_terms(os.environ.get("DHZ_SPLIT_BF16", "0"))
+SPLIT_BF16 = _split_terms(os.environ.get("DHZ_SPLIT_BF16", "6"))
 SPLIT_MIN_K = int(os.environ.get("DHZ_SPLIT_MIN_K", "128"))      # smallest contraction the forward / backward-data GEMMs split
 
 

@@ -86,23 +86,26 @@ def test_bench_bf16_contract_line():
     assert "bf16" in ro["kernel"] and ro["peak"] == 2500.0 and ro["unit"] == "TFLOP/s" and 0 < ro["frac"] < 1 and ro["launches"] > 0
 
 
-def test_bench_split_experiment_is_a_separate_object_and_never_the_headline():
-    """bench.py --split-bf16: the headline is measured on the fp32 pipe even with DHZ_SPLIT_BF16 set in the environment (no
-    experiment object, no change of dtype without the flag); with the flag the experiment is a separate object that states its
-    arithmetic and is marked not-headline."""
-    env = dict(os.environ, DHZ_SPLIT_BF16="3")
+def test_bench_headline_is_the_default_six_term_arithmetic_with_the_fp32_pipe_beside_it():
+    """bench.py: the headline runs the product's default arithmetic (six-term bf16 split: fp32 error class) and SAYS so
+    (dtype f32 + config.arithmetic), and carries the same step on the fp32 matrix pipe as the `fp32_pipe` object, measured in the
+    same process; DHZ_SPLIT_BF16=0 makes the fp32 pipe the headline (no second object)."""
+    env = {k: v for k, v in os.environ.items() if k != "DHZ_SPLIT_BF16"}
     base = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "2", "--batch", "4",
             "--no-cpu-baseline", "--no-kernel-timing"]
     r0 = subprocess.run(base, capture_output=True, text=True, timeout=800, cwd=ROOT, env=env)
     assert r0.returncode == 0, r0.stderr[-2000:]
     d0 = json.loads([ln for ln in r0.stdout.splitlines() if ln.startswith("{")][0])
-    assert "experiment_split_bf16" not in d0 and d0["dtype"] == "f32"
-    r1 = subprocess.run(base + ["--split-bf16", "6"], capture_output=True, text=True, timeout=800, cwd=ROOT, env=env)
+    assert d0["dtype"] == "f32" and d0["config"]["split_terms"] == 6
+    assert d0["config"]["arithmetic"] == "fp32 storage/accumulate; products 6xbf16 MFMA, dropped <= 2^-24"
+    fp = d0["fp32_pipe"]
+    assert fp["value"] > 0 and fp["ms_per_step"] > 0 and "fp32 matrix pipe" in fp["arithmetic"]
+    r1 = subprocess.run(base, capture_output=True, text=True, timeout=800, cwd=ROOT, env=dict(env, DHZ_SPLIT_BF16="0"))
     assert r1.returncode == 0, r1.stderr[-2000:]
     d1 = json.loads([ln for ln in r1.stdout.splitlines() if ln.startswith("{")][0])
-    ex = d1["experiment_split_bf16"]
-    assert d1["dtype"] == "f32" and ex["headline"] is False and ex["terms"] == 6 and "bf16 MFMA" in ex["dtype"] and ex["value"] > 0
-    # same seed, same batch, same steps on the fp32 pipe: the headline does not depend on the flag (two fp32 runs agree to the
-    # run-to-run noise of the atomic summation order amplified over five training steps, not bit for bit)
+    assert d1["config"]["split_terms"] == 0 and "fp32_pipe" not in d1 and "fp32 matrix pipe" in d1["config"]["arithmetic"]
+    # same seed, same batch, same steps: the two arithmetics agree to the run-to-run noise of the atomic summation order
+    # amplified over five training steps
     assert abs(d0["config"]["loss_last_step"] - d1["config"]["loss_last_step"]) < 1e-2 * abs(d0["config"]["loss_last_step"])
+    assert fp["loss_last_step"] > 0          # (measured after the headline's steps: further along the same training run)
     assert d0["config"]["workload"] == d1["config"]["workload"]

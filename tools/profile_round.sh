@@ -6,7 +6,7 @@ N=${1:?name}
 R=$(pwd); O=$R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 rm -rf $O/p_*
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/p_trace -- python3 $R/bench.py --steps 6 --warmup 4 --no-cpu-baseline $BENCH_ARGS > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/p_trace -- python3 $R/bench.py --steps 6 --warmup 4 --no-cpu-baseline --no-fp32-pipe $BENCH_ARGS > /dev/null 2>&1
 if [ "$2" = "trace" ]; then
   cd $R
   T=$(ls $O/p_trace/*/*kernel_trace.csv | head -1)
@@ -15,9 +15,9 @@ if [ "$2" = "trace" ]; then
   rm -rf $O/p_*
   exit 0
 fi
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/p_fetch -- python3 $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-kernel-timing $BENCH_ARGS > /dev/null 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/p_write -- python3 $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-kernel-timing $BENCH_ARGS > /dev/null 2>&1
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY GRBM_GUI_ACTIVE --output-format csv -d $O/p_mfma -- python3 $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-kernel-timing $BENCH_ARGS > /dev/null 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/p_fetch -- python3 $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-kernel-timing --no-fp32-pipe $BENCH_ARGS > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/p_write -- python3 $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-kernel-timing --no-fp32-pipe $BENCH_ARGS > /dev/null 2>&1
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY GRBM_GUI_ACTIVE --output-format csv -d $O/p_mfma -- python3 $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-kernel-timing --no-fp32-pipe $BENCH_ARGS > /dev/null 2>&1
 cd $R
 python tools/pmc_kernel.py $O/p_mfma --mfma "fused_window|winograd|linear_|gemm_bf16|wgrad_bf16|leff_fused|ps_attn|dense_attn|thin_conv" > $O/${N}_pmc_mfma.txt
 T=$(ls $O/p_trace/*/*kernel_trace.csv | head -1)
