@@ -207,6 +207,18 @@ int dhz_linear_fwd_split(const float* x, int ldx, const float* w, const float* b
                          int terms, void* stream);
 int dhz_linear_dgrad_split(const float* dy, int ldy, const float* w, float* dx, int ldx, int T, int N, int K, int terms,
                            void* stream);
+/* The product's default form of the two GEMMs above (dehaze_hip.ops.SPLIT_BF16 == 6; csrc/split6_gemm.hip): the six-term split with
+ *     the WEIGHT operand pre-split - w_hi / w_mid / w_lo are the three bf16 planes of w[N,K] (same layout, truncation pieces:
+ *     hi + mid + lo == w exactly), written once per optimizer step by dhz_adamw_step_split3 or by dhz_split3_planes.  The
+ *     activation operand is split inside the kernel.  fp32 activations, bias, accumulation and results; replaces the same
+ *     aten::addmm / aten::mm as dhz_linear_fwd / dhz_linear_dgrad.  K % 32 == 0; N % 32 == 0 (forward), N % 32 == 0 and
+ *     K % 64 == 0 (backward-data: its output features are w's K columns); planes 16-byte aligned. */
+int dhz_linear_fwd_split6(const float* x, int ldx, const void* w_hi, const void* w_mid, const void* w_lo, const float* bias, float* y,
+                          int ldy, int T, int N, int K, void* stream);
+int dhz_linear_dgrad_split6(const float* dy, int ldy, const void* w_hi, const void* w_mid, const void* w_lo, float* dx, int ldx, int T,
+                            int N, int K, void* stream);
+/*     hi[i] + mid[i] + lo[i] == src[i] exactly (three bf16 by truncation); n % 8 == 0, 16-byte aligned pointers. */
+int dhz_split3_planes(const float* src, int64_t n, void* hi, void* mid, void* lo, void* stream);
 /*     ... and the weight gradient (contract of dhz_linear_wgrad_multi + the row scale of dhz_linear_wgrad_rs: row_scale may be NULL;
  *     dw / db HOST arrays of nmat device pointers; ACCUMULATED; db exact fp32 column sums).  T % 64 == 0, nper % 64 == 0, K % 64 == 0. */
 int dhz_linear_wgrad_split(const float* dy, int ldy, const float* x, int ldx, int T, int nmat, int nper, int K, float* const* dw,

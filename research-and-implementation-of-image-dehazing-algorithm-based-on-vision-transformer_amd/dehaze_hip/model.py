@@ -607,6 +607,7 @@ class Uformer(nn.Module):
             b._staged_scales = [r[2 * i], r[2 * i + 1]]
 
     def forward(self, x, mask=None):
+        ops.sync_shadows()          # derived weight copies (bf16 / split planes) follow parameters written outside the optimizer
         self._stage_sample_indices(x.device)
         self._stage_drop_path(x)
         self.input_proj.out_dtype = self.act_dtype if x.is_cuda else torch.float32

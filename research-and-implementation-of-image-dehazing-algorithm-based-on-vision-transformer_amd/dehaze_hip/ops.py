@@ -59,12 +59,22 @@ def _dt(t):
     return 1 if t.dtype == BF16 else 0
 
 
-# (flat fp32 parameter buffer, its bf16 shadow) when FlatAdamW keeps one (config 4): a weight that is a view of the flat buffer
-# gets the matching view of the shadow - one cast launch per step for all parameters instead of one per Linear and pass.
-# The third element is the flat buffer's autograd version counter at the last cast: parameters written through torch (a loaded
-# checkpoint, a landscape probe; views share the counter) bump it and the next bf16_copy re-casts, so a forward outside
-# train_step never reads stale weights.  (The AdamW kernel writes through raw pointers; FlatAdamW.step refreshes itself.)
+# Derived copies of the flat fp32 parameter buffer that FlatAdamW keeps for the GEMMs:
+#   BF16_SHADOW  = [flat f32, its bf16 copy]                      (config 4: the bf16 GEMMs' weight operand)
+#   SPLIT_SHADOW = [flat f32, hi plane, mid plane, lo plane]      (the six-term split GEMMs' pre-split weight operand, bf16 each)
+# A weight that is a view of the flat buffer gets the matching views - one launch per optimizer step for all parameters instead
+# of one per Linear and pass.  The optimizer kernel keeps them current; writes that bypass it (a loaded checkpoint, a landscape
+# probe - parameters are views with autograd version counters of their own, so the flat buffer's counter does NOT see them) are
+# caught by SHADOW_SYNC: FlatAdamW registers a callable that compares the sum of the parameters' version counters and re-derives
+# the copies; train_step and Uformer.forward call sync_shadows() before the first GEMM.
 BF16_SHADOW = None
+SPLIT_SHADOW = None
+SHADOW_SYNC = None
+
+
+def sync_shadows():
+    if SHADOW_SYNC is not None:
+        SHADOW_SYNC()
 
 # Which matrix pipe takes the PRODUCTS of the fp32 path's GEMM-shaped kernels (storage, accumulation, bias / statistics stay fp32):
 #   6 (default) - the bf16 pipe by operand splitting into three bf16 pieces (hi + mid + lo = all 24 mantissa bits, exactly) and the
@@ -88,16 +98,21 @@ SPLIT_MIN_K = int(os.environ.get("DHZ_SPLIT_MIN_K", "128"))      # smallest cont
 
 def set_bf16_shadow(f32, b16):
     global BF16_SHADOW
-    BF16_SHADOW = None if f32 is None else [f32, b16, f32._version]
+    BF16_SHADOW = None if f32 is None else [f32, b16]
 
 
-def refresh_bf16_shadow(cast=True):
-    """cast=False: the shadow was just written by the optimizer kernel itself - only record the version"""
+def refresh_bf16_shadow():
     sh = BF16_SHADOW
     if sh is not None:
-        if cast:
-            sh[1].copy_(sh[0])               # one cast launch for all parameters
-        sh[2] = sh[0]._version
+        sh[1].copy_(sh[0])                   # one cast launch for all parameters
+
+
+def _view_of(flat, W):
+    """element offset of contiguous W inside the flat buffer, or -1"""
+    off = W.data_ptr() - flat.data_ptr()
+    if 0 <= off < 4 * flat.numel() and W.untyped_storage().data_ptr() == flat.untyped_storage().data_ptr():
+        return off // 4
+    return -1
 
 
 def bf16_copy(W):
@@ -106,13 +121,57 @@ def bf16_copy(W):
         return W
     sh = BF16_SHADOW
     if sh is not None and W.is_contiguous():
-        f32, b16, ver = sh
-        if f32._version != ver:
-            refresh_bf16_shadow()
-        off = W.data_ptr() - f32.data_ptr()
-        if 0 <= off < 4 * f32.numel() and W.untyped_storage().data_ptr() == f32.untyped_storage().data_ptr():
-            return b16[off // 4: off // 4 + W.numel()].view(W.shape)
+        o = _view_of(sh[0], W)
+        if o >= 0:
+            return sh[1][o: o + W.numel()].view(W.shape)
     return W.detach().to(BF16)
+
+
+def set_split_shadow(f32, planes):
+    global SPLIT_SHADOW
+    SPLIT_SHADOW = None if f32 is None else [f32, planes[0], planes[1], planes[2]]
+
+
+def refresh_split_shadow():
+    sh = SPLIT_SHADOW
+    if sh is not None:
+        _lib.call("dhz_split3_planes", sh[0].data_ptr(), sh[0].numel(), sh[1].data_ptr(), sh[2].data_ptr(), sh[3].data_ptr(), _stream())
+
+
+def split_planes(W):
+    """(hi, mid, lo): the three bf16 truncation pieces of a contiguous fp32 weight (hi + mid + lo == W exactly) - views of
+    FlatAdamW's planes when W lives in its flat buffer, otherwise one dhz_split3_planes launch."""
+    assert W.dtype == torch.float32 and W.is_contiguous() and W.numel() % 8 == 0
+    sh = SPLIT_SHADOW
+    if sh is not None:
+        o = _view_of(sh[0], W)
+        if o >= 0 and o % 8 == 0:
+            n = W.numel()
+            return sh[1][o: o + n], sh[2][o: o + n], sh[3][o: o + n]
+    pl = torch.empty((3, W.numel()), device=W.device, dtype=BF16)
+    _lib.call("dhz_split3_planes", _p(W), W.numel(), pl[0].data_ptr(), pl[1].data_ptr(), pl[2].data_ptr(), _stream())
+    _RECENT.append(pl)
+    return pl[0], pl[1], pl[2]
+
+
+def _route6(T, contraction, out, dgrad):
+    """which kernel takes a six-term GEMM of T tokens (measured per shape on the config-2 step, tools/bench_split6.py):
+    'new' = csrc/split6_gemm.hip (pre-split weight planes; 256 x 128 / 128 x 128 tiles), 'old' = csrc/linear_split.hip (both
+    operands split in the kernel; 128 x 64 tiles, two workgroups per CU: ahead on narrow outputs and few-tile problems),
+    'f32' = the fp32 pipe (HBM-bound shapes where the split buys nothing)."""
+    if contraction % 32 or out % 32 or contraction < 64 or out < 64:
+        return "f32"
+    old_ok = contraction % 64 == 0 and out % 64 == 0
+    new_ok = not dgrad or out % 64 == 0
+    if T <= 2048 and out < 2048 and old_ok:
+        return "old"
+    if dgrad and out == 64 and old_ok:
+        return "old"
+    if not dgrad and contraction <= 64 and out % 128 and T >= (1 << 19):
+        return "f32"
+    if new_ok and out <= 2048:
+        return "new"
+    return "old" if old_ok else "f32"
 
 
 def _terms():
@@ -151,8 +210,14 @@ def gemm_fwd(x, W, b=None):
         ev = _timed("dhz_linear_bf16")
         _lib.call("dhz_linear_fwd_bf16", _p(x), x.stride(0), _p(Wb), _p(b), _p(y), N, T, N, K, _stream())
         _timed_end(ev, 2.0 * T * N * K)
-    elif SPLIT_BF16 and K >= SPLIT_MIN_K and K % 64 == 0 and N % 64 == 0:
-        _lib.call("dhz_linear_fwd_split", _p(x), x.stride(0), _p(W), _p(b), _p(y), N, T, N, K, _terms(), _stream())
+    elif SPLIT_BF16 == 6 and x.stride(0) % 4 == 0 and _route6(T, K, N, False) != "f32":
+        if _route6(T, K, N, False) == "new":
+            hi, mid, lo = split_planes(W)
+            _lib.call("dhz_linear_fwd_split6", _p(x), x.stride(0), _p(hi), _p(mid), _p(lo), _p(b), _p(y), N, T, N, K, _stream())
+        else:
+            _lib.call("dhz_linear_fwd_split", _p(x), x.stride(0), _p(W), _p(b), _p(y), N, T, N, K, 6, _stream())
+    elif SPLIT_BF16 == 3 and K >= SPLIT_MIN_K and K % 64 == 0 and N % 64 == 0:      # experiment
+        _lib.call("dhz_linear_fwd_split", _p(x), x.stride(0), _p(W), _p(b), _p(y), N, T, N, K, 3, _stream())
     else:
         _lib.call("dhz_linear_fwd", _p(x), x.stride(0), _p(W), _p(b), _p(y), N, T, N, K, _stream())
     return y
@@ -171,8 +236,14 @@ def gemm_dgrad(dy, W):
         ev = _timed("dhz_linear_bf16")
         _lib.call("dhz_linear_dgrad_bf16", _p(dy), dy.stride(0), _p(Wb), _p(dx), K, T, N, K, _stream())
         _timed_end(ev, 2.0 * T * N * K)
-    elif SPLIT_BF16 and N >= SPLIT_MIN_K and N % 64 == 0 and K % 64 == 0:
-        _lib.call("dhz_linear_dgrad_split", _p(dy), dy.stride(0), _p(W), _p(dx), K, T, N, K, _terms(), _stream())
+    elif SPLIT_BF16 == 6 and dy.stride(0) % 4 == 0 and _route6(T, N, K, True) != "f32":
+        if _route6(T, N, K, True) == "new":
+            hi, mid, lo = split_planes(W)
+            _lib.call("dhz_linear_dgrad_split6", _p(dy), dy.stride(0), _p(hi), _p(mid), _p(lo), _p(dx), K, T, N, K, _stream())
+        else:
+            _lib.call("dhz_linear_dgrad_split", _p(dy), dy.stride(0), _p(W), _p(dx), K, T, N, K, 6, _stream())
+    elif SPLIT_BF16 == 3 and N >= SPLIT_MIN_K and N % 64 == 0 and K % 64 == 0:      # experiment
+        _lib.call("dhz_linear_dgrad_split", _p(dy), dy.stride(0), _p(W), _p(dx), K, T, N, K, 3, _stream())
     else:
         _lib.call("dhz_linear_dgrad", _p(dy), dy.stride(0), _p(W), _p(dx), K, T, N, K, _stream())
     return dx

@@ -117,21 +117,42 @@ class FlatAdamW(torch.optim.Optimizer):
         shadowed = "p16" in f
         ops.adamw_step_(f["p"], f["g"], f["m"], f["v"], g["lr"], g["betas"][0], g["betas"][1], g["eps"],
                         g["weight_decay"], self._step, self.grad_scale, p16=f["p16"] if shadowed else None)
-        if shadowed and ops.BF16_SHADOW is not None and ops.BF16_SHADOW[0] is f["p"]:
-            ops.refresh_bf16_shadow(cast=False)  # the kernel wrote the bf16 copy in its own pass
-            self._pver = self._param_versions()
+        if "p3" in f and ops.SPLIT_SHADOW is not None and ops.SPLIT_SHADOW[0] is f["p"]:
+            ops.refresh_split_shadow()           # the three bf16 planes of the updated parameters: one launch
+        self._pver = self._param_versions()
 
     def _param_versions(self):
         """sum of the version counters of the parameters (views of the flat buffer with counters of their own): changes when
         anything but the optimizer kernel writes a parameter in place (a loaded checkpoint, a landscape probe)"""
         return sum(p._version for p in self._live) + self._flat["p"]._version
 
-    def sync_bf16_shadow(self):
-        """Start-of-step check of train_step: re-cast the shadow only if a parameter was written since the last update."""
+    def sync_shadows(self):
+        """Re-derive the bf16 copy / the split planes if a parameter was written since the last update (registered as
+        ops.SHADOW_SYNC: train_step and Uformer.forward call it before the first GEMM)."""
+        f = self._flat
+        if f is None:
+            return
         v = self._param_versions()
         if getattr(self, "_pver", None) != v:
-            ops.refresh_bf16_shadow()
+            if "p16" in f and ops.BF16_SHADOW is not None and ops.BF16_SHADOW[0] is f["p"]:
+                ops.refresh_bf16_shadow()
+            if "p3" in f and ops.SPLIT_SHADOW is not None and ops.SPLIT_SHADOW[0] is f["p"]:
+                ops.refresh_split_shadow()
             self._pver = self._param_versions()
+
+    sync_bf16_shadow = sync_shadows               # (earlier name)
+
+    def enable_split_shadow(self):
+        """Keep the three bf16 truncation planes of the flat parameter buffer (the pre-split weight operand of the six-term
+        GEMMs, csrc/split6_gemm.hip), refreshed after every update; ops.split_planes hands out views of them."""
+        self._ensure_flat()
+        f = self._flat
+        if "p3" not in f:
+            f["p3"] = torch.empty((3, f["p"].numel()), device=f["p"].device, dtype=torch.bfloat16)
+        ops.set_split_shadow(f["p"], f["p3"])
+        ops.refresh_split_shadow()
+        self._pver = self._param_versions()
+        ops.SHADOW_SYNC = self.sync_shadows
 
     def enable_bf16_shadow(self):
         """Keep a bf16 copy of the flat parameter buffer, refreshed after every update, and let ops.bf16_copy hand out views
@@ -141,6 +162,9 @@ class FlatAdamW(torch.optim.Optimizer):
         if "p16" not in f:
             f["p16"] = f["p"].to(torch.bfloat16)
         ops.set_bf16_shadow(f["p"], f["p16"])
+        ops.refresh_bf16_shadow()
+        self._pver = self._param_versions()
+        ops.SHADOW_SYNC = self.sync_shadows
 
     def __del__(self):
         # the process-global shadow must not pin the flat buffers of a discarded optimizer
@@ -148,6 +172,10 @@ class FlatAdamW(torch.optim.Optimizer):
             f = self._flat
             if f is not None and ops.BF16_SHADOW is not None and ops.BF16_SHADOW[0] is f["p"]:
                 ops.set_bf16_shadow(None, None)
+            if f is not None and ops.SPLIT_SHADOW is not None and ops.SPLIT_SHADOW[0] is f["p"]:
+                ops.set_split_shadow(None, None)
+            if getattr(ops.SHADOW_SYNC, "__self__", None) is self:
+                ops.SHADOW_SYNC = None
         except Exception:
             pass
 
@@ -314,12 +342,15 @@ def train_step(model, char_loss, cr_loss, optimizer, reducer, input_, target, w_
     clamp(0,1) -> w_char*Charbonnier + w_cr*Contrast -> backward (bucketed all-reduce overlapped) ->
     AdamW.  Returns (loss, loss_rec, loss_cr) as device scalars (no host sync here; the reference's
     per-step .item() calls, TR:250-254, are left to the caller's logging cadence)."""
-    if getattr(model, "act_dtype", None) == torch.bfloat16 and isinstance(optimizer, FlatAdamW):
-        if ops.BF16_SHADOW is None or optimizer._flat is None or ops.BF16_SHADOW[0] is not optimizer._flat["p"]:
-            optimizer.enable_bf16_shadow()
-        else:
-            optimizer.sync_bf16_shadow()       # parameters written outside step() (a loaded checkpoint, a landscape probe)
-                                               # must reach the bf16 GEMMs too: one cast launch, only when that happened
+    if isinstance(optimizer, FlatAdamW):
+        if getattr(model, "act_dtype", None) == torch.bfloat16:
+            if ops.BF16_SHADOW is None or optimizer._flat is None or ops.BF16_SHADOW[0] is not optimizer._flat["p"]:
+                optimizer.enable_bf16_shadow()
+        elif ops.SPLIT_BF16 == 6:
+            if ops.SPLIT_SHADOW is None or optimizer._flat is None or ops.SPLIT_SHADOW[0] is not optimizer._flat["p"]:
+                optimizer.enable_split_shadow()
+        optimizer.sync_shadows()               # parameters written outside step() (a loaded checkpoint, a landscape probe)
+                                               # must reach the GEMMs' derived weight copies: one launch, only when that happened
     if cr_loss is not None and hasattr(cr_loss, "vgg") and hasattr(cr_loss.vgg, "feature_dtype"):
         # config 4: the frozen feature stack follows the model's activation type (autocast covers the loss in the reference)
         cr_loss.vgg.feature_dtype = getattr(model, "act_dtype", None) or torch.float32

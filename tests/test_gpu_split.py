@@ -140,3 +140,136 @@ def test_split_model_step_close_to_fp32_step(terms):
     print("split(%d) vs fp32: PSNR %.1f dB, loss %.7f vs %.7f, grad cos %.8f rel %.2e" % (terms, psnr, l0, l1, cos, rel))
     # measured (three terms): PSNR 132 dB, equal loss to 7 digits, gradient relative difference 1.4e-6
     assert psnr > 100 and abs(l0 - l1) < 1e-5 * abs(l0) and cos > 0.999999 and rel < 1e-4, (psnr, l0, l1, cos, rel)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# csrc/split6_gemm.hip: the six-term GEMMs with the weight operand pre-split into three bf16 planes
+
+
+def _planes(w):
+    from dehaze_hip import _lib
+    s = torch.cuda.current_stream().cuda_stream
+    pl = torch.empty((3, w.numel()), dtype=torch.bfloat16, device=w.device)
+    _lib.call("dhz_split3_planes", w.data_ptr(), w.numel(), pl[0].data_ptr(), pl[1].data_ptr(), pl[2].data_ptr(), s)
+    return pl
+
+
+@pytest.mark.parametrize("n", [8, 4096, 1 << 20])
+def test_split3_planes_are_exact(n):
+    """hi + mid + lo == x bit for bit (three bf16 pieces by truncation hold all 24 mantissa bits) for zeros, negative values, values
+    whose lower pieces vanish and every magnitude whose lowest piece is still a normal number (|x| >= 2^-100; below that the
+    remainders are subnormal and the split is only good to 2^-126 absolute - no weight or activation of this model comes close)"""
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(n)
+    x = torch.randn(n, generator=g) * torch.exp(8 * torch.randn(n, generator=g))
+    x[:4] = torch.tensor([0.0, -0.0, 1.0, -1.5])
+    x[4:8] = torch.tensor([1e-30, -3e-29, 65536.0, 3.0e38])
+    x = torch.where((x.abs() < 1e-30) & (x != 0), torch.full_like(x, 1e-30), x).to(dev)
+    pl = _planes(x)
+    rec = (pl[0].double() + pl[1].double() + pl[2].double())
+    assert torch.equal(rec, x.double())
+    assert torch.equal(pl[0].float(), (x.view(torch.int32) & -65536).view(torch.float32))          # hi = the top 16 bits
+
+
+# tile selection of csrc/split6_gemm.hip: features % 128 -> 128-wide tiles (256 x 128 when the problem has >= one tile per CU),
+# % 64 -> 128 x 64, % 32 -> 128 x 32 (forward only); ragged T; strided activations (a packed QKV buffer); no bias
+@pytest.mark.parametrize("T,K,N,ldx_pad", [(128, 32, 32, 0), (1000, 64, 96, 0), (777, 128, 512, 0), (4096, 128, 128, 64),
+                                           (32768, 256, 256, 0), (65536, 64, 128, 0), (5000, 192, 64, 32), (64, 1024, 256, 0),
+                                           (33000, 96, 384, 0)])
+def test_split6_planes_gemm_forward_and_dgrad_vs_fp64(T, K, N, ldx_pad):
+    from dehaze_hip import _lib
+    dev = torch.device("cuda:0")
+    s = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator().manual_seed(T + K + N)
+    xb = torch.randn(T, K + ldx_pad, generator=g).to(dev)
+    x = xb[:, :K]
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(dev)
+    b = torch.randn(N, generator=g).to(dev)
+    pl = _planes(w)
+    for bias in (b, None):
+        y = torch.full((T, N), float("nan"), device=dev)
+        _lib.call("dhz_linear_fwd_split6", x.data_ptr(), K + ldx_pad, pl[0].data_ptr(), pl[1].data_ptr(), pl[2].data_ptr(),
+                  bias.data_ptr() if bias is not None else None, y.data_ptr(), N, T, N, K, s)
+        ref = x.double() @ w.double().t() + (bias.double() if bias is not None else 0.0)
+        mag = x.double().abs() @ w.double().abs().t() + (bias.double().abs() if bias is not None else 0.0)
+        err = (y.double() - ref).abs()
+        assert (err <= BOUND[6] * mag).all(), (err / mag).max().item()
+    y32 = torch.empty(T, N, device=dev)
+    _lib.call("dhz_linear_fwd", x.data_ptr(), K + ldx_pad, w.data_ptr(), None, y32.data_ptr(), N, T, N, K, s)
+    e32 = (y32.double() - ref).abs().max().item()
+    assert err.max().item() < 4 * max(e32, 1e-7), (err.max().item(), e32)            # the error class of the fp32 pipe
+    if K % 64 == 0:                                  # backward-data: its output features are w's K columns (64- or 128-wide tiles)
+        dyb = torch.randn(T, N + ldx_pad, generator=g).to(dev)
+        dy = dyb[:, :N]
+        dx = torch.full((T, K), float("nan"), device=dev)
+        _lib.call("dhz_linear_dgrad_split6", dy.data_ptr(), N + ldx_pad, pl[0].data_ptr(), pl[1].data_ptr(), pl[2].data_ptr(),
+                  dx.data_ptr(), K, T, N, K, s)
+        ref = dy.double() @ w.double()
+        mag = dy.double().abs() @ w.double().abs()
+        err = (dx.double() - ref).abs()
+        assert (err <= BOUND[6] * mag).all(), (err / mag).max().item()
+        dx32 = torch.empty(T, K, device=dev)
+        _lib.call("dhz_linear_dgrad", dy.data_ptr(), N + ldx_pad, w.data_ptr(), dx32.data_ptr(), K, T, N, K, s)
+        e32 = (dx32.double() - ref).abs().max().item()
+        assert err.max().item() < 4 * max(e32, 1e-7), (err.max().item(), e32)
+
+
+def test_split6_gemm_is_deterministic_and_rejects_bad_shapes():
+    from dehaze_hip import _lib
+    dev = torch.device("cuda:0")
+    s = torch.cuda.current_stream().cuda_stream
+    T, K, N = 8192, 256, 512
+    x = torch.randn(T, K, device=dev)
+    w = torch.randn(N, K, device=dev) / 16
+    pl = _planes(w)
+    ys = []
+    for _ in range(3):
+        y = torch.empty(T, N, device=dev)
+        _lib.call("dhz_linear_fwd_split6", x.data_ptr(), K, pl[0].data_ptr(), pl[1].data_ptr(), pl[2].data_ptr(), None, y.data_ptr(),
+                  N, T, N, K, s)
+        ys.append(y)
+    assert torch.equal(ys[0], ys[1]) and torch.equal(ys[0], ys[2])
+    with pytest.raises(_lib.DehazeHipError, match="multiple of 32"):
+        _lib.call("dhz_linear_fwd_split6", x.data_ptr(), K, pl[0].data_ptr(), pl[1].data_ptr(), pl[2].data_ptr(), None, y.data_ptr(),
+                  N, T, N, 48, s)
+    with pytest.raises(_lib.DehazeHipError, match="null pointer"):
+        _lib.call("dhz_linear_fwd_split6", x.data_ptr(), K, None, pl[1].data_ptr(), pl[2].data_ptr(), None, y.data_ptr(), N, T, N, K, s)
+
+
+def test_split_planes_shadow_follows_optimizer_and_outside_writes():
+    """FlatAdamW keeps the three planes of its flat parameter buffer: (a) current after every step (hi + mid + lo == parameters),
+    (b) ops.split_planes hands out VIEWS of them for weights that live in the flat buffer (the packed Q / K / V operand included),
+    (c) a parameter written outside the optimizer reaches them before the next forward - train_step's or a bare model(x)."""
+    import My_model_1 as M1
+    from dehaze_hip import ops
+    from dehaze_hip.train import FlatAdamW, synthetic_batch, train_step
+    from losses import CharbonnierLoss
+    if ops.SPLIT_BF16 != 6:
+        pytest.skip("the six-term split is not the active arithmetic (DHZ_SPLIT_BF16)")
+    dev = torch.device("cuda:0")
+    torch.manual_seed(5)
+    model = M1.Uformer(img_size=128, embed_dim=32, win_size=8, token_projection='linear', token_mlp='leff',
+                       drop_path_rate=0.).to(dev).train()
+    opt = FlatAdamW(model, lr=2e-4, weight_decay=0.02)
+    gt, hazy = synthetic_batch(1, 128, seed=3, device=dev)
+    train_step(model, CharbonnierLoss(), None, opt, None, hazy, gt, 1.0, 0.0)
+    f = opt._flat
+    rec = lambda: f["p3"][0].double() + f["p3"][1].double() + f["p3"][2].double()
+    assert ops.SPLIT_SHADOW is not None and ops.SPLIT_SHADOW[0] is f["p"]
+    assert torch.equal(rec(), f["p"].double())                                           # (a)
+    W = model.encoderlayer_2.blocks[0].mlp.linear1[0].weight
+    hi, mid, lo = ops.split_planes(W.detach())
+    assert hi.data_ptr() - f["p3"][0].data_ptr() == (W.data_ptr() - f["p"].data_ptr()) // 2    # (b) a view, no launch
+    assert torch.equal((hi.double() + mid.double() + lo.double()).view_as(W), W.detach().double())
+    with torch.no_grad():
+        W.mul_(1.5)                                                                       # (c) an outside write ...
+    assert not torch.equal(rec(), f["p"].double())
+    model.eval()
+    with torch.no_grad():
+        model(hazy)                                                                       # ... reaches the planes in a bare forward
+    assert torch.equal(rec(), f["p"].double())
+    model.train()
+    with torch.no_grad():
+        W.mul_(0.5)
+    train_step(model, CharbonnierLoss(), None, opt, None, hazy, gt, 1.0, 0.0)             # ... and in train_step
+    assert torch.equal(rec(), f["p"].double())
