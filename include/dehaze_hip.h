@@ -432,6 +432,20 @@ int dhz_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, floa
 int dhz_adamw_step_shadow(float* p, const float* g, float* m, float* v, void* p16, int64_t n, float lr, float beta1,
                           float beta2, float eps, float wd, int step, float grad_scale, void* stream);
 
+/* C1   The gradient exchange of the data-parallel path (one process per GPU, batch-axis sharding): thin wrappers over RCCL for a
+ *      host that binds only this library - replaces nn.DataParallel's gradient reduction (My_train.py:97).  RCCL is resolved at
+ *      run time (dlopen; a copy the process already holds, e.g. PyTorch's, is shared), so single-GPU users never load it.
+ *      dhz_comm_unique_id : rank 0 fills id128 (128 bytes) and hands it to the other ranks out of band (a file, MPI, a socket)
+ *      dhz_comm_init      : every rank, after hipSetDevice(its GPU); *comm receives the communicator
+ *      dhz_comm_allreduce_sum_f32 : in-place SUM all-reduce of buf[n] (a bucket of the flat gradient), enqueued on `stream`; the
+ *                           1/world factor belongs to dhz_adamw_step's grad_scale
+ *      dhz_comm_destroy   : releases the communicator.
+ *      The Python host of this repository reaches the same RCCL through torch.distributed("nccl") (dehaze_hip/train.py::GradReducer). */
+int dhz_comm_unique_id(void* id128);
+int dhz_comm_init(void** comm, int rank, int nranks, const void* id128);
+int dhz_comm_allreduce_sum_f32(void* comm, float* buf, int64_t n, void* stream);
+int dhz_comm_destroy(void* comm);
+
 #ifdef __cplusplus
 }
 #endif

@@ -26,4 +26,8 @@ int dhz_num_cus() {
 
 extern "C" const char* dhz_last_error(void) { return g_err; }
 extern "C" int dhz_abi_version(void) { return 1; }
+#ifdef DHZ_VARIANT_TAG          // diagnostic builds (tools/variants.sh, tools/abl_fused.sh) link variant kernels: their id must not be the product's
+extern "C" const char* dhz_build_id(void) { return DHZ_BUILD_ID "-" DHZ_VARIANT_TAG; }
+#else
 extern "C" const char* dhz_build_id(void) { return DHZ_BUILD_ID; }
+#endif

@@ -10,8 +10,9 @@ mkdir -p "$HERE/build"
 # build id = content hash of every source the library is made of; dhz_build_id() returns it, the PMC passes stamp it into
 # profiles/pmc_traffic.json and bench.py refuses a traffic figure whose stamp is not the loaded library's
 ID=$(cat "$HERE"/*.hip "$HERE/common.h" "$ROOT/include/dehaze_hip.h" | sha256sum | cut -c1-16)
-if [ ! -f "$HERE/build/build_id.h" ] || ! grep -q "$ID" "$HERE/build/build_id.h"; then
-  echo "#define DHZ_BUILD_ID \"$ID${DHZ_BUILD_TAG:+-$DHZ_BUILD_TAG}\"" > "$HERE/build/build_id.h"
+LINE="#define DHZ_BUILD_ID \"$ID${DHZ_BUILD_TAG:+-$DHZ_BUILD_TAG}\""
+if [ ! -f "$HERE/build/build_id.h" ] || [ "$(cat "$HERE/build/build_id.h")" != "$LINE" ]; then      # the whole line: a changed tag alone re-stamps too
+  echo "$LINE" > "$HERE/build/build_id.h"
 fi
 FLAGS="$FLAGS -I$HERE/build"
 objs=()
@@ -28,5 +29,5 @@ for f in "$HERE"/*.hip; do
   objs+=("$o")
 done
 for p in "${pids[@]}"; do wait "$p" || { echo "build.sh: compile failed" >&2; exit 1; }; done
-"$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$OUT" "${objs[@]}"
+"$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$OUT" "${objs[@]}" -ldl
 echo "built $OUT"

@@ -98,6 +98,21 @@ class DataLoaderTest(_PngFolder):                      # dataset.py:115-138: haz
         return _chw(f), os.path.basename(f)
 
 
+class DataLoaderTestSR(Dataset):                       # dataset.py:205-232: PNGs directly under rgb_dir -> (tensor, file name)
+    def __init__(self, rgb_dir, target_transform=None):
+        super().__init__()
+        self.target_transform = target_transform
+        self.LR_filenames = [os.path.join(rgb_dir, f) for f in sorted(os.listdir(rgb_dir)) if is_png_file(f)]
+        self.tar_size = len(self.LR_filenames)
+
+    def __len__(self):
+        return self.tar_size
+
+    def __getitem__(self, index):
+        f = self.LR_filenames[index % self.tar_size]
+        return _chw(f), os.path.split(f)[-1]
+
+
 class PatchStoreHBM:
     """All (gt, hazy) patch pairs of a directory as uint8 [N,H,W,3] tensors in HBM + the batch kernel."""
 

@@ -101,6 +101,10 @@ SIGNATURES = {
     "dhz_charbonnier_fwd": [c_f, c_f, c_f, c_f, c_l, c_fl, c_i, c_p],
     "dhz_charbonnier_bwd": [c_f, c_f, c_f, c_f, c_f, c_l, c_fl, c_fl, c_i, c_p],
     "dhz_adamw_step": [c_f, c_f, c_f, c_f, c_l, c_fl, c_fl, c_fl, c_fl, c_fl, c_i, c_fl, c_p],
+    "dhz_comm_unique_id": [c_p],
+    "dhz_comm_init": [c_p, c_i, c_i, c_p],
+    "dhz_comm_allreduce_sum_f32": [c_p, c_f, c_l, c_p],
+    "dhz_comm_destroy": [c_p],
     "dhz_adamw_step_shadow": [c_f, c_f, c_f, c_f, c_f, c_l, c_fl, c_fl, c_fl, c_fl, c_fl, c_i, c_fl, c_p],
 }
 _RESTYPE = {"dhz_last_error": ctypes.c_char_p, "dhz_build_id": ctypes.c_char_p}

@@ -279,37 +279,7 @@ class _AttnBranchChain(Function):
         return out
 
     @staticmethod
-    def _backward_fused(ctx, dout):
-        """One kernel from d(out) to dx and every parameter gradient (csrc/fused_attn_bwd.hip)."""
-        x, gamma, beta, rank, bias, mask, dscale, wqkv_p, bqkv, wt = ctx.saved_tensors
-        wq, bq, wk, bk, wv, bv, wo, bo, gamma_p, beta_p, table_p = ctx.params
-        B, Hres, Wres, C, shift, H = ctx.geom
-        dev = x.device
-        f32 = dict(device=dev, dtype=torch.float32)
-        plist = (wq, wk, wv, bq, bk, bv, wo, bo, gamma_p, beta_p)
-        bufs = [_grad_buf(p) if p is not None else None for p in plist]
-        inplace = all(b is not None or p is None for b, p in zip(bufs, plist))
-        if not inplace:
-            bufs = [torch.zeros_like(p, memory_format=torch.contiguous_format) if p is not None else None for p in plist]
-        gwq, gwk, gwv, gbq, gbk, gbv, gwo, gbo, gg, gb = bufs
-        nwin = B * (Hres // 8) * (Wres // 8)
-        parts = _lib.load().dhz_fused_attn_bwd_parts(nwin)
-        dpart = torch.empty((parts, NTOK, NTOK), **f32) if bias is not None else None
-        dx = torch.empty_like(x)
-        _lib.call("dhz_fused_window_attn_bwd", _p(x), _p(dout.contiguous()), _p(gamma), _p(beta), _p(wqkv_p), _p(bqkv), _p(wt),
-                  _p(bias), _p(mask), _p(dscale), _p(rank), _p(dx), _p(gwq), _p(gwk), _p(gwv), _p(gbq), _p(gbk), _p(gbv), _p(gwo),
-                  _p(gbo), _p(gg), _p(gb), _p(dpart), B, Hres, Wres, C, shift, _stream())
-        dtable = _table_backward(dpart, parts, table_p, H, dev) if bias is not None else None
-        if inplace:
-            _ready(*[p for p in plist if p is not None])
-            return (dx, None, None, None, None, None, None, None, None, None, None, dtable,
-                    None, None, None, None, None, None, None, None)
-        return (dx, gg, gb, gwq, gbq, gwk, gbk, gwv, gbv, gwo, gbo, dtable, None, None, None, None, None, None, None, None)
-
-    @staticmethod
     def backward(ctx, dout):
-        if getattr(ctx, "fused_bwd", False):
-            return _FusedAttnBranch._backward_fused(ctx, dout)
         x, gamma, stats, xn, qkv, cx, rank, bias, mask, dscale, wq_, wk_, wv_, wo_ = ctx.saved_tensors
         wq, bq, wk, bk, wv, bv, wo, bo, gamma_p, beta_p, table_p = ctx.params
         B, Hres, Wres, C, shift, H = ctx.geom

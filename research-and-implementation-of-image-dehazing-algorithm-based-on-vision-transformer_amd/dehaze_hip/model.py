@@ -2,8 +2,9 @@
 
 The module TREE, parameter registration order, initialisation stream and `state_dict` keys are those
 of the reference (Uformer_ProbSparse/My_model_1.py and My_model.py) so checkpoints and optimizer
-states are interchangeable; the COMPUTE inside every block runs through dehaze_hip.ops (hand-written
-HIP kernels) plus rocBLAS/MIOpen calls for the plain GEMMs / strided convolutions.
+states are interchangeable; the COMPUTE inside every block runs through dehaze_hip.ops (hand-written HIP
+kernels - token GEMMs, projections and resampling convolutions included; the library convolution is reached only
+for shapes the kernels do not tile, with a one-time warning naming the shape).
 
 Reference map (M1 = My_model_1.py, M0 = My_model.py, ATT = ProbSparse/attn.py):
   Uformer M1:955-1207 | BasicUformerLayer M1:894-946 | LeWinTransformerBlock M1:738-875 |
@@ -467,9 +468,11 @@ class OutputProj(nn.Module):
             s_ = int(math.sqrt(x.shape[1]))
             x = ops.thin_conv3x3(x, conv.weight, conv.bias, s_, s_)
         elif x.dtype == torch.bfloat16:
+            ops.warn_library_fallback("OutputProj (bf16)", (self.in_channel, self.out_channel, tuple(conv.stride)))
             with torch.autocast("cuda", dtype=torch.bfloat16):
                 x = self.proj(_tokens_to_map(x)).float()
         elif x.is_cuda and len(self.proj) == 1 and conv.bias is not None:
+            ops.warn_library_fallback("OutputProj", (self.in_channel, self.out_channel, tuple(conv.stride)))
             # the convolution without its bias + an explicit bias add whose backward sums in two stages: the library's
             # bias gradient of a 3-channel map is ONE 4-block reduction over the whole gradient image (190 us per step)
             x = _BiasAddMap.apply(F.conv2d(_tokens_to_map(x), conv.weight, None, conv.stride, conv.padding), conv.bias)

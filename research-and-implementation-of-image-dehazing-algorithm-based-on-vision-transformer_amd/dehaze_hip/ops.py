@@ -53,6 +53,18 @@ def _require_gpu(*tensors):
 
 BF16 = torch.bfloat16
 
+_WARNED = set()
+
+
+def warn_library_fallback(what, shape):
+    """One warning per (layer kind, shape): a shape the hand-written kernels do not tile went to the library convolution."""
+    key = (what, tuple(shape))
+    if key not in _WARNED:
+        _WARNED.add(key)
+        import warnings
+        warnings.warn(f"dehaze_hip: {what} with shape {tuple(shape)} is not tiled by the HIP kernels - running the library "
+                      "convolution (MIOpen) for it", stacklevel=3)
+
 
 def _dt(t):
     """dtype code of the dhz_*_dt entry points (include/dehaze_hip.h: DHZ_F32 = 0, DHZ_BF16 = 1)."""

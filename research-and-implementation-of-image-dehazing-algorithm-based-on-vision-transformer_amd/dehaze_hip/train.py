@@ -225,8 +225,9 @@ class GradReducer:
     Dead parameters never enter a bucket (find_unused_parameters-equivalent).
     """
 
-    def __init__(self, optimizer=None, params=None, bucket_mb=25.0, group=None):
+    def __init__(self, optimizer=None, params=None, bucket_mb=25.0, group=None, overlap=True):
         self.group = group
+        self.overlap = overlap        # False (bench.py --no-overlap): every bucket's collective is launched by wait(), after backward
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.opt = optimizer
         if optimizer is not None:
@@ -293,7 +294,7 @@ class GradReducer:
         self._seen.add(id(p))
         b = self.bucket_of[id(p)]
         self._pending[b] += 1
-        if self._pending[b] == self.buckets[b][2]:
+        if self._pending[b] == self.buckets[b][2] and self.overlap:
             lo, hi, _ = self.buckets[b]
             self._handles.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
@@ -302,7 +303,7 @@ class GradReducer:
         if self.world > 1:
             # buckets whose hooks did not all fire (a parameter unused this step) are reduced here
             for b, (lo, hi, n) in enumerate(self.buckets):
-                if 0 < self._pending[b] < n or (self._pending[b] == 0 and n > 0):
+                if 0 < self._pending[b] < n or (self._pending[b] == 0 and n > 0) or (not self.overlap and n > 0):
                     self._handles.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group,
                                                          async_op=True))
             for h in self._handles:

@@ -139,6 +139,7 @@ class VggEngine:
             if i == 12 and not wino_supported(cur.shape[2], cur.shape[3]):
                 # conv 12 on maps the kernel does not tile (e.g. 24x24 for 384x384 patches): library convolution, NCHW tap
                 c12 = self.convs[12]
+                ops.warn_library_fallback("VGG19 conv5_1", tuple(cur.shape))
                 x12 = to_plain(cur)
                 cur = F.relu(F.conv2d(x12, c12.weight, c12.bias, padding=1))
             else:

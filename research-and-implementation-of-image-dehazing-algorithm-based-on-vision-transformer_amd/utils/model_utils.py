@@ -124,6 +124,12 @@ def load_rng_state(weights, rank=0):
         st = [st]
     if rank >= len(st) or st[rank] is None:
         return False
+    if not isinstance(st[rank], dict) or "python_mt" not in st[rank]:
+        # a checkpoint of an earlier commit of this repository ('host': pickled bytes) or a foreign format: never unpickled;
+        # the run continues on fresh seeds, as it does for a reference checkpoint
+        import warnings
+        warnings.warn(f"{weights}: 'rng_state' is not in this version's format (legacy or foreign file): generator states not restored")
+        return False
     set_rng_state(st[rank])
     return True
 
@@ -138,7 +144,11 @@ def get_arch(opt):
         return Uformer(img_size=opt.train_ps, embed_dim=opt.embed_dim, win_size=opt.win_size,
                        token_projection=opt.token_projection, token_mlp=opt.token_mlp)
     if arch == 'Uformer16':
-        return Uformer(img_size=opt.train_ps, embed_dim=16, win_size=8, token_projection='linear', token_mlp='leff')
+        # model_utils.py:96-98.  embed_dim 16 gives head_dim 16; the attention kernels of this build are instantiated for head_dim
+        # 32 and 64 (one MFMA contraction step of 4 over 8 / 16 steps; LDS tiles sized per head_dim) - say so here, not as an
+        # argument error from the first forward
+        raise NotImplementedError("arch 'Uformer16' (embed_dim 16 -> head_dim 16): this build's window-attention kernels cover "
+                                  "head_dim 32 and 64 (embed_dim 32 / 64); use --arch Uformer32 or --arch Uformer --embed_dim 32|64")
     if arch == 'Uformer32':
         return Uformer(img_size=opt.train_ps, embed_dim=32, win_size=8, token_projection='linear', token_mlp='leff')
     raise Exception("Arch error!")

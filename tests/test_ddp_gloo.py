@@ -27,14 +27,14 @@ def _build():
     return net, dead
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, overlap=True):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from dehaze_hip import ops
     from dehaze_hip.train import GradReducer
     net, dead = _build()
     params = list(net.parameters())
-    red = GradReducer(params=params, bucket_mb=0.002)      # tiny buckets -> several collectives
+    red = GradReducer(params=params, bucket_mb=0.002, overlap=overlap)      # tiny buckets -> several collectives
     assert len(red.buckets) >= 3
     g = torch.Generator().manual_seed(5)
     x = torch.randn(8, 16, generator=g)
@@ -44,6 +44,7 @@ def _worker(rank, world, port, q):
         red.flat.zero_()
         loss = ((net(xs) - ys) ** 2).sum()
         loss.backward()
+        assert overlap or not red._handles                  # --no-overlap: nothing is launched before wait()
         red.wait()
         red.average_()
     grads = [p.grad.clone() for p in params]
@@ -107,11 +108,13 @@ def _worker(rank, world, port, q):
 
 
 @pytest.mark.timeout(300)
-def test_grad_reducer_world2_gloo():
+@pytest.mark.parametrize("overlap", [True, False])
+def test_grad_reducer_world2_gloo(overlap):
+    """overlap=False is bench.py --no-overlap: every bucket's collective is launched by wait(), after backward"""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, overlap)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=120) for _ in range(2)], key=lambda t: t[0])

@@ -275,9 +275,9 @@ def test_config4_full_size_bf16_properties():
     """BASELINE config 4 AT FULL SIZE and in its dtype (E = 64, 256 x 256 patches, 8 per GPU, bf16 activations), where the CPU
     oracle is too slow to be the checker - size-independent properties instead: (1) a patch restored inside the batch equals the
     same patch restored alone to within bf16 rounding of a [0, 1] image: max |difference| <= 2^-6, mean < 1e-3 (this build's own
-    kernels accumulate per token in an order that does not depend on the batch size, but the resampling / projection
-    convolutions of the bf16 path still run on the library, which picks its algorithm by batch size: an fp32 ulp there becomes
-    a bf16 step downstream - measured max 4.4e-3, mean 4.8e-4); (2) the fp32
+    kernels accumulate per token in an order that does not depend on the batch size, but the GEMM tile shape follows the token
+    count, so the summation order of a product can differ between the two runs: an fp32 ulp there becomes a bf16 step downstream
+    - measured max 4.4e-3, mean 4.8e-4); (2) the fp32
     gradient of the 8-patch batch equals the mean of the gradients of its halves (the loss scale differs by a factor of two, which
     commutes with bf16 rounding; bound 2 % norm-wise, for the same reason as (1)); (3) one finite step that moves the weights."""
     import My_model_1 as M1

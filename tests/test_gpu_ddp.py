@@ -122,3 +122,32 @@ def test_two_rank_step_equals_full_batch_step(tmp_path):
         assert worst[0][0] < 2e-3, worst[:3]
         assert gerr < 2e-4, (rank, gerr)                                   # fp32 atomics order + summation split
         assert perr < 2e-6, (rank, perr)                                   # AdamW's first step moves every weight by ~lr
+
+
+def test_c_abi_comm_single_rank_allreduce():
+    """include/dehaze_hip.h C1: dhz_comm_unique_id / _init / _allreduce_sum_f32 / _destroy - the RCCL wrappers a host that binds only
+    the C library uses for the gradient exchange.  One rank on one device: the collective must run on the caller's stream and leave
+    a SUM over one rank, i.e. the buffer itself; with two visible devices tests/test_gpu_bench.py covers the two-rank exchange."""
+    import ctypes
+    import torch
+    from dehaze_hip import _lib
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    uid = (ctypes.c_char * 128)()
+    _lib.call("dhz_comm_unique_id", ctypes.cast(uid, ctypes.c_void_p))
+    assert any(bytes(uid))
+    comm = ctypes.c_void_p()
+    _lib.call("dhz_comm_init", ctypes.cast(ctypes.pointer(comm), ctypes.c_void_p), 0, 1, ctypes.cast(uid, ctypes.c_void_p))
+    assert comm.value
+    g = torch.arange(1 << 20, device=dev, dtype=torch.float32) * 0.5
+    ref = g.clone()
+    st = torch.cuda.Stream()
+    st.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(st):
+        _lib.call("dhz_comm_allreduce_sum_f32", comm, g.data_ptr(), g.numel(), st.cuda_stream)
+    st.synchronize()
+    assert torch.equal(g, ref)
+    _lib.call("dhz_comm_destroy", comm)
+    lib = _lib.load()
+    assert lib.dhz_comm_init(None, 0, 1, None) == -22 and b"null pointer" in lib.dhz_last_error()
+    assert lib.dhz_comm_init(ctypes.cast(ctypes.pointer(comm), ctypes.c_void_p), 3, 2, ctypes.cast(uid, ctypes.c_void_p)) == -22
