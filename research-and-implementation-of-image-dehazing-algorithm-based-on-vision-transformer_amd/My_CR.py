@@ -121,14 +121,24 @@ class ContrastLoss(nn.Module):
         self.weights = [1.0 / 32, 1.0 / 16, 1.0 / 8, 1.0 / 4, 1.0]
         self.ab = ablation
 
-    def forward(self, a, p, n):
+    def reference_taps(self, p, n):
+        """The no-gradient half of forward(): the feature taps of (p, n) in the engine's layout, or None when the engine does not
+        apply.  train_step can run it on a side stream beside the model's forward (the inputs exist before the step starts) and
+        hand the result to forward(..., pn_taps=)."""
+        eng = self.vgg.engine_for(p)
+        if eng is None:
+            return None
+        from dehaze_hip.vgg import vgg_taps
+        with torch.no_grad():
+            return vgg_taps(eng, torch.cat([p, n], 0) if not self.ab else p)
+
+    def forward(self, a, p, n, pn_taps=None):
         # p and n never need gradients: one batched VGG pass for both, one (with grad) for a
         eng = self.vgg.engine_for(a)
         if eng is not None:
             # features stay in the engine's channel-blocked layout: the L1 means do not care about element order
             from dehaze_hip.vgg import vgg_taps
-            with torch.no_grad():
-                pn = vgg_taps(eng, torch.cat([p, n], 0) if not self.ab else p)
+            pn = pn_taps if pn_taps is not None else self.reference_taps(p, n)
             a_vgg = vgg_taps(eng, a)
         else:
             with torch.no_grad():

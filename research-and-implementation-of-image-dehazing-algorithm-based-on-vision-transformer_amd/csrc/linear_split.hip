@@ -15,6 +15,7 @@
 // matrix time.
 // LDS images and fragment reads are those of csrc/linear_bf16.hip (one hi and one lo image per operand); operands and results stay
 // fp32 in HBM.
+#include <stdlib.h>
 #include "common.h"
 
 namespace {
@@ -462,6 +463,193 @@ __global__ __launch_bounds__(256, 2) void wgrad_split_kernel(const float* __rest
     }
 }
 
+// ---- round 4: the six-term weight gradient as a software pipeline.  The kernel above puts the split of a stage between two
+// barriers (nothing multiplies while 216 vector instructions and 18 LDS writes per thread run).  Here a stage is 32 token rows, the
+// LDS holds two stages, and the split + LDS writes of stage s+1 (registers loaded during stage s-1) ride BETWEEN the MFMAs of
+// stage s - a bf16 MFMA holds the vector issue for 8 of its 16 cycles, a wave's own vector / LDS instructions go into the other 8
+// (csrc/split6_gemm.hip) - with one barrier per stage.
+constexpr int BK2 = 32;
+template <int WM, int WN>
+__global__ __launch_bounds__(256, 2) void wgrad_split6_kernel(const float* __restrict__ dy, int ldy, const float* __restrict__ x,
+                                                              int ldx, int T, int N, int K, WgradOut out, int nsplit,
+                                                              const float* __restrict__ row_scale, int rows_per_scale) {
+    constexpr int FM = 32 * WM, FN = 32 * WN;
+    constexpr int A_BYTES = BK2 * FM * 2, B_BYTES = BK2 * FN * 2;          // one piece of one stage
+    constexpr int STAGE = 3 * (A_BYTES + B_BYTES);
+    constexpr int NA = BK2 * (FM / 8) / 256, NB = BK2 * (FN / 8) / 256;    // 8-element chunks per thread per stage (1 or 2)
+    static_assert(NA >= 1 && NB >= 1, "tile too narrow for 256 threads");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int i16 = lane & 15, g = lane >> 4;
+    const int wm = w >> 1, wn = w & 1;
+    const int tiles_n = K / FN;
+    int bid = blockIdx.x;
+    const int split = bid % nsplit; bid /= nsplit;
+    const int tn = bid % tiles_n, tm = bid / tiles_n;
+    const int n0 = tm * FM, k0 = tn * FN;
+    const int mat = n0 / out.nper, nloc = n0 - mat * out.nper;
+    float* __restrict__ const dw = out.dw[mat];
+    float* __restrict__ const db = out.db[mat];
+    const int nst = T / BK2;
+    const int st0 = (int)((long long)nst * split / nsplit), st1 = (int)((long long)nst * (split + 1) / nsplit);
+
+    f32x4 acc[WM][WN];
+#pragma unroll
+    for (int a = 0; a < WM; ++a)
+#pragma unroll
+        for (int b = 0; b < WN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 ra[NA][2], rb[NB][2];
+    float rs[NA];
+    float dbacc[NA][8];
+#pragma unroll
+    for (int i = 0; i < NA; ++i)
+#pragma unroll
+        for (int c = 0; c < 8; ++c) dbacc[i][c] = 0.f;
+    const bool do_db = (db != nullptr) && (tn == 0);
+    int a_off[NA], b_off[NB];                                    // LDS byte offsets of this thread's chunks inside a piece image
+    const float* pa[NA];
+    const float* pb[NB];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const int e = t + 256 * i;
+        a_off[i] = off_tr<FM>(e / (FM / 8), e % (FM / 8));
+        pa[i] = dy + (size_t)(e / (FM / 8)) * ldy + n0 + 8 * (e % (FM / 8));
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const int e = t + 256 * i;
+        b_off[i] = off_tr<FN>(e / (FN / 8), e % (FN / 8));
+        pb[i] = x + (size_t)(e / (FN / 8)) * ldx + k0 + 8 * (e % (FN / 8));
+    }
+    auto gload = [&](int st) {
+        const size_t tok0 = (size_t)st * BK2;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const float* p = pa[i] + tok0 * ldy;
+            ra[i][0] = *reinterpret_cast<const f32x4*>(p);
+            ra[i][1] = *reinterpret_cast<const f32x4*>(p + 4);
+            rs[i] = row_scale ? row_scale[(tok0 + (t + 256 * i) / (FM / 8)) / rows_per_scale] : 1.f;
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const float* p = pb[i] + tok0 * ldx;
+            rb[i][0] = *reinterpret_cast<const f32x4*>(p);
+            rb[i][1] = *reinterpret_cast<const f32x4*>(p + 4);
+        }
+    };
+    auto swrite = [&](int buf) {
+        unsigned char* As = smem + buf * STAGE;
+        unsigned char* Bs = As + 3 * A_BYTES;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const f32x4 v0 = ra[i][0] * rs[i], v1 = ra[i][1] * rs[i];
+            u32x4 hi, mid, lo;
+            split8x3(v0, v1, hi, mid, lo);
+            *reinterpret_cast<u32x4*>(As + a_off[i]) = hi;
+            *reinterpret_cast<u32x4*>(As + A_BYTES + a_off[i]) = mid;
+            *reinterpret_cast<u32x4*>(As + 2 * A_BYTES + a_off[i]) = lo;
+            if (do_db) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) { dbacc[i][c] += v0[c]; dbacc[i][4 + c] += v1[c]; }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            u32x4 hi, mid, lo;
+            split8x3(rb[i][0], rb[i][1], hi, mid, lo);
+            *reinterpret_cast<u32x4*>(Bs + b_off[i]) = hi;
+            *reinterpret_cast<u32x4*>(Bs + B_BYTES + b_off[i]) = mid;
+            *reinterpret_cast<u32x4*>(Bs + 2 * B_BYTES + b_off[i]) = lo;
+        }
+    };
+    if (st0 < st1) {
+        gload(st0);
+        swrite(st0 & 1);
+        if (st0 + 1 < st1) gload(st0 + 1);
+    }
+    __syncthreads();
+    for (int st = st0; st < st1; ++st) {
+        const int buf = st & 1;
+        const unsigned char* As = smem + buf * STAGE;
+        const unsigned char* Bs = As + 3 * A_BYTES;
+        s16x8 af[3][WM], bf[3][WN];
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) {
+#pragma unroll
+            for (int a = 0; a < WM; ++a) af[pc][a] = tr_frag<FM>(As + pc * A_BYTES, 8 * g, wm * WM + a, lane);
+#pragma unroll
+            for (int b = 0; b < WN; ++b) bf[pc][b] = tr_frag<FN>(Bs + pc * B_BYTES, 8 * g, wn * WN + b, lane);
+        }
+        // ---- one stream: the stage's MFMAs (term-major: consecutive ones never share an accumulator), between them the split and
+        //      the LDS writes of stage st+1 (the other buffer: its readers passed the barrier at the end of stage st-1)
+        constexpr int TA[6] = {2, 0, 1, 1, 0, 0}, TB[6] = {0, 2, 1, 0, 1, 0};      // (dy piece, x piece): lh hl mm mh hm hh
+#pragma unroll
+        for (int term = 0; term < 6; ++term)
+#pragma unroll
+            for (int a = 0; a < WM; ++a)
+#pragma unroll
+                for (int b = 0; b < WN; ++b) acc[a][b] = mfma_bf16(af[TA[term]][a], bf[TB[term]][b], acc[a][b]);
+        if (st + 1 < st1) swrite(buf ^ 1);
+#pragma unroll
+        for (int i = 0; i < WM * WN * 6; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x202, 3, 0);     // up to three vector instructions / LDS writes per MFMA
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (st + 2 < st1) gload(st + 2);
+        // raw barrier: a __syncthreads() would also drain vmcnt, i.e. wait for the loads just issued
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    }
+    // ---- epilogue: tile -> LDS (row-major FM x FN fp32) -> full-line fp32 atomics
+    float* Cs = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int a = 0; a < WM; ++a)
+#pragma unroll
+        for (int b = 0; b < WN; ++b)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) Cs[(wm * WM * 16 + a * 16 + 4 * g + j) * FN + wn * WN * 16 + b * 16 + i16] = acc[a][b][j];
+    __syncthreads();
+    for (int e = t; e < FM * FN; e += 256) atomicAdd(dw + (size_t)(nloc + e / FN) * K + k0 + e % FN, Cs[e]);
+    if (do_db) {
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(smem);          // [rows of chunks][FM]
+        constexpr int CPR = FM / 8;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int e = t + 256 * i;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) red[(e / CPR) * FM + 8 * (e % CPR) + c] = dbacc[i][c];
+        }
+        __syncthreads();
+        if (t < FM) {
+            float tot = 0.f;
+            for (int r = 0; r < 256 * NA / CPR; ++r) tot += red[r * FM + t];
+            atomicAdd(db + nloc + t, tot);
+        }
+    }
+}
+
+template <int WM, int WN>
+void launch_wgrad_split6(const float* dy, int ldy, const float* x, int ldx, int T, int N, int K, const WgradOut& out,
+                         const float* row_scale, int rows_per_scale, hipStream_t s) {
+    constexpr int FM = 32 * WM, FN = 32 * WN;
+    constexpr size_t stage = (size_t)BK2 * (FM + FN) * 2 * 3;
+    constexpr size_t ring = 2 * stage;
+    constexpr size_t smem = ring > (size_t)FM * FN * 4 ? ring : (size_t)FM * FN * 4;
+    const int tiles = (N / FM) * (K / FN);
+    int nsplit = 2 * dhz_num_cus() / tiles;
+    const int max_split = T / (BK2 * 8) > 0 ? T / (BK2 * 8) : 1;          // at least 8 stages per workgroup
+    if (nsplit > max_split) nsplit = max_split;
+    if (nsplit < 1) nsplit = 1;
+    if (smem > 48 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_split6_kernel<WM, WN>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)smem);
+    hipLaunchKernelGGL((wgrad_split6_kernel<WM, WN>), dim3(tiles * nsplit), dim3(256), smem, s, dy, ldy, x, ldx, T, N, K, out, nsplit,
+                       row_scale, rows_per_scale);
+}
+
 template <int WM, int WN, bool SIX>
 void launch_wgrad_split(const float* dy, int ldy, const float* x, int ldx, int T, int N, int K, const WgradOut& out,
                         const float* row_scale, int rows_per_scale, hipStream_t s) {
@@ -516,6 +704,16 @@ extern "C" int dhz_linear_wgrad_split(const float* dy, int ldy, const float* x, 
     const int wm = nper % 128 == 0 ? 4 : 2, wn = (K % 128 == 0 && !(terms == 6 && wm == 4)) ? 4 : 2;
     hipStream_t s = (hipStream_t)stream;
     const int rps = rows_per_scale > 0 ? rows_per_scale : 1;
+    static const bool old6 = getenv("DHZ_WGRAD6_OLD") != nullptr;       // diagnostics: the round-3 kernel for the six-term form
+    if (terms == 6 && !old6) {
+        // pipelined kernel: 128 x 64 / 64 x 128 / 64 x 64 tiles (two piece-image stages of 32 rows: <= 72 KB, two workgroups per CU)
+        const int wm6 = nper % 128 == 0 ? 4 : 2, wn6 = (K % 128 == 0 && wm6 == 2) ? 4 : 2;
+        if (wm6 == 4) launch_wgrad_split6<4, 2>(dy, ldy, x, ldx, T, N, K, out, row_scale, rps, s);
+        else if (wn6 == 4) launch_wgrad_split6<2, 4>(dy, ldy, x, ldx, T, N, K, out, row_scale, rps, s);
+        else launch_wgrad_split6<2, 2>(dy, ldy, x, ldx, T, N, K, out, row_scale, rps, s);
+        DHZ_CHECK_LAUNCH(who);
+        return DHZ_OK;
+    }
 #define CASE(a, b) \
     if (wm == a && wn == b) {                                                                                  \
         if (terms == 3) launch_wgrad_split<a, b, false>(dy, ldy, x, ldx, T, N, K, out, row_scale, rps, s);     \

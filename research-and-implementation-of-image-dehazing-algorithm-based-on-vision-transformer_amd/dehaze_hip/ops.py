@@ -166,6 +166,9 @@ def split_planes(W):
     return pl[0], pl[1], pl[2]
 
 
+_ROUTE6_FORCE = os.environ.get("DHZ_S6_ROUTE", "")
+
+
 def _route6(T, contraction, out, dgrad):
     """which kernel takes a six-term GEMM of T tokens (measured per shape on the config-2 step, tools/bench_split6.py):
     'new' = csrc/split6_gemm.hip (pre-split weight planes; 256 x 128 / 128 x 128 tiles), 'old' = csrc/linear_split.hip (both
@@ -174,6 +177,10 @@ def _route6(T, contraction, out, dgrad):
     if contraction % 32 or out % 32 or contraction < 64 or out < 64:
         return "f32"
     old_ok = contraction % 64 == 0 and out % 64 == 0
+    if _ROUTE6_FORCE == "old" and old_ok and contraction >= 128:          # diagnostics: the round-3 dispatch
+        return "old"
+    if _ROUTE6_FORCE == "old":
+        return "f32"
     new_ok = not dgrad or out % 64 == 0
     if T <= 2048 and out < 2048 and old_ok:
         return "old"

@@ -338,11 +338,48 @@ def synthetic_batch(batch, ps=128, seed=1234, device="cpu"):
     return gt.to(device), hazy.to(device)
 
 
-def train_step(model, char_loss, cr_loss, optimizer, reducer, input_, target, w_char=1.0, w_cr=1.0):
+class SideStream:
+    """A second HIP stream, optionally restricted to a subset of the compute units (hipExtStreamCreateWithCUMask), for work that is
+    independent of the main stream's critical path: train_step(side=...) puts the no-gradient VGG19 passes of the contrastive
+    loss (ground truth and hazy input: known before the step starts) on it, beside the model's forward.  cus = 0: an ordinary
+    stream (all CUs).  Measured on MI355X: profiles/r04_concurrency.txt."""
+
+    def __init__(self, device, cus=0, first=0):
+        import ctypes
+        self.device = torch.device(device)
+        self.cus = int(cus)
+        self._hip = None
+        if self.cus > 0:
+            hip = ctypes.CDLL("libamdhip64.so")
+            total = torch.cuda.get_device_properties(self.device).multi_processor_count
+            words = (total + 31) // 32
+            mask = (ctypes.c_uint32 * words)()
+            for i in range(first, min(first + self.cus, total)):
+                mask[i // 32] |= 1 << (i % 32)
+            st = ctypes.c_void_p()
+            with torch.cuda.device(self.device):
+                rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(st), ctypes.c_uint32(words), mask)
+            if rc != 0 or not st.value:
+                raise RuntimeError(f"hipExtStreamCreateWithCUMask failed with {rc}")
+            self._hip, self._raw = hip, st
+            self.stream = torch.cuda.ExternalStream(st.value, device=self.device)
+        else:
+            self.stream = torch.cuda.Stream(device=self.device)
+
+    def __del__(self):
+        try:
+            if self._hip is not None:
+                self._hip.hipStreamDestroy(self._raw)
+        except Exception:
+            pass
+
+
+def train_step(model, char_loss, cr_loss, optimizer, reducer, input_, target, w_char=1.0, w_cr=1.0, side=None):
     """One optimisation step, the body of TR:212-250 in fp32: zero_grad -> restored = model(input_) ->
     clamp(0,1) -> w_char*Charbonnier + w_cr*Contrast -> backward (bucketed all-reduce overlapped) ->
     AdamW.  Returns (loss, loss_rec, loss_cr) as device scalars (no host sync here; the reference's
-    per-step .item() calls, TR:250-254, are left to the caller's logging cadence)."""
+    per-step .item() calls, TR:250-254, are left to the caller's logging cadence).
+    side: a SideStream - the contrastive loss' no-gradient feature passes (target, input_) run on it beside the model's forward."""
     if isinstance(optimizer, FlatAdamW):
         if getattr(model, "act_dtype", None) == torch.bfloat16:
             if ops.BF16_SHADOW is None or optimizer._flat is None or ops.BF16_SHADOW[0] is not optimizer._flat["p"]:
@@ -360,12 +397,27 @@ def train_step(model, char_loss, cr_loss, optimizer, reducer, input_, target, w_
         reducer.zero_grad()
     else:
         optimizer.zero_grad()
+    pn_taps, pn_done = None, None
+    use_cr = w_cr > 0 and cr_loss is not None
+    if use_cr and side is not None and hasattr(cr_loss, "reference_taps"):
+        main = torch.cuda.current_stream()
+        side.stream.wait_stream(main)                                 # the batch is resident
+        with torch.cuda.stream(side.stream):
+            pn_taps = cr_loss.reference_taps(target, input_)
+            pn_done = torch.cuda.Event()
+            pn_done.record(side.stream)
     restored = model(input_)
     loss_rec, clamped = char_loss.forward_clamped(restored, target)
     loss = w_char * loss_rec if w_char > 0 else 0
     loss_cr = None
-    if w_cr > 0 and cr_loss is not None:
-        loss_cr, _, _ = cr_loss(clamped, target, input_)
+    if use_cr:
+        if pn_taps is not None:
+            torch.cuda.current_stream().wait_event(pn_done)
+            for t in pn_taps:
+                t.record_stream(torch.cuda.current_stream())          # allocated on the side stream, consumed here
+            loss_cr, _, _ = cr_loss(clamped, target, input_, pn_taps=pn_taps)
+        else:
+            loss_cr, _, _ = cr_loss(clamped, target, input_)
         loss = loss + w_cr * loss_cr
     loss.backward()
     if reducer is not None:
