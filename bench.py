@@ -272,7 +272,7 @@ def main():
     timing = None
     if not args.no_kernel_timing and rank == 0:
         ops.KERNEL_TIMING = {"dhz_ps_attn_fwd": [], "dhz_fused_window_attn_fwd": [], "dhz_winograd_conv3x3": [],
-                             "dhz_linear_bf16": [], "dhz_vgg_conv3x3_bf16": []}
+                             "dhz_linear_bf16": [], "dhz_vgg_conv3x3_bf16": [], "dhz_linear_split6": [], "dhz_linear_wgrad_split": []}
     if not args.no_kernel_timing:
         for _ in range(min(args.steps, 5)):
             step()                                # every rank runs it (the step holds a collective)
@@ -403,6 +403,22 @@ def main():
                                         "traffic": round(traffic) if traffic else None, "traffic_source": traffic_source,
                                         "launches": len(ev), "avg_launch_us": round(1e3 * ms / len(ev), 2),
                                         "alg_flops_per_launch": int(direct / 2.25 / len(ev))}
+        for key, name, kern in (("dhz_linear_split6", "roofline_split6_gemm",
+                                 "split6_wide_kernel / split6_gemm_kernel / gemm_split_kernel (dhz_linear_fwd_split6, dhz_linear_dgrad_split6, "
+                                 "dhz_linear_fwd_split, dhz_linear_dgrad_split): six-term forward / backward-data token-Linear GEMMs"),
+                                ("dhz_linear_wgrad_split", "roofline_split6_wgrad",
+                                 "wgrad_split6_kernel (dhz_linear_wgrad_split): six-term weight gradients")):
+            ev = (timing or {}).get(key) or []
+            if ev:
+                # condition (v) of the round-3 ruling: a split kernel is priced on the bf16 FLOPs it ISSUES (six MFMA products per
+                # multiply-add) against the dense bf16 matrix peak - never against the fp32 pipe's 157.3
+                ms = sum(a.elapsed_time(b_) for a, b_, _ in ev)
+                flops = sum(f for _, _, f in ev)
+                tf = flops / (ms * 1e-3) / 1e12
+                out[name] = {"kernel": kern, "bound": "mfma", "achieved": round(tf, 1), "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s",
+                             "frac": round(tf / MFMA_BF16_PEAK_TF, 4), "flops_counted": "issued bf16 MFMA FLOPs = 6 x algorithmic",
+                             "algorithmic_tflops": round(tf / 6.0, 1), "traffic": None, "launches": len(ev),
+                             "avg_launch_us": round(1e3 * ms / len(ev), 2), "issued_flops_per_launch": int(flops / len(ev))}
         if fp32_pipe is not None:
             out["fp32_pipe"] = fp32_pipe
         if world == 1 and not args.no_config4 and (args.dtype, args.embed_dim, args.ps, args.batch) == ("f32", 32, 128, 32) \

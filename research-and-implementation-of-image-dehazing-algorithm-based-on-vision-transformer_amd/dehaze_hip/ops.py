@@ -232,9 +232,12 @@ def gemm_fwd(x, W, b=None):
     elif SPLIT_BF16 == 6 and x.stride(0) % 4 == 0 and _route6(T, K, N, False) != "f32":
         if _route6(T, K, N, False) == "new":
             hi, mid, lo = split_planes(W)
+            ev = _timed("dhz_linear_split6")
             _lib.call("dhz_linear_fwd_split6", _p(x), x.stride(0), _p(hi), _p(mid), _p(lo), _p(b), _p(y), N, T, N, K, _stream())
         else:
+            ev = _timed("dhz_linear_split6")
             _lib.call("dhz_linear_fwd_split", _p(x), x.stride(0), _p(W), _p(b), _p(y), N, T, N, K, 6, _stream())
+        _timed_end(ev, 12.0 * T * N * K)                         # ISSUED bf16 FLOPs: six products per multiply-add
     elif SPLIT_BF16 == 3 and K >= SPLIT_MIN_K and K % 64 == 0 and N % 64 == 0:      # experiment
         _lib.call("dhz_linear_fwd_split", _p(x), x.stride(0), _p(W), _p(b), _p(y), N, T, N, K, 3, _stream())
     else:
@@ -256,11 +259,13 @@ def gemm_dgrad(dy, W):
         _lib.call("dhz_linear_dgrad_bf16", _p(dy), dy.stride(0), _p(Wb), _p(dx), K, T, N, K, _stream())
         _timed_end(ev, 2.0 * T * N * K)
     elif SPLIT_BF16 == 6 and dy.stride(0) % 4 == 0 and _route6(T, N, K, True) != "f32":
+        ev = _timed("dhz_linear_split6")
         if _route6(T, N, K, True) == "new":
             hi, mid, lo = split_planes(W)
             _lib.call("dhz_linear_dgrad_split6", _p(dy), dy.stride(0), _p(hi), _p(mid), _p(lo), _p(dx), K, T, N, K, _stream())
         else:
             _lib.call("dhz_linear_dgrad_split", _p(dy), dy.stride(0), _p(W), _p(dx), K, T, N, K, 6, _stream())
+        _timed_end(ev, 12.0 * T * N * K)
     elif SPLIT_BF16 == 3 and N >= SPLIT_MIN_K and N % 64 == 0 and K % 64 == 0:      # experiment
         _lib.call("dhz_linear_dgrad_split", _p(dy), dy.stride(0), _p(W), _p(dx), K, T, N, K, 3, _stream())
     else:
@@ -439,10 +444,12 @@ def _accumulate_param_grads(dy, ldy_off, x, params, row_scale=None):
             Ng = grp[0][0].shape[0]
             dws = (ctypes.c_void_p * n)(*[W.grad.data_ptr() for W, _ in grp])
             dbs = (ctypes.c_void_p * n)(*[(b.grad.data_ptr() if b is not None else None) for _, b in grp])
+            ev = _timed("dhz_linear_wgrad_split")
             _lib.call("dhz_linear_wgrad_split", dy.data_ptr() + 4 * off, dy.stride(0), _p(x), x.stride(0), T, n, Ng, K,
                       ctypes.cast(dws, ctypes.c_void_p), ctypes.cast(dbs, ctypes.c_void_p),
                       _p(row_scale[0]) if row_scale is not None else None, int(row_scale[1]) if row_scale is not None else 0,
                       _terms(), _stream())
+            _timed_end(ev, 2.0 * _terms() * T * n * Ng * K)
             off += n * Ng
     elif same:
         n = len(params)
