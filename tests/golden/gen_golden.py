@@ -200,6 +200,38 @@ def gen_blocks(M1, M0):
             **sd_arrays(blk), **grad_arrays(blk))
 
 
+def gen_block_c128(M1):
+    """round 4: the ProbSparse block at C = 128 (four heads), shifted, 16 x 16 - the widest instance of the fused window-attention
+    forward (csrc/fused_attn.hip) - so that it is checked against the REFERENCE, not only against the kernel chain"""
+    seed_all(31)
+    blk = M1.LeWinTransformerBlock(dim=128, input_resolution=(16, 16), num_heads=4, win_size=8, shift_size=4, token_mlp='leff',
+                                   drop_path=0.)
+    g = torch.Generator().manual_seed(7)
+    with torch.no_grad():
+        for p in blk.parameters():
+            if p.ndim == 1:
+                p.add_(0.1 * torch.randn(p.shape, generator=g))
+    x = torch.randn(1, 256, 128, generator=g).requires_grad_()
+    gout = torch.randn(1, 256, 128, generator=g)
+    torch.manual_seed(79)
+    idx = torch.randint(64, (64, 25))
+    torch.manual_seed(79)
+    y = blk(x)
+    (y * gout).sum().backward()
+    # kept small: the weights, x and gout are NOT stored (the test rebuilds them with this seed recipe - the package's init stream equals the
+    # reference's, tests/test_host.py), the parameter gradients as norm + every 97th element
+    gs = {}
+    for k, p in blk.named_parameters():
+        if p.grad is None:
+            gs["gn/" + k] = torch.zeros(0)
+        else:
+            gs["gn/" + k] = p.grad.double().norm().reshape(1)
+            gs["gs/" + k] = p.grad.reshape(-1)[::97].clone()
+    first = next(iter(blk.parameters()))
+    npz("block_m1_c128_shift4", x_probe=x.detach().reshape(-1)[:16].clone(), gout_probe=gout.reshape(-1)[:16].clone(),
+        idx=idx.to(torch.int8), y=y, dx=x.grad, w_probe=first.detach().reshape(-1)[:16].clone(), **gs)
+
+
 def gen_masks(M1):
     m16 = ref_shift_mask(M1, 16)
     m128 = ref_shift_mask(M1, 128)
@@ -406,6 +438,14 @@ def main():
     if len(sys.argv) > 2 and sys.argv[1] == "--only" and sys.argv[2] == "data":
         gen_data()
         return
+    if len(sys.argv) > 2 and sys.argv[1] == "--only" and sys.argv[2] == "block128":
+        install_shims()
+        import warnings
+        warnings.filterwarnings("ignore")
+        import My_model_1 as M1
+        torch.set_num_threads(8)
+        gen_block_c128(M1)
+        return
     install_shims()
     import warnings
     warnings.filterwarnings("ignore")
@@ -419,6 +459,7 @@ def main():
     gen_probattn(M1, ATT)
     gen_masks(M1)
     gen_blocks(M1, M0)
+    gen_block_c128(M1)
     gen_small_modules(M1)
     gen_losses(losses)
     gen_options()

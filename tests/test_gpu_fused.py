@@ -122,3 +122,27 @@ def test_fused_block_vs_reference_golden(golden, dev, name, heads, shift, C):
         if ref.size:
             err = (p.grad.cpu() - T(ref)).abs().max().item()
             assert err <= 2e-4 + 2e-3 * np.abs(ref).max(), (n, err)
+
+
+@pytest.mark.parametrize("use_fused", [True, False])
+def test_block_c128_vs_reference_golden(golden, dev, use_fused):
+    """C = 128 (four heads), shifted windows, 16 x 16: the widest instance of the fused window-attention forward - and the kernel
+    chain - against the REFERENCE's numbers (tests/golden/block_m1_c128_shift4.npz), not only against each other"""
+    import My_model_1 as M1
+    from dehaze_hip import fused
+    from test_oracle_golden import _c128_block_inputs, check_c128_grads
+    g = golden("block_m1_c128_shift4")
+    blk, x, gout = _c128_block_inputs(g, M1)
+    blk.to(dev)
+    x = x.to(dev).requires_grad_()
+    blk._staged_idx = T(g["idx"].astype(np.uint8)).to(dev)
+    old = fused.ENABLED
+    fused.ENABLED = use_fused
+    try:
+        y = blk(x)
+        assert torch.allclose(y.cpu(), T(g["y"]), atol=5e-5, rtol=1e-4), (y.cpu() - T(g["y"])).abs().max()
+        (y * gout.to(dev)).sum().backward()
+    finally:
+        fused.ENABLED = old
+    assert torch.allclose(x.grad.cpu(), T(g["dx"]), atol=1e-4, rtol=1e-3)
+    check_c128_grads(g, {n: p.grad for n, p in blk.named_parameters()}, 2e-3)
