@@ -480,6 +480,11 @@ __global__ __launch_bounds__(NT, 1) void split6_wide_kernel(const float* __restr
     static_assert(NDMA % 8 == 0, "whole DMA instructions per wave");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* const bsm = reinterpret_cast<float*>(smem + 2 * SLOT);
+#ifdef DHZ_S6_STAMP
+    unsigned* const stamp_lds = reinterpret_cast<unsigned*>(bsm + NF);
+    for (int i = threadIdx.x; i < 8 * NSTAMP * 8; i += NT) stamp_lds[i] = 0;
+    int nstamp = 0;
+#endif
 
     const int t = threadIdx.x, lane = t & 63;
     const int w = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -635,6 +640,7 @@ __global__ __launch_bounds__(NT, 1) void split6_wide_kernel(const float* __restr
     for (int p = 0;; ++p) {
         const int buf = p & 1;
         const bool have1 = p1.tile >= 0;
+        STAMP(0);
         // ---- stream 1: rows 0, 1 (48 MFMAs); between them the DMA of stage p+1 -> the other slot, the fragment reads of rows 2, 3,
         //      the split of stage p+1's raw activations (loaded during stage p-1) and the address arithmetic of the loads below
         b_dma(valid(p1), buf ^ 1);
@@ -642,6 +648,7 @@ __global__ __launch_bounds__(NT, 1) void split6_wide_kernel(const float* __restr
         read_a(buf, 0, 2);
         a_waitN();                                                 // older than this stage's DMA (and the previous tile's stores)
         __builtin_amdgcn_sched_barrier(0);
+        STAMP(1);
         read_a(buf, 2, 4);
         u32x4 sh[NA], sm[NA], sl[NA];
 #pragma unroll
@@ -656,6 +663,7 @@ __global__ __launch_bounds__(NT, 1) void split6_wide_kernel(const float* __restr
             __builtin_amdgcn_sched_group_barrier(0x382, 2, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
+        STAMP(2);
 #pragma unroll
         for (int i = 0; i < NA; ++i) gload32(pa[i], ra[i][0], ra[i][1]);      // stage p + 2
         __builtin_amdgcn_sched_barrier(0);
@@ -668,6 +676,7 @@ __global__ __launch_bounds__(NT, 1) void split6_wide_kernel(const float* __restr
             __builtin_amdgcn_sched_group_barrier(0x382, 1, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
+        STAMP(3);
         const bool stored = p0.st == nst - 1;
         bool full = true;
         if (stored) full = epilogue(p0.tile);
@@ -677,18 +686,32 @@ __global__ __launch_bounds__(NT, 1) void split6_wide_kernel(const float* __restr
         if (!stored) wait_vm<2 * NA>();
         else if (full) wait_vm<2 * NA + WM * WN>();
         else wait_vm<0>();
+        STAMP(4);
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        STAMP(5);
+#ifdef DHZ_S6_STAMP
+        ++nstamp;
+#endif
         p0 = p1; p1 = p2; p2 = next(p2);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef DHZ_S6_STAMP
+    __syncthreads();
+    if (g_s6_stamp && blockIdx.x == DHZ_S6_STAMP)
+        for (int i = threadIdx.x; i < 8 * NSTAMP * 8; i += NT) g_s6_stamp[i] = stamp_lds[i];
+#endif
 }
 
 template <bool BTR>
 void launch_wide(const float* A, int lda, const uint16_t* Bh, const uint16_t* Bm, const uint16_t* Bl, int ldb, const float* bias, float* C,
                  int ldc, int M, int NF, int KC, hipStream_t s) {
     constexpr int BM = 256, BN = 128;
+#ifdef DHZ_S6_STAMP
+    const size_t smem = 2 * 3 * (size_t)(BM * 64 + BN * 64) + (size_t)NF * sizeof(float) + 8 * NSTAMP * 8 * 4;
+#else
     const size_t smem = 2 * 3 * (size_t)(BM * 64 + BN * 64) + (size_t)NF * sizeof(float);
+#endif
     const int tiles_n = NF / BN, tiles_m = (M + BM - 1) / BM;
     const int ntiles = tiles_n * tiles_m;
     const int slots = dhz_num_cus();

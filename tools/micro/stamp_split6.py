@@ -38,5 +38,8 @@ for w in range(8):
         r = a[w, i]
         if r[0] == 0:
             break
-        out.append(f"[{d(r[0], t0):6d}] s1 {d(r[1], r[0]):4d} s2 {d(r[2], r[1]):4d} ep+wt {d(r[3], r[2]):4d} bar {d(r[4], r[3]):4d}")
+        if os.environ.get("DHZ_S6_TILE") == "2":       # wide kernel: frag reads + wait | stream 1 | loads + stream 2 | epilogue + wait | barrier
+            out.append(f"[{d(r[0], t0):6d}] fr {d(r[1], r[0]):4d} s1 {d(r[2], r[1]):4d} s2 {d(r[3], r[2]):4d} ep+wt {d(r[4], r[3]):4d} bar {d(r[5], r[4]):4d}")
+        else:
+            out.append(f"[{d(r[0], t0):6d}] s1 {d(r[1], r[0]):4d} s2 {d(r[2], r[1]):4d} ep+wt {d(r[3], r[2]):4d} bar {d(r[4], r[3]):4d}")
     print(f"wave {w}: " + " | ".join(out[4:14]))
