@@ -211,13 +211,20 @@ __global__ __launch_bounds__(NT, 1) void split6_gemm_kernel(const float* __restr
     }
     const uint16_t* const planes[3] = {Bh, Bm, Bl};
 
-    struct Pos { int tile, st, ti; };
+    // (tile, stage) position of the stream; the tile's row / column origin is derived once per tile (an integer division per stage
+    // and use costs ~20 scalar instructions of an in-order wave)
+    struct Pos { int tile, st, ti, m0, n0; };
+    auto at_tile = [&](int ti) -> Pos {
+        const int tile = tile_of(ti);
+        const int tm = tile < 0 ? 0 : tile / tiles_n;
+        return Pos{tile, 0, ti, tm * BM, (tile - tm * tiles_n) * BN};
+    };
     auto next = [&](const Pos& p) -> Pos {
         if (p.tile < 0) return p;
-        if (p.st + 1 < nst) return Pos{p.tile, p.st + 1, p.ti};
-        return Pos{tile_of(p.ti + 1), 0, p.ti + 1};
+        if (p.st + 1 < nst) return Pos{p.tile, p.st + 1, p.ti, p.m0, p.n0};
+        return at_tile(p.ti + 1);
     };
-    const Pos pz{tile_of(0), 0, 0};
+    const Pos pz = at_tile(0);
     if (pz.tile < 0) return;
     // past the end of the stream every load / DMA re-fetches the workgroup's first stage (into slots and registers nobody reads
     // any more): the loop body carries no tests around its memory operations
@@ -225,7 +232,7 @@ __global__ __launch_bounds__(NT, 1) void split6_gemm_kernel(const float* __restr
 
     f32x4 ra[2][NA][2];                                            // raw activations: stage q in set q & 1
     auto a_addr = [&](const Pos& q, int i) -> const float* {
-        const int m0 = (DHZ_S6_DBG & 32) ? 0 : (q.tile / tiles_n) * BM, k0 = q.st * BK;
+        const int m0 = (DHZ_S6_DBG & 32) ? 0 : q.m0, k0 = q.st * BK;
         return A + (size_t)min(m0 + a_row[i], M - 1) * lda + k0 + 8 * a_kc[i];
     };
     auto a_load = [&](auto set, const Pos& q) {
@@ -253,7 +260,7 @@ __global__ __launch_bounds__(NT, 1) void split6_gemm_kernel(const float* __restr
     };
     auto b_dma = [&](const Pos& q, int slot) {
         if (abl & 8) return;
-        const int n0 = (DHZ_S6_DBG & 64) ? 0 : (q.tile % tiles_n) * BN, k0 = q.st * BK;
+        const int n0 = (DHZ_S6_DBG & 64) ? 0 : q.n0, k0 = q.st * BK;
         const size_t base = BTR ? (size_t)k0 * ldb + n0 : (size_t)n0 * ldb + k0;
         unsigned char* Bs = Bring + slot * B_SLOT;
 #pragma unroll
@@ -523,23 +530,30 @@ __global__ __launch_bounds__(NT, 1) void split6_wide_kernel(const float* __restr
         }
     }
     const uint16_t* const planes[3] = {Bh, Bm, Bl};
-    struct Pos { int tile, st, ti; };
+    // (tile, stage) position of the stream; the tile's row / column origin is derived once per tile (an integer division per stage
+    // and use costs ~20 scalar instructions of an in-order wave)
+    struct Pos { int tile, st, ti, m0, n0; };
+    auto at_tile = [&](int ti) -> Pos {
+        const int tile = tile_of(ti);
+        const int tm = tile < 0 ? 0 : tile / tiles_n;
+        return Pos{tile, 0, ti, tm * BM, (tile - tm * tiles_n) * BN};
+    };
     auto next = [&](const Pos& p) -> Pos {
         if (p.tile < 0) return p;
-        if (p.st + 1 < nst) return Pos{p.tile, p.st + 1, p.ti};
-        return Pos{tile_of(p.ti + 1), 0, p.ti + 1};
+        if (p.st + 1 < nst) return Pos{p.tile, p.st + 1, p.ti, p.m0, p.n0};
+        return at_tile(p.ti + 1);
     };
-    const Pos pz{tile_of(0), 0, 0};
+    const Pos pz = at_tile(0);
     if (pz.tile < 0) return;
     auto valid = [&](const Pos& p) -> Pos { return p.tile >= 0 ? p : pz; };
 
     f32x4 ra[NA][2];
     auto a_addr = [&](const Pos& q, int i) -> const float* {
-        const int m0 = (q.tile / tiles_n) * BM, k0 = q.st * BK;
+        const int m0 = q.m0, k0 = q.st * BK;
         return A + (size_t)min(m0 + a_row[i], M - 1) * lda + k0 + 8 * a_kc[i];
     };
     auto b_dma = [&](const Pos& q, int buf) {
-        const int n0 = (q.tile % tiles_n) * BN, k0 = q.st * BK;
+        const int n0 = q.n0, k0 = q.st * BK;
         const size_t base = BTR ? (size_t)k0 * ldb + n0 : (size_t)n0 * ldb + k0;
         unsigned char* Bs = smem + buf * SLOT;
 #pragma unroll
