@@ -219,6 +219,10 @@ int dhz_linear_dgrad_split6(const float* dy, int ldy, const void* w_hi, const vo
                             int N, int K, void* stream);
 /*     hi[i] + mid[i] + lo[i] == src[i] exactly (three bf16 by truncation); n % 8 == 0, 16-byte aligned pointers. */
 int dhz_split3_planes(const float* src, int64_t n, void* hi, void* mid, void* lo, void* stream);
+/*     ... and the planes of the TRANSPOSES of nmat matrices inside one buffer: desc (device, int[nmat][4]) = {offset, rows R, cols C, index
+ *     of the matrix's first 32 x 32 tile}; matrix m ([R][C] at src + offset) is written as [C][R] at the same offset of the planes.
+ *     dx = dy . w is then dhz_linear_fwd_split6 on them (no bias): the backward-data GEMM without transposed fragment reads. */
+int dhz_split3_planes_t(const float* src, void* hi, void* mid, void* lo, const int* desc, int nmat, int ntiles, void* stream);
 /*     ... and the weight gradient (contract of dhz_linear_wgrad_multi + the row scale of dhz_linear_wgrad_rs: row_scale may be NULL;
  *     dw / db HOST arrays of nmat device pointers; ACCUMULATED; db exact fp32 column sums).  T % 64 == 0, nper % 64 == 0, K % 64 == 0. */
 int dhz_linear_wgrad_split(const float* dy, int ldy, const float* x, int ldx, int T, int nmat, int nper, int K, float* const* dw,

@@ -795,11 +795,57 @@ __global__ __launch_bounds__(256) void split3_planes_kernel(const float* __restr
     }
 }
 
+// ---- the planes of the TRANSPOSES of a set of matrices that live in one fp32 buffer (the flat parameter buffer): matrix m occupies
+// src[off, off + R C) as [R][C]; its transpose goes to the SAME offsets of the three planes as [C][R].  Backward-data then runs the
+// forward kernel on them (dx = dy . W = dy . (W^T)^T): no transposed fragment reads - in front of those the compiler waits for every
+// LDS-DMA in flight - and measured 12 % faster over the step's shapes, bit-identical results.  desc[m] = {off, R, C, first tile};
+// 32 x 32 tiles through LDS; R, C multiples of 32.
+__global__ __launch_bounds__(256) void split3_planes_t_kernel(const float* __restrict__ src, uint16_t* __restrict__ hi,
+                                                              uint16_t* __restrict__ mid, uint16_t* __restrict__ lo,
+                                                              const int* __restrict__ desc, int nmat, int ntiles) {
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;       // 32 x 8
+    for (int tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
+        int m = 0;
+        while (m + 1 < nmat && desc[4 * (m + 1) + 3] <= tl) ++m;   // a few dozen matrices
+        const int off = desc[4 * m], R = desc[4 * m + 1], Cc = desc[4 * m + 2], t0 = desc[4 * m + 3];
+        const int tpr = Cc / 32, ti = (tl - t0) / tpr, tj = (tl - t0) % tpr;
+        const float* s0 = src + off + (size_t)(32 * ti) * Cc + 32 * tj;
+#pragma unroll
+        for (int r = ty; r < 32; r += 8) tile[r][tx] = s0[(size_t)r * Cc + tx];
+        __syncthreads();
+        const size_t d0 = (size_t)off + (size_t)(32 * tj) * R + 32 * ti;
+#pragma unroll
+        for (int c = ty; c < 32; c += 8) {
+            const float x = tile[tx][c];                           // element (row 32 ti + tx, column 32 tj + c) -> its transposed position
+            const float h = __uint_as_float(__float_as_uint(x) & 0xffff0000u);
+            const float r1 = x - h;
+            const float mdl = __uint_as_float(__float_as_uint(r1) & 0xffff0000u);
+            const float r2 = r1 - mdl;
+            const size_t o = d0 + (size_t)c * R + tx;
+            hi[o] = (uint16_t)(__float_as_uint(x) >> 16);
+            mid[o] = (uint16_t)(__float_as_uint(r1) >> 16);
+            lo[o] = (uint16_t)(__float_as_uint(r2) >> 16);
+        }
+        __syncthreads();
+    }
+}
+
 }  // namespace
 
 #ifdef DHZ_S6_STAMP
 extern "C" int dhz_debug_s6_stamp(void* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_s6_stamp), &p, sizeof(p)); }
 #endif
+
+extern "C" int dhz_split3_planes_t(const float* src, void* hi, void* mid, void* lo, const int* desc, int nmat, int ntiles, void* stream) {
+    const char* who = "dhz_split3_planes_t";
+    DHZ_REQUIRE(src && hi && mid && lo && desc && nmat > 0 && ntiles > 0, "%s: null pointer or empty table", who);
+    const int cap = 8 * dhz_num_cus();
+    hipLaunchKernelGGL(split3_planes_t_kernel, dim3(ntiles < cap ? ntiles : cap), dim3(256), 0, (hipStream_t)stream, src, (uint16_t*)hi,
+                       (uint16_t*)mid, (uint16_t*)lo, desc, nmat, ntiles);
+    DHZ_CHECK_LAUNCH(who);
+    return DHZ_OK;
+}
 
 extern "C" int dhz_split3_planes(const float* src, int64_t n, void* hi, void* mid, void* lo, void* stream) {
     const char* who = "dhz_split3_planes";

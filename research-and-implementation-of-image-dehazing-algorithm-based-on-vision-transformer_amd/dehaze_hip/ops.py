@@ -139,15 +139,36 @@ def bf16_copy(W):
     return W.detach().to(BF16)
 
 
-def set_split_shadow(f32, planes):
+def set_split_shadow(f32, planes, planes_t=None, desc=None, index=None, ntiles=0):
+    """planes: [3, n] bf16 mirror of the flat buffer; planes_t (optional): the same with every registered matrix stored TRANSPOSED at
+    its offset; desc / ntiles: device int32 [nmat, 4] table of dhz_split3_planes_t and its tile count; index: {(offset, rows, cols)} of
+    the registered matrices."""
     global SPLIT_SHADOW
-    SPLIT_SHADOW = None if f32 is None else [f32, planes[0], planes[1], planes[2]]
+    SPLIT_SHADOW = None if f32 is None else [f32, planes[0], planes[1], planes[2], planes_t, desc, index or set(), int(ntiles)]
 
 
 def refresh_split_shadow():
     sh = SPLIT_SHADOW
     if sh is not None:
         _lib.call("dhz_split3_planes", sh[0].data_ptr(), sh[0].numel(), sh[1].data_ptr(), sh[2].data_ptr(), sh[3].data_ptr(), _stream())
+        if sh[4] is not None:
+            pt, desc = sh[4], sh[5]
+            _lib.call("dhz_split3_planes_t", sh[0].data_ptr(), pt[0].data_ptr(), pt[1].data_ptr(), pt[2].data_ptr(), desc.data_ptr(),
+                      desc.shape[0], sh[7], _stream())
+
+
+def split_planes_t(W):
+    """(hi, mid, lo) planes of W^T ([K, N] row-major for W [N, K]) when FlatAdamW keeps them for this matrix (every Linear weight of
+    the flat buffer; the adjacent Q / K / V weights as ONE packed [3C, C] matrix), else None."""
+    sh = SPLIT_SHADOW
+    if sh is None or sh[4] is None or not W.is_contiguous() or W.dim() != 2:
+        return None
+    o = _view_of(sh[0], W)
+    if o < 0 or (o, W.shape[0], W.shape[1]) not in sh[6]:
+        return None
+    n = W.numel()
+    pt = sh[4]
+    return pt[0][o: o + n], pt[1][o: o + n], pt[2][o: o + n]
 
 
 def split_planes(W):
@@ -167,6 +188,7 @@ def split_planes(W):
 
 
 _ROUTE6_FORCE = os.environ.get("DHZ_S6_ROUTE", "")
+_NO_TPLANES = bool(os.environ.get("DHZ_S6_NO_TPLANES"))       # diagnostics: backward-data through the transposed-read kernel
 
 
 def _route6(T, contraction, out, dgrad):
@@ -258,6 +280,13 @@ def gemm_dgrad(dy, W):
         ev = _timed("dhz_linear_bf16")
         _lib.call("dhz_linear_dgrad_bf16", _p(dy), dy.stride(0), _p(Wb), _p(dx), K, T, N, K, _stream())
         _timed_end(ev, 2.0 * T * N * K)
+    elif SPLIT_BF16 == 6 and dy.stride(0) % 4 == 0 and _route6(T, N, K, False) == "new" and not _NO_TPLANES \
+            and split_planes_t(W) is not None:
+        # dx = dy . W = dy . (W^T)^T: the FORWARD kernel on the planes of W^T (kept by the optimizer) - no transposed fragment reads
+        hi, mid, lo = split_planes_t(W)
+        ev = _timed("dhz_linear_split6")
+        _lib.call("dhz_linear_fwd_split6", _p(dy), dy.stride(0), _p(hi), _p(mid), _p(lo), None, _p(dx), K, T, K, N, _stream())
+        _timed_end(ev, 12.0 * T * N * K)
     elif SPLIT_BF16 == 6 and dy.stride(0) % 4 == 0 and _route6(T, N, K, True) != "f32":
         ev = _timed("dhz_linear_split6")
         if _route6(T, N, K, True) == "new":

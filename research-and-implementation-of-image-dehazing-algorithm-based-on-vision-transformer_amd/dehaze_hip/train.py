@@ -149,7 +149,34 @@ class FlatAdamW(torch.optim.Optimizer):
         f = self._flat
         if "p3" not in f:
             f["p3"] = torch.empty((3, f["p"].numel()), device=f["p"].device, dtype=torch.bfloat16)
-        ops.set_split_shadow(f["p"], f["p3"])
+            # transposed planes for the backward-data GEMMs: every 2-D weight with dimensions in 32s; the adjacent Q / K / V weights
+            # of an attention layer as ONE packed [3C, C] matrix (what the packed backward-data GEMM multiplies with)
+            slices = self.param_slices()
+            mats, i = [], 0
+            while i < len(slices):
+                p, off, k = slices[i]
+                name = self._names.get(id(p), "")
+                if name.endswith("query_projection.weight") and i + 2 < len(slices) and p.dim() == 2:
+                    pk, pv = slices[i + 1][0], slices[i + 2][0]
+                    if self._names.get(id(pk), "").endswith("key_projection.weight") and self._names.get(id(pv), "").endswith(
+                            "value_projection.weight") and slices[i + 1][1] == off + k and slices[i + 2][1] == off + 2 * k \
+                            and pk.shape == p.shape == pv.shape and p.shape[0] % 32 == 0 and p.shape[1] % 32 == 0:
+                        mats.append((off, 3 * p.shape[0], p.shape[1]))
+                        i += 3
+                        continue
+                if p.dim() == 2 and p.shape[0] % 32 == 0 and p.shape[1] % 32 == 0 and off % 8 == 0:
+                    mats.append((off, p.shape[0], p.shape[1]))
+                i += 1
+            if mats:
+                rows, t0 = [], 0
+                for off, R, Cc in mats:
+                    rows.append([off, R, Cc, t0])
+                    t0 += (R // 32) * (Cc // 32)
+                f["p3t"] = torch.zeros((3, f["p"].numel()), device=f["p"].device, dtype=torch.bfloat16)
+                f["p3t_desc"] = torch.tensor(rows, dtype=torch.int32, device=f["p"].device)
+                f["p3t_index"] = {(off, R, Cc) for off, R, Cc in mats}
+                f["p3t_ntiles"] = t0
+        ops.set_split_shadow(f["p"], f["p3"], f.get("p3t"), f.get("p3t_desc"), f.get("p3t_index"), f.get("p3t_ntiles", 0))
         ops.refresh_split_shadow()
         self._pver = self._param_versions()
         ops.SHADOW_SYNC = self.sync_shadows

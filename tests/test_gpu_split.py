@@ -261,6 +261,24 @@ def test_split_planes_shadow_follows_optimizer_and_outside_writes():
     hi, mid, lo = ops.split_planes(W.detach())
     assert hi.data_ptr() - f["p3"][0].data_ptr() == (W.data_ptr() - f["p"].data_ptr()) // 2    # (b) a view, no launch
     assert torch.equal((hi.double() + mid.double() + lo.double()).view_as(W), W.detach().double())
+    # (b') the transposed planes of the backward-data GEMMs: W^T at W's offset; the packed Q / K / V weights as one [3C, C] matrix
+    ht, mt, lt = ops.split_planes_t(W.detach())
+    assert torch.equal((ht.double() + mt.double() + lt.double()).view(W.shape[1], W.shape[0]), W.detach().double().t())
+    al = model.encoderlayer_3.blocks[1].attn.ProbSpare
+    wq, wk, wv = al.query_projection.weight, al.key_projection.weight, al.value_projection.weight
+    Wp = ops.cat_rows([wq.detach(), wk.detach(), wv.detach()])
+    assert Wp.data_ptr() == wq.data_ptr() and Wp.shape == (3 * wq.shape[0], wq.shape[1])          # a view of the flat buffer
+    ht, mt, lt = ops.split_planes_t(Wp)
+    assert torch.equal((ht.double() + mt.double() + lt.double()).view(Wp.shape[1], Wp.shape[0]), Wp.double().t())
+    assert ops.split_planes_t(wq.detach()) is None                                       # (not registered on its own)
+    dyy = torch.randn(8192, W.shape[0], device=dev)
+    d1 = ops.gemm_dgrad(dyy, W.detach())                                                 # forward kernel on the planes of W^T
+    ops._NO_TPLANES = True
+    try:
+        d2 = ops.gemm_dgrad(dyy, W.detach())                                             # transposed-read kernel on the planes of W
+    finally:
+        ops._NO_TPLANES = False
+    assert torch.equal(d1, d2)                                                           # the same products in the same order
     with torch.no_grad():
         W.mul_(1.5)                                                                       # (c) an outside write ...
     assert not torch.equal(rec(), f["p"].double())
@@ -268,6 +286,8 @@ def test_split_planes_shadow_follows_optimizer_and_outside_writes():
     with torch.no_grad():
         model(hazy)                                                                       # ... reaches the planes in a bare forward
     assert torch.equal(rec(), f["p"].double())
+    ht, mt, lt = ops.split_planes_t(W.detach())
+    assert torch.equal((ht.double() + mt.double() + lt.double()).view(W.shape[1], W.shape[0]), W.detach().double().t())
     model.train()
     with torch.no_grad():
         W.mul_(0.5)
