@@ -33,7 +33,7 @@ __device__ __forceinline__ f32x4 mfma_bf16(s16x8 a, s16x8 b, f32x4 c) {
 __device__ __forceinline__ int off_row(int row, int ch) { return row * 128 + 16 * (ch ^ ((row >> 1) & 7)); }
 template <int F>
 __device__ __forceinline__ int off_tr(int row, int ch) {
-    if (F == 128) return row * 256 + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3)));
+    if (F >= 128) return row * (2 * F) + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3)));   // 256 / 512-byte rows: XOR on the low four chunk bits
     return row * 128 + 16 * (ch ^ ((row & 2) | ((row & 8) >> 1)));
 }
 template <int F>
@@ -469,19 +469,25 @@ __global__ __launch_bounds__(256, 2) void wgrad_split_kernel(const float* __rest
 // stage s - a bf16 MFMA holds the vector issue for 8 of its 16 cycles, a wave's own vector / LDS instructions go into the other 8
 // (csrc/split6_gemm.hip) - with one barrier per stage.
 constexpr int BK2 = 32;
-template <int WM, int WN>
-__global__ __launch_bounds__(256, 2) void wgrad_split6_kernel(const float* __restrict__ dy, int ldy, const float* __restrict__ x,
+// phase ablation for timing diagnostics: a COMPILE-TIME constant of a variant build (tools/variants.sh, -DDHZ_W6_ABL=<mask>;
+// outputs are then wrong).  1 no global loads, 2 no split arithmetic, 4 no LDS writes, 8 no fragment reads, 16 no MFMAs, 32 no atomics
+#ifndef DHZ_W6_ABL
+#define DHZ_W6_ABL 0
+#endif
+template <int WM, int WN, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_M * WAVES_N == 4 ? 2 : 1) void wgrad_split6_kernel(const float* __restrict__ dy, int ldy, const float* __restrict__ x,
                                                               int ldx, int T, int N, int K, WgradOut out, int nsplit,
                                                               const float* __restrict__ row_scale, int rows_per_scale) {
-    constexpr int FM = 32 * WM, FN = 32 * WN;
+    constexpr int NT = 64 * WAVES_M * WAVES_N;
+    constexpr int FM = 16 * WM * WAVES_M, FN = 16 * WN * WAVES_N;
     constexpr int A_BYTES = BK2 * FM * 2, B_BYTES = BK2 * FN * 2;          // one piece of one stage
     constexpr int STAGE = 3 * (A_BYTES + B_BYTES);
-    constexpr int NA = BK2 * (FM / 8) / 256, NB = BK2 * (FN / 8) / 256;    // 8-element chunks per thread per stage (1 or 2)
-    static_assert(NA >= 1 && NB >= 1, "tile too narrow for 256 threads");
+    constexpr int NA = BK2 * (FM / 8) / NT, NB = BK2 * (FN / 8) / NT;    // 8-element chunks per thread per stage (1 or 2)
+    static_assert(NA >= 1 && NB >= 1, "tile too narrow for the workgroup");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int i16 = lane & 15, g = lane >> 4;
-    const int wm = w >> 1, wn = w & 1;
+    const int wm = w / WAVES_N, wn = w % WAVES_N;
     const int tiles_n = K / FN;
     int bid = blockIdx.x;
     const int split = bid % nsplit; bid /= nsplit;
@@ -500,6 +506,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_split6_kernel(const float* __res
         for (int b = 0; b < WN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
     f32x4 ra[NA][2], rb[NB][2];
     float rs[NA];
+    if constexpr (DHZ_W6_ABL & 1) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) { ra[i][0] = ra[i][1] = f32x4{1.f, 1.f, 1.f, 1.f}; rs[i] = 1.f; }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) rb[i][0] = rb[i][1] = f32x4{1.f, 1.f, 1.f, 1.f};
+    }
     float dbacc[NA][8];
 #pragma unroll
     for (int i = 0; i < NA; ++i)
@@ -511,24 +523,25 @@ __global__ __launch_bounds__(256, 2) void wgrad_split6_kernel(const float* __res
     const float* pb[NB];
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
-        const int e = t + 256 * i;
+        const int e = t + NT * i;
         a_off[i] = off_tr<FM>(e / (FM / 8), e % (FM / 8));
         pa[i] = dy + (size_t)(e / (FM / 8)) * ldy + n0 + 8 * (e % (FM / 8));
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
-        const int e = t + 256 * i;
+        const int e = t + NT * i;
         b_off[i] = off_tr<FN>(e / (FN / 8), e % (FN / 8));
         pb[i] = x + (size_t)(e / (FN / 8)) * ldx + k0 + 8 * (e % (FN / 8));
     }
     auto gload = [&](int st) {
+        if constexpr (DHZ_W6_ABL & 1) return;
         const size_t tok0 = (size_t)st * BK2;
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             const float* p = pa[i] + tok0 * ldy;
             ra[i][0] = *reinterpret_cast<const f32x4*>(p);
             ra[i][1] = *reinterpret_cast<const f32x4*>(p + 4);
-            rs[i] = row_scale ? row_scale[(tok0 + (t + 256 * i) / (FM / 8)) / rows_per_scale] : 1.f;
+            rs[i] = row_scale ? row_scale[(tok0 + (t + NT * i) / (FM / 8)) / rows_per_scale] : 1.f;
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
@@ -544,10 +557,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_split6_kernel(const float* __res
         for (int i = 0; i < NA; ++i) {
             const f32x4 v0 = ra[i][0] * rs[i], v1 = ra[i][1] * rs[i];
             u32x4 hi, mid, lo;
-            split8x3(v0, v1, hi, mid, lo);
+            if constexpr (DHZ_W6_ABL & 2) { hi = __builtin_bit_cast(u32x4, v0); mid = __builtin_bit_cast(u32x4, v1); lo = hi ^ mid; }
+            else split8x3(v0, v1, hi, mid, lo);
+            if constexpr (DHZ_W6_ABL & 4) { asm volatile("" :: "v"(hi), "v"(mid), "v"(lo)); }
+            else {
             *reinterpret_cast<u32x4*>(As + a_off[i]) = hi;
             *reinterpret_cast<u32x4*>(As + A_BYTES + a_off[i]) = mid;
             *reinterpret_cast<u32x4*>(As + 2 * A_BYTES + a_off[i]) = lo;
+            }
             if (do_db) {
 #pragma unroll
                 for (int c = 0; c < 4; ++c) { dbacc[i][c] += v0[c]; dbacc[i][4 + c] += v1[c]; }
@@ -556,10 +573,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_split6_kernel(const float* __res
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             u32x4 hi, mid, lo;
-            split8x3(rb[i][0], rb[i][1], hi, mid, lo);
+            if constexpr (DHZ_W6_ABL & 2) { hi = __builtin_bit_cast(u32x4, rb[i][0]); mid = __builtin_bit_cast(u32x4, rb[i][1]); lo = hi ^ mid; }
+            else split8x3(rb[i][0], rb[i][1], hi, mid, lo);
+            if constexpr (DHZ_W6_ABL & 4) { asm volatile("" :: "v"(hi), "v"(mid), "v"(lo)); }
+            else {
             *reinterpret_cast<u32x4*>(Bs + b_off[i]) = hi;
             *reinterpret_cast<u32x4*>(Bs + B_BYTES + b_off[i]) = mid;
             *reinterpret_cast<u32x4*>(Bs + 2 * B_BYTES + b_off[i]) = lo;
+            }
         }
     };
     if (st0 < st1) {
@@ -576,9 +597,15 @@ __global__ __launch_bounds__(256, 2) void wgrad_split6_kernel(const float* __res
 #pragma unroll
         for (int pc = 0; pc < 3; ++pc) {
 #pragma unroll
-            for (int a = 0; a < WM; ++a) af[pc][a] = tr_frag<FM>(As + pc * A_BYTES, 8 * g, wm * WM + a, lane);
+            for (int a = 0; a < WM; ++a) {
+                if constexpr (DHZ_W6_ABL & 8) { af[pc][a] = s16x8{(short)lane, 1, 2, 3, 4, 5, 6, (short)st}; asm volatile("" : "+v"(af[pc][a])); }
+                else af[pc][a] = tr_frag<FM>(As + pc * A_BYTES, 8 * g, wm * WM + a, lane);
+            }
 #pragma unroll
-            for (int b = 0; b < WN; ++b) bf[pc][b] = tr_frag<FN>(Bs + pc * B_BYTES, 8 * g, wn * WN + b, lane);
+            for (int b = 0; b < WN; ++b) {
+                if constexpr (DHZ_W6_ABL & 8) { bf[pc][b] = s16x8{(short)lane, 1, 2, 3, 4, 5, 6, (short)st}; asm volatile("" : "+v"(bf[pc][b])); }
+                else bf[pc][b] = tr_frag<FN>(Bs + pc * B_BYTES, 8 * g, wn * WN + b, lane);
+            }
         }
         // ---- one stream: the stage's MFMAs (term-major: consecutive ones never share an accumulator), between them the split and
         //      the LDS writes of stage st+1 (the other buffer: its readers passed the barrier at the end of stage st-1)
@@ -588,7 +615,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_split6_kernel(const float* __res
 #pragma unroll
             for (int a = 0; a < WM; ++a)
 #pragma unroll
-                for (int b = 0; b < WN; ++b) acc[a][b] = mfma_bf16(af[TA[term]][a], bf[TB[term]][b], acc[a][b]);
+                for (int b = 0; b < WN; ++b) {
+                    if constexpr (DHZ_W6_ABL & 16) { if (term == 0) asm volatile("" : "+v"(acc[a][b]) : "v"(af[0][a]), "v"(af[1][a]), "v"(af[2][a]), "v"(bf[0][b]), "v"(bf[1][b]), "v"(bf[2][b])); }
+                    else acc[a][b] = mfma_bf16(af[TA[term]][a], bf[TB[term]][b], acc[a][b]);
+                }
         if (st + 1 < st1) swrite(buf ^ 1);
 #pragma unroll
         for (int i = 0; i < WM * WN * 6; ++i) {
@@ -611,42 +641,44 @@ __global__ __launch_bounds__(256, 2) void wgrad_split6_kernel(const float* __res
 #pragma unroll
             for (int j = 0; j < 4; ++j) Cs[(wm * WM * 16 + a * 16 + 4 * g + j) * FN + wn * WN * 16 + b * 16 + i16] = acc[a][b][j];
     __syncthreads();
-    for (int e = t; e < FM * FN; e += 256) atomicAdd(dw + (size_t)(nloc + e / FN) * K + k0 + e % FN, Cs[e]);
+    if constexpr (DHZ_W6_ABL & 32) { if (Cs[t] == 123.456f) dw[t] = 1.f; }
+    else
+    for (int e = t; e < FM * FN; e += NT) atomicAdd(dw + (size_t)(nloc + e / FN) * K + k0 + e % FN, Cs[e]);
     if (do_db) {
         __syncthreads();
         float* red = reinterpret_cast<float*>(smem);          // [rows of chunks][FM]
         constexpr int CPR = FM / 8;
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
-            const int e = t + 256 * i;
+            const int e = t + NT * i;
 #pragma unroll
             for (int c = 0; c < 8; ++c) red[(e / CPR) * FM + 8 * (e % CPR) + c] = dbacc[i][c];
         }
         __syncthreads();
         if (t < FM) {
             float tot = 0.f;
-            for (int r = 0; r < 256 * NA / CPR; ++r) tot += red[r * FM + t];
+            for (int r = 0; r < NT * NA / CPR; ++r) tot += red[r * FM + t];
             atomicAdd(db + nloc + t, tot);
         }
     }
 }
 
-template <int WM, int WN>
+template <int WM, int WN, int WAVES_M, int WAVES_N>
 void launch_wgrad_split6(const float* dy, int ldy, const float* x, int ldx, int T, int N, int K, const WgradOut& out,
                          const float* row_scale, int rows_per_scale, hipStream_t s) {
-    constexpr int FM = 32 * WM, FN = 32 * WN;
+    constexpr int FM = 16 * WM * WAVES_M, FN = 16 * WN * WAVES_N, NT = 64 * WAVES_M * WAVES_N;
     constexpr size_t stage = (size_t)BK2 * (FM + FN) * 2 * 3;
     constexpr size_t ring = 2 * stage;
     constexpr size_t smem = ring > (size_t)FM * FN * 4 ? ring : (size_t)FM * FN * 4;
     const int tiles = (N / FM) * (K / FN);
-    int nsplit = 2 * dhz_num_cus() / tiles;
+    int nsplit = (NT == 256 ? 2 : 1) * dhz_num_cus() / tiles;
     const int max_split = T / (BK2 * 8) > 0 ? T / (BK2 * 8) : 1;          // at least 8 stages per workgroup
     if (nsplit > max_split) nsplit = max_split;
     if (nsplit < 1) nsplit = 1;
     if (smem > 48 * 1024)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_split6_kernel<WM, WN>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_split6_kernel<WM, WN, WAVES_M, WAVES_N>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)smem);
-    hipLaunchKernelGGL((wgrad_split6_kernel<WM, WN>), dim3(tiles * nsplit), dim3(256), smem, s, dy, ldy, x, ldx, T, N, K, out, nsplit,
+    hipLaunchKernelGGL((wgrad_split6_kernel<WM, WN, WAVES_M, WAVES_N>), dim3(tiles * nsplit), dim3(NT), smem, s, dy, ldy, x, ldx, T, N, K, out, nsplit,
                        row_scale, rows_per_scale);
 }
 
@@ -708,9 +740,16 @@ extern "C" int dhz_linear_wgrad_split(const float* dy, int ldy, const float* x, 
     if (terms == 6 && !old6) {
         // pipelined kernel: 128 x 64 / 64 x 128 / 64 x 64 tiles (two piece-image stages of 32 rows: <= 72 KB, two workgroups per CU)
         const int wm6 = nper % 128 == 0 ? 4 : 2, wn6 = (K % 128 == 0 && wm6 == 2) ? 4 : 2;
-        if (wm6 == 4) launch_wgrad_split6<4, 2>(dy, ldy, x, ldx, T, N, K, out, row_scale, rps, s);
-        else if (wn6 == 4) launch_wgrad_split6<2, 4>(dy, ldy, x, ldx, T, N, K, out, row_scale, rps, s);
-        else launch_wgrad_split6<2, 2>(dy, ldy, x, ldx, T, N, K, out, row_scale, rps, s);
+        // 512-thread tiles (256 x 128 / 128 x 256 / 128 x 128, one workgroup per CU) halve the traffic through L2 and the split work
+        // per product, and measured -3..-7 % on the four largest shapes of the step, +25..50 % on the small ones
+        // (profiles/r04_wgrad6_ablation.txt): not dispatched; DHZ_WGRAD6_TILE=1 / 2 selects them for measurements.
+        static const int big = getenv("DHZ_WGRAD6_TILE") ? atoi(getenv("DHZ_WGRAD6_TILE")) : 0;
+        if (big && nper % 256 == 0 && K % 128 == 0) launch_wgrad_split6<4, 4, 4, 2>(dy, ldy, x, ldx, T, N, K, out, row_scale, rps, s);
+        else if (big && nper % 128 == 0 && K % 256 == 0) launch_wgrad_split6<4, 4, 2, 4>(dy, ldy, x, ldx, T, N, K, out, row_scale, rps, s);
+        else if (big == 2 && nper % 128 == 0 && K % 128 == 0) launch_wgrad_split6<2, 4, 4, 2>(dy, ldy, x, ldx, T, N, K, out, row_scale, rps, s);
+        else if (wm6 == 4) launch_wgrad_split6<4, 2, 2, 2>(dy, ldy, x, ldx, T, N, K, out, row_scale, rps, s);
+        else if (wn6 == 4) launch_wgrad_split6<2, 4, 2, 2>(dy, ldy, x, ldx, T, N, K, out, row_scale, rps, s);
+        else launch_wgrad_split6<2, 2, 2, 2>(dy, ldy, x, ldx, T, N, K, out, row_scale, rps, s);
         DHZ_CHECK_LAUNCH(who);
         return DHZ_OK;
     }
