@@ -223,6 +223,10 @@ int dhz_split3_planes(const float* src, int64_t n, void* hi, void* mid, void* lo
  *     of the matrix's first 32 x 32 tile}; matrix m ([R][C] at src + offset) is written as [C][R] at the same offset of the planes.
  *     dx = dy . w is then dhz_linear_fwd_split6 on them (no bias): the backward-data GEMM without transposed fragment reads. */
 int dhz_split3_planes_t(const float* src, void* hi, void* mid, void* lo, const int* desc, int nmat, int ntiles, void* stream);
+/* bf16 (round to nearest even) copies of the TRANSPOSES of the same table of matrices: dst (bf16, as many elements as src) receives
+ *     matrix m transposed at its own offset.  dhz_linear_fwd_bf16(dy, ldy, dst + off, NULL, dx, ldx, T, K, N) is then the backward-data
+ *     product dx = dy . W of a Linear with weight W [N, K] (M1:487-492 under autocast) on the software-pipelined forward kernel. */
+int dhz_bf16_transpose_batched(const float* src, void* dst, const int* desc, int nmat, int ntiles, void* stream);
 /*     ... and the weight gradient (contract of dhz_linear_wgrad_multi + the row scale of dhz_linear_wgrad_rs: row_scale may be NULL;
  *     dw / db HOST arrays of nmat device pointers; ACCUMULATED; db exact fp32 column sums).  T % 64 == 0, nper % 64 == 0, K % 64 == 0. */
 int dhz_linear_wgrad_split(const float* dy, int ldy, const float* x, int ldx, int T, int nmat, int nper, int K, float* const* dw,

@@ -17,7 +17,13 @@ __device__ __forceinline__ uint16_t f32_to_bf16(float f) {           // round to
     return __builtin_bit_cast(uint16_t, b);
 }
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
-__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+#ifndef DHZ_ST4_NT
+#define DHZ_ST4_NT 0          // diagnostics (tools/variants.sh): every st4 of a translation unit as a non-temporal store
+#endif
+__device__ __forceinline__ void st4(float* p, float4 v) {
+    if (DHZ_ST4_NT) __builtin_nontemporal_store(f32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<f32x4*>(p));
+    else *reinterpret_cast<float4*>(p) = v;
+}
 __device__ __forceinline__ float4 ld4(const bf16s* p) {
     const uint2 r = *reinterpret_cast<const uint2*>(p);
     return make_float4(__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u), __uint_as_float(r.y << 16),
@@ -27,7 +33,9 @@ __device__ __forceinline__ void st4(bf16s* p, float4 v) {
     uint2 r;
     r.x = (uint32_t)f32_to_bf16(v.x) | ((uint32_t)f32_to_bf16(v.y) << 16);
     r.y = (uint32_t)f32_to_bf16(v.z) | ((uint32_t)f32_to_bf16(v.w) << 16);
-    *reinterpret_cast<uint2*>(p) = r;
+    typedef uint32_t u32x2_ __attribute__((ext_vector_type(2)));
+    if (DHZ_ST4_NT) __builtin_nontemporal_store(u32x2_{r.x, r.y}, reinterpret_cast<u32x2_*>(p));
+    else *reinterpret_cast<uint2*>(p) = r;
 }
 __device__ __forceinline__ f32x4 ld4v(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ void st4v(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }

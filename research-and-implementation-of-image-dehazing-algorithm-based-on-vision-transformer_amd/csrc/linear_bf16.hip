@@ -20,6 +20,9 @@
 #define BF_ABL 0        // timing diagnostics (tools/variants.sh): 1 no epilogue stores, 2 no MFMAs, 4 no global operand loads, 8 weight gradient: no atomics
 #endif
 
+bool dhz_gemm_bf16_pipe_try(const uint16_t* A, int lda, const uint16_t* B, int ldb, const float* bias, uint16_t* C, int ldc, int M, int NF,
+                            int KC, hipStream_t s);          // csrc/gemm_bf16_pipe.hip
+
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -251,6 +254,13 @@ int dispatch_gemm(const char* who, const uint16_t* A, int lda, const uint16_t* B
                 K);
     DHZ_REQUIRE(lda % 8 == 0 && ldb % 8 == 0 && ldc % 8 == 0 && ldc >= N && lda >= K, "%s: bad leading dimensions", who);
     DHZ_REQUIRE((((uintptr_t)A | (uintptr_t)B | (uintptr_t)C) & 15) == 0, "%s: operands must be 16-byte aligned", who);
+    if constexpr (!BTR) {
+        // the software-pipelined 256 x 128 kernel (csrc/gemm_bf16_pipe.hip) where the problem has a tile per CU
+        if (dhz_gemm_bf16_pipe_try(A, lda, B, ldb, bias, C, ldc, M, N, K, s)) {
+            DHZ_CHECK_LAUNCH(who);
+            return DHZ_OK;
+        }
+    }
     const int wn = N % 128 == 0 ? 4 : 2;
     const long blocks128 = (long)((M + 127) / 128) * (N / (32 * wn));
     const int wm = blocks128 >= 256 ? 4 : 2;

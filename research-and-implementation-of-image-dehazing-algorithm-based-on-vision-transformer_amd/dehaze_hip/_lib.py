@@ -79,6 +79,7 @@ SIGNATURES = {
     "dhz_split3_planes": [c_f, c_l, c_p, c_p, c_p, c_p],
     "dhz_split3_planes_t": [c_f, c_p, c_p, c_p, c_p, c_i, c_i, c_p],
     "dhz_linear_fwd_bf16": [c_f, c_i, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_p],
+    "dhz_bf16_transpose_batched": [c_f, c_p, c_p, c_i, c_i, c_p],
     "dhz_linear_dgrad_bf16": [c_f, c_i, c_f, c_f, c_i, c_i, c_i, c_i, c_p],
     "dhz_linear_wgrad_bf16": [c_f, c_i, c_f, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p],
     "dhz_ln_partition_fwd_dt": [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p],

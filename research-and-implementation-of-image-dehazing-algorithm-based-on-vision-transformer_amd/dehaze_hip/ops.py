@@ -108,15 +108,35 @@ SPLIT_BF16 = _split_terms(os.environ.get("DHZ_SPLIT_BF16", "6"))
 SPLIT_MIN_K = int(os.environ.get("DHZ_SPLIT_MIN_K", "128"))      # smallest contraction the forward / backward-data GEMMs split
 
 
-def set_bf16_shadow(f32, b16):
+def set_bf16_shadow(f32, b16, b16t=None, desc=None, index=None, ntiles=0):
+    """b16: bf16 mirror of the flat buffer; b16t (optional): the same with every registered matrix stored TRANSPOSED at its offset
+    (desc / ntiles: the table of dhz_bf16_transpose_batched, index: {(offset, rows, cols)})."""
     global BF16_SHADOW
-    BF16_SHADOW = None if f32 is None else [f32, b16]
+    BF16_SHADOW = None if f32 is None else [f32, b16, b16t, desc, index or set(), int(ntiles)]
+
+
+def refresh_bf16_shadow_t():
+    sh = BF16_SHADOW
+    if sh is not None and sh[2] is not None:
+        _lib.call("dhz_bf16_transpose_batched", sh[0].data_ptr(), sh[2].data_ptr(), sh[3].data_ptr(), sh[3].shape[0], sh[5], _stream())
+
+
+def bf16_copy_t(W):
+    """bf16 copy of W^T ([K, N] row-major for W [N, K]) when FlatAdamW keeps one for this matrix, else None."""
+    sh = BF16_SHADOW
+    if sh is None or sh[2] is None or not W.is_contiguous() or W.dim() != 2:
+        return None
+    o = _view_of(sh[0], W)
+    if o < 0 or (o, W.shape[0], W.shape[1]) not in sh[4]:
+        return None
+    return sh[2][o: o + W.numel()]
 
 
 def refresh_bf16_shadow():
     sh = BF16_SHADOW
     if sh is not None:
         sh[1].copy_(sh[0])                   # one cast launch for all parameters
+        refresh_bf16_shadow_t()
 
 
 def _view_of(flat, W):
@@ -276,9 +296,14 @@ def gemm_dgrad(dy, W):
     W = W if W.is_contiguous() else W.contiguous()
     dx = torch.empty((T, K), device=dy.device, dtype=dy.dtype)
     if dy.dtype == BF16:
-        Wb = bf16_copy(W)
+        Wt = None if _NO_TPLANES else bf16_copy_t(W)
         ev = _timed("dhz_linear_bf16")
-        _lib.call("dhz_linear_dgrad_bf16", _p(dy), dy.stride(0), _p(Wb), _p(dx), K, T, N, K, _stream())
+        if Wt is not None:
+            # dx = dy . W = dy . (W^T)^T: the forward kernel (software-pipelined, csrc/gemm_bf16_pipe.hip) on the optimizer's bf16 copy of W^T
+            _lib.call("dhz_linear_fwd_bf16", _p(dy), dy.stride(0), Wt.data_ptr(), None, _p(dx), K, T, K, N, _stream())
+        else:
+            Wb = bf16_copy(W)
+            _lib.call("dhz_linear_dgrad_bf16", _p(dy), dy.stride(0), _p(Wb), _p(dx), K, T, N, K, _stream())
         _timed_end(ev, 2.0 * T * N * K)
     elif SPLIT_BF16 == 6 and dy.stride(0) % 4 == 0 and _route6(T, N, K, False) == "new" and not _NO_TPLANES \
             and split_planes_t(W) is not None:

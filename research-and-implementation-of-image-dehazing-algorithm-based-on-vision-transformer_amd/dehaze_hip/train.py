@@ -117,6 +117,8 @@ class FlatAdamW(torch.optim.Optimizer):
         shadowed = "p16" in f
         ops.adamw_step_(f["p"], f["g"], f["m"], f["v"], g["lr"], g["betas"][0], g["betas"][1], g["eps"],
                         g["weight_decay"], self._step, self.grad_scale, p16=f["p16"] if shadowed else None)
+        if shadowed and ops.BF16_SHADOW is not None and ops.BF16_SHADOW[0] is f["p"]:
+            ops.refresh_bf16_shadow_t()          # (the AdamW kernel wrote the bf16 copy itself; its transposes: one launch)
         if "p3" in f and ops.SPLIT_SHADOW is not None and ops.SPLIT_SHADOW[0] is f["p"]:
             ops.refresh_split_shadow()           # the three bf16 planes of the updated parameters: one launch
         self._pver = self._param_versions()
@@ -142,6 +144,37 @@ class FlatAdamW(torch.optim.Optimizer):
 
     sync_bf16_shadow = sync_shadows               # (earlier name)
 
+    def _matrix_table(self):
+        """[(offset, rows, cols)] of the matrices whose TRANSPOSES the shadows also keep (for the backward-data GEMMs): every 2-D
+        weight with dimensions in 32s; the adjacent Q / K / V weights of an attention layer as ONE packed [3C, C] matrix (what the
+        packed backward-data GEMM multiplies with)."""
+        slices = self.param_slices()
+        mats, i = [], 0
+        while i < len(slices):
+            p, off, k = slices[i]
+            name = self._names.get(id(p), "")
+            if name.endswith("query_projection.weight") and i + 2 < len(slices) and p.dim() == 2:
+                pk, pv = slices[i + 1][0], slices[i + 2][0]
+                if self._names.get(id(pk), "").endswith("key_projection.weight") and self._names.get(id(pv), "").endswith(
+                        "value_projection.weight") and slices[i + 1][1] == off + k and slices[i + 2][1] == off + 2 * k \
+                        and pk.shape == p.shape == pv.shape and p.shape[0] % 32 == 0 and p.shape[1] % 32 == 0:
+                    mats.append((off, 3 * p.shape[0], p.shape[1]))
+                    i += 3
+                    continue
+            if p.dim() == 2 and p.shape[0] % 32 == 0 and p.shape[1] % 32 == 0 and off % 8 == 0:
+                mats.append((off, p.shape[0], p.shape[1]))
+            i += 1
+        return mats
+
+    def _matrix_desc(self, mats):
+        """device table [nmat, 4] = (offset, rows, cols, first 32 x 32 tile) of dhz_split3_planes_t / dhz_bf16_transpose_batched, the
+        lookup set, and the tile count"""
+        rows, t0 = [], 0
+        for off, R, Cc in mats:
+            rows.append([off, R, Cc, t0])
+            t0 += (R // 32) * (Cc // 32)
+        return torch.tensor(rows, dtype=torch.int32, device=self._flat["p"].device), {(off, R, Cc) for off, R, Cc in mats}, t0
+
     def enable_split_shadow(self):
         """Keep the three bf16 truncation planes of the flat parameter buffer (the pre-split weight operand of the six-term
         GEMMs, csrc/split6_gemm.hip), refreshed after every update; ops.split_planes hands out views of them."""
@@ -149,33 +182,10 @@ class FlatAdamW(torch.optim.Optimizer):
         f = self._flat
         if "p3" not in f:
             f["p3"] = torch.empty((3, f["p"].numel()), device=f["p"].device, dtype=torch.bfloat16)
-            # transposed planes for the backward-data GEMMs: every 2-D weight with dimensions in 32s; the adjacent Q / K / V weights
-            # of an attention layer as ONE packed [3C, C] matrix (what the packed backward-data GEMM multiplies with)
-            slices = self.param_slices()
-            mats, i = [], 0
-            while i < len(slices):
-                p, off, k = slices[i]
-                name = self._names.get(id(p), "")
-                if name.endswith("query_projection.weight") and i + 2 < len(slices) and p.dim() == 2:
-                    pk, pv = slices[i + 1][0], slices[i + 2][0]
-                    if self._names.get(id(pk), "").endswith("key_projection.weight") and self._names.get(id(pv), "").endswith(
-                            "value_projection.weight") and slices[i + 1][1] == off + k and slices[i + 2][1] == off + 2 * k \
-                            and pk.shape == p.shape == pv.shape and p.shape[0] % 32 == 0 and p.shape[1] % 32 == 0:
-                        mats.append((off, 3 * p.shape[0], p.shape[1]))
-                        i += 3
-                        continue
-                if p.dim() == 2 and p.shape[0] % 32 == 0 and p.shape[1] % 32 == 0 and off % 8 == 0:
-                    mats.append((off, p.shape[0], p.shape[1]))
-                i += 1
+            mats = self._matrix_table()
             if mats:
-                rows, t0 = [], 0
-                for off, R, Cc in mats:
-                    rows.append([off, R, Cc, t0])
-                    t0 += (R // 32) * (Cc // 32)
                 f["p3t"] = torch.zeros((3, f["p"].numel()), device=f["p"].device, dtype=torch.bfloat16)
-                f["p3t_desc"] = torch.tensor(rows, dtype=torch.int32, device=f["p"].device)
-                f["p3t_index"] = {(off, R, Cc) for off, R, Cc in mats}
-                f["p3t_ntiles"] = t0
+                f["p3t_desc"], f["p3t_index"], f["p3t_ntiles"] = self._matrix_desc(mats)
         ops.set_split_shadow(f["p"], f["p3"], f.get("p3t"), f.get("p3t_desc"), f.get("p3t_index"), f.get("p3t_ntiles", 0))
         ops.refresh_split_shadow()
         self._pver = self._param_versions()
@@ -188,7 +198,11 @@ class FlatAdamW(torch.optim.Optimizer):
         f = self._flat
         if "p16" not in f:
             f["p16"] = f["p"].to(torch.bfloat16)
-        ops.set_bf16_shadow(f["p"], f["p16"])
+            mats = self._matrix_table()
+            if mats:                            # bf16 copies of the transposes: backward-data runs the forward kernel on them
+                f["p16t"] = torch.zeros_like(f["p16"])
+                f["p16t_desc"], f["p16t_index"], f["p16t_ntiles"] = self._matrix_desc(mats)
+        ops.set_bf16_shadow(f["p"], f["p16"], f.get("p16t"), f.get("p16t_desc"), f.get("p16t_index"), f.get("p16t_ntiles", 0))
         ops.refresh_bf16_shadow()
         self._pver = self._param_versions()
         ops.SHADOW_SYNC = self.sync_shadows

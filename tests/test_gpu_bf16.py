@@ -17,7 +17,10 @@ def _s():
 
 @pytest.mark.parametrize("T,N,K", [(4096, 64, 64), (8192, 192, 64), (4096, 256, 64), (2048, 64, 256), (1024, 384, 128),
                                    (1000, 512, 128), (512, 1536, 512), (64, 2048, 512), (300, 512, 2048), (131072, 128, 128),
-                                   (1, 64, 64), (65536, 256, 64)])
+                                   (1, 64, 64), (65536, 256, 64),
+                                   # the software-pipelined 256 x 128 kernel (csrc/gemm_bf16_pipe.hip: a tile per CU and more): a ragged
+                                   # last row block, one stage per tile, sixteen stages per tile, a result written with non-temporal stores
+                                   (70000, 256, 128), (66000, 128, 64), (33000, 256, 1024), (131072, 768, 64)])
 def test_linear_bf16_c_abi(T, N, K):
     """dhz_linear_fwd_bf16 / dhz_linear_dgrad_bf16 through the raw C-ABI against fp64 matmuls of the same bf16 operands."""
     from dehaze_hip import _lib
@@ -444,6 +447,48 @@ def test_bf16_shadow_written_by_optimizer_and_resynced_after_outside_writes():
         assert seen == [1] and torch.equal(f["p16"], f["p"].to(BF))
     finally:
         ops.refresh_bf16_shadow = orig
+
+
+def test_bf16_transposed_shadow_and_backward_data_on_the_forward_kernel():
+    """The optimizer also keeps bf16 copies of every Linear weight's TRANSPOSE (dhz_bf16_transpose_batched; Q | K | V as one packed
+    matrix): they equal the transposed bf16 copy after a step and after an outside write, and ops.gemm_dgrad - which runs the forward
+    kernel on them - returns what the transposed-read backward-data kernel returns."""
+    import My_model_1 as M1
+    from dehaze_hip import _lib, ops
+    from dehaze_hip.train import FlatAdamW, synthetic_batch, train_step
+    from losses import CharbonnierLoss
+    dev = torch.device("cuda:0")
+    torch.manual_seed(5)
+    model = M1.Uformer(img_size=128, embed_dim=64, win_size=8, token_projection='linear', token_mlp='leff',
+                       drop_path_rate=0.).to(dev).train()
+    model.act_dtype = BF
+    opt = FlatAdamW(model, lr=2e-4, weight_decay=0.02)
+    gt, hazy = synthetic_batch(1, 128, seed=5, device=dev)
+    train_step(model, CharbonnierLoss(), None, opt, None, hazy, gt, 1.0, 0.0)
+    f = opt._flat
+    assert "p16t" in f and len(f["p16t_index"]) > 50
+
+    def check_all():
+        for off, R, Cc in sorted(f["p16t_index"]):
+            assert torch.equal(f["p16t"][off: off + R * Cc].view(Cc, R), f["p16"][off: off + R * Cc].view(R, Cc).t()), (off, R, Cc)
+    check_all()
+    blk = model.encoderlayer_1.blocks[0]
+    with torch.no_grad():
+        blk.mlp.linear1[0].weight.mul_(1.5)                                       # an outside write
+    opt.sync_shadows()
+    check_all()
+    for W in (blk.mlp.linear1[0].weight, blk.mlp.linear2[0].weight,
+              ops.cat_rows([blk.attn.ProbSpare.query_projection.weight.detach(), blk.attn.ProbSpare.key_projection.weight.detach(),
+                            blk.attn.ProbSpare.value_projection.weight.detach()])):
+        W = W.detach()
+        N, K = W.shape
+        assert ops.bf16_copy_t(W) is not None, (N, K)
+        dy = torch.randn(70000, N, device=dev).to(BF)
+        dx = ops.gemm_dgrad(dy, W)
+        ref = torch.empty_like(dx)
+        _lib.call("dhz_linear_dgrad_bf16", dy.data_ptr(), N, ops.bf16_copy(W).data_ptr(), ref.data_ptr(), K, dy.shape[0], N, K, _s())
+        d = (dx.float() - ref.float()).abs()
+        assert (d <= EPS * ref.float().abs() + 1e-6).all(), d.max().item()       # at most the last rounding of a different summation order
 
 
 @pytest.mark.parametrize("n", [1003, 4096, 7])
