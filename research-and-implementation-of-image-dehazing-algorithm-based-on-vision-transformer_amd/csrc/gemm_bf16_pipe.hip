@@ -311,7 +311,7 @@ bool dhz_gemm_bf16_pipe_try(const uint16_t* A, int lda, const uint16_t* B, int l
     if (mode != 2 && ntiles < cus) return false;                  // fewer 256 x 128 tiles than CUs: the 128 x 128 kernel fills the chip better
     const size_t smem = (size_t)RING * SLOT + (size_t)NF * sizeof(float);
     const int grid = ntiles < cus ? ntiles : cus;
-    static const int nt_env = getenv("DHZ_BF16_PIPE_NT") ? atoi(getenv("DHZ_BF16_PIPE_NT")) : -1;       // diagnostics: 0 / 1 force
+    static const int nt_env = (getenv("DHZ_BF16_PIPE_NT") && *getenv("DHZ_BF16_PIPE_NT")) ? atoi(getenv("DHZ_BF16_PIPE_NT")) : -1;       // diagnostics: 0 / 1 force
     const int nt_store = nt_env >= 0 ? nt_env : ((double)M * NF * 2 >= 192e6);
     if (nt_store) launch_pipe<2, true>(A, lda, B, ldb, bias, C, ldc, M, NF, KC, tiles_n, ntiles, grid, smem, s);
     else launch_pipe<2, false>(A, lda, B, ldb, bias, C, ldc, M, NF, KC, tiles_n, ntiles, grid, smem, s);

@@ -63,14 +63,9 @@ constexpr int NSTAMP = 24;
 __device__ __forceinline__ f32x4 mfma_bf16(s16x8 a, s16x8 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
-// NTS: non-temporal stores for results of 192 MB and more - a result that does not fit the 256 MB memory-side cache anyway should not
-// be written through it (tools/bench_split6_few.py, variant builds: T = 524288, 64 -> 256: 170 -> 146 us; backward-data 256 <- 64:
-// 180 -> 154; T = 131072, backward-data 512 <- 128: 143 -> 125; results of 134 MB: 148 -> 158, 191 -> 206)
-template <bool NTS = false>
-__device__ __forceinline__ void st_out(f32x4* p, f32x4 v) {
-    if constexpr (NTS) __builtin_nontemporal_store(v, p);
-    else *p = v;
-}
+// (Non-temporal result stores were tried on the 256 x 128 kernel for results of 192 MB and more: in isolation T = 524288, 64 -> 256:
+// 170 -> 146 us, backward-data 256 <- 64: 180 -> 154 - but the training step did not move (35.11 / 35.26 ms without, 35.17 / 35.30 with):
+// what the store saves, the kernel that reads the result next pays.  Not used.)
 __device__ __forceinline__ void dma16(const void* g, void* l) {
     __builtin_amdgcn_global_load_lds((glb_void*)g, (lds_void*)l, 16, 0, 0);
 }
@@ -336,13 +331,13 @@ __global__ __launch_bounds__(NT, 1) void split6_gemm_kernel(const float* __restr
 #pragma unroll
                 for (int b = 0; b < WN; ++b)
                     if (!(abl & 1) || acc[a][b][0] == 12345.678f)
-                        st_out(reinterpret_cast<f32x4*>(c0 + (size_t)(16 * a) * ldc + 16 * b), acc[a][b] + bv[b]);
+                        *reinterpret_cast<f32x4*>(c0 + (size_t)(16 * a) * ldc + 16 * b) = acc[a][b] + bv[b];
         } else {
 #pragma unroll
             for (int a = 0; a < WM; ++a)
                 if (m0 + 16 * a < M) {
 #pragma unroll
-                    for (int b = 0; b < WN; ++b) st_out(reinterpret_cast<f32x4*>(c0 + (size_t)(16 * a) * ldc + 16 * b), acc[a][b] + bv[b]);
+                    for (int b = 0; b < WN; ++b) *reinterpret_cast<f32x4*>(c0 + (size_t)(16 * a) * ldc + 16 * b) = acc[a][b] + bv[b];
                 }
         }
 #pragma unroll
@@ -481,7 +476,7 @@ __global__ __launch_bounds__(NT, 1) void split6_gemm_kernel(const float* __restr
 // per product) and a 256 x 128 workgroup tile 0.7 x the L2 bytes per product; a stage then carries 96 MFMAs per wave (two
 // waves per SIMD: ~3000 cycles), long enough for a plain two-slot ring: the DMA of stage p+1 and the split of its activations
 // go into the other slot during stage p and have the whole stage to land.
-template <bool BTR, bool NTS>
+template <bool BTR>
 __global__ __launch_bounds__(NT, 1) void split6_wide_kernel(const float* __restrict__ A, int lda, const uint16_t* __restrict__ Bh,
                                                             const uint16_t* __restrict__ Bm, const uint16_t* __restrict__ Bl,
                                                             int ldb, const float* __restrict__ bias, float* __restrict__ C, int ldc,
@@ -623,13 +618,13 @@ __global__ __launch_bounds__(NT, 1) void split6_wide_kernel(const float* __restr
 #pragma unroll
             for (int a = 0; a < WM; ++a)
 #pragma unroll
-                for (int b = 0; b < WN; ++b) st_out<NTS>(reinterpret_cast<f32x4*>(c0 + (size_t)(16 * a) * ldc + 16 * b), acc[a][b] + bv[b]);
+                for (int b = 0; b < WN; ++b) *reinterpret_cast<f32x4*>(c0 + (size_t)(16 * a) * ldc + 16 * b) = acc[a][b] + bv[b];
         } else {
 #pragma unroll
             for (int a = 0; a < WM; ++a)
                 if (m0 + 16 * a < M) {
 #pragma unroll
-                    for (int b = 0; b < WN; ++b) st_out<NTS>(reinterpret_cast<f32x4*>(c0 + (size_t)(16 * a) * ldc + 16 * b), acc[a][b] + bv[b]);
+                    for (int b = 0; b < WN; ++b) *reinterpret_cast<f32x4*>(c0 + (size_t)(16 * a) * ldc + 16 * b) = acc[a][b] + bv[b];
                 }
         }
 #pragma unroll
@@ -725,7 +720,7 @@ __global__ __launch_bounds__(NT, 1) void split6_wide_kernel(const float* __restr
 #endif
 }
 
-template <bool BTR, bool NTS>
+template <bool BTR>
 void launch_wide(const float* A, int lda, const uint16_t* Bh, const uint16_t* Bm, const uint16_t* Bl, int ldb, const float* bias, float* C,
                  int ldc, int M, int NF, int KC, hipStream_t s) {
     constexpr int BM = 256, BN = 128;
@@ -738,8 +733,8 @@ void launch_wide(const float* A, int lda, const uint16_t* Bh, const uint16_t* Bm
     const int ntiles = tiles_n * tiles_m;
     const int slots = dhz_num_cus();
     const int grid = ntiles < slots ? ntiles : slots;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&split6_wide_kernel<BTR, NTS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    hipLaunchKernelGGL((split6_wide_kernel<BTR, NTS>), dim3(grid), dim3(NT), smem, s, A, lda, Bh, Bm, Bl, ldb, bias, C, ldc, M, NF, KC, tiles_n,
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&split6_wide_kernel<BTR>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipLaunchKernelGGL((split6_wide_kernel<BTR>), dim3(grid), dim3(NT), smem, s, A, lda, Bh, Bm, Bl, ldb, bias, C, ldc, M, NF, KC, tiles_n,
                        ntiles);
 }
 
@@ -781,10 +776,7 @@ int dispatch(const char* who, const float* A, int lda, const uint16_t* Bh, const
 #define GO(WM_, WN_, WV_) launch<WM_, WN_, WV_, BTR>(A, lda, Bh, Bm, Bl, ldb, bias, C, ldc, M, NF, KC, s)
     static const int force = getenv("DHZ_S6_TILE") ? atoi(getenv("DHZ_S6_TILE")) : 0;          // diagnostics: 1 = never wide, 2 = always wide
     const bool wide = bn == 128 && force != 1 && (force == 2 || (long)((M + 255) / 256) * (NF / 128) >= cus);
-    static const int nt_env = getenv("DHZ_S6_NT") ? atoi(getenv("DHZ_S6_NT")) : -1;             // diagnostics: 0 / 1 force
-    const bool nts = nt_env >= 0 ? nt_env != 0 : (double)M * NF * 4 >= 192e6;
-    if (wide && nts) launch_wide<BTR, true>(A, lda, Bh, Bm, Bl, ldb, bias, C, ldc, M, NF, KC, s);       // 256 x 128
-    else if (wide) launch_wide<BTR, false>(A, lda, Bh, Bm, Bl, ldb, bias, C, ldc, M, NF, KC, s);
+    if (wide) launch_wide<BTR>(A, lda, Bh, Bm, Bl, ldb, bias, C, ldc, M, NF, KC, s);        // 256 x 128
     else if (bn == 128) GO(4, 2, 2);                              // 128 x 128
     else if (bn == 64) GO(2, 2, 4);                               // 128 x 64
     else if constexpr (!BTR) GO(1, 2, 8);                         // 128 x 32

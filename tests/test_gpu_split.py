@@ -175,7 +175,7 @@ def test_split3_planes_are_exact(n):
 # % 64 -> 128 x 64, % 32 -> 128 x 32 (forward only); ragged T; strided activations (a packed QKV buffer); no bias
 @pytest.mark.parametrize("T,K,N,ldx_pad", [(128, 32, 32, 0), (1000, 64, 96, 0), (777, 128, 512, 0), (4096, 128, 128, 64),
                                            (32768, 256, 256, 0), (65536, 64, 128, 0), (5000, 192, 64, 32), (64, 1024, 256, 0),
-                                           (33000, 96, 384, 0)])
+                                           (33000, 96, 384, 0), (66000, 128, 256, 64)])
 def test_split6_planes_gemm_forward_and_dgrad_vs_fp64(T, K, N, ldx_pad):
     from dehaze_hip import _lib
     dev = torch.device("cuda:0")
