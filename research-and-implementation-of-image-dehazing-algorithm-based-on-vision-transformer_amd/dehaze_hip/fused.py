@@ -25,6 +25,9 @@ ATTN_FUSED_C128_MAX_HW = 1024   # C = 128 takes the fused attention forward up t
 ATTN_FUSED_BWD_C = (32,)
 LEFF_FUSED = True           # False forces the kernel chain everywhere
 LEFF_FUSED_C = (32, 64)     # widths that take the fused forward
+# ... C = 64 only below this many tokens when the chain's GEMMs run in the six-term form (tools/bench_leff.py, bs 32, forward with the
+# training saves: 64 x 64 maps 204 us fused / 218 chain, 128 x 128 maps 794 / 765; forward + backward 2058 / 2010)
+LEFF_FUSED_C64_MAX_T = 262144
 
 
 def _wgrad(dy, off, x, w, b, row_scale=None):
@@ -341,7 +344,7 @@ class _LeffBranch(Function):
         out = torch.empty_like(x)
         tiled = Hres % 8 == 0 and Wres % 16 == 0
         fp32 = x.dtype == torch.float32                      # the fused LeFF kernels are fp32-only
-        if LEFF_FUSED and C in LEFF_FUSED_C and tiled and fp32:
+        if LEFF_FUSED and C in LEFF_FUSED_C and tiled and fp32 and not (C == 64 and T > LEFF_FUSED_C64_MAX_T and ops.SPLIT_BF16 == 6):
             # one kernel: norm2, linear1, GELU, depthwise 3x3, GELU, linear2, DropPath scale, residual (csrc/leff_fused.hip)
             xn = stats = u = tg = z = None
             if train:
