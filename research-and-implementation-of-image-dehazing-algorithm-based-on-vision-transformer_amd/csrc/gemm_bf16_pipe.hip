@@ -317,3 +317,9 @@ bool dhz_gemm_bf16_pipe_try(const uint16_t* A, int lda, const uint16_t* B, int l
     else launch_pipe<2, false>(A, lda, B, ldb, bias, C, ldc, M, NF, KC, tiles_n, ntiles, grid, smem, s);
     return true;
 }
+
+// (The weight gradient was given the same division of labour - two loading waves bring 64-token stages of dy and x [token][feature]
+// into a three-slot ring by DMA, eight multiplying waves read them with ds_read_b64_tr_b16, 256 x 128 / 128 x 256 tiles, the bias gradient
+// as an MFMA with a fragment of ones - and measured against csrc/linear_bf16.hip's register-staged 128 x 128 kernel on the config-4
+// shapes (tools/bench_bf16_wgrad.py): T = 8192, N = 4096, K = 1024: 99.6 -> 89.5 us, T = 131072, N = 1024, K = 256: 113 -> 100, most
+// others within 3 %, several small ones 10 % slower; sum over the step's 36 shapes 2515 -> 2483 us.  Removed.)
