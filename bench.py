@@ -156,7 +156,7 @@ def run_config4(dev, steps, warmup):
                        "accumulation / master weights, Charbonnier+CR(VGG19, seeded-random weights) + AdamW (BASELINE configs[3])",
            "value": round(bs * steps / el, 3), "unit": "patches/s", "ms_per_step": round(1e3 * el / steps, 3), "steps": steps,
            "warmup": warmup, "dtype": "bf16", "loss_last_step": round(float(loss), 6)}
-    for key, name, kern in (("dhz_linear_bf16", "roofline", "gemm_bf16_kernel<WM,WN,BTR> (dhz_linear_fwd_bf16 / dhz_linear_dgrad_bf16)"),
+    for key, name, kern in (("dhz_linear_bf16", "roofline", "gemm_bf16_pipe_kernel<2,NTS> / gemm_bf16_kernel<WM,WN,BTR> (dhz_linear_fwd_bf16 / dhz_linear_dgrad_bf16; backward-data mostly as the forward kernel on the bf16 copy of W^T)"),
                             ("dhz_vgg_conv3x3_bf16", "roofline_conv_bf16", "conv3_bf16_kernel<WM,WN> (dhz_vgg_conv3x3_bf16)")):
         ev = timing.get(key) or []
         if ev:
@@ -344,7 +344,7 @@ def main():
             ms = sum(a.elapsed_time(b_) for a, b_, _ in ev)
             flops = sum(f for _, _, f in ev)
             tf = flops / (ms * 1e-3) / 1e12
-            out["roofline"] = {"kernel": "gemm_bf16_kernel<WM,WN,BTR> (dhz_linear_fwd_bf16 / dhz_linear_dgrad_bf16)", "bound": "mfma",
+            out["roofline"] = {"kernel": "gemm_bf16_pipe_kernel<2,NTS> / gemm_bf16_kernel<WM,WN,BTR> (dhz_linear_fwd_bf16 / dhz_linear_dgrad_bf16; backward-data mostly as the forward kernel on the bf16 copy of W^T)", "bound": "mfma",
                                "achieved": round(tf, 1), "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s",
                                "frac": round(tf / MFMA_BF16_PEAK_TF, 4), "traffic": None, "launches": len(ev),
                                "avg_launch_us": round(1e3 * ms / len(ev), 2), "alg_flops_per_launch": int(flops / len(ev))}
