@@ -200,19 +200,28 @@ def gen_blocks(M1, M0):
             **sd_arrays(blk), **grad_arrays(blk))
 
 
-def gen_block_c128(M1):
-    """round 4: the ProbSparse block at C = 128 (four heads), shifted, 16 x 16 - the widest instance of the fused window-attention
-    forward (csrc/fused_attn.hip) - so that it is checked against the REFERENCE, not only against the kernel chain"""
+WIDE_BLOCKS = {     # name -> (C, heads, map side, shift): the widths whose blocks run the kernel chain (C >= 256) or the widest fused instance
+    "block_m1_c128_shift4": (128, 4, 16, 4),
+    "block_m1_c256_shift4": (256, 8, 16, 4),
+    "block_m1_c512_shift0": (512, 16, 8, 0),       # the bottleneck's geometry: one 8 x 8 window per image
+}
+
+
+def gen_block_wide(M1, name):
+    """round 4: ProbSparse blocks at C = 128 (the widest instance of the fused window-attention forward, csrc/fused_attn.hip), C = 256
+    and C = 512 (8 / 16 heads on the kernel chain) - so that they are checked against the REFERENCE block by block, not only through
+    the whole-model golden"""
+    C, heads, side, shift = WIDE_BLOCKS[name]
     seed_all(31)
-    blk = M1.LeWinTransformerBlock(dim=128, input_resolution=(16, 16), num_heads=4, win_size=8, shift_size=4, token_mlp='leff',
+    blk = M1.LeWinTransformerBlock(dim=C, input_resolution=(side, side), num_heads=heads, win_size=8, shift_size=shift, token_mlp='leff',
                                    drop_path=0.)
     g = torch.Generator().manual_seed(7)
     with torch.no_grad():
         for p in blk.parameters():
             if p.ndim == 1:
                 p.add_(0.1 * torch.randn(p.shape, generator=g))
-    x = torch.randn(1, 256, 128, generator=g).requires_grad_()
-    gout = torch.randn(1, 256, 128, generator=g)
+    x = torch.randn(1, side * side, C, generator=g).requires_grad_()
+    gout = torch.randn(1, side * side, C, generator=g)
     torch.manual_seed(79)
     idx = torch.randint(64, (64, 25))
     torch.manual_seed(79)
@@ -228,8 +237,12 @@ def gen_block_c128(M1):
             gs["gn/" + k] = p.grad.double().norm().reshape(1)
             gs["gs/" + k] = p.grad.reshape(-1)[::97].clone()
     first = next(iter(blk.parameters()))
-    npz("block_m1_c128_shift4", x_probe=x.detach().reshape(-1)[:16].clone(), gout_probe=gout.reshape(-1)[:16].clone(),
+    npz(name, x_probe=x.detach().reshape(-1)[:16].clone(), gout_probe=gout.reshape(-1)[:16].clone(),
         idx=idx.to(torch.int8), y=y, dx=x.grad, w_probe=first.detach().reshape(-1)[:16].clone(), **gs)
+
+
+def gen_block_c128(M1):
+    gen_block_wide(M1, "block_m1_c128_shift4")
 
 
 def gen_masks(M1):
@@ -438,6 +451,15 @@ def main():
     if len(sys.argv) > 2 and sys.argv[1] == "--only" and sys.argv[2] == "data":
         gen_data()
         return
+    if len(sys.argv) > 2 and sys.argv[1] == "--only" and sys.argv[2] == "blockwide":
+        install_shims()
+        import warnings
+        warnings.filterwarnings("ignore")
+        import My_model_1 as M1
+        torch.set_num_threads(8)
+        for name in WIDE_BLOCKS:
+            gen_block_wide(M1, name)
+        return
     if len(sys.argv) > 2 and sys.argv[1] == "--only" and sys.argv[2] == "block128":
         install_shims()
         import warnings
@@ -459,7 +481,8 @@ def main():
     gen_probattn(M1, ATT)
     gen_masks(M1)
     gen_blocks(M1, M0)
-    gen_block_c128(M1)
+    for name in WIDE_BLOCKS:
+        gen_block_wide(M1, name)
     gen_small_modules(M1)
     gen_losses(losses)
     gen_options()

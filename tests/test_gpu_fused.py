@@ -124,15 +124,17 @@ def test_fused_block_vs_reference_golden(golden, dev, name, heads, shift, C):
             assert err <= 2e-4 + 2e-3 * np.abs(ref).max(), (n, err)
 
 
-@pytest.mark.parametrize("use_fused", [True, False])
-def test_block_c128_vs_reference_golden(golden, dev, use_fused):
-    """C = 128 (four heads), shifted windows, 16 x 16: the widest instance of the fused window-attention forward - and the kernel
-    chain - against the REFERENCE's numbers (tests/golden/block_m1_c128_shift4.npz), not only against each other"""
+@pytest.mark.parametrize("name,use_fused", [("block_m1_c128_shift4", True), ("block_m1_c128_shift4", False),
+                                            ("block_m1_c256_shift4", False), ("block_m1_c512_shift0", False)])
+def test_block_wide_vs_reference_golden(golden, dev, name, use_fused):
+    """C = 128 (four heads, shifted windows, 16 x 16): the widest instance of the fused window-attention forward - and the kernel chain;
+    C = 256 (eight heads) and C = 512 (sixteen heads, the bottleneck's single 8 x 8 window): the kernel chain every block of those widths
+    runs - against the REFERENCE's numbers (tests/golden/block_m1_c*.npz), not only against each other or through the whole model"""
     import My_model_1 as M1
     from dehaze_hip import fused
-    from test_oracle_golden import _c128_block_inputs, check_c128_grads
-    g = golden("block_m1_c128_shift4")
-    blk, x, gout = _c128_block_inputs(g, M1)
+    from test_oracle_golden import _wide_block_inputs, check_c128_grads
+    g = golden(name)
+    blk, x, gout = _wide_block_inputs(g, M1, name)
     blk.to(dev)
     x = x.to(dev).requires_grad_()
     blk._staged_idx = T(g["idx"].astype(np.uint8)).to(dev)

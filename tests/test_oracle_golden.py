@@ -204,23 +204,35 @@ def test_full_model_oracle(golden, gname, variant):
     assert abs(float(y.double().sum()) - float(g["y_eval_sum"])) < 1e-4 * float(g["y_eval_abs"])
 
 
-def _c128_block_inputs(g, M1):
-    """rebuild weights / x / gout of tests/golden/gen_golden.py::gen_block_c128 (the golden stores probes of them, not the tensors)"""
+WIDE_BLOCKS = {     # tests/golden/gen_golden.py::WIDE_BLOCKS: name -> (C, heads, map side, shift)
+    "block_m1_c128_shift4": (128, 4, 16, 4),
+    "block_m1_c256_shift4": (256, 8, 16, 4),
+    "block_m1_c512_shift0": (512, 16, 8, 0),
+}
+
+
+def _wide_block_inputs(g, M1, name):
+    """rebuild weights / x / gout of tests/golden/gen_golden.py::gen_block_wide (the golden stores probes of them, not the tensors)"""
     import random
+    C, heads, side, shift = WIDE_BLOCKS[name]
     random.seed(31); np.random.seed(31); torch.manual_seed(31)
-    blk = M1.LeWinTransformerBlock(dim=128, input_resolution=(16, 16), num_heads=4, win_size=8, shift_size=4, token_mlp='leff',
+    blk = M1.LeWinTransformerBlock(dim=C, input_resolution=(side, side), num_heads=heads, win_size=8, shift_size=shift, token_mlp='leff',
                                    drop_path=0.)
     gen = torch.Generator().manual_seed(7)
     with torch.no_grad():
         for p in blk.parameters():
             if p.ndim == 1:
                 p.add_(0.1 * torch.randn(p.shape, generator=gen))
-    x = torch.randn(1, 256, 128, generator=gen)
-    gout = torch.randn(1, 256, 128, generator=gen)
+    x = torch.randn(1, side * side, C, generator=gen)
+    gout = torch.randn(1, side * side, C, generator=gen)
     first = next(iter(blk.parameters()))
     assert torch.equal(first.detach().reshape(-1)[:16], T(g["w_probe"])) and torch.equal(x.reshape(-1)[:16], T(g["x_probe"]))
     assert torch.equal(gout.reshape(-1)[:16], T(g["gout_probe"]))
     return blk, x, gout
+
+
+def _c128_block_inputs(g, M1):
+    return _wide_block_inputs(g, M1, "block_m1_c128_shift4")
 
 
 def check_c128_grads(g, named_grads, tol_rel):
@@ -239,14 +251,17 @@ def check_c128_grads(g, named_grads, tol_rel):
         assert torch.allclose(gr.reshape(-1)[::97].cpu(), samp, atol=tol_rel * float(samp.abs().max()) + 1e-6, rtol=10 * tol_rel), name
 
 
-def test_block_c128_oracle_vs_reference(golden):
-    """the oracle's block at C = 128 (four heads, shifted windows) against the reference's own numbers"""
+@pytest.mark.parametrize("name", sorted(WIDE_BLOCKS))
+def test_block_wide_oracle_vs_reference(golden, name):
+    """the oracle's block at C = 128 / 256 / 512 (4 / 8 / 16 heads; shifted windows; the bottleneck's single-window geometry) against the
+    reference's own numbers"""
     import My_model_1 as M1
-    g = golden("block_m1_c128_shift4")
-    blk, x, gout = _c128_block_inputs(g, M1)
+    C, heads, side, shift = WIDE_BLOCKS[name]
+    g = golden(name)
+    blk, x, gout = _wide_block_inputs(g, M1, name)
     P = {k: v.detach().clone().requires_grad_(v.dtype.is_floating_point) for k, v in blk.state_dict().items()}
     x = x.requires_grad_()
-    y = O.lewin_block(x, P, "", 4, 8, 4, "probsparse", T(g["idx"].astype(np.int64)))
+    y = O.lewin_block(x, P, "", heads, 8, shift, "probsparse", T(g["idx"].astype(np.int64)))
     assert torch.allclose(y, T(g["y"]), atol=2e-5, rtol=1e-5)
     (y * gout).sum().backward()
     assert torch.allclose(x.grad, T(g["dx"]), atol=5e-5, rtol=1e-4)
