@@ -75,7 +75,11 @@ def test_six_term_split_is_the_default_and_the_switch_routes():
 
 @pytest.mark.parametrize("terms", [3, 6])
 @pytest.mark.parametrize("T,nmat,nper,K,scaled", [(4096, 1, 128, 64, False), (2048, 3, 64, 64, False), (8192, 1, 64, 256, True),
-                                                  (1024, 1, 512, 128, False), (4096, 3, 128, 128, False)])
+                                                  (1024, 1, 512, 128, False), (4096, 3, 128, 128, False),
+                                                  # step-sized problems: many token splits per tile, the packed three-matrix form, the
+                                                  # row-scaled form, a token count that does not divide evenly over the splits
+                                                  (16384, 1, 256, 256, False), (65536, 1, 256, 64, True), (65536, 1, 64, 256, False),
+                                                  (32768, 3, 128, 128, False), (33280, 1, 128, 256, True)])
 def test_split_wgrad_vs_fp64(T, nmat, nper, K, scaled, terms):
     import ctypes
     from dehaze_hip import _lib
@@ -85,7 +89,7 @@ def test_split_wgrad_vs_fp64(T, nmat, nper, K, scaled, terms):
     N = nmat * nper
     dy = torch.randn(T, N, generator=g).to(dev)
     x = torch.randn(T, K, generator=g).to(dev)
-    rps = 512
+    rps = 512 if T % 512 == 0 else 32
     rs = (0.5 + torch.rand(T // rps, generator=g)).to(dev) if scaled else None
     dws = [torch.zeros(nper, K, device=dev) for _ in range(nmat)]
     dbs = [torch.zeros(nper, device=dev) for _ in range(nmat)]
