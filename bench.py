@@ -219,9 +219,6 @@ def main():
     from dehaze_hip import ops, _lib
     from dehaze_hip.train import FlatAdamW, GradReducer, synthetic_batch, train_step
 
-    # MIOpen picks the convolution algorithms of the projection / resampling layers by measurement during the warm-up steps,
-    # as the reference's driver does (My_train.py:35, cudnn.benchmark = True); DHZ_CONV_FIND=0 keeps the heuristic pick
-    torch.backends.cudnn.benchmark = bool(int(os.environ.get("DHZ_CONV_FIND", "1")))
     torch.manual_seed(1234)                       # identical replicas on every rank
     model = M1.Uformer(img_size=args.ps, embed_dim=args.embed_dim, win_size=8, token_projection='linear',
                        token_mlp='leff').to(dev)
@@ -317,7 +314,7 @@ def main():
                                    f"{'Charbonnier' if args.no_cr else 'Charbonnier+CR(VGG19, seeded-random weights)'} + AdamW "
                                    + ("(BASELINE configs[1])" if (args.dtype, args.embed_dim, args.ps, args.batch) == ("f32", 32, 128, 32)
                                       else "(BASELINE configs[3])" if (args.dtype, args.embed_dim, args.ps) == ("bf16", 64, 256) else "(not a BASELINE config)"),
-                       "global_batch": args.batch * world, "parallelism": f"dp{world}", "miopen_find": bool(torch.backends.cudnn.benchmark),
+                       "global_batch": args.batch * world, "parallelism": f"dp{world}",
                        "loss_last_step": round(float(loss), 6)},
         }
         if args.dtype == "f32":

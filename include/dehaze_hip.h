@@ -209,7 +209,7 @@ int dhz_linear_dgrad_split(const float* dy, int ldy, const float* w, float* dx, 
                            void* stream);
 /* The product's default form of the two GEMMs above (dehaze_hip.ops.SPLIT_BF16 == 6; csrc/split6_gemm.hip): the six-term split with
  *     the WEIGHT operand pre-split - w_hi / w_mid / w_lo are the three bf16 planes of w[N,K] (same layout, truncation pieces:
- *     hi + mid + lo == w exactly), written once per optimizer step by dhz_adamw_step_split3 or by dhz_split3_planes.  The
+ *     hi + mid + lo == w exactly), written by dhz_split3_planes (one launch over the flat parameter buffer after every dhz_adamw_step; + dhz_split3_planes_t for W^T).  The
  *     activation operand is split inside the kernel.  fp32 activations, bias, accumulation and results; replaces the same
  *     aten::addmm / aten::mm as dhz_linear_fwd / dhz_linear_dgrad.  K % 32 == 0; N % 32 == 0 (forward), N % 32 == 0 and
  *     K % 64 == 0 (backward-data: its output features are w's K columns); planes 16-byte aligned. */

@@ -10,15 +10,15 @@
 //
 // Round 4 structure (csrc/linear_split.hip is the round-3 form: both operands split inside the kernel, one LDS stage, two
 // barriers per stage with the split between them):
-//   * the WEIGHTS arrive pre-split: three bf16 planes that mirror the flat fp32 parameter buffer (written once per step by the
-//     optimizer kernel, dhz_adamw_step_split3, or by dhz_split3_planes after an outside write).  They go global -> LDS by
+//   * the WEIGHTS arrive pre-split: three bf16 planes that mirror the flat fp32 parameter buffer (written by one dhz_split3_planes
+//     launch after every optimizer step, and again after an outside write).  They go global -> LDS by
 //     LDS-DMA (global_load_lds_dwordx4: no VGPR, no VALU, no ds_write); the bank swizzle is carried by the per-lane SOURCE
 //     address.  Backward-data reads the same planes as they lie ([N][K], the contraction index is the row) through the
 //     hardware transpose ds_read_b64_tr_b16.
 //   * only the ACTIVATION operand is split in the kernel: global -> registers one stage ahead, 4.5 VALU instructions per
 //     element, three ds_write_b128 per 8 elements - placed INSIDE the MFMA stream of the previous stage (a bf16 MFMA holds the
 //     vector issue for 8 of its 16 cycles: a wave's own vector instructions ride in the other 8).
-//   * 512-thread workgroups, one per CU, 32-deep contraction stages in a two-buffer LDS ring, ONE raw s_barrier per stage; the
+//   * 512-thread workgroups, one per CU, 32-deep contraction stages in a three-slot LDS ring, ONE raw s_barrier per stage; the
 //     persistent workgroup treats its (tile, stage) pairs as one stream, so a tile's stores drain behind the next tile's
 //     matrix work (counted vmcnt waits).
 //   * LDS images: [row][32 k] bf16 = 64-byte rows, the four 16-byte chunks of a row XOR-ed with P[(row >> 2) & 3],

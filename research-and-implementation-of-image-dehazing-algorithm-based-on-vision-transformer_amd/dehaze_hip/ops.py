@@ -75,18 +75,45 @@ def _dt(t):
 #   BF16_SHADOW  = [flat f32, its bf16 copy]                      (config 4: the bf16 GEMMs' weight operand)
 #   SPLIT_SHADOW = [flat f32, hi plane, mid plane, lo plane]      (the six-term split GEMMs' pre-split weight operand, bf16 each)
 # A weight that is a view of the flat buffer gets the matching views - one launch per optimizer step for all parameters instead
-# of one per Linear and pass.  The optimizer kernel keeps them current; writes that bypass it (a loaded checkpoint, a landscape
-# probe - parameters are views with autograd version counters of their own, so the flat buffer's counter does NOT see them) are
-# caught by SHADOW_SYNC: FlatAdamW registers a callable that compares the sum of the parameters' version counters and re-derives
-# the copies; train_step and Uformer.forward call sync_shadows() before the first GEMM.
+# of one per Linear and pass.  The optimizer kernel keeps them current.  Writes that bypass it (a loaded checkpoint, a landscape
+# probe, `with torch.no_grad(): p.add_(...)`) bump the autograd version counter of the PARAMETER (parameters are views with counters
+# of their own: the flat buffer's counter does not see them).  Two guards, both through SHADOW_OWNER (a weak reference to the
+# FlatAdamW that registered the copies - weak, so that dropping the optimizer frees its buffers and un-registers the copies):
+#   * every lookup (split_planes, split_planes_t, bf16_copy, bf16_copy_t) validates itself: the counters of the parameters that
+#     overlap the requested region are compared with the values recorded when the copies were derived (_shadow_fresh); on a
+#     mismatch ALL copies are re-derived before the views are handed out.  So any entry that reaches a GEMM - a block, a layer, a
+#     bare ops.* call - multiplies with current weights, not only train_step / Uformer.forward;
+#   * sync_shadows() (train_step, Uformer.forward) checks all parameters at once.
+# NOT seen by either: writes that bump no counter - `p.data.copy_(...)` / `p.data.add_(...)` (a fresh view with a fresh counter) and
+# raw-pointer kernels.  After such a write call FlatAdamW.sync_shadows(force=True).
 BF16_SHADOW = None
 SPLIT_SHADOW = None
-SHADOW_SYNC = None
+SHADOW_OWNER = None          # weakref.ref(FlatAdamW) or None
 
 
-def sync_shadows():
-    if SHADOW_SYNC is not None:
-        SHADOW_SYNC()
+def _shadow_owner():
+    global SHADOW_OWNER
+    if SHADOW_OWNER is None:
+        return None
+    o = SHADOW_OWNER()
+    if o is None:                # the optimizer is gone: its copies are meaningless
+        SHADOW_OWNER = None
+        set_bf16_shadow(None, None)
+        set_split_shadow(None, None)
+    return o
+
+
+def sync_shadows(force=False):
+    o = _shadow_owner()
+    if o is not None:
+        o.sync_shadows(force)
+
+
+def _shadow_fresh(off, n):
+    """called by the lookups with the flat-buffer region they are about to hand out views for"""
+    o = _shadow_owner()
+    if o is not None and not o.region_current(off, n):
+        o.sync_shadows()
 
 # Which matrix pipe takes the PRODUCTS of the fp32 path's GEMM-shaped kernels (storage, accumulation, bias / statistics stay fp32):
 #   6 (default) - the bf16 pipe by operand splitting into three bf16 pieces (hi + mid + lo = all 24 mantissa bits, exactly) and the
@@ -129,6 +156,7 @@ def bf16_copy_t(W):
     o = _view_of(sh[0], W)
     if o < 0 or (o, W.shape[0], W.shape[1]) not in sh[4]:
         return None
+    _shadow_fresh(o, W.numel())
     return sh[2][o: o + W.numel()]
 
 
@@ -155,6 +183,7 @@ def bf16_copy(W):
     if sh is not None and W.is_contiguous():
         o = _view_of(sh[0], W)
         if o >= 0:
+            _shadow_fresh(o, W.numel())
             return sh[1][o: o + W.numel()].view(W.shape)
     return W.detach().to(BF16)
 
@@ -187,6 +216,7 @@ def split_planes_t(W):
     if o < 0 or (o, W.shape[0], W.shape[1]) not in sh[6]:
         return None
     n = W.numel()
+    _shadow_fresh(o, n)
     pt = sh[4]
     return pt[0][o: o + n], pt[1][o: o + n], pt[2][o: o + n]
 
@@ -200,6 +230,7 @@ def split_planes(W):
         o = _view_of(sh[0], W)
         if o >= 0 and o % 8 == 0:
             n = W.numel()
+            _shadow_fresh(o, n)
             return sh[1][o: o + n], sh[2][o: o + n], sh[3][o: o + n]
     pl = torch.empty((3, W.numel()), device=W.device, dtype=BF16)
     _lib.call("dhz_split3_planes", _p(W), W.numel(), pl[0].data_ptr(), pl[1].data_ptr(), pl[2].data_ptr(), _stream())
@@ -490,7 +521,7 @@ def _accumulate_param_grads(dy, ldy_off, x, params, row_scale=None):
                       ctypes.cast(dws, ctypes.c_void_p), ctypes.cast(dbs, ctypes.c_void_p), _stream())
             off += n * Ng
     elif SPLIT_BF16 and T % 64 == 0 and K % 64 == 0 and all(W.shape[0] % 64 == 0 for W, _ in params):
-        # EXPERIMENT (off by default): contraction over T on the bf16 pipe with split operands (csrc/linear_split.hip)
+        # the default fp32-class path (SPLIT_BF16 == 6): contraction over T on the bf16 pipe with split operands (csrc/linear_split.hip)
         groups = [params] if (same or len(params) == 1) else [[pr] for pr in params]
         off = ldy_off
         for grp in groups:

@@ -2,7 +2,9 @@
 (one process per GPU over xGMI - replaces the reference's nn.DataParallel, TR:97), synthetic haze
 batches and the step body of My_train.py (TR:212-250).
 """
+import bisect
 import math
+import weakref
 
 import torch
 import torch.distributed as dist
@@ -121,26 +123,48 @@ class FlatAdamW(torch.optim.Optimizer):
             ops.refresh_bf16_shadow_t()          # (the AdamW kernel wrote the bf16 copy itself; its transposes: one launch)
         if "p3" in f and ops.SPLIT_SHADOW is not None and ops.SPLIT_SHADOW[0] is f["p"]:
             ops.refresh_split_shadow()           # the three bf16 planes of the updated parameters: one launch
-        self._pver = self._param_versions()
+        self._record_versions()
 
-    def _param_versions(self):
-        """sum of the version counters of the parameters (views of the flat buffer with counters of their own): changes when
-        anything but the optimizer kernel writes a parameter in place (a loaded checkpoint, a landscape probe)"""
-        return sum(p._version for p in self._live) + self._flat["p"]._version
+    def _record_versions(self):
+        """the version counters of the parameters (views of the flat buffer with counters of their own) and of the flat buffer at the
+        moment the derived copies are current: a counter moves when anything but the optimizer kernel writes a parameter in place (a
+        loaded checkpoint, a landscape probe)"""
+        if getattr(self, "_vtab", None) is None:
+            sl = self.param_slices()
+            self._vtab = ([off for _, off, _ in sl], [p for p, _, _ in sl])
+        self._pver = [p._version for p in self._vtab[1]]
+        self._fver = self._flat["p"]._version
 
-    def sync_shadows(self):
-        """Re-derive the bf16 copy / the split planes if a parameter was written since the last update (registered as
-        ops.SHADOW_SYNC: train_step and Uformer.forward call it before the first GEMM)."""
+    def region_current(self, off, n):
+        """True when no parameter overlapping flat[off : off + n] was written (counter-visibly) since the copies were derived -
+        the per-lookup guard of ops.split_planes / split_planes_t / bf16_copy / bf16_copy_t."""
+        pv = getattr(self, "_pver", None)
+        if pv is None or self._flat["p"]._version != self._fver:
+            return False
+        offs, ps = self._vtab
+        i = max(bisect.bisect_right(offs, off) - 1, 0)
+        end = off + n
+        while i < len(offs) and offs[i] < end:
+            if ps[i]._version != pv[i]:
+                return False
+            i += 1
+        return True
+
+    def sync_shadows(self, force=False):
+        """Re-derive the bf16 copy / the split planes if a parameter was written since the last update (or unconditionally with
+        force=True: after writes that bump no version counter - p.data.copy_(...), raw-pointer kernels).  Reached through
+        ops.sync_shadows() (train_step, Uformer.forward) and from any stale lookup (ops._shadow_fresh)."""
         f = self._flat
         if f is None:
             return
-        v = self._param_versions()
-        if getattr(self, "_pver", None) != v:
+        stale = force or getattr(self, "_pver", None) is None or f["p"]._version != self._fver \
+            or any(p._version != v for p, v in zip(self._vtab[1], self._pver))
+        if stale:
             if "p16" in f and ops.BF16_SHADOW is not None and ops.BF16_SHADOW[0] is f["p"]:
                 ops.refresh_bf16_shadow()
             if "p3" in f and ops.SPLIT_SHADOW is not None and ops.SPLIT_SHADOW[0] is f["p"]:
                 ops.refresh_split_shadow()
-            self._pver = self._param_versions()
+            self._record_versions()
 
     sync_bf16_shadow = sync_shadows               # (earlier name)
 
@@ -188,8 +212,8 @@ class FlatAdamW(torch.optim.Optimizer):
                 f["p3t_desc"], f["p3t_index"], f["p3t_ntiles"] = self._matrix_desc(mats)
         ops.set_split_shadow(f["p"], f["p3"], f.get("p3t"), f.get("p3t_desc"), f.get("p3t_index"), f.get("p3t_ntiles", 0))
         ops.refresh_split_shadow()
-        self._pver = self._param_versions()
-        ops.SHADOW_SYNC = self.sync_shadows
+        self._record_versions()
+        ops.SHADOW_OWNER = weakref.ref(self)
 
     def enable_bf16_shadow(self):
         """Keep a bf16 copy of the flat parameter buffer, refreshed after every update, and let ops.bf16_copy hand out views
@@ -204,8 +228,8 @@ class FlatAdamW(torch.optim.Optimizer):
                 f["p16t_desc"], f["p16t_index"], f["p16t_ntiles"] = self._matrix_desc(mats)
         ops.set_bf16_shadow(f["p"], f["p16"], f.get("p16t"), f.get("p16t_desc"), f.get("p16t_index"), f.get("p16t_ntiles", 0))
         ops.refresh_bf16_shadow()
-        self._pver = self._param_versions()
-        ops.SHADOW_SYNC = self.sync_shadows
+        self._record_versions()
+        ops.SHADOW_OWNER = weakref.ref(self)
 
     def __del__(self):
         # the process-global shadow must not pin the flat buffers of a discarded optimizer
@@ -215,8 +239,8 @@ class FlatAdamW(torch.optim.Optimizer):
                 ops.set_bf16_shadow(None, None)
             if f is not None and ops.SPLIT_SHADOW is not None and ops.SPLIT_SHADOW[0] is f["p"]:
                 ops.set_split_shadow(None, None)
-            if getattr(ops.SHADOW_SYNC, "__self__", None) is self:
-                ops.SHADOW_SYNC = None
+            if ops.SHADOW_OWNER is not None and ops.SHADOW_OWNER() in (None, self):
+                ops.SHADOW_OWNER = None
         except Exception:
             pass
 

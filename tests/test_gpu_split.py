@@ -297,3 +297,33 @@ def test_split_planes_shadow_follows_optimizer_and_outside_writes():
         W.mul_(0.5)
     train_step(model, CharbonnierLoss(), None, opt, None, hazy, gt, 1.0, 0.0)             # ... and in train_step
     assert torch.equal(rec(), f["p"].double())
+    # (d) every LOOKUP validates itself: a bare GEMM on a weight written outside the optimizer (no forward, no train_step in
+    #     between) multiplies with the current weight - also through the packed Q / K / V view, whose second and third parts are
+    #     parameters with version counters of their own
+    xx = torch.randn(4096, W.shape[1], device=dev)
+    with torch.no_grad():
+        W.mul_(-2.0)
+    assert not torch.equal(rec(), f["p"].double())
+    y1 = ops.gemm_fwd(xx, W.detach())
+    assert torch.equal(rec(), f["p"].double())
+    ref = xx.double() @ W.detach().double().t()
+    assert (y1.double() - ref).abs().max().item() < 1e-5 * ref.abs().max().item()
+    with torch.no_grad():
+        wk.add_(0.25)                                                                      # the MIDDLE third of the packed operand
+    xq = torch.randn(4096, Wp.shape[1], device=dev)
+    y2 = ops.gemm_fwd(xq, ops.cat_rows([wq.detach(), wk.detach(), wv.detach()]))
+    ref = xq.double() @ torch.cat([wq, wk, wv]).detach().double().t()
+    assert (y2.double() - ref).abs().max().item() < 1e-5 * ref.abs().max().item()
+    d3 = ops.gemm_dgrad(dyy, W.detach())
+    refd = dyy.double() @ W.detach().double()
+    assert (d3.double() - refd).abs().max().item() < 1e-5 * refd.abs().max().item()
+    # writes that bump no counter need the forced form (documented in ops.py)
+    W.data.mul_(3.0)
+    assert not torch.equal(rec(), f["p"].double())
+    opt.sync_shadows(force=True)
+    assert torch.equal(rec(), f["p"].double())
+    # (e) the registration is weak: dropping the optimizer un-registers the copies (and frees its buffers)
+    import gc
+    del opt, f, rec
+    gc.collect()
+    assert ops._shadow_owner() is None and ops.SPLIT_SHADOW is None
