@@ -241,12 +241,15 @@ extern "C" int dhz_dense_attn_fwd(const float* q, const float* k, const float* v
                                   const float* mask, float* out, int ldo, int B_, int H, int nW, int d, float scale,
                                   void* stream) {
     DHZ_REQUIRE(q && k && v && out, "dhz_dense_attn_fwd: null pointer");
-    DHZ_REQUIRE(B_ > 0 && H > 0 && (d == 32 || d == 64), "dhz_dense_attn_fwd: bad B_=%d H=%d d=%d", B_, H, d);
+    DHZ_REQUIRE(B_ > 0 && H > 0 && (d == 16 || d == 32 || d == 64), "dhz_dense_attn_fwd: bad B_=%d H=%d d=%d", B_, H, d);
     DHZ_REQUIRE(ld % 4 == 0 && ldo % 4 == 0, "dhz_dense_attn_fwd: leading dims must be multiples of 4");
     DHZ_REQUIRE(!mask || (nW > 0 && B_ % nW == 0), "dhz_dense_attn_fwd: B_=%d not a multiple of nW=%d", B_, nW);
     hipStream_t s = (hipStream_t)stream;
     if (nW <= 0) nW = 1;
-    if (d == 32) {
+    if (d == 16) {                                 // embed_dim 16 (utils/model_utils.py:96-98)
+        hipLaunchKernelGGL(dense_attn_fwd_kernel<16>, dim3(B_ * H), dim3(256), sizeof(DenseFwdSmem<16>), s, q, k, v, ld,
+                           bias, mask, out, ldo, H, nW, scale);
+    } else if (d == 32) {
         allow_smem(&dense_attn_fwd_kernel<32>, sizeof(DenseFwdSmem<32>));
         hipLaunchKernelGGL(dense_attn_fwd_kernel<32>, dim3(B_ * H), dim3(256), sizeof(DenseFwdSmem<32>), s, q, k, v, ld,
                            bias, mask, out, ldo, H, nW, scale);
@@ -263,7 +266,7 @@ extern "C" int dhz_dense_attn_bwd(const float* q, const float* k, const float* v
                                   const float* mask, const float* dout, int ldo, float* dq, float* dk, float* dv,
                                   int ldg, float* dbias_part, int B_, int H, int nW, int d, float scale, void* stream) {
     DHZ_REQUIRE(q && k && v && dout && dq && dk && dv, "dhz_dense_attn_bwd: null pointer");
-    DHZ_REQUIRE(B_ > 0 && H > 0 && (d == 32 || d == 64), "dhz_dense_attn_bwd: bad B_=%d H=%d d=%d", B_, H, d);
+    DHZ_REQUIRE(B_ > 0 && H > 0 && (d == 16 || d == 32 || d == 64), "dhz_dense_attn_bwd: bad B_=%d H=%d d=%d", B_, H, d);
     DHZ_REQUIRE(!bias || dbias_part, "dhz_dense_attn_bwd: bias given but dbias_part is NULL");
     DHZ_REQUIRE(!mask || (nW > 0 && B_ % nW == 0), "dhz_dense_attn_bwd: B_=%d not a multiple of nW=%d", B_, nW);
     hipStream_t s = (hipStream_t)stream;
@@ -275,7 +278,8 @@ extern "C" int dhz_dense_attn_bwd(const float* q, const float* k, const float* v
         hipLaunchKernelGGL((dense_attn_bwd_kernel<DD, HB>), dim3(parts), dim3(256), sizeof(DenseBwdSmem<DD>), s, q, \
                            k, v, ld, bias, mask, dout, ldo, dq, dk, dv, ldg, dbias_part, B_, H, nW, scale);         \
     } while (0)
-    if (d == 32) { if (bias) LAUNCH(32, true); else LAUNCH(32, false); }
+    if (d == 16) { if (bias) LAUNCH(16, true); else LAUNCH(16, false); }
+    else if (d == 32) { if (bias) LAUNCH(32, true); else LAUNCH(32, false); }
     else { if (bias) LAUNCH(64, true); else LAUNCH(64, false); }
 #undef LAUNCH
     DHZ_CHECK_LAUNCH("dhz_dense_attn_bwd");

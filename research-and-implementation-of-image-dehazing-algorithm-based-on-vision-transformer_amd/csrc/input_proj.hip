@@ -145,11 +145,11 @@ __global__ __launch_bounds__(256) void input_proj_bwd_kernel(const T* __restrict
 extern "C" int dhz_input_proj_fwd_dt(const float* img, const float* w, const float* bias, void* y, int B, int H, int W, int E,
                                      float slope, int dtype, void* stream) {
     DHZ_REQUIRE(img && w && bias && y, "dhz_input_proj_fwd: null pointer");
-    DHZ_REQUIRE(B > 0 && H > 0 && W > 0 && (E == 32 || E == 64), "dhz_input_proj_fwd: E=%d (supported: 32, 64)", E);
+    DHZ_REQUIRE(B > 0 && H > 0 && W > 0 && (E == 16 || E == 32 || E == 64), "dhz_input_proj_fwd: E=%d (supported: 16, 32, 64)", E);
     const int tiles_x = (W + TS - 1) / TS, tiles_y = (H + TS - 1) / TS;
     hipStream_t s = (hipStream_t)stream;
 #define LAUNCH(EE) hipLaunchKernelGGL((input_proj_fwd_kernel<EE, T>), dim3(B * tiles_x * tiles_y), dim3(256), 0, s, img, w, bias, (T*)y, H, W, slope, tiles_x, tiles_y)
-    DT_SWITCH(dtype, "dhz_input_proj_fwd", if (E == 32) LAUNCH(32); else LAUNCH(64));
+    DT_SWITCH(dtype, "dhz_input_proj_fwd", if (E == 16) LAUNCH(16); else if (E == 32) LAUNCH(32); else LAUNCH(64));
 #undef LAUNCH
     DHZ_CHECK_LAUNCH("dhz_input_proj_fwd");
     return DHZ_OK;
@@ -162,14 +162,14 @@ extern "C" int dhz_input_proj_fwd(const float* img, const float* w, const float*
 extern "C" int dhz_input_proj_bwd_dt(const void* dy, const void* y, const float* img, float* dw, float* db, int B, int H, int W, int E,
                                      float slope, int dtype, void* stream) {
     DHZ_REQUIRE(dy && y && img && dw && db, "dhz_input_proj_bwd: null pointer");
-    DHZ_REQUIRE(B > 0 && H > 0 && W > 0 && (E == 32 || E == 64), "dhz_input_proj_bwd: E=%d (supported: 32, 64)", E);
+    DHZ_REQUIRE(B > 0 && H > 0 && W > 0 && (E == 16 || E == 32 || E == 64), "dhz_input_proj_bwd: E=%d (supported: 16, 32, 64)", E);
     const int tiles_x = (W + TS - 1) / TS, tiles_y = (H + 8 - 1) / 8;
     const int ntiles = B * tiles_x * tiles_y;
     const int ncu = dhz_num_cus();
     const int grid = ntiles < ncu ? ntiles : ncu;      // every workgroup ends with 28 E same-address atomics: keep them few
     hipStream_t s = (hipStream_t)stream;
 #define LAUNCH(EE) hipLaunchKernelGGL((input_proj_bwd_kernel<EE, T>), dim3(grid), dim3(256), 0, s, (const T*)dy, (const T*)y, img, dw, db, H, W, slope, tiles_x, tiles_y, ntiles)
-    DT_SWITCH(dtype, "dhz_input_proj_bwd", if (E == 32) LAUNCH(32); else LAUNCH(64));
+    DT_SWITCH(dtype, "dhz_input_proj_bwd", if (E == 16) LAUNCH(16); else if (E == 32) LAUNCH(32); else LAUNCH(64));
 #undef LAUNCH
     DHZ_CHECK_LAUNCH("dhz_input_proj_bwd");
     return DHZ_OK;

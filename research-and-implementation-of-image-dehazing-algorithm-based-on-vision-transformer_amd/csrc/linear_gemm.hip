@@ -412,11 +412,50 @@ void launch(const float* A, int lda, const float* W, int ldw, const float* bias,
                        K, tiles_n, ntiles);
 }
 
+// Narrow shapes (output features or contraction a multiple of 16 but not of 32: the embed_dim = 16 model, utils/model_utils.py:96-98
+// "Uformer16"; its C = 16 stage has Linears 16 -> 48 / 16 / 64 and 64 -> 16).  One wave = 16 token rows x all output features, operands
+// straight from global memory / L1 (these tensors are 16 .. 64 floats wide: nothing to tile); lane (i16, g) of MFMA k-step s takes
+// contraction index 16 kc + 4 g + s for BOTH operands, so the A fragment of a 16-deep chunk is one float4 load.
+template <bool WT>
+__global__ __launch_bounds__(256) void narrow_gemm_kernel(const float* __restrict__ A, int lda, const float* __restrict__ W, int ldw,
+                                                          const float* __restrict__ bias, float* __restrict__ Y, int ldy, int M, int N,
+                                                          int K) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, i16 = lane & 15, g = lane >> 4;
+    const long row0 = ((long)blockIdx.x * 4 + w) * 16;
+    if (row0 >= M) return;
+    const long arow = row0 + i16 < M ? row0 + i16 : M - 1;                  // ragged last tile: clamp the read, guard the store
+    for (int nt = 0; nt < N / 16; ++nt) {
+        const float b0 = bias ? bias[16 * nt + i16] : 0.f;
+        f32x4 acc = {b0, b0, b0, b0};
+        for (int kc = 0; kc < K / 16; ++kc) {
+            const f32x4 a4 = *reinterpret_cast<const f32x4*>(A + arow * lda + 16 * kc + 4 * g);
+            f32x4 b4;
+            if (WT) b4 = *reinterpret_cast<const f32x4*>(W + (long)(16 * nt + i16) * ldw + 16 * kc + 4 * g);
+            else {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) b4[s] = W[(long)(16 * kc + 4 * g + s) * ldw + 16 * nt + i16];
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) acc = mfma16(a4[s], b4[s], acc);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (row0 + 4 * g + j < M) Y[(row0 + 4 * g + j) * ldy + 16 * nt + i16] = acc[j];
+    }
+}
+
 template <bool WT>
 int dispatch(const char* who, const float* A, int lda, const float* W, int ldw, const float* bias, float* Y, int ldy, int M,
              int N, int K, hipStream_t s) {
     DHZ_REQUIRE(A && W && Y, "%s: null pointer", who);
-    DHZ_REQUIRE(M > 0 && N > 0 && K > 0 && N % 32 == 0 && K % 32 == 0, "%s: T=%d N=%d K=%d (N, K must be multiples of 32)", who,
+    if (M > 0 && N > 0 && K > 0 && (N % 32 || K % 32) && N % 16 == 0 && K % 16 == 0) {        // narrow shapes (embed_dim 16)
+        DHZ_REQUIRE(lda % 4 == 0 && ldw % 4 == 0 && lda >= K && ldy >= N && (((uintptr_t)A | (uintptr_t)W) & 15) == 0,
+                    "%s: bad leading dimensions / alignment (narrow form)", who);
+        hipLaunchKernelGGL((narrow_gemm_kernel<WT>), dim3((M + 63) / 64), dim3(256), 0, s, A, lda, W, ldw, bias, Y, ldy, M, N, K);
+        DHZ_CHECK_LAUNCH(who);
+        return DHZ_OK;
+    }
+    DHZ_REQUIRE(M > 0 && N > 0 && K > 0 && N % 32 == 0 && K % 32 == 0, "%s: T=%d N=%d K=%d (N, K must be multiples of 16)", who,
                 M, N, K);
     DHZ_REQUIRE(N <= 16384, "%s: N=%d (at most 16384 output features: the bias vector is staged in LDS)", who, N);
     DHZ_REQUIRE(lda % 4 == 0 && ldy % 4 == 0 && ldw % 4 == 0 && lda >= K && ldy >= N, "%s: bad leading dimensions", who);

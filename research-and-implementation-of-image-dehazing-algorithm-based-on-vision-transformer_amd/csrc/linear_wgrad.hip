@@ -267,6 +267,39 @@ int launch(const float* dy, int ldy, const float* x, int ldx, int T, int N, int 
     return 0;
 }
 
+// Narrow shapes (parameter rows or columns a multiple of 16 but not of 32: the embed_dim = 16 model): 16 x 16 tiles of dW, one wave per
+// tile and token slab, operands straight from global memory (lanes along the features: 64-byte runs), fp32 atomics at the end.
+__global__ __launch_bounds__(256) void narrow_wgrad_kernel(const float* __restrict__ dy, int ldy, const float* __restrict__ x, int ldx,
+                                                           int T, int N, int K, WgradOut out, int nslab) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, i16 = lane & 15, g = lane >> 4;
+    const int tiles_k = K / 16, ntile = (N / 16) * tiles_k;
+    const int slab = blockIdx.x % nslab, tgrp = blockIdx.x / nslab;
+    const int tile = tgrp * 4 + w;
+    if (tile >= ntile) return;
+    const int n0 = (tile / tiles_k) * 16, k0 = (tile % tiles_k) * 16;
+    const int mat = n0 / out.nper, nloc = n0 - mat * out.nper;
+    const long c0 = (long)(T / 16) * slab / nslab, c1 = (long)(T / 16) * (slab + 1) / nslab;       // 16-token chunks of this slab
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    float bsum = 0.f;
+    for (long c = c0; c < c1; ++c) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const long tk = 16 * c + 4 * g + s;
+            float a = dy[tk * ldy + n0 + i16];
+            if (out.rs) a *= out.rs[tk / out.rps];
+            bsum += a;
+            acc = mfma16(a, x[tk * ldx + k0 + i16], acc);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) atomicAdd(out.dw[mat] + (long)(nloc + 4 * g + j) * K + k0 + i16, acc[j]);
+    if (out.db[mat] && k0 == 0) {
+        bsum += __shfl_xor(bsum, 16);
+        bsum += __shfl_xor(bsum, 32);
+        if (g == 0) atomicAdd(out.db[mat] + nloc + i16, bsum);
+    }
+}
+
 }  // namespace
 
 // nmat parameters of nper rows each (N = nmat * nper columns of dy, consecutive)
@@ -274,7 +307,16 @@ static int wgrad_dispatch(const char* who, const float* dy, int ldy, const float
                           const WgradOut& out, hipStream_t s) {
     const int N = nmat * nper;
     DHZ_REQUIRE(T > 0 && T % TK == 0, "%s: T=%d must be a multiple of %d", who, T, TK);
-    DHZ_REQUIRE(nper % 32 == 0 && K % 32 == 0 && nper > 0 && K > 0, "%s: N=%d K=%d must be multiples of 32", who, nper, K);
+    if (nper > 0 && K > 0 && (nper % 32 || K % 32) && nper % 16 == 0 && K % 16 == 0) {         // narrow shapes (embed_dim 16)
+        const int ntile = (N / 16) * (K / 16), groups = (ntile + 3) / 4;
+        int nslab = 2048 / groups;                                                             // ~2048 workgroups, slabs of >= 64 tokens
+        if (nslab > T / 64) nslab = T / 64;
+        if (nslab < 1) nslab = 1;
+        hipLaunchKernelGGL(narrow_wgrad_kernel, dim3(groups * nslab), dim3(256), 0, s, dy, ldy, x, ldx, T, N, K, out, nslab);
+        DHZ_CHECK_LAUNCH(who);
+        return DHZ_OK;
+    }
+    DHZ_REQUIRE(nper % 32 == 0 && K % 32 == 0 && nper > 0 && K > 0, "%s: N=%d K=%d must be multiples of 16", who, nper, K);
     DHZ_REQUIRE(ldy % 4 == 0 && ldx % 4 == 0 && ldy >= N && ldx >= K, "%s: bad leading dims", who);
     // tile rows divide nper, so that a tile never straddles two parameters
     const int wm = (nper % 128 == 0) ? 4 : (nper % 96 == 0) ? 3 : (nper % 64 == 0) ? 2 : 1;

@@ -54,8 +54,9 @@ struct FwdSmem {
     float s[NT * SS];      // d = 64: Q as staged (64 x DS) -> S (after every wave holds its Q fragments); S -> O (32 x DS)
     float k[NT * DS];      // K -> rank partial counts; d = 64: -> P (32 x SS)
     float v[NT * DS];
-    float q[D == 32 ? NT * DS : 4];   // d = 32: Q, later P (its own tile: one barrier less per window-head, and three workgroups fit a CU
-                                      // either way; parking Q in the S tile measured 6 % slower there)
+    float q[D == 32 ? NT * DS : D == 16 ? 32 * SS : 4];   // d = 32: Q, later P (its own tile: one barrier less per window-head, and three
+                                      // workgroups fit a CU either way; parking Q in the S tile measured 6 % slower there); d = 16: Q parks
+                                      // in the S tile like d = 64, but P (32 x SS) does not fit the 64 x 20 K tile and gets this one
     float m[NT];
     int top[32];
     uint8_t rank[NT];
@@ -234,7 +235,7 @@ __global__ __launch_bounds__(256) void ps_attn_fwd_kernel(const T* __restrict__ 
 
     // ---- P = softmax(softmax(scale * S[top]) + bias[top] + mask[top])  -> LDS (over the dead K tile; the partial counts in its
     //      first KB were consumed before the barrier above)
-    float* P = D == 32 ? sm.q : sm.k;
+    float* P = D == 64 ? sm.k : sm.q;
     {
         const int r = t >> 3, c0 = (t & 7) * 8;
         float p2[8];
@@ -265,8 +266,9 @@ __global__ __launch_bounds__(256) void ps_attn_fwd_kernel(const T* __restrict__ 
         const int i = lane & 15, g = lane >> 4;
         const int tr = w & 1;
 #pragma unroll
-        for (int ii = 0; ii < D / 32; ++ii) {
+        for (int ii = 0; ii < (D >= 32 ? D / 32 : 1); ++ii) {
             const int tc = (w >> 1) + 2 * ii;
+            if (D == 16 && tc > 0) break;                 // d = 16: two tiles, waves 0 and 1
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
             acc = tile_mma<16>(P + 16 * tr * SS, SS, 1, sm.v + 16 * tc, 1, DS, acc);
 #pragma unroll
@@ -301,7 +303,7 @@ struct BwdSmem {
     float p1[32 * SS];     // scores -> P1 ; later dQ[top] staging (32 x DS)
     float p2[32 * SS];     // P2 ; later dA (gradient w.r.t. the bias-added logits) for the bias-gradient owners
     float ds[32 * SS];     // dP2 -> dS ; before that (first phase only) the 4 x D partial column sums of dO
-    float acc[D == 32 ? NT * NT : 4];   // d = 32: per-workgroup bias-gradient accumulator (d = 64 keeps it in registers, see the kernel)
+    float acc[D != 64 ? NT * NT : 4];   // d = 16 / 32: per-workgroup bias-gradient accumulator (d = 64 keeps it in registers, see the kernel)
     int top[32];
     uint8_t rank[NT];
 };
@@ -522,14 +524,16 @@ __global__ __launch_bounds__(256) void ps_attn_bwd_kernel(
         }
 
         // ---- dQ[top] = dS K (32 x D, K = 64) ; dK = dS^T Q[top] (64 x D, K = 32)
-        f32x4 accq[D / 32];
+        constexpr int NQ = D >= 32 ? D / 32 : 1;      // dQ tiles per wave (d = 16: two tiles in all, waves 0 and 1)
+        f32x4 accq[NQ];
         f32x4 acck[D / 16];
         {
             const int tr = w & 1;
 #pragma unroll
-            for (int ii = 0; ii < D / 32; ++ii) {
+            for (int ii = 0; ii < NQ; ++ii) {
                 const int tc = (w >> 1) + 2 * ii;
                 f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                if (D == 16 && tc > 0) { accq[ii] = acc; continue; }
                 // A(i=r,k=n) = dS[16tr + r][n] ; B(k=n, j=e) = K[n][16tc + e]
                 accq[ii] = tile_mma<16>(sm.ds + 16 * tr * SS, SS, 1, sm.k + 16 * tc, 1, DS, acc);
             }
@@ -545,8 +549,9 @@ __global__ __launch_bounds__(256) void ps_attn_bwd_kernel(
             const int tr = w & 1;
             float* dqs = sm.p1;   // 32 x DS
 #pragma unroll
-            for (int ii = 0; ii < D / 32; ++ii) {
+            for (int ii = 0; ii < NQ; ++ii) {
                 const int tc = (w >> 1) + 2 * ii;
+                if (D == 16 && tc > 0) continue;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) dqs[(16 * tr + 4 * g + j) * DS + 16 * tc + i16] = accq[ii][j];
             }
@@ -651,14 +656,17 @@ static int ps_attn_fwd_t(const T* q, const T* k, const T* v, int ld, const uint8
                                int H, int nW, int d, void* stream) {
     DHZ_REQUIRE(q && k && v && idx && out && rank, "dhz_ps_attn_fwd: null pointer");
     DHZ_REQUIRE(B_ > 0 && H > 0, "dhz_ps_attn_fwd: B_=%d H=%d", B_, H);
-    DHZ_REQUIRE(d == 32 || d == 64, "dhz_ps_attn_fwd: head_dim %d unsupported (32 or 64)", d);
+    DHZ_REQUIRE(d == 16 || d == 32 || d == 64, "dhz_ps_attn_fwd: head_dim %d unsupported (16, 32 or 64)", d);
     DHZ_REQUIRE(ld % 4 == 0 && ldo % 4 == 0 && ld >= H * d && ldo >= H * d, "dhz_ps_attn_fwd: bad ld %d/%d", ld, ldo);
     DHZ_REQUIRE(!mask || (nW > 0 && B_ % nW == 0), "dhz_ps_attn_fwd: B_=%d not a multiple of nW=%d", B_, nW);
     hipStream_t s = (hipStream_t)stream;
     // persistent workgroups, three per CU (LDS: 36.3 KiB at d = 32, 52.7 KiB at d = 64)
     const int resident = 256 * (d == 32 ? PSF_WG32 : PSF_WG64);
     const int grid = B_ * H < resident ? B_ * H : resident;
-    if (d == 32) {
+    if (d == 16) {                                 // embed_dim 16 ("Uformer16", utils/model_utils.py:96-98): four MFMA k-steps per score tile
+        hipLaunchKernelGGL((ps_attn_fwd_kernel<16, T>), dim3(grid), dim3(256), sizeof(FwdSmem<16>), s, q, k, v, ld, idx,
+                           bias, mask, out, ldo, rank, H, nW > 0 ? nW : 1, B_ * H);
+    } else if (d == 32) {
         allow_smem(reinterpret_cast<const void*>(&ps_attn_fwd_kernel<32, T>), sizeof(FwdSmem<32>));
         hipLaunchKernelGGL((ps_attn_fwd_kernel<32, T>), dim3(grid), dim3(256), sizeof(FwdSmem<32>), s, q, k, v, ld, idx,
                            bias, mask, out, ldo, rank, H, nW > 0 ? nW : 1, B_ * H);
@@ -716,14 +724,17 @@ static int ps_attn_bwd_t(const T* q, const T* k, const T* v, int ld, const float
                          T* dk, T* dv, int ldg, float* dbias_part, int B_, int H, int nW, int d,
                          void* stream) {
     DHZ_REQUIRE(q && k && v && rank && dout && dq && dk && dv, "dhz_ps_attn_bwd: null pointer");
-    DHZ_REQUIRE(d == 32 || d == 64, "dhz_ps_attn_bwd: head_dim %d unsupported (32 or 64)", d);
+    DHZ_REQUIRE(d == 16 || d == 32 || d == 64, "dhz_ps_attn_bwd: head_dim %d unsupported (16, 32 or 64)", d);
     DHZ_REQUIRE(!bias || dbias_part, "dhz_ps_attn_bwd: bias given but dbias_part is NULL");
     DHZ_REQUIRE(ld % 4 == 0 && ldo % 4 == 0 && ldg % 4 == 0, "dhz_ps_attn_bwd: leading dims must be multiples of 4");
     DHZ_REQUIRE(!mask || (nW > 0 && B_ % nW == 0), "dhz_ps_attn_bwd: B_=%d not a multiple of nW=%d", B_, nW);
     hipStream_t s = (hipStream_t)stream;
     const int parts = dhz_ps_attn_bwd_parts_d(B_, H, d);
     if (nW <= 0) nW = 1;
-    if (d == 32) {
+    if (d == 16) {
+        if (bias) launch_bwd<16, true>(parts, s, q, k, v, ld, bias, mask, rank, dout, ldo, dq, dk, dv, ldg, dbias_part, B_, H, nW);
+        else launch_bwd<16, false>(parts, s, q, k, v, ld, bias, mask, rank, dout, ldo, dq, dk, dv, ldg, dbias_part, B_, H, nW);
+    } else if (d == 32) {
         if (bias) launch_bwd<32, true>(parts, s, q, k, v, ld, bias, mask, rank, dout, ldo, dq, dk, dv, ldg, dbias_part, B_, H, nW);
         else launch_bwd<32, false>(parts, s, q, k, v, ld, bias, mask, rank, dout, ldo, dq, dk, dv, ldg, dbias_part, B_, H, nW);
     } else {

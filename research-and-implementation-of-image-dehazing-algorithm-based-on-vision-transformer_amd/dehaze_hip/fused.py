@@ -37,8 +37,8 @@ def _wgrad(dy, off, x, w, b, row_scale=None):
     N = w.shape[0]
     if not w.requires_grad and (b is None or not b.requires_grad):
         return None, None                                   # frozen Linear: nothing to compute
-    q = 64 if dy.dtype == ops.BF16 else 32
-    mine = T % q == 0 and N % q == 0 and K % q == 0         # (the kernel's shape contract; always true on this model)
+    q = 64 if dy.dtype == ops.BF16 else 16                  # fp32: 16-wide tiles for the embed_dim = 16 model (csrc/linear_wgrad.hip)
+    mine = T % 32 == 0 and N % q == 0 and K % q == 0        # (the kernel's shape contract; always true on this model)
     if mine and w.is_leaf and w.requires_grad and (b is None or (b.is_leaf and b.requires_grad)):
         ops._accumulate_param_grads(dy, off, x, [(w, b)], row_scale)
         return None, None
@@ -47,7 +47,7 @@ def _wgrad(dy, off, x, w, b, row_scale=None):
         db = torch.zeros_like(b) if b is not None else None
         ops.wgrad_into(dy, off, x, N, dw, db, row_scale)
         return dw, db
-    raise RuntimeError(f"dehaze_hip: Linear weight gradient for T={T}, N={N}, K={K}: the HIP kernel needs multiples of 32 "
+    raise RuntimeError(f"dehaze_hip: Linear weight gradient for T={T}, N={N}, K={K}: the HIP kernel needs multiples of 16 "
                        "(there is deliberately no library fallback)")
 
 
@@ -55,8 +55,8 @@ def _wgrad_qkv(dqkv, xn, C, pairs):
     """The three projections' gradients from the packed dqkv [T,3C]: one launch (x read once) when all of them can be
     accumulated in place, else one _wgrad each.  Returns the six autograd slots (g_wq, g_bq, g_wk, g_bk, g_wv, g_bv)."""
     T, K = xn.shape
-    q = 64 if dqkv.dtype == ops.BF16 else 32
-    if T % q == 0 and C % q == 0 and K % q == 0 and all(w.is_leaf and w.requires_grad and (b is None or (b.is_leaf and b.requires_grad))
+    q = 64 if dqkv.dtype == ops.BF16 else 16
+    if T % 32 == 0 and C % q == 0 and K % q == 0 and all(w.is_leaf and w.requires_grad and (b is None or (b.is_leaf and b.requires_grad))
                                                            for w, b in pairs):
         ops._accumulate_param_grads(dqkv, 0, xn, pairs)
         return (None,) * 6

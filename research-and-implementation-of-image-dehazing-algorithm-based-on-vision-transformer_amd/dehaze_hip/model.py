@@ -284,7 +284,7 @@ class LeWinTransformerBlock(nn.Module):
             attn_mask = attn_mask + sm if attn_mask is not None else sm
         idx, self._staged_idx = self._staged_idx, None
 
-        if self.attn.variant == "probsparse" and self.win_size == 8 and C in (32 * self.num_heads, 64 * self.num_heads) and mask is None:
+        if self.attn.variant == "probsparse" and self.win_size == 8 and C in (16 * self.num_heads, 32 * self.num_heads, 64 * self.num_heads) and mask is None:
             # attention branch as ONE autograd node: the fused kernel (LN, roll, partition, QKV, ProbSparse core,
             # out-proj, residual) where it wins, the kernel chain elsewhere; hand-sequenced backward in both cases
             import options
@@ -367,6 +367,8 @@ class Downsample(nn.Module):
                 and self.out_channel % 64 == 0):
             # config 4: patch matrix + the bf16-MFMA token-Linear GEMMs (csrc/conv_bf16.hip), fp32 master weights
             return ops.conv4s2_tokens(x, conv.weight, conv.bias, s_, s_)
+        if x.is_cuda:
+            ops.warn_library_fallback("Downsample", (self.in_channel, self.out_channel, tuple(x.shape[1:])))
         if x.dtype == torch.bfloat16:       # shapes the kernels do not tile: library convolution in bf16
             with torch.autocast("cuda", dtype=torch.bfloat16):
                 return _map_to_tokens(self.conv(_tokens_to_map(x)))
@@ -437,7 +439,7 @@ class InputProj(nn.Module):
 
     def forward(self, x):
         conv, act = self.proj[0], self.proj[1]
-        if (x.is_cuda and x.dtype == torch.float32 and self.in_channel == 3 and self.out_channel in (32, 64)
+        if (x.is_cuda and x.dtype == torch.float32 and self.in_channel == 3 and self.out_channel in (16, 32, 64)
                 and conv.stride == (1, 1) and isinstance(act, nn.LeakyReLU) and not x.requires_grad):
             # convolution + LeakyReLU straight into the token layout (csrc/input_proj.hip)
             # (out_dtype: bf16 tokens straight from the kernel when the model runs BASELINE config 4's storage type)

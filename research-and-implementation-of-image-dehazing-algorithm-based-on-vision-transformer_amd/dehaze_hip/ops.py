@@ -637,8 +637,9 @@ class _LinearTokens(Function):
         T, K = x.shape
         grads = []
         off = 0
-        q = 64 if dy.dtype == BF16 else 32
-        if T % q == 0 and K % q == 0 and all(w.shape[0] % q == 0 and w.is_leaf and w.requires_grad
+        q = 64 if dy.dtype == BF16 else 16          # fp32: 16-wide tile forms exist for the embed_dim = 16 model (csrc/linear_wgrad.hip)
+        tq = 64 if dy.dtype == BF16 else 32         # token rows per stage
+        if T % tq == 0 and K % q == 0 and all(w.shape[0] % q == 0 and w.is_leaf and w.requires_grad
                                                and (b is None or (b.is_leaf and b.requires_grad)) for w, b in ctx.params):
             _accumulate_param_grads(dy, 0, x, ctx.params)           # one launch for equal-shaped parameters (Q / K / V)
             return (dx,) + (None, None) * len(ctx.params)
@@ -647,7 +648,7 @@ class _LinearTokens(Function):
             # measured on MI355X (tools/bench_wgrad.py): the split-T kernel wins 2-18x for T >= 16k tokens; on the deep
             # stages (T <= 8k) it is within 0.9-1.2x of the library's TN GEMM and delivers the bias gradient for free
             # (the library path pays a separate ~20 us column-sum kernel), so it is used everywhere
-            mine = T % q == 0 and N % q == 0 and K % q == 0         # (the kernel's shape contract; always true on this model)
+            mine = T % tq == 0 and N % q == 0 and K % q == 0        # (the kernel's shape contract; always true on this model)
             if not w.requires_grad and (b is None or not b.requires_grad):
                 grads += [None, None]                                 # frozen Linear
             elif mine and w.is_leaf and w.requires_grad and (b is None or (b.is_leaf and b.requires_grad)):
@@ -660,7 +661,7 @@ class _LinearTokens(Function):
                 grads += [dw, db]
             else:
                 raise RuntimeError(f"dehaze_hip: Linear weight gradient for T={T}, N={N}, K={K}: the HIP kernel needs "
-                                   "multiples of 32 in fp32 and of 64 in bf16 (there is deliberately no library fallback)")
+                                   "multiples of 16 in fp32 and of 64 in bf16 (there is deliberately no library fallback)")
             off += N
         return (dx,) + tuple(grads)
 

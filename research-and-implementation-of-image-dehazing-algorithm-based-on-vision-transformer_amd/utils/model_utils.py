@@ -144,11 +144,10 @@ def get_arch(opt):
         return Uformer(img_size=opt.train_ps, embed_dim=opt.embed_dim, win_size=opt.win_size,
                        token_projection=opt.token_projection, token_mlp=opt.token_mlp)
     if arch == 'Uformer16':
-        # model_utils.py:96-98.  embed_dim 16 gives head_dim 16; the attention kernels of this build are instantiated for head_dim
-        # 32 and 64 (one MFMA contraction step of 4 over 8 / 16 steps; LDS tiles sized per head_dim) - say so here, not as an
-        # argument error from the first forward
-        raise NotImplementedError("arch 'Uformer16' (embed_dim 16 -> head_dim 16): this build's window-attention kernels cover "
-                                  "head_dim 32 and 64 (embed_dim 32 / 64); use --arch Uformer32 or --arch Uformer --embed_dim 32|64")
+        # model_utils.py:96-98: embed_dim 16 -> head_dim 16 in every block (heads 1, 2, 4, 8, 16, 16, 8, 4, 2).  The window-attention
+        # kernels carry head_dim-16 instances, the C = 16 stage's Linears (16 -> 48 / 16 / 64, 64 -> 16) run the 16-wide GEMM /
+        # weight-gradient forms; its two thin convolutions (Downsample 16 -> 32, OutputProj 32 -> 3) go to the library, with a warning
+        return Uformer(img_size=opt.train_ps, embed_dim=16, win_size=8, token_projection='linear', token_mlp='leff')
     if arch == 'Uformer32':
         return Uformer(img_size=opt.train_ps, embed_dim=32, win_size=8, token_projection='linear', token_mlp='leff')
     raise Exception("Arch error!")

@@ -122,14 +122,16 @@ def gen_rng():
     npz("rng_stream", idx=torch.stack(a).to(torch.int8))
 
 
-def gen_probattn(M1, ATT):
+def gen_probattn(M1, ATT, only=None):
     import options
     mask16 = ref_shift_mask(M1, 16)  # [4,64,64] 0/-100
     cases = [("h1_nomask_bias", 8, 1, False, True), ("h2_mask_bias", 4, 2, True, True),
              ("h16_nomask_nobias", 1, 16, False, False), ("h2_mask_nobias", 4, 2, True, False),
-             ("h2_mask_bias_d64", 4, 2, True, True)]
+             ("h2_mask_bias_d64", 4, 2, True, True), ("h2_mask_bias_d16", 4, 2, True, True)]      # d16: round 5, embed_dim 16
     for name, B_, H, use_mask, use_bias in cases:
-        d = 64 if name.endswith("d64") else 32
+        if only is not None and name not in only:
+            continue
+        d = 64 if name.endswith("d64") else 16 if name.endswith("d16") else 32
         g = torch.Generator().manual_seed(100 + H + 7 * use_mask + 13 * use_bias + d)
         q = torch.randn(B_, 64, H, d, generator=g).requires_grad_()
         k = torch.randn(B_, 64, H, d, generator=g).requires_grad_()
@@ -204,6 +206,10 @@ WIDE_BLOCKS = {     # name -> (C, heads, map side, shift): the widths whose bloc
     "block_m1_c128_shift4": (128, 4, 16, 4),
     "block_m1_c256_shift4": (256, 8, 16, 4),
     "block_m1_c512_shift0": (512, 16, 8, 0),       # the bottleneck's geometry: one 8 x 8 window per image
+    # round 5: head_dim 16 (the embed_dim = 16 model, utils/model_utils.py:96-98 'Uformer16'): its first stage (one head, every Linear
+    # 16 wide) and its last decoder stage (C = 32 as TWO heads of 16)
+    "block_m1_c16_shift4": (16, 1, 16, 4),
+    "block_m1_c32h2_shift4": (32, 2, 16, 4),
 }
 
 
@@ -324,6 +330,32 @@ def gen_full(M1, M0, losses):
             act_names=np.array(list(acts.keys())), act_stats=np.array(list(acts.values())),
             loss=np.float64(loss.item()), gnorm=gnorm, gsum=gsum,
             shapes=np.array([str(tuple(v.shape)) for v in sd.values()]))
+
+
+def gen_full_e16(M1, losses):
+    """round 5: the embed_dim = 16 model that get_arch builds for --arch Uformer16 (utils/model_utils.py:96-98): eval output, loss and
+    gradient norms of a Charbonnier step, same recipe as gen_full"""
+    seed_all(1234)
+    model = M1.Uformer(img_size=128, embed_dim=16, win_size=8, token_projection='linear', token_mlp='leff')
+    sd = model.state_dict()
+    g = torch.Generator().manual_seed(7)
+    gt = torch.rand(1, 3, 128, 128, generator=g)
+    hazy = (0.6 * gt + 0.4 * torch.rand(1, 1, 1, 1, generator=g)).clamp(0, 1)
+    gt, hazy = gt.half().float(), hazy.half().float()
+    model.eval()
+    torch.manual_seed(99)
+    with torch.no_grad():
+        y_eval = model(hazy)
+    torch.manual_seed(99)
+    y = model(hazy)
+    loss = losses.CharbonnierLoss()(torch.clamp(y, 0, 1), gt)
+    loss.backward()
+    gnorm = np.array([float(p.grad.double().norm()) if p.grad is not None else -1.0 for p in model.parameters()])
+    gsum = np.array([float(p.grad.double().sum()) if p.grad is not None else 0.0 for p in model.parameters()])
+    npz("full_m1_e16", keys=np.array(list(sd.keys())), sd_sha256=np.array(tensor_digest(sd)), gt=gt.half(), hazy=hazy.half(),
+        y_eval_crop=y_eval[0, :, 40:72, 40:72], y_eval_sum=np.float64(y_eval.double().sum()),
+        y_eval_abs=np.float64(y_eval.double().abs().sum()), y_eval_lowres=torch.nn.functional.avg_pool2d(y_eval, 4),
+        loss=np.float64(loss.item()), gnorm=gnorm, gsum=gsum, shapes=np.array([str(tuple(v.shape)) for v in sd.values()]))
 
 
 def gen_trajectory(M1, losses):
@@ -460,6 +492,19 @@ def main():
         for name in WIDE_BLOCKS:
             gen_block_wide(M1, name)
         return
+    if len(sys.argv) > 2 and sys.argv[1] == "--only" and sys.argv[2] == "uformer16":        # the round-5 fixtures alone
+        install_shims()
+        import warnings
+        warnings.filterwarnings("ignore")
+        import My_model_1 as M1
+        import ProbSparse.attn as ATT
+        import losses
+        torch.set_num_threads(8)
+        gen_probattn(M1, ATT, only=("h2_mask_bias_d16",))
+        gen_block_wide(M1, "block_m1_c16_shift4")
+        gen_block_wide(M1, "block_m1_c32h2_shift4")
+        gen_full_e16(M1, losses)
+        return
     if len(sys.argv) > 2 and sys.argv[1] == "--only" and sys.argv[2] == "block128":
         install_shims()
         import warnings
@@ -488,6 +533,7 @@ def main():
     gen_options()
     gen_misc()
     gen_full(M1, M0, losses)
+    gen_full_e16(M1, losses)
     gen_trajectory(M1, losses)
     gen_data()
 

@@ -34,7 +34,7 @@ def rank_to_sets(rank):
 
 # ----------------------------------------------------------------------------- K3 vs golden (reference outputs)
 @pytest.mark.parametrize("case", ["h1_nomask_bias", "h2_mask_bias", "h16_nomask_nobias", "h2_mask_nobias",
-                                  "h2_mask_bias_d64"])
+                                  "h2_mask_bias_d64", "h2_mask_bias_d16"])
 def test_ps_attention_golden(golden, dev, ops, case):
     g = golden("probattn_" + case)
     q, k, v = T(g["q"]), T(g["k"]), T(g["v"])                       # [B_,64,H,d]
@@ -82,7 +82,8 @@ def test_ps_attention_golden(golden, dev, ops, case):
 
 
 # ----------------------------------------------------------------------------- K3 vs oracle, larger random case
-@pytest.mark.parametrize("B_,H,d,use_mask", [(64, 1, 32, True), (32, 4, 32, False), (8, 16, 32, True), (16, 2, 64, True)])
+@pytest.mark.parametrize("B_,H,d,use_mask", [(64, 1, 32, True), (32, 4, 32, False), (8, 16, 32, True), (16, 2, 64, True),
+                                             (16, 1, 16, True), (8, 16, 16, False)])
 def test_ps_attention_oracle(dev, ops, B_, H, d, use_mask):
     g = torch.Generator().manual_seed(B_ * 131 + H)
     C = H * d

@@ -10,7 +10,9 @@ pytestmark = pytest.mark.gpu
                                    (256, 2048, 512), (512, 512, 2048), (64, 64, 64),
                                    # long token slabs: the two-token-group variant of the kernel (>= 8 stages per workgroup),
                                    # the last two with an odd number of stages per workgroup (groups of unequal length)
-                                   (65536, 128, 128), (65536, 96, 64), (32768, 384, 128), (8192, 1536, 512), (2336 * 32, 32, 64)])
+                                   (65536, 128, 128), (65536, 96, 64), (32768, 384, 128), (8192, 1536, 512), (2336 * 32, 32, 64),
+                                   # 16-wide forms (the embed_dim = 16 model: 16 -> 16 / 64, 64 -> 16, 32 -> 48); a ragged token count
+                                   (4096, 16, 16), (32768, 64, 16), (32768, 16, 64), (8192, 48, 32), (128032, 16, 16), (96, 80, 48)])
 def test_linear_tokens_grads(T, N, K):
     from dehaze_hip import ops
     dev = torch.device("cuda:0")
@@ -37,7 +39,7 @@ def test_linear_tokens_grads(T, N, K):
     assert (Wd.grad.cpu().double() - 2 * Wr.grad).abs().max() < 4e-5 * scale
 
 
-@pytest.mark.parametrize("T,C", [(2048, 64), (65536, 32), (32768, 128), (4096, 512)])
+@pytest.mark.parametrize("T,C", [(2048, 64), (65536, 32), (32768, 128), (4096, 512), (16384, 16), (2048, 48)])
 def test_packed_qkv_grads(T, C):
     """Q / K / V share their input: one dhz_linear_wgrad_multi launch fills the three separate .grad buffers."""
     from dehaze_hip import ops

@@ -86,6 +86,54 @@ def test_full_model_vs_reference_golden(golden, dev):
     assert rel.max() < 5e-3, rel.max()
 
 
+def test_uformer16_vs_reference_golden_and_one_training_step(golden, dev):
+    """--arch Uformer16 (utils/model_utils.py:96-98): embed_dim 16 -> head_dim 16 in all 18 blocks.  get_arch builds
+    it, the eval output / Charbonnier loss / gradient norms match the REFERENCE's (tests/golden/full_m1_e16.npz), and one complete
+    training step (Charbonnier + contrastive loss, backward, AdamW) runs and moves the weights."""
+    import argparse
+    import warnings
+    import My_CR
+    import utils
+    from dehaze_hip.train import FlatAdamW, train_step
+    from losses import CharbonnierLoss
+    g = golden("full_m1_e16")
+    seed_all(1234)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        model = utils.get_arch(argparse.Namespace(arch="Uformer16", train_ps=128, embed_dim=32, win_size=8,
+                                                  token_projection="linear", token_mlp="leff")).to(dev)
+        assert model.embed_dim == 16 and [b.num_heads for b in (model.encoderlayer_0.blocks[0], model.conv.blocks[0],
+                                                                 model.decoderlayer_3.blocks[0])] == [1, 16, 2]
+        assert list(model.state_dict().keys()) == list(g["keys"])
+        gt, hazy = T(g["gt"]).float().to(dev), T(g["hazy"]).float().to(dev)
+        model.eval()
+        torch.manual_seed(99)
+        with torch.no_grad():
+            y = model(hazy)
+        crop, ref_crop = y[0, :, 40:72, 40:72].cpu(), T(g["y_eval_crop"])
+        assert torch.allclose(crop, ref_crop, atol=2e-4, rtol=1e-3), (crop - ref_crop).abs().max()
+        assert torch.allclose(torch.nn.functional.avg_pool2d(y, 4).cpu(), T(g["y_eval_lowres"]), atol=1e-4, rtol=1e-3)
+        assert torch.mean((crop.double() - ref_crop.double()) ** 2).item() < 1e-7       # PSNR(build vs reference) > 70 dB
+        torch.manual_seed(99)
+        loss, _ = CharbonnierLoss().forward_clamped(model(hazy), gt)
+        assert abs(loss.item() - float(g["loss"])) < 2e-6
+        loss.backward()
+        gn = np.array([float(p.grad.double().norm()) if p.grad is not None else -1.0 for p in model.parameters()])
+        ref = g["gnorm"]
+        assert np.array_equal(gn < 0, ref < 0)
+        live = ref >= 0
+        rel = np.abs(gn[live] - ref[live]) / (ref[live] + 1e-8)
+        assert rel.max() < 5e-3, rel.max()
+        # one full training step of My_train.py's body on this architecture
+        model.zero_grad(set_to_none=True)
+        model.train()
+        opt = FlatAdamW(model, lr=2e-4, weight_decay=0.02)
+        cr = My_CR.ContrastLoss().to(dev)
+        w0 = model.encoderlayer_0.blocks[0].attn.ProbSpare.query_projection.weight.detach().clone()
+        loss, lrec, lcr = train_step(model, CharbonnierLoss(), cr, opt, None, hazy, gt)
+        assert torch.isfinite(loss).item() and not torch.equal(w0, model.encoderlayer_0.blocks[0].attn.ProbSpare.query_projection.weight)
+
+
 def test_training_steps_vs_oracle(dev):
     """3 AdamW steps (Charbonnier only, DropPath off so that host and device RNG use is identical):
     product on GPU vs CPU oracle + torch.optim.AdamW, same seeds, same sampled-key stream."""

@@ -21,7 +21,7 @@ def test_rng_stream(golden):
 
 
 @pytest.mark.parametrize("case", ["h1_nomask_bias", "h2_mask_bias", "h16_nomask_nobias", "h2_mask_nobias",
-                                  "h2_mask_bias_d64"])
+                                  "h2_mask_bias_d64", "h2_mask_bias_d16"])
 def test_prob_attention(golden, case):
     g = golden("probattn_" + case)
     q, k, v = (T(g[n]).transpose(1, 2).contiguous().requires_grad_() for n in "qkv")   # -> B_,H,N,d
@@ -131,7 +131,7 @@ def _c_oracle():
 
 
 @pytest.mark.parametrize("case", ["h1_nomask_bias", "h2_mask_bias", "h16_nomask_nobias", "h2_mask_nobias",
-                                  "h2_mask_bias_d64"])
+                                  "h2_mask_bias_d64", "h2_mask_bias_d16"])
 def test_c_oracle_prob_attention(golden, case):
     """The double-precision C restatement reproduces the reference's outputs and gradients."""
     import ctypes
@@ -204,10 +204,30 @@ def test_full_model_oracle(golden, gname, variant):
     assert abs(float(y.double().sum()) - float(g["y_eval_sum"])) < 1e-4 * float(g["y_eval_abs"])
 
 
+def test_full_model_e16_oracle(golden):
+    """the embed_dim = 16 model of --arch Uformer16 (utils/model_utils.py:96-98; head_dim 16 everywhere): oracle vs the reference"""
+    import random
+    import My_model_1 as M1
+    g = golden("full_m1_e16")
+    random.seed(1234); np.random.seed(1234); torch.manual_seed(1234)
+    model = M1.Uformer(img_size=128, embed_dim=16, win_size=8, token_projection='linear', token_mlp='leff')
+    P = {k: v.detach() for k, v in model.state_dict().items()}
+    assert list(P.keys()) == list(g["keys"])
+    assert [str(tuple(v.shape)) for v in P.values()] == list(g["shapes"])
+    hazy = T(g["hazy"]).float()
+    torch.manual_seed(99)
+    with torch.no_grad():
+        y = O.uformer_forward(P, hazy, variant="probsparse")
+    assert torch.allclose(y[0, :, 40:72, 40:72], T(g["y_eval_crop"]), atol=1e-5, rtol=1e-4)
+    assert abs(float(y.double().sum()) - float(g["y_eval_sum"])) < 1e-4 * float(g["y_eval_abs"])
+
+
 WIDE_BLOCKS = {     # tests/golden/gen_golden.py::WIDE_BLOCKS: name -> (C, heads, map side, shift)
     "block_m1_c128_shift4": (128, 4, 16, 4),
     "block_m1_c256_shift4": (256, 8, 16, 4),
     "block_m1_c512_shift0": (512, 16, 8, 0),
+    "block_m1_c16_shift4": (16, 1, 16, 4),          # head_dim 16: the embed_dim = 16 model's first stage ...
+    "block_m1_c32h2_shift4": (32, 2, 16, 4),        # ... and its last decoder stage (C = 32 as two heads of 16)
 }
 
 
