@@ -190,6 +190,9 @@ def main():
     ap.add_argument("--no-overlap", action="store_true",
                     help="N > 1 diagnostics: launch every gradient bucket's all-reduce AFTER backward instead of from the hooks (separates "
                          "'RCCL starved by the persistent compute grids' from 'RCCL slow')")
+    ap.add_argument("--reserve-cus", type=int, default=None,
+                    help="CUs the persistent compute grids leave free (dhz_set_reserved_cus).  N > 1: for RCCL's kernels beside the backward "
+                         "pass (default: DHZ_COMM_RESERVE_CUS or 0).  N = 1: applied as given - measures what a reservation costs the step")
     ap.add_argument("--no-fp32-pipe", action="store_true",
                     help="skip the second measurement of the same step on the fp32 matrix pipe (the `fp32_pipe` object)")
     args = ap.parse_args()
@@ -230,7 +233,9 @@ def main():
         model.act_dtype = torch.bfloat16          # bf16 activations / weight copies, fp32 accumulation and master weights
     opt = FlatAdamW(model, lr=2e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.02)
     opt.zero_grad()
-    reducer = GradReducer(opt, bucket_mb=args.bucket_mb, overlap=not args.no_overlap) if world > 1 else None
+    reducer = GradReducer(opt, bucket_mb=args.bucket_mb, overlap=not args.no_overlap, reserve_cus=args.reserve_cus) if world > 1 else None
+    if world == 1 and args.reserve_cus:
+        _lib.call("dhz_set_reserved_cus", int(args.reserve_cus))
     char = CharbonnierLoss()
     import warnings
     with warnings.catch_warnings():
@@ -315,6 +320,7 @@ def main():
                                    + ("(BASELINE configs[1])" if (args.dtype, args.embed_dim, args.ps, args.batch) == ("f32", 32, 128, 32)
                                       else "(BASELINE configs[3])" if (args.dtype, args.embed_dim, args.ps) == ("bf16", 64, 256) else "(not a BASELINE config)"),
                        "global_batch": args.batch * world, "parallelism": f"dp{world}",
+                       **({"reserve_cus": int(args.reserve_cus), "grid_cus": _lib.load().dhz_grid_cus()} if world == 1 and args.reserve_cus else {}),
                        "loss_last_step": round(float(loss), 6)},
         }
         if args.dtype == "f32":
@@ -327,7 +333,8 @@ def main():
             # the exchange of one step as performed (bucket byte ranges in launch order, single-ring xGMI time): makes a
             # scaling run diagnosable from its JSON line alone
             plan = reducer.plan()
-            out["exchange"] = {"backend": backend, "bucket_mb": args.bucket_mb, "overlap_with_backward": not args.no_overlap, "payload_bytes": plan["payload_bytes"],
+            out["exchange"] = {"backend": backend, "bucket_mb": args.bucket_mb, "overlap_with_backward": not args.no_overlap, "reserve_cus": reducer.reserve_cus,
+                               "grid_cus": _lib.load().dhz_grid_cus(), "payload_bytes": plan["payload_bytes"],
                                "n_buckets": len(plan["buckets"]), "bucket_bytes": [b["bytes"] for b in plan["buckets"]],
                                "ring_time_ms_single_link": round(plan["ring_time_ms"], 3),
                                "measured": "ring time is the plan's figure, not a measurement"}

@@ -42,6 +42,13 @@ const char* dhz_last_error(void);
 /* 16 hex digits: content hash of the sources (every .hip file under csrc/, common.h, this header) the loaded library was built from.  The PMC
  * passes stamp it into profiles/pmc_traffic.json; bench.py reports `roofline.traffic` only when the stamp matches. */
 const char* dhz_build_id(void);
+/* Compute units the persistent grids of this library leave free (default 0 = none).  One process per GPU with the gradient exchange
+ * overlapping the backward pass (replaces nn.DataParallel, My_train.py:97): RCCL's collective kernels need CUs beside grids that are sized
+ * "resident workgroups per CU x CUs"; dhz_set_reserved_cus(k) sizes every such grid for (CUs - k).  Results do not depend on it.
+ * dhz_grid_cus() = the CU count the grids are sized for (physical - reserved). */
+int dhz_set_reserved_cus(int k);
+int dhz_get_reserved_cus(void);
+int dhz_grid_cus(void);
 
 /* ---------------------------------------------------------------------------------------------
  * K3  ProbSparse window attention core.   Replaces ProbAttention.forward  ATT:287-342

@@ -20,6 +20,9 @@ SIGNATURES = {
     "dhz_abi_version": [],
     "dhz_last_error": [],
     "dhz_build_id": [],
+    "dhz_set_reserved_cus": [ctypes.c_int],
+    "dhz_get_reserved_cus": [],
+    "dhz_grid_cus": [],
     "dhz_ps_attn_fwd": [c_f, c_f, c_f, c_i, c_p, c_f, c_f, c_f, c_i, c_p, c_i, c_i, c_i, c_i, c_p],
     "dhz_ps_attn_bwd_parts": [c_i, c_i],
     "dhz_ps_attn_bwd_parts_d": [c_i, c_i, c_i],

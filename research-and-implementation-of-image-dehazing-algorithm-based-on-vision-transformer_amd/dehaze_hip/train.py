@@ -4,6 +4,7 @@ batches and the step body of My_train.py (TR:212-250).
 """
 import bisect
 import math
+import os
 import weakref
 
 import torch
@@ -290,10 +291,20 @@ class GradReducer:
     Dead parameters never enter a bucket (find_unused_parameters-equivalent).
     """
 
-    def __init__(self, optimizer=None, params=None, bucket_mb=25.0, group=None, overlap=True):
+    def __init__(self, optimizer=None, params=None, bucket_mb=25.0, group=None, overlap=True, reserve_cus=None):
         self.group = group
         self.overlap = overlap        # False (bench.py --no-overlap): every bucket's collective is launched by wait(), after backward
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        # CUs left to the collective kernels: every persistent grid of the HIP library is sized "workgroups per CU x (CUs - k)" from
+        # here on (dhz_set_reserved_cus; csrc/api.hip).  Only with more than one rank, only on a GPU; default DHZ_COMM_RESERVE_CUS or 0.
+        # Its single-GPU cost is recorded in profiles/r05_reserve_cus.txt; bench.py reports it as exchange.reserve_cus.
+        if reserve_cus is None:
+            reserve_cus = int(os.environ.get("DHZ_COMM_RESERVE_CUS", "0"))
+        self.reserve_cus = 0
+        if self.world > 1 and reserve_cus > 0 and torch.cuda.is_available() and overlap:
+            from . import _lib
+            _lib.call("dhz_set_reserved_cus", int(reserve_cus))
+            self.reserve_cus = int(reserve_cus)
         self.opt = optimizer
         if optimizer is not None:
             slices = optimizer.param_slices()

@@ -151,3 +151,54 @@ def test_c_abi_comm_single_rank_allreduce():
     lib = _lib.load()
     assert lib.dhz_comm_init(None, 0, 1, None) == -22 and b"null pointer" in lib.dhz_last_error()
     assert lib.dhz_comm_init(ctypes.cast(ctypes.pointer(comm), ctypes.c_void_p), 3, 2, ctypes.cast(uid, ctypes.c_void_p)) == -22
+
+
+def test_c_abi_comm_two_ranks_bucketed_exchange(tmp_path):
+    """The C-ABI exchange itself across TWO devices: dhz_comm_unique_id on rank 0, dhz_comm_init on both, one dhz_comm_allreduce_sum_f32
+    per GradReducer bucket on an exchange stream, SUM checked on both ranks (tests/_comm_worker.py).  Collected next to
+    test_bench_two_ranks_rccl on boxes with two visible devices; one-GPU boxes run the one-rank form above."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("one visible GPU: the two-rank C-ABI exchange needs two devices")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    idf = str(tmp_path / "rccl_id")
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_comm_worker.py")
+    procs = [subprocess.Popen([sys.executable, worker, str(r), "2", idf], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
+             for r in range(2)]
+    outs = [p.communicate(timeout=600) for p in procs]
+    for p, (o, e) in zip(procs, outs):
+        assert p.returncode == 0, e[-3000:]
+        assert "ok" in o
+
+
+def test_reserved_cus_shrink_the_persistent_grids_not_the_results():
+    """dhz_set_reserved_cus(k): every persistent grid is sized for (CUs - k) - what GradReducer asks for when world > 1
+    (DHZ_COMM_RESERVE_CUS) so that RCCL's kernels find CUs beside the backward pass; kernels walk their work with grid-stride loops, so
+    the results are bit-identical."""
+    import torch
+    from dehaze_hip import _lib, ops
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    full = lib.dhz_grid_cus()
+    assert lib.dhz_get_reserved_cus() == 0 and full >= 64
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(65536, 128, generator=g).to(dev)
+    W = (0.1 * torch.randn(256, 128, generator=g)).to(dev)
+    b = torch.randn(256, generator=g).to(dev)
+    y0 = ops.gemm_fwd(x, W, b)
+    qkv = torch.randn(64 * 64, 3 * 64, generator=g).to(dev)
+    table = (0.3 * torch.randn(225, 2, generator=g)).to(dev)
+    idx = torch.randint(64, (64, 25), generator=g).to(torch.uint8).to(dev)
+    a0 = ops.ps_window_attention(qkv, table, idx, None, 2, 32)
+    try:
+        _lib.call("dhz_set_reserved_cus", 16)
+        assert lib.dhz_get_reserved_cus() == 16 and lib.dhz_grid_cus() == full - 16
+        assert lib.dhz_ps_attn_bwd_parts_d(8192, 1, 32) == 2 * (full - 16)
+        assert torch.equal(ops.gemm_fwd(x, W, b), y0)
+        assert torch.equal(ops.ps_window_attention(qkv, table, idx, None, 2, 32), a0)
+        assert lib.dhz_set_reserved_cus(-1) == -22 and lib.dhz_set_reserved_cus(100000) == -22
+    finally:
+        _lib.call("dhz_set_reserved_cus", 0)
+    assert lib.dhz_grid_cus() == full
