@@ -1,0 +1,380 @@
+// K11b - the 3x3 / stride 1 / pad 1 convolutions of the VGG19 feature extractor (My_CR.py:56-86) on maps of 16 x 16 and more as
+// Winograd F(4x4, 3x3): 36 transform-domain products per 16 outputs instead of F(2x2, 3x3)'s 16 per 4 (csrc/winograd_conv.hip) -
+// 1.78 x fewer v_mfma_f32_16x16x4_f32 on the same fp32 matrix pipe.
+//
+// Accuracy (profiles/r05_winograd_f43_error_table.txt).  F(4x4) in fp32 with the textbook points (0, +-1, +-2) is 10 x less accurate than
+// F(2x2) and fails the kernel-level tolerance of tests/test_gpu_winograd.py; two measures bring it to ~2 x F(2x2)'s error:
+//   * interpolation points (0, +-3/4, +-3/2, inf): every constant of B^T and A^T is a dyadic rational, the transforms' amplification
+//     is the smallest of the symmetric sets searched (symmetric: B^T d shares the even / odd parts between +-p: 14 packed
+//     operations per 6-point transform);
+//   * the error is dominated by the fp32 ACCUMULATION over input channels of transform-domain values that are larger than the
+//     outputs: every FLUSH_GROUPS channel groups (128 channels) the accumulators are taken through A^T . A into a second, output-
+//     domain accumulator and restart from zero;
+//   * the frozen filters are transformed once (G g G^T in double, rounded once).
+//
+// Structure (it differs from the F(2x2) kernel because 36 positions x 16 tiles x 32 output channels = 288 accumulator registers do
+// not leave room for anything else): 256 threads, ONE wave per SIMD with the whole register file; a wave owns a 16 x 16-pixel
+// output block (16 tiles of 4 x 4) x 16 output channels for all 36 positions (144 accumulators + 64 output-domain ones).  Lane
+// (tile i16, channel pair g) transforms ITS OWN tile for ITS OWN two channels, and the MFMA contraction index of lane group g at
+// step s is channel 2 g + s - so the 36 x 2 transformed values a lane computes ARE its B operands: the transformed input never
+// leaves the registers (two sets: one feeds the MFMAs of channel group cb while the other receives the transform of cb + 1).
+// The four waves of a workgroup take four blocks and share the filter slice (16 k x 8 c x 36 positions = 18 KiB per group).
+// Both operands arrive by LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write): the filter slices into a
+// three-slot ring (one barrier per group, placed inside the MFMA stream), the 18 x 18-pixel halo patch of a wave into its own
+// two-slot ring; out-of-image pixels are slots zeroed once that no DMA lane ever writes.
+#include <stdlib.h>
+#include <type_traits>
+#include "common.h"
+
+#ifndef W43_ABL
+#define W43_ABL 0       // timing diagnostics: 1 no input transform, 2 no DMA, 4 no MFMAs
+#endif
+
+namespace {
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void glb_void;
+
+constexpr int KB = 16;              // output channels per workgroup
+constexpr int CC = 8;               // input channels per group (the layout's channel block)
+constexpr int NXI = 36;             // transform positions
+constexpr int UF = NXI * CC * KB;   // floats of one (kb, cb) filter slice: 4608 = 18 KiB = 18 DMA runs of 1 KiB
+constexpr int NUBUF = 3;
+constexpr int URUNS = UF / 256;     // 18
+// halo patch of a wave: 18 x 18 pixels x 8 channels as 16-byte chunks (4 channels of one pixel), plane hf = channels 4 hf .. 4 hf + 3:
+//   chunk(hf, row, px) = hf * PLANE + row * 18 + px + (row >> 2)
+// the one-chunk skew per four rows makes the ds_read_b64 of the 64 lanes (tile rows 4 ty + a, tile columns 4 tx + p, channel pair g)
+// conflict-free: bank starts 16 tx + {0, 36, 8, 44}[ty] + 2 (g & 1) are the 32 even numbers
+constexpr int PLANE = 332;
+constexpr int PCHUNKS = 2 * PLANE;                  // 664 chunks = 10.4 KiB
+constexpr int PRUNS = (PCHUNKS + 63) / 64;          // 11 DMA runs
+constexpr int PFLOATS = PRUNS * 256;                // one patch slot (floats), runs are whole KiB
+#ifndef W43_FLUSH
+#define W43_FLUSH 0
+#endif
+constexpr int FLUSH_GROUPS = W43_FLUSH;                    // accumulation flush every 128 input channels
+constexpr size_t W43_SMEM = (size_t)(NUBUF * UF + 4 * 2 * PFLOATS + KB) * sizeof(float);      // 55.3 + 88 KiB
+
+// interpolation points 0, +-PA, +-PB, inf
+constexpr float PA = 0.75f, PB = 1.5f;
+constexpr float A2 = PA * PA, B2 = PB * PB, A2B2 = A2 * B2, SAB = A2 + B2, AB2 = PA * B2, A2B = A2 * PB;
+constexpr float A3 = A2 * PA, B3 = B2 * PB;
+
+__device__ __forceinline__ void dma16(const float* g, float* l) {
+    __builtin_amdgcn_global_load_lds((glb_void*)g, (lds_void*)l, 16, 0, 0);
+}
+
+// B^T d for one 6-vector (packed over the lane's two channels): rows for the points 0, +a, -a, +b, -b, inf
+__device__ __forceinline__ void bt6(f32x2& d0, f32x2& d1, f32x2& d2, f32x2& d3, f32x2& d4, f32x2& d5) {
+    const f32x2 t0 = A2B2 * d0 - SAB * d2 + d4;
+    const f32x2 ea = d4 - B2 * d2, oa = PA * d3 - AB2 * d1;
+    const f32x2 eb = d4 - A2 * d2, ob = PB * d3 - A2B * d1;
+    const f32x2 t5 = A2B2 * d1 - SAB * d3 + d5;
+    d0 = t0; d1 = ea + oa; d2 = ea - oa; d3 = eb + ob; d4 = eb - ob; d5 = t5;
+}
+// A^T m for one 6-vector -> 4 outputs
+__device__ __forceinline__ void at6(float m0, float m1, float m2, float m3, float m4, float m5, float& y0, float& y1, float& y2,
+                                    float& y3) {
+    const float s1 = m1 + m2, d1 = m1 - m2, s2 = m3 + m4, d2 = m3 - m4;
+    y0 = m0 + s1 + s2;
+    y1 = PA * d1 + PB * d2;
+    y2 = A2 * s1 + B2 * s2;
+    y3 = A3 * d1 + B3 * d2 + m5;
+}
+
+template <bool FWD>
+__global__ __launch_bounds__(256, 1) void winograd43_conv3x3_kernel(const float* __restrict__ x, const float* __restrict__ upack,
+                                                                    const float* __restrict__ bias, int relu,
+                                                                    const float* __restrict__ out_mask,
+                                                                    const float* __restrict__ out_addend, float* __restrict__ y, int H,
+                                                                    int W, int C, int K, int nblk, int xcd_group) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int t = threadIdx.x, lane = t & 63;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int i16 = lane & 15, g = lane >> 4;
+    const int ty = i16 >> 2, tx = i16 & 3, hf = g >> 1, sub = g & 1;
+    float* const us = smem;                                        // filter ring [NUBUF][UF]
+    float* const pw = smem + NUBUF * UF + w * 2 * PFLOATS;         // this wave's patch ring [2][PFLOATS]
+    float* const bias_s = smem + NUBUF * UF + 4 * 2 * PFLOATS;
+    const int KBn = K / KB, CBn = C / CC;
+    int lid = blockIdx.x;
+    if (xcd_group) lid = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    const int kb = lid % KBn;
+    int blk = (lid / KBn) * 4 + w;
+    const bool live = blk < nblk;                                  // ragged last workgroup: the extra waves recompute, store nothing
+    if (!live) blk = nblk - 1;
+    const int bx_n = W / 16, by_n = H / 16;
+    const int bimg = blk / (bx_n * by_n);
+    const int by = (blk / bx_n) % by_n, bx = blk % bx_n;
+    const int oy0 = by * 16, ox0 = bx * 16;                        // the wave's output block; patch origin (oy0 - 1, ox0 - 1)
+    const size_t plane = (size_t)H * W * 8;                        // floats per (image, channel-group) plane
+
+    // ---- zero both patch slots (padding pixels and layout gaps are never written again) and stage the bias
+    {
+        f32x4* z = reinterpret_cast<f32x4*>(pw);
+#pragma unroll
+        for (int i = 0; i < 2 * PFLOATS / 4 / 64; ++i) z[lane + 64 * i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    if (FWD && t < KB) bias_s[t] = bias ? bias[kb * KB + t] : 0.f;
+
+    // ---- per-lane DMA sources of the patch: run r moves LDS chunks 64 r .. 64 r + 63, lane -> chunk 64 r + lane
+    int poff[PRUNS];                    // float offset inside a plane, or -1: no pixel (gap of the layout / outside the image)
+#pragma unroll
+    for (int r = 0; r < PRUNS; ++r) {
+        const int c = 64 * r + lane;
+        const int ph = c / PLANE, rr = c - ph * PLANE;
+        const int k4 = rr / 73;                                    // row group (4 rows + one skew chunk = 73 chunks)
+        const int q = rr - 73 * k4;
+        const int row = 4 * k4 + q / 18, px = q % 18;
+        const int iy = oy0 - 1 + row, ix = ox0 - 1 + px;
+        const bool ok = ph < 2 && q < 72 && row < 18 && iy >= 0 && iy < H && ix >= 0 && ix < W;
+        poff[r] = ok ? (iy * W + ix) * 8 + ph * 4 : -1;
+    }
+    const float* const xbase = x + (size_t)bimg * CBn * plane;
+    const float* const ubase = upack + (size_t)kb * CBn * UF + lane * 4;
+    auto dma_patch = [&](int cb) {                                 // -> slot cb & 1
+        if (W43_ABL & 2) return;
+        const float* xp = xbase + (size_t)cb * plane;
+        float* dst = pw + (cb & 1) * PFLOATS;
+#pragma unroll
+        for (int r = 0; r < PRUNS; ++r)
+            if (poff[r] >= 0) dma16(xp + poff[r], dst + 256 * r);
+    };
+    auto dma_u = [&](int cb) {                                     // -> ring slot cb % 3; runs w, w + 4, ...
+        if (W43_ABL & 2) return;
+        const float* up = ubase + (size_t)cb * UF;
+        float* dst = us + (cb % NUBUF) * UF;
+#pragma unroll
+        for (int r = 0; r < (URUNS + 3) / 4; ++r) {
+            const int run = w + 4 * r;
+            if (run < URUNS) dma16(up + 256 * run, dst + 256 * run);
+        }
+    };
+
+    // ---- input transform of the lane's tile (ty, tx), channels 2 g, 2 g + 1
+    const float* const pread0 = pw + (hf * PLANE + 73 * ty + 4 * tx) * 4 + 2 * sub;
+    auto read_row = [&](const float* pr, f32x2 (&d)[6][6], int a) {
+        const float* p = pr + (a * 18 + (a >> 2)) * 4;
+#pragma unroll
+        for (int b = 0; b < 6; ++b) d[a][b] = *reinterpret_cast<const f32x2*>(p + 4 * b);
+    };
+    // (the empty asm pins a transform piece where it is written: without it LLVM sinks the whole transform - it has no side effect - down
+    // to its first use, the next group's MFMAs, and the matrix pipe waits for 170 packed instructions in one burst)
+#define PIN6(a, b, c, d_, e, f) asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d_), "+v"(e), "+v"(f))
+    auto col_tr = [&](f32x2 (&d)[6][6], int b) {
+        bt6(d[0][b], d[1][b], d[2][b], d[3][b], d[4][b], d[5][b]);
+        PIN6(d[0][b], d[1][b], d[2][b], d[3][b], d[4][b], d[5][b]);
+    };
+    auto row_tr = [&](f32x2 (&d)[6][6], int a) {
+        bt6(d[a][0], d[a][1], d[a][2], d[a][3], d[a][4], d[a][5]);
+        PIN6(d[a][0], d[a][1], d[a][2], d[a][3], d[a][4], d[a][5]);
+    };
+
+    f32x4 acc[NXI];
+#pragma unroll
+    for (int xi = 0; xi < NXI; ++xi) acc[xi] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float yacc[4][16];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int p = 0; p < 16; ++p) yacc[j][p] = 0.f;
+
+    // acc (transform domain, 128 channels' worth) -> yacc (output domain), acc = 0
+    auto flush = [&]() {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float tm[4][6];
+#pragma unroll
+            for (int c = 0; c < 6; ++c)
+                at6(acc[c][j], acc[6 + c][j], acc[12 + c][j], acc[18 + c][j], acc[24 + c][j], acc[30 + c][j], tm[0][c], tm[1][c],
+                    tm[2][c], tm[3][c]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float y0, y1, y2, y3;
+                at6(tm[i][0], tm[i][1], tm[i][2], tm[i][3], tm[i][4], tm[i][5], y0, y1, y2, y3);
+                yacc[j][4 * i + 0] += y0; yacc[j][4 * i + 1] += y1; yacc[j][4 * i + 2] += y2; yacc[j][4 * i + 3] += y3;
+            }
+        }
+#pragma unroll
+        for (int xi = 0; xi < NXI; ++xi) acc[xi] = f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+
+    f32x2 va[6][6], vb[6][6];           // the two register sets of transformed input (V of the group being multiplied / being made)
+
+    // ---- prologue: patch 0, 1 and filter slices 0, 1 requested; group 0 transformed into va
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // the zero fill is in LDS before any DMA lane can land on top of it
+    __builtin_amdgcn_wave_barrier();
+    dma_patch(0);
+    dma_u(0);
+    if (CBn > 1) { dma_patch(1); dma_u(1); }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    {
+        const float* pr = pread0;
+#pragma unroll
+        for (int a = 0; a < 6; ++a) read_row(pr, va, a);
+#pragma unroll
+        for (int b = 0; b < 6; ++b) col_tr(va, b);
+#pragma unroll
+        for (int a = 0; a < 6; ++a) row_tr(va, a);
+    }
+
+    const float* const ufrag = us + (g * 16 + i16) * 4;            // [xi pair][g][k][xi & 1][c & 1]: one ds_read_b128 per two positions
+    // One channel group: 72 MFMAs on V = `vc`; in the gaps the next group's patch is read, transformed into `vn`, and the operands
+    // of group cb + 2 are requested (after the barrier that proves every wave is done with group cb - 1).
+    auto group = [&](int cb, f32x2 (&vc)[6][6], f32x2 (&vn)[6][6], auto with_next) {
+        constexpr bool WITH_NEXT = decltype(with_next)::value;
+        const float* up = ufrag + (cb % NUBUF) * UF;
+        const float* pr = pread0 + ((cb + 1) & 1) * PFLOATS;      // slot of group cb + 1
+        f32x4 a_cur = *reinterpret_cast<const f32x4*>(up);
+#pragma unroll
+        for (int j = 0; j < 18; ++j) {
+            f32x4 a_nxt = a_cur;
+            if (j + 1 < 18) a_nxt = *reinterpret_cast<const f32x4*>(up + (j + 1) * 256);
+            const int xi = 2 * j;
+            f32x2& v0 = vc[xi / 6][xi % 6];
+            f32x2& v1 = vc[(xi + 1) / 6][(xi + 1) % 6];
+            if (j == 1) {
+                // my DMAs of the previous group (patch cb + 1, my runs of filter slice cb + 1) have landed; after the barrier every wave's
+                // have, and every wave is done with group cb - 1: its filter slot and patch slot may be overwritten
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (WITH_NEXT && cb + 2 < CBn) { dma_u(cb + 2); dma_patch(cb + 2); }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (!(W43_ABL & 4)) {
+                acc[xi] = mfma16(a_cur[0], v0[0], acc[xi]);
+                acc[xi + 1] = mfma16(a_cur[2], v1[0], acc[xi + 1]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (WITH_NEXT && !(W43_ABL & 1)) {
+                if (j >= 2 && j < 8) read_row(pr, vn, j - 2);
+                if (j >= 9 && j < 12) { col_tr(vn, 2 * (j - 9)); }
+                if (j >= 12 && j < 15) { row_tr(vn, 2 * (j - 12)); }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (!(W43_ABL & 4)) {
+                acc[xi] = mfma16(a_cur[1], v0[1], acc[xi]);
+                acc[xi + 1] = mfma16(a_cur[3], v1[1], acc[xi + 1]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (WITH_NEXT && !(W43_ABL & 1)) {
+                if (j >= 9 && j < 12) { col_tr(vn, 2 * (j - 9) + 1); }
+                if (j >= 12 && j < 15) { row_tr(vn, 2 * (j - 12) + 1); }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            a_cur = a_nxt;
+        }
+    };
+
+    for (int cb = 0; cb + 2 < CBn; cb += 2) {
+        group(cb, va, vb, std::true_type{});
+        group(cb + 1, vb, va, std::true_type{});
+        if (FLUSH_GROUPS > 0 && ((cb + 2) % (FLUSH_GROUPS > 0 ? FLUSH_GROUPS : 1)) == 0) flush();
+    }
+    group(CBn - 2, va, vb, std::true_type{});
+    group(CBn - 1, vb, va, std::false_type{});
+    flush();
+
+    // ---- epilogue: lane (tile i16, g) holds output channels 4 g .. 4 g + 3 of its 4 x 4 pixels: one 16-byte store per pixel
+    if (live) {
+        const int KG = K / 8;
+        const float lo = relu ? 0.f : -__builtin_inff();
+        const float4 bv = FWD ? *reinterpret_cast<const float4*>(bias_s + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+        float* const ybase = y + (((size_t)bimg * KG + kb * 2 + hf) * H + oy0 + 4 * ty) * W * 8 + (size_t)(ox0 + 4 * tx) * 8 + sub * 4;
+        const size_t obase = ybase - y;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int jx = 0; jx < 4; ++jx) {
+                const int p = 4 * i + jx;
+                float4 v4 = make_float4(yacc[0][p] + bv.x, yacc[1][p] + bv.y, yacc[2][p] + bv.z, yacc[3][p] + bv.w);
+                const size_t o = obase + ((size_t)i * W + jx) * 8;
+                if (FWD) {
+                    v4.x = fmaxf(v4.x, lo); v4.y = fmaxf(v4.y, lo); v4.z = fmaxf(v4.z, lo); v4.w = fmaxf(v4.w, lo);
+                } else {
+                    if (out_addend) {
+                        const float4 ad = *reinterpret_cast<const float4*>(out_addend + o);
+                        v4.x += ad.x; v4.y += ad.y; v4.z += ad.z; v4.w += ad.w;
+                    }
+                    if (out_mask) {
+                        const float4 m = *reinterpret_cast<const float4*>(out_mask + o);
+                        v4.x = m.x > 0.f ? v4.x : 0.f; v4.y = m.y > 0.f ? v4.y : 0.f;
+                        v4.z = m.z > 0.f ? v4.z : 0.f; v4.w = m.w > 0.f ? v4.w : 0.f;
+                    }
+                }
+                *reinterpret_cast<float4*>(y + o) = v4;
+            }
+    }
+}
+
+// U = G g G^T for every (k, c) in double, rounded once; packed [k / 16][c / 8][xi / 2][(c % 8) / 2][k % 16][xi % 2][c % 2] (the kernel's
+// LDS order: a slice is copied verbatim).  transposed_rot: the backward-data filters g'[c][k][i][j] = g[k][c][2 - i][2 - j].
+__global__ void winograd43_prepack_kernel(const float* __restrict__ wgt, float* __restrict__ upack, int Kout, int Cin,
+                                          int transposed_rot) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= Kout * Cin) return;
+    const int k = e / Cin, c = e % Cin;
+    const double pts[5] = {0.0, (double)PA, -(double)PA, (double)PB, -(double)PB};
+    double G[6][3];
+    for (int i = 0; i < 5; ++i) {
+        double f = 1.0;
+        for (int j = 0; j < 5; ++j)
+            if (j != i) f *= pts[i] - pts[j];
+        G[i][0] = 1.0 / f; G[i][1] = pts[i] / f; G[i][2] = pts[i] * pts[i] / f;
+    }
+    G[5][0] = 0.0; G[5][1] = 0.0; G[5][2] = 1.0;
+    double gk[3][3];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j)
+            gk[i][j] = transposed_rot ? (double)wgt[((size_t)c * Kout + k) * 9 + (2 - i) * 3 + (2 - j)]
+                                      : (double)wgt[((size_t)k * Cin + c) * 9 + i * 3 + j];
+    double tg[6][3];
+    for (int i = 0; i < 6; ++i)
+        for (int j = 0; j < 3; ++j) tg[i][j] = G[i][0] * gk[0][j] + G[i][1] * gk[1][j] + G[i][2] * gk[2][j];
+    const int kk = k % KB, cc = c % CC;
+    float* base = upack + ((size_t)(k / KB) * (Cin / CC) + c / CC) * UF;
+    for (int i = 0; i < 6; ++i)
+        for (int j = 0; j < 6; ++j) {
+            const int xi = 6 * i + j;
+            const double u = tg[i][0] * G[j][0] + tg[i][1] * G[j][1] + tg[i][2] * G[j][2];
+            base[(xi >> 1) * 256 + ((cc >> 1) * 16 + kk) * 4 + (xi & 1) * 2 + (cc & 1)] = (float)u;
+        }
+}
+
+}  // namespace
+
+extern "C" int dhz_winograd43_prepack(const float* weight, float* upack, int Kout, int Cin, int transposed_rot, void* stream) {
+    DHZ_REQUIRE(weight && upack && Kout % KB == 0 && Cin % 16 == 0, "dhz_winograd43_prepack: Kout=%d Cin=%d", Kout, Cin);
+    const int n = Kout * Cin;
+    hipLaunchKernelGGL(winograd43_prepack_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, weight, upack, Kout, Cin,
+                       transposed_rot);
+    DHZ_CHECK_LAUNCH("dhz_winograd43_prepack");
+    return DHZ_OK;
+}
+
+extern "C" int dhz_winograd43_conv3x3(const float* x, const float* upack, const float* bias, int relu, const float* out_mask,
+                                      const float* out_addend, float* y, int B, int H, int W, int C, int K, void* stream) {
+    DHZ_REQUIRE(x && upack && y, "dhz_winograd43_conv3x3: null pointer");
+    DHZ_REQUIRE(B > 0 && H % 16 == 0 && W % 16 == 0 && H >= 16 && W >= 16 && C % 16 == 0 && K % KB == 0,
+                "dhz_winograd43_conv3x3: unsupported shape B=%d H=%d W=%d C=%d K=%d", B, H, W, C, K);
+    const bool fwd = !(out_mask || out_addend);
+    DHZ_REQUIRE(fwd || !(bias || relu), "dhz_winograd43_conv3x3: bias/relu and out_mask/out_addend are exclusive");
+    DHZ_REQUIRE((long long)H * W * 8 * (C / 8) < (1ll << 31), "dhz_winograd43_conv3x3: image too large");
+    const int nblk = B * (H / 16) * (W / 16);
+    const int grid = ((nblk + 3) / 4) * (K / KB);
+    const int xcd_group = (grid % 8 == 0) ? 1 : 0;
+    hipStream_t s = (hipStream_t)stream;
+#define GO(F)                                                                                                          \
+    do {                                                                                                               \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&winograd43_conv3x3_kernel<F>),                        \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)W43_SMEM);                          \
+        hipLaunchKernelGGL((winograd43_conv3x3_kernel<F>), dim3(grid), dim3(256), W43_SMEM, s, x, upack, bias, relu,   \
+                           out_mask, out_addend, y, H, W, C, K, nblk, xcd_group);                                      \
+    } while (0)
+    if (fwd) GO(true); else GO(false);
+#undef GO
+    DHZ_CHECK_LAUNCH("dhz_winograd43_conv3x3");
+    return DHZ_OK;
+}

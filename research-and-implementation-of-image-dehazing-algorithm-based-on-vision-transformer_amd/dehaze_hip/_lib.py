@@ -50,6 +50,8 @@ SIGNATURES = {
     "dhz_crop_augment_pair": [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_p],
     "dhz_winograd_prepack": [c_f, c_f, c_i, c_i, c_i, c_p],
     "dhz_winograd_conv3x3": [c_f, c_f, c_f, c_i, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_p],
+    "dhz_winograd43_prepack": [c_f, c_f, c_i, c_i, c_i, c_p],
+    "dhz_winograd43_conv3x3": [c_f, c_f, c_f, c_i, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_p],
     "dhz_maxpool2x2_blocked_fwd": [c_f, c_f, c_i, c_i, c_i, c_p],
     "dhz_maxpool2x2_blocked_bwd": [c_f, c_f, c_f, c_i, c_i, c_i, c_p],
     "dhz_layout_blocked8": [c_f, c_f, c_i, c_i, c_i, c_i, c_f, c_i, c_p],
