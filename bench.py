@@ -395,18 +395,24 @@ def main():
             # the kernel with the largest share of the step (VGG19 convolutions of the contrastive loss): Winograd F(2x2,3x3),
             # so the matrix pipe executes direct-conv FLOPs / 2.25; frac is the ISSUED MFMA rate against the fp32 peak
             ev = timing["dhz_winograd_conv3x3"]
-            ms = sum(a.elapsed_time(b) for a, b, _ in ev)
-            direct = sum(f for _, _, f in ev)
+            ms = sum(e[0].elapsed_time(e[1]) for e in ev)
+            direct = sum(e[2] for e in ev)
+            issued = sum(e[3] for e in ev)                           # direct / 2.25 on the F(2x2,3x3) launches, / 4 on the F(4x4,3x3) ones
             tf_direct = direct / (ms * 1e-3) / 1e12
-            inst = [v for k, v in pmc.items() if k.startswith("winograd_conv3x3_kernel")]
+            tf_issued = issued / (ms * 1e-3) / 1e12
+            inst = [v for k, v in pmc.items() if k.startswith("winograd_conv3x3_kernel") or k.startswith("winograd43_conv3x3_kernel")]
             traffic = (sum(v["hbm_bytes_per_launch"] * v["launches"] for v in inst) / sum(v["launches"] for v in inst)) if inst else None
-            out["roofline_dominant"] = {"kernel": "winograd_conv3x3_kernel<FWD> (dhz_winograd_conv3x3): largest share of the step",
-                                        "bound": "mfma", "achieved": round(tf_direct / 2.25, 2), "peak": MFMA_F32_PEAK_TF,
-                                        "unit": "TFLOP/s", "frac": round(tf_direct / 2.25 / MFMA_F32_PEAK_TF, 4),
+            out["roofline_dominant"] = {"kernel": "winograd43_conv3x3_kernel<FWD> (dhz_winograd43_conv3x3: F(4x4,3x3), maps >= 32 x 32) + "
+                                                  "winograd_conv3x3_kernel<FWD,Q8> (dhz_winograd_conv3x3: F(2x2,3x3), 16 x 16 and 8 x 8 maps): "
+                                                  "the VGG19 convolutions, largest share of the step",
+                                        "bound": "mfma", "achieved": round(tf_issued, 2), "peak": MFMA_F32_PEAK_TF,
+                                        "unit": "TFLOP/s", "frac": round(tf_issued / MFMA_F32_PEAK_TF, 4),
+                                        "counts": "ISSUED transform-domain matrix FLOPs (direct-convolution FLOPs / 4 on the F(4x4) launches, "
+                                                  "/ 2.25 on the F(2x2) ones)",
                                         "direct_conv_equivalent_tflops": round(tf_direct, 1),
                                         "traffic": round(traffic) if traffic else None, "traffic_source": traffic_source,
                                         "launches": len(ev), "avg_launch_us": round(1e3 * ms / len(ev), 2),
-                                        "alg_flops_per_launch": int(direct / 2.25 / len(ev))}
+                                        "alg_flops_per_launch": int(issued / len(ev))}
         for key, name, kern in (("dhz_linear_split6", "roofline_split6_gemm",
                                  "split6_wide_kernel / split6_gemm_kernel / gemm_split_kernel (dhz_linear_fwd_split6, dhz_linear_dgrad_split6, "
                                  "dhz_linear_fwd_split, dhz_linear_dgrad_split): six-term forward / backward-data token-Linear GEMMs"),

@@ -36,12 +36,12 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void glb_void;
 
-constexpr int KB = 16;              // output channels per workgroup
+constexpr int KB = 32;              // output channels per workgroup (= per wave)
 constexpr int CC = 8;               // input channels per group (the layout's channel block)
 constexpr int NXI = 36;             // transform positions
-constexpr int UF = NXI * CC * KB;   // floats of one (kb, cb) filter slice: 4608 = 18 KiB = 18 DMA runs of 1 KiB
-constexpr int NUBUF = 3;
-constexpr int URUNS = UF / 256;     // 18
+constexpr int UF = NXI * CC * KB;   // floats of one (kb, cb) filter slice: 9216 = 36 KiB = 36 DMA runs of 1 KiB
+constexpr int NUBUF = 2;
+constexpr int URUNS = UF / 256;     // 36: nine per wave
 // halo patch of a wave: 18 x 18 pixels x 8 channels as 16-byte chunks (4 channels of one pixel), plane hf = channels 4 hf .. 4 hf + 3:
 //   chunk(hf, row, px) = hf * PLANE + row * 18 + px + (row >> 2)
 // the one-chunk skew per four rows makes the ds_read_b64 of the 64 lanes (tile rows 4 ty + a, tile columns 4 tx + p, channel pair g)
@@ -49,12 +49,8 @@ constexpr int URUNS = UF / 256;     // 18
 constexpr int PLANE = 332;
 constexpr int PCHUNKS = 2 * PLANE;                  // 664 chunks = 10.4 KiB
 constexpr int PRUNS = (PCHUNKS + 63) / 64;          // 11 DMA runs
-constexpr int PFLOATS = PRUNS * 256;                // one patch slot (floats), runs are whole KiB
-#ifndef W43_FLUSH
-#define W43_FLUSH 0
-#endif
-constexpr int FLUSH_GROUPS = W43_FLUSH;                    // accumulation flush every 128 input channels
-constexpr size_t W43_SMEM = (size_t)(NUBUF * UF + 4 * 2 * PFLOATS + KB) * sizeof(float);      // 55.3 + 88 KiB
+constexpr int PFLOATS = PRUNS * 256;                // the patch slot (floats), runs are whole KiB
+constexpr size_t W43_SMEM = (size_t)(NUBUF * UF + 4 * PFLOATS + KB) * sizeof(float);      // 72 + 44 KiB
 
 // interpolation points 0, +-PA, +-PB, inf
 constexpr float PA = 0.75f, PB = 1.5f;
@@ -95,8 +91,8 @@ __global__ __launch_bounds__(256, 1) void winograd43_conv3x3_kernel(const float*
     const int i16 = lane & 15, g = lane >> 4;
     const int ty = i16 >> 2, tx = i16 & 3, hf = g >> 1, sub = g & 1;
     float* const us = smem;                                        // filter ring [NUBUF][UF]
-    float* const pw = smem + NUBUF * UF + w * 2 * PFLOATS;         // this wave's patch ring [2][PFLOATS]
-    float* const bias_s = smem + NUBUF * UF + 4 * 2 * PFLOATS;
+    float* const pw = smem + NUBUF * UF + w * PFLOATS;             // this wave's patch slot
+    float* const bias_s = smem + NUBUF * UF + 4 * PFLOATS;
     const int KBn = K / KB, CBn = C / CC;
     int lid = blockIdx.x;
     if (xcd_group) lid = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
@@ -110,11 +106,11 @@ __global__ __launch_bounds__(256, 1) void winograd43_conv3x3_kernel(const float*
     const int oy0 = by * 16, ox0 = bx * 16;                        // the wave's output block; patch origin (oy0 - 1, ox0 - 1)
     const size_t plane = (size_t)H * W * 8;                        // floats per (image, channel-group) plane
 
-    // ---- zero both patch slots (padding pixels and layout gaps are never written again) and stage the bias
+    // ---- zero the patch slot (padding pixels and layout gaps are never written again) and stage the bias
     {
         f32x4* z = reinterpret_cast<f32x4*>(pw);
 #pragma unroll
-        for (int i = 0; i < 2 * PFLOATS / 4 / 64; ++i) z[lane + 64 * i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < PFLOATS / 4 / 64; ++i) z[lane + 64 * i] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     if (FWD && t < KB) bias_s[t] = bias ? bias[kb * KB + t] : 0.f;
 
@@ -133,183 +129,141 @@ __global__ __launch_bounds__(256, 1) void winograd43_conv3x3_kernel(const float*
     }
     const float* const xbase = x + (size_t)bimg * CBn * plane;
     const float* const ubase = upack + (size_t)kb * CBn * UF + lane * 4;
-    auto dma_patch = [&](int cb) {                                 // -> slot cb & 1
+    auto dma_patch_run = [&](int cb, int r) {
         if (W43_ABL & 2) return;
-        const float* xp = xbase + (size_t)cb * plane;
-        float* dst = pw + (cb & 1) * PFLOATS;
-#pragma unroll
-        for (int r = 0; r < PRUNS; ++r)
-            if (poff[r] >= 0) dma16(xp + poff[r], dst + 256 * r);
+        if (poff[r] >= 0) dma16(xbase + (size_t)cb * plane + poff[r], pw + 256 * r);
     };
-    auto dma_u = [&](int cb) {                                     // -> ring slot cb % 3; runs w, w + 4, ...
+    auto dma_u_run = [&](int cb, int r) {                          // run w + 4 r of slice cb -> ring slot cb & 1
         if (W43_ABL & 2) return;
-        const float* up = ubase + (size_t)cb * UF;
-        float* dst = us + (cb % NUBUF) * UF;
-#pragma unroll
-        for (int r = 0; r < (URUNS + 3) / 4; ++r) {
-            const int run = w + 4 * r;
-            if (run < URUNS) dma16(up + 256 * run, dst + 256 * run);
-        }
+        const int run = w + 4 * r;
+        dma16(ubase + (size_t)cb * UF + 256 * run, us + (cb & 1) * UF + 256 * run);
     };
 
-    // ---- input transform of the lane's tile (ty, tx), channels 2 g, 2 g + 1
     const float* const pread0 = pw + (hf * PLANE + 73 * ty + 4 * tx) * 4 + 2 * sub;
-    auto read_row = [&](const float* pr, f32x2 (&d)[6][6], int a) {
-        const float* p = pr + (a * 18 + (a >> 2)) * 4;
+    f32x4 acc[NXI][2];
 #pragma unroll
-        for (int b = 0; b < 6; ++b) d[a][b] = *reinterpret_cast<const f32x2*>(p + 4 * b);
-    };
-    // (the empty asm pins a transform piece where it is written: without it LLVM sinks the whole transform - it has no side effect - down
-    // to its first use, the next group's MFMAs, and the matrix pipe waits for 170 packed instructions in one burst)
-#define PIN6(a, b, c, d_, e, f) asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d_), "+v"(e), "+v"(f))
-    auto col_tr = [&](f32x2 (&d)[6][6], int b) {
-        bt6(d[0][b], d[1][b], d[2][b], d[3][b], d[4][b], d[5][b]);
-        PIN6(d[0][b], d[1][b], d[2][b], d[3][b], d[4][b], d[5][b]);
-    };
-    auto row_tr = [&](f32x2 (&d)[6][6], int a) {
-        bt6(d[a][0], d[a][1], d[a][2], d[a][3], d[a][4], d[a][5]);
-        PIN6(d[a][0], d[a][1], d[a][2], d[a][3], d[a][4], d[a][5]);
-    };
+    for (int xi = 0; xi < NXI; ++xi) { acc[xi][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[xi][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
-    f32x4 acc[NXI];
+    // ---- prologue: patch 0 and filter slice 0
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // the zero fill is in LDS before any DMA lane can land on top of it
+    __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int xi = 0; xi < NXI; ++xi) acc[xi] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float yacc[4][16];
+    for (int r = 0; r < PRUNS; ++r) dma_patch_run(0, r);
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int p = 0; p < 16; ++p) yacc[j][p] = 0.f;
+    for (int r = 0; r < URUNS / 4; ++r) dma_u_run(0, r);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
-    // acc (transform domain, 128 channels' worth) -> yacc (output domain), acc = 0
-    auto flush = [&]() {
+    const float* const ufrag = us + (g * 16 + i16) * 4;            // [xi pair][k half][g][k][xi & 1][c & 1]: one ds_read_b128 per two positions
+    // One channel group, two phases (vector and fp32 matrix instructions of a wave do not overlap on this part - csrc/leff_fused.hip,
+    // DESIGN 4a - so there is nothing to gain from interleaving them, and one set of transformed values is enough):
+    //   (1) the lane's 6 x 6 x 2-channel patch window from LDS, B^T d B in registers;
+    //   (2) barrier (filter slice cb complete for every wave, every wave done with slice cb - 1), 144 MFMAs; in their first half the
+    //       DMA of the next group's operands, one request per MFMA pair so that the address unit never queues
+#pragma unroll 1
+    for (int cb = 0; cb < CBn; ++cb) {
+        f32x2 v[6][6];
+        if (!(W43_ABL & 1)) {
+#pragma unroll
+            for (int a = 0; a < 6; ++a) {
+                const float* p = pread0 + (a * 18 + (a >> 2)) * 4;
+#pragma unroll
+                for (int b = 0; b < 6; ++b) v[a][b] = *reinterpret_cast<const f32x2*>(p + 4 * b);
+            }
+#pragma unroll
+            for (int b = 0; b < 6; ++b) bt6(v[0][b], v[1][b], v[2][b], v[3][b], v[4][b], v[5][b]);
+#pragma unroll
+            for (int a = 0; a < 6; ++a) bt6(v[a][0], v[a][1], v[a][2], v[a][3], v[a][4], v[a][5]);
+        } else {
+#pragma unroll
+            for (int a = 0; a < 6; ++a)
+#pragma unroll
+                for (int b = 0; b < 6; ++b) v[a][b] = f32x2{1.f, 1.f};
+        }
+        __syncthreads();
+        const bool next = cb + 1 < CBn;
+        const float* up = ufrag + (cb & 1) * UF;
+        f32x4 alo = *reinterpret_cast<const f32x4*>(up), ahi = *reinterpret_cast<const f32x4*>(up + 256);
+#pragma unroll
+        for (int j = 0; j < 18; ++j) {
+            f32x4 nlo = alo, nhi = ahi;
+            if (j + 1 < 18) {
+                nlo = *reinterpret_cast<const f32x4*>(up + (j + 1) * 512);
+                nhi = *reinterpret_cast<const f32x4*>(up + (j + 1) * 512 + 256);
+            }
+            const int xi = 2 * j;
+            const f32x2 v0 = v[xi / 6][xi % 6], v1 = v[(xi + 1) / 6][(xi + 1) % 6];
+            __builtin_amdgcn_sched_barrier(0);
+            if (!(W43_ABL & 4)) {
+                acc[xi][0] = mfma16(alo[0], v0[0], acc[xi][0]);
+                acc[xi][1] = mfma16(ahi[0], v0[0], acc[xi][1]);
+                acc[xi + 1][0] = mfma16(alo[2], v1[0], acc[xi + 1][0]);
+                acc[xi + 1][1] = mfma16(ahi[2], v1[0], acc[xi + 1][1]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (next && j < URUNS / 4) dma_u_run(cb + 1, j);
+            __builtin_amdgcn_sched_barrier(0);
+            if (!(W43_ABL & 4)) {
+                acc[xi][0] = mfma16(alo[1], v0[1], acc[xi][0]);
+                acc[xi][1] = mfma16(ahi[1], v0[1], acc[xi][1]);
+                acc[xi + 1][0] = mfma16(alo[3], v1[1], acc[xi + 1][0]);
+                acc[xi + 1][1] = mfma16(ahi[3], v1[1], acc[xi + 1][1]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (next && j < PRUNS) dma_patch_run(cb + 1, j);
+            __builtin_amdgcn_sched_barrier(0);
+            alo = nlo; ahi = nhi;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the next patch and my runs of the next filter slice have landed
+    }
+
+    // ---- epilogue: Y = A^T M A per (k half, accumulator row); lane (tile i16, g) holds output channels 16 kh + 4 g .. + 3 of its 4 x 4 pixels
+    const int KG = K / 8;
+    const float lo = relu ? 0.f : -__builtin_inff();
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh) {
+        float yv[4][16];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             float tm[4][6];
 #pragma unroll
             for (int c = 0; c < 6; ++c)
-                at6(acc[c][j], acc[6 + c][j], acc[12 + c][j], acc[18 + c][j], acc[24 + c][j], acc[30 + c][j], tm[0][c], tm[1][c],
-                    tm[2][c], tm[3][c]);
+                at6(acc[c][kh][j], acc[6 + c][kh][j], acc[12 + c][kh][j], acc[18 + c][kh][j], acc[24 + c][kh][j], acc[30 + c][kh][j],
+                    tm[0][c], tm[1][c], tm[2][c], tm[3][c]);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                float y0, y1, y2, y3;
-                at6(tm[i][0], tm[i][1], tm[i][2], tm[i][3], tm[i][4], tm[i][5], y0, y1, y2, y3);
-                yacc[j][4 * i + 0] += y0; yacc[j][4 * i + 1] += y1; yacc[j][4 * i + 2] += y2; yacc[j][4 * i + 3] += y3;
-            }
+            for (int i = 0; i < 4; ++i)
+                at6(tm[i][0], tm[i][1], tm[i][2], tm[i][3], tm[i][4], tm[i][5], yv[j][4 * i], yv[j][4 * i + 1], yv[j][4 * i + 2],
+                    yv[j][4 * i + 3]);
         }
+        if (live) {
+            const float4 bv = FWD ? *reinterpret_cast<const float4*>(bias_s + 16 * kh + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const size_t obase = (((size_t)bimg * KG + kb * 4 + kh * 2 + hf) * H + oy0 + 4 * ty) * W * 8 + (size_t)(ox0 + 4 * tx) * 8 + sub * 4;
 #pragma unroll
-        for (int xi = 0; xi < NXI; ++xi) acc[xi] = f32x4{0.f, 0.f, 0.f, 0.f};
-    };
-
-    f32x2 va[6][6], vb[6][6];           // the two register sets of transformed input (V of the group being multiplied / being made)
-
-    // ---- prologue: patch 0, 1 and filter slices 0, 1 requested; group 0 transformed into va
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // the zero fill is in LDS before any DMA lane can land on top of it
-    __builtin_amdgcn_wave_barrier();
-    dma_patch(0);
-    dma_u(0);
-    if (CBn > 1) { dma_patch(1); dma_u(1); }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    {
-        const float* pr = pread0;
+            for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int a = 0; a < 6; ++a) read_row(pr, va, a);
-#pragma unroll
-        for (int b = 0; b < 6; ++b) col_tr(va, b);
-#pragma unroll
-        for (int a = 0; a < 6; ++a) row_tr(va, a);
-    }
-
-    const float* const ufrag = us + (g * 16 + i16) * 4;            // [xi pair][g][k][xi & 1][c & 1]: one ds_read_b128 per two positions
-    // One channel group: 72 MFMAs on V = `vc`; in the gaps the next group's patch is read, transformed into `vn`, and the operands
-    // of group cb + 2 are requested (after the barrier that proves every wave is done with group cb - 1).
-    auto group = [&](int cb, f32x2 (&vc)[6][6], f32x2 (&vn)[6][6], auto with_next) {
-        constexpr bool WITH_NEXT = decltype(with_next)::value;
-        const float* up = ufrag + (cb % NUBUF) * UF;
-        const float* pr = pread0 + ((cb + 1) & 1) * PFLOATS;      // slot of group cb + 1
-        f32x4 a_cur = *reinterpret_cast<const f32x4*>(up);
-#pragma unroll
-        for (int j = 0; j < 18; ++j) {
-            f32x4 a_nxt = a_cur;
-            if (j + 1 < 18) a_nxt = *reinterpret_cast<const f32x4*>(up + (j + 1) * 256);
-            const int xi = 2 * j;
-            f32x2& v0 = vc[xi / 6][xi % 6];
-            f32x2& v1 = vc[(xi + 1) / 6][(xi + 1) % 6];
-            if (j == 1) {
-                // my DMAs of the previous group (patch cb + 1, my runs of filter slice cb + 1) have landed; after the barrier every wave's
-                // have, and every wave is done with group cb - 1: its filter slot and patch slot may be overwritten
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
-                if (WITH_NEXT && cb + 2 < CBn) { dma_u(cb + 2); dma_patch(cb + 2); }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            if (!(W43_ABL & 4)) {
-                acc[xi] = mfma16(a_cur[0], v0[0], acc[xi]);
-                acc[xi + 1] = mfma16(a_cur[2], v1[0], acc[xi + 1]);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            if (WITH_NEXT && !(W43_ABL & 1)) {
-                if (j >= 2 && j < 8) read_row(pr, vn, j - 2);
-                if (j >= 9 && j < 12) { col_tr(vn, 2 * (j - 9)); }
-                if (j >= 12 && j < 15) { row_tr(vn, 2 * (j - 12)); }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            if (!(W43_ABL & 4)) {
-                acc[xi] = mfma16(a_cur[1], v0[1], acc[xi]);
-                acc[xi + 1] = mfma16(a_cur[3], v1[1], acc[xi + 1]);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            if (WITH_NEXT && !(W43_ABL & 1)) {
-                if (j >= 9 && j < 12) { col_tr(vn, 2 * (j - 9) + 1); }
-                if (j >= 12 && j < 15) { row_tr(vn, 2 * (j - 12) + 1); }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            a_cur = a_nxt;
-        }
-    };
-
-    for (int cb = 0; cb + 2 < CBn; cb += 2) {
-        group(cb, va, vb, std::true_type{});
-        group(cb + 1, vb, va, std::true_type{});
-        if (FLUSH_GROUPS > 0 && ((cb + 2) % (FLUSH_GROUPS > 0 ? FLUSH_GROUPS : 1)) == 0) flush();
-    }
-    group(CBn - 2, va, vb, std::true_type{});
-    group(CBn - 1, vb, va, std::false_type{});
-    flush();
-
-    // ---- epilogue: lane (tile i16, g) holds output channels 4 g .. 4 g + 3 of its 4 x 4 pixels: one 16-byte store per pixel
-    if (live) {
-        const int KG = K / 8;
-        const float lo = relu ? 0.f : -__builtin_inff();
-        const float4 bv = FWD ? *reinterpret_cast<const float4*>(bias_s + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
-        float* const ybase = y + (((size_t)bimg * KG + kb * 2 + hf) * H + oy0 + 4 * ty) * W * 8 + (size_t)(ox0 + 4 * tx) * 8 + sub * 4;
-        const size_t obase = ybase - y;
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int jx = 0; jx < 4; ++jx) {
-                const int p = 4 * i + jx;
-                float4 v4 = make_float4(yacc[0][p] + bv.x, yacc[1][p] + bv.y, yacc[2][p] + bv.z, yacc[3][p] + bv.w);
-                const size_t o = obase + ((size_t)i * W + jx) * 8;
-                if (FWD) {
-                    v4.x = fmaxf(v4.x, lo); v4.y = fmaxf(v4.y, lo); v4.z = fmaxf(v4.z, lo); v4.w = fmaxf(v4.w, lo);
-                } else {
-                    if (out_addend) {
-                        const float4 ad = *reinterpret_cast<const float4*>(out_addend + o);
-                        v4.x += ad.x; v4.y += ad.y; v4.z += ad.z; v4.w += ad.w;
+                for (int jx = 0; jx < 4; ++jx) {
+                    const int p = 4 * i + jx;
+                    float4 v4 = make_float4(yv[0][p] + bv.x, yv[1][p] + bv.y, yv[2][p] + bv.z, yv[3][p] + bv.w);
+                    const size_t o = obase + ((size_t)i * W + jx) * 8;
+                    if (FWD) {
+                        v4.x = fmaxf(v4.x, lo); v4.y = fmaxf(v4.y, lo); v4.z = fmaxf(v4.z, lo); v4.w = fmaxf(v4.w, lo);
+                    } else {
+                        if (out_addend) {
+                            const float4 ad = *reinterpret_cast<const float4*>(out_addend + o);
+                            v4.x += ad.x; v4.y += ad.y; v4.z += ad.z; v4.w += ad.w;
+                        }
+                        if (out_mask) {
+                            const float4 m = *reinterpret_cast<const float4*>(out_mask + o);
+                            v4.x = m.x > 0.f ? v4.x : 0.f; v4.y = m.y > 0.f ? v4.y : 0.f;
+                            v4.z = m.z > 0.f ? v4.z : 0.f; v4.w = m.w > 0.f ? v4.w : 0.f;
+                        }
                     }
-                    if (out_mask) {
-                        const float4 m = *reinterpret_cast<const float4*>(out_mask + o);
-                        v4.x = m.x > 0.f ? v4.x : 0.f; v4.y = m.y > 0.f ? v4.y : 0.f;
-                        v4.z = m.z > 0.f ? v4.z : 0.f; v4.w = m.w > 0.f ? v4.w : 0.f;
-                    }
+                    *reinterpret_cast<float4*>(y + o) = v4;
                 }
-                *reinterpret_cast<float4*>(y + o) = v4;
-            }
+        }
     }
 }
 
-// U = G g G^T for every (k, c) in double, rounded once; packed [k / 16][c / 8][xi / 2][(c % 8) / 2][k % 16][xi % 2][c % 2] (the kernel's
+// U = G g G^T for every (k, c) in double, rounded once; packed [k / 32][c / 8][xi / 2][(k % 32) / 16][(c % 8) / 2][k % 16][xi % 2][c % 2] (the kernel's
 // LDS order: a slice is copied verbatim).  transposed_rot: the backward-data filters g'[c][k][i][j] = g[k][c][2 - i][2 - j].
 __global__ void winograd43_prepack_kernel(const float* __restrict__ wgt, float* __restrict__ upack, int Kout, int Cin,
                                           int transposed_rot) {
@@ -339,7 +293,7 @@ __global__ void winograd43_prepack_kernel(const float* __restrict__ wgt, float* 
         for (int j = 0; j < 6; ++j) {
             const int xi = 6 * i + j;
             const double u = tg[i][0] * G[j][0] + tg[i][1] * G[j][1] + tg[i][2] * G[j][2];
-            base[(xi >> 1) * 256 + ((cc >> 1) * 16 + kk) * 4 + (xi & 1) * 2 + (cc & 1)] = (float)u;
+            base[(xi >> 1) * 512 + (kk >> 4) * 256 + ((cc >> 1) * 16 + (kk & 15)) * 4 + (xi & 1) * 2 + (cc & 1)] = (float)u;
         }
 }
 

@@ -11,6 +11,8 @@ Forward-only passes (target / hazy input, My_CR.py:102) save nothing; the pass o
 node whose backward walks the stack with the same kernel (rotated/transposed filters, ReLU mask fused into the patch
 load) - weight gradients are never formed (the reference freezes the VGG, My_CR.py:75-77).
 """
+import os
+
 import torch
 import torch.nn.functional as F
 from torch.autograd import Function
@@ -70,11 +72,30 @@ def _timing_begin():
     return timing, e0
 
 
-def _timing_end(ev, B, H, W, Cin, Kout):
+def _timing_end(ev, B, H, W, Cin, Kout, f43=False):
     if ev is not None:
         e1 = torch.cuda.Event(enable_timing=True)
         e1.record()
-        ev[0].append((ev[1], e1, 2.0 * 9 * B * H * W * Cin * Kout))          # direct-convolution FLOPs of this launch
+        direct = 2.0 * 9 * B * H * W * Cin * Kout                             # direct-convolution FLOPs of this launch
+        # ISSUED matrix FLOPs: F(2x2,3x3) multiplies 16 / 4 per output and tap-sum instead of 9 (direct / 2.25), F(4x4,3x3) 36 / 16 (/ 4)
+        ev[0].append((ev[1], e1, direct, direct / (4.0 if f43 else 2.25)))
+
+
+# Which Winograd form a layer takes: F(4x4,3x3) (csrc/winograd43_conv.hip, 1.78 x fewer matrix products) or F(2x2,3x3)
+# (csrc/winograd_conv.hip).  Measured per layer (tools/bench_wino.py): F(4x4) is 1.14 - 1.22 x faster whenever its grid - one workgroup
+# per four 16 x 16 blocks and 32 output channels - fills the CUs in whole rounds: always on the 128 / 64 / 32-pixel maps (thousands of
+# workgroups), on the 16-pixel maps only for some batches (64 images x 512 channels = 256 workgroups = one round: faster; 96 images = 1.5
+# rounds: 0.91 x; 32 images = half a round: slower still) - hence the occupancy rule below.  DHZ_WINO_F43=0 disables the F(4x4) form.
+F43_ON = os.environ.get("DHZ_WINO_F43", "1") != "0"
+
+
+def use_f43(B, H, W, Cin, Kout):
+    if not F43_ON or H % 16 or W % 16 or H < 16 or W < 16 or Cin % 16 or Kout % 32:
+        return False
+    wgs = (B * (H // 16) * (W // 16) + 3) // 4 * (Kout // 32)
+    cus = _lib.load().dhz_grid_cus()
+    rounds = (wgs + cus - 1) // cus
+    return wgs >= 0.92 * rounds * cus          # the last round of workgroups nearly full
 
 
 class VggEngine:
@@ -82,6 +103,7 @@ class VggEngine:
         """convs: the 13 nn.Conv2d modules of vgg19.features[0:30]."""
         self.convs = convs
         self._packed = {}
+        self._packed43 = {}
 
     def packed(self, i, device):
         key = (i, str(device), self.convs[i].weight.data_ptr(), self.convs[i].weight._version)
@@ -97,15 +119,32 @@ class VggEngine:
             self._packed[i] = hit
         return hit[1], hit[2]
 
+    def packed43(self, i, device):
+        """F(4x4,3x3) filters of layer i (forward and backward-data forms, 36 K C floats each), built at first use"""
+        key = (i, str(device), self.convs[i].weight.data_ptr(), self.convs[i].weight._version)
+        hit = self._packed43.get(i)
+        if hit is None or hit[0] != key:
+            w = self.convs[i].weight.detach().contiguous()
+            K, C = w.shape[0], w.shape[1]
+            uf = torch.empty(36 * K * C, device=device, dtype=torch.float32)
+            ub = torch.empty(36 * K * C, device=device, dtype=torch.float32)
+            _lib.call("dhz_winograd43_prepack", _p(w), _p(uf), K, C, 0, _stream())
+            _lib.call("dhz_winograd43_prepack", _p(w), _p(ub), C, K, 1, _stream())
+            hit = (key, uf, ub)
+            self._packed43[i] = hit
+        return hit[1], hit[2]
+
     # ---- one Winograd layer
-    def conv(self, i, xb):
+    def conv(self, i, xb, allow43=True):
         B, CG, H, W, _ = xb.shape
         C, K = CONVS[i]
-        uf, _ = self.packed(i, xb.device)
+        f43 = allow43 and use_f43(B, H, W, C, K)
+        uf, _ = self.packed43(i, xb.device) if f43 else self.packed(i, xb.device)
         yb = torch.empty((B, K // 8, H, W, 8), device=xb.device, dtype=torch.float32)
         ev = _timing_begin()
-        _lib.call("dhz_winograd_conv3x3", _p(xb), _p(uf), _p(self.convs[i].bias), 1, None, None, _p(yb), B, H, W, C, K, _stream())
-        _timing_end(ev, B, H, W, C, K)
+        _lib.call("dhz_winograd43_conv3x3" if f43 else "dhz_winograd_conv3x3", _p(xb), _p(uf), _p(self.convs[i].bias), 1, None, None,
+                  _p(yb), B, H, W, C, K, _stream())
+        _timing_end(ev, B, H, W, C, K, f43)
         return yb
 
     def conv_dgrad(self, i, gb, below_act=None, addend=None):
@@ -114,12 +153,14 @@ class VggEngine:
         applied in the kernel's store, i.e. the result is the gradient w.r.t. the pre-activation of conv i-1."""
         B, KG, H, W, _ = gb.shape
         C, K = CONVS[i]
-        _, ub = self.packed(i, gb.device)
+        f43 = use_f43(B, H, W, K, C)                       # the backward-data form: K input channels, C outputs
+        _, ub = self.packed43(i, gb.device) if f43 else self.packed(i, gb.device)
         dxb = torch.empty((B, C // 8, H, W, 8), device=gb.device, dtype=torch.float32)
         ev = _timing_begin()
-        _lib.call("dhz_winograd_conv3x3", _p(gb), _p(ub), None, 0, _p(below_act) if below_act is not None else None,
+        _lib.call("dhz_winograd43_conv3x3" if f43 else "dhz_winograd_conv3x3", _p(gb), _p(ub), None, 0,
+                  _p(below_act) if below_act is not None else None,
                   _p(addend.contiguous()) if addend is not None else None, _p(dxb), B, H, W, K, C, _stream())
-        _timing_end(ev, B, H, W, K, C)
+        _timing_end(ev, B, H, W, K, C, f43)
         return dxb
 
     # ---- full stack, forward only
@@ -143,7 +184,13 @@ class VggEngine:
                 x12 = to_plain(cur)
                 cur = F.relu(F.conv2d(x12, c12.weight, c12.bias, padding=1))
             else:
-                cur = self.conv(i, cur)
+                # F(4x4,3x3) carries ~3 x the rounding error of F(2x2,3x3) (1.1 - 2.1e-6 rms on O(1) features against 3.7 - 6.7e-7).  Harmless
+                # for feature VALUES (the no-gradient passes over the target and the input, two thirds of the forward work) and for
+                # backward-data products; in the forward pass that is differentiated it would decide the ReLU masks of the backward
+                # pass and flip three times as many near-zero units as F(2x2) does (tests/test_gpu_winograd.py::
+                # test_vgg_engine_backward_smooth_loss pins the gradient to 2e-4 of its maximum: ONE flipped first-layer unit is 1.6e-2)
+                # - that pass stays on F(2x2)
+                cur = self.conv(i, cur, allow43=(save is None))
             acts[i] = cur
             if i in TAPS:
                 taps.append(cur)

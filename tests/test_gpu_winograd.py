@@ -78,6 +78,49 @@ def test_maxpool_blocked(B, C, H):
     assert torch.equal(gx, a.grad * (a.detach() > 0))
 
 
+# F(4x4,3x3) (csrc/winograd43_conv.hip, round 5): the layers of the VGG19 stack it takes (maps of 32 x 32 and more; 64 .. 256 input
+# channels), a 16 x 16 map, a ragged block count - at the SAME tolerances as the F(2x2,3x3) kernel above
+@pytest.mark.parametrize("B,C,K,H", [(2, 64, 64, 32), (1, 64, 128, 64), (2, 128, 128, 32), (1, 128, 256, 32), (1, 256, 256, 32),
+                                     (1, 256, 512, 16), (3, 64, 32, 16), (1, 16, 32, 48), (5, 32, 64, 16)])
+def test_winograd43_forward_and_dgrad(B, C, K, H):
+    from dehaze_hip import _lib
+    dev = torch.device("cuda:0")
+    s = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator().manual_seed(C + K + H)
+    x = torch.randn(B, C, H, H, generator=g).to(dev)
+    w = (torch.randn(K, C, 3, 3, generator=g) * (2.0 / (9 * C)) ** 0.5).to(dev)
+    b = (0.1 * torch.randn(K, generator=g)).to(dev)
+    up = torch.empty(36 * K * C, device=dev)
+    _lib.call("dhz_winograd43_prepack", w.data_ptr(), up.data_ptr(), K, C, 0, s)
+    xb = _blocked(x)
+    yb = torch.empty(B, K // 8, H, H, 8, device=dev)
+    _lib.call("dhz_winograd43_conv3x3", xb.data_ptr(), up.data_ptr(), b.data_ptr(), 1, None, None, yb.data_ptr(), B, H, H, C, K, s)
+    y = _plain(yb, K)
+    ref = F.relu(F.conv2d(x.double(), w.double(), b.double(), padding=1)).float()
+    assert torch.allclose(y, ref, atol=2e-5, rtol=1e-4), (y - ref).abs().max()
+    # without bias / ReLU
+    _lib.call("dhz_winograd43_conv3x3", xb.data_ptr(), up.data_ptr(), None, 0, None, None, yb.data_ptr(), B, H, H, C, K, s)
+    ref0 = F.conv2d(x.double(), w.double(), padding=1).float()
+    assert torch.allclose(_plain(yb, K), ref0, atol=2e-5, rtol=1e-4)
+    if C % 32 == 0:
+        dy = torch.randn(B, K, H, H, generator=g).to(dev)
+        add = torch.randn(B, C, H, H, generator=g).to(dev)
+        upt = torch.empty(36 * K * C, device=dev)
+        _lib.call("dhz_winograd43_prepack", w.data_ptr(), upt.data_ptr(), C, K, 1, s)      # Kout = C (of fwd), Cin = K
+        dxb = torch.empty(B, C // 8, H, H, 8, device=dev)
+        refdx = F.conv_transpose2d(dy.double(), w.double(), padding=1).float()
+        dyb, addb = _blocked(dy), _blocked(add)
+        _lib.call("dhz_winograd43_conv3x3", dyb.data_ptr(), upt.data_ptr(), None, 0, xb.data_ptr(), addb.data_ptr(),
+                  dxb.data_ptr(), B, H, H, K, C, s)
+        want = (refdx + add) * (x > 0)
+        assert torch.allclose(_plain(dxb, C), want, atol=5e-5, rtol=1e-4), (_plain(dxb, C) - want).abs().max()
+        _lib.call("dhz_winograd43_conv3x3", dyb.data_ptr(), upt.data_ptr(), None, 0, None, addb.data_ptr(),
+                  dxb.data_ptr(), B, H, H, K, C, s)
+        assert torch.allclose(_plain(dxb, C), refdx + add, atol=5e-5, rtol=1e-4)
+    lib = _lib.load()
+    assert lib.dhz_winograd43_conv3x3(xb.data_ptr(), up.data_ptr(), None, 0, None, None, yb.data_ptr(), B, 8, 8, C, K, s) == -22
+
+
 @pytest.mark.parametrize("ablation", [False, True])
 def test_contrast_loss_engine_vs_oracle(ablation):
     """ContrastLoss on the Winograd feature engine (128x128 patches) vs the CPU oracle in float64: value, the two L1
@@ -226,3 +269,54 @@ def test_first_vgg_layer_backward_data_from_blocked_gradient(B, H, W):
               torch.cuda.current_stream().cuda_stream)
     ref = F.conv_transpose2d(G.double(), w.double(), padding=1).float()
     assert torch.allclose(dx, ref, atol=1e-4, rtol=1e-4), (dx - ref).abs().max()
+
+
+def test_vgg_engine_f43_dispatch_at_step_size():
+    """The F(4x4,3x3) form inside the feature engine at the training step's sizes (32 restored images with gradient, 64 reference images
+    without): it is taken exactly where dehaze_hip.vgg.use_f43 says - never in the differentiated forward pass (ReLU masks), on the
+    no-gradient pass and the backward-data products when the grid fills the CUs in whole rounds - and the contrastive loss, its two
+    distances and d(loss)/d(restored) agree with the all-F(2x2) engine (DHZ_WINO_F43=0) to rounding."""
+    import warnings
+    import My_CR
+    from dehaze_hip import _lib, vgg as V
+    dev = torch.device("cuda:0")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        cl = My_CR.ContrastLoss().to(dev)
+    g = torch.Generator().manual_seed(3)
+    a0, p, n = (torch.rand(32, 3, 128, 128, generator=g).to(dev) for _ in range(3))
+    calls = []
+    real = _lib.call
+
+    def spy(name, *args):
+        if name in ("dhz_winograd43_conv3x3", "dhz_winograd_conv3x3"):
+            calls.append((name, args[7], args[8], args[10], args[11], args[3] == 0))   # B, H, C, K, backward-data product? (no ReLU)
+        return real(name, *args)
+
+    res = {}
+    old = V.F43_ON
+    try:
+        for on in (False, True):
+            V.F43_ON = on
+            calls.clear()
+            _lib.call = V._lib.call = spy
+            a = a0.clone().requires_grad_()
+            loss, ap, an = cl(a, p, n)
+            loss.backward()
+            _lib.call = V._lib.call = real
+            res[on] = (loss.item(), float(ap), float(an), a.grad.clone(), list(calls))
+    finally:
+        V.F43_ON = old
+        _lib.call = V._lib.call = real
+    off, on = res[False], res[True]
+    assert not any(c[0] == "dhz_winograd43_conv3x3" for c in off[4])
+    f43 = [c for c in on[4] if c[0] == "dhz_winograd43_conv3x3"]
+    assert len(f43) >= 15, len(f43)
+    assert not any(c[1] == 32 and not c[5] for c in f43)                   # never the forward pass of the 32 differentiated images
+    assert any(c[1] == 64 and c[2] == 16 for c in f43)                     # 64 reference images on the 16 x 16 maps: 256 workgroups
+    assert not any(c[1] == 32 and c[2] == 16 for c in f43)                 # 32 images there: half a round - stays on F(2x2)
+    assert abs(on[0] - off[0]) < 2e-5 * abs(off[0]) and abs(on[1] - off[1]) < 2e-5 * off[1] and abs(on[2] - off[2]) < 2e-5 * off[2]
+    d = (on[3] - off[3]).abs()
+    # (same ReLU masks in both runs: the differentiated forward pass is F(2x2) either way; sign(fa - fp) may flip where the reference
+    # features moved by their ~1e-6 rounding difference)
+    assert d.mean().item() < 2e-3 * off[3].abs().mean().item(), (d.mean().item(), off[3].abs().mean().item())
