@@ -160,8 +160,8 @@ def run_config4(dev, steps, warmup):
                             ("dhz_vgg_conv3x3_bf16", "roofline_conv_bf16", "conv3_bf16_kernel<WM,WN> (dhz_vgg_conv3x3_bf16)")):
         ev = timing.get(key) or []
         if ev:
-            ms = sum(a.elapsed_time(b_) for a, b_, _ in ev)
-            flops = sum(f for _, _, f in ev)
+            ms = sum(e[0].elapsed_time(e[1]) for e in ev)
+            flops = sum(e[2] for e in ev)
             tf = flops / (ms * 1e-3) / 1e12
             out[name] = {"kernel": kern, "bound": "mfma", "achieved": round(tf, 1), "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s",
                          "frac": round(tf / MFMA_BF16_PEAK_TF, 4), "traffic": None, "launches": len(ev),
