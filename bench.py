@@ -345,8 +345,8 @@ def main():
             # config 4: the token-Linear GEMMs on v_mfma_f32_16x16x32_bf16 (forward + backward-data launches), against the dense
             # bf16 matrix peak; most of their shapes are HBM-bound at bf16 MFMA rates, so the HBM view is given beside it
             ev = timing["dhz_linear_bf16"]
-            ms = sum(a.elapsed_time(b_) for a, b_, _ in ev)
-            flops = sum(f for _, _, f in ev)
+            ms = sum(e[0].elapsed_time(e[1]) for e in ev)
+            flops = sum(e[2] for e in ev)
             tf = flops / (ms * 1e-3) / 1e12
             out["roofline"] = {"kernel": "gemm_bf16_pipe_kernel<2,NTS> / gemm_bf16_kernel<WM,WN,BTR> (dhz_linear_fwd_bf16 / dhz_linear_dgrad_bf16; backward-data mostly as the forward kernel on the bf16 copy of W^T)", "bound": "mfma",
                                "achieved": round(tf, 1), "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s",
@@ -356,8 +356,8 @@ def main():
             # config 4: the VGG19 convolutions of the contrastive loss as implicit GEMMs on the bf16 matrix pipe (direct-convolution
             # FLOPs, nothing skipped); LDS bandwidth caps this tiling near 0.5 of the dense peak
             ev = timing["dhz_vgg_conv3x3_bf16"]
-            ms = sum(a.elapsed_time(b_) for a, b_, _ in ev)
-            flops = sum(f for _, _, f in ev)
+            ms = sum(e[0].elapsed_time(e[1]) for e in ev)
+            flops = sum(e[2] for e in ev)
             tf = flops / (ms * 1e-3) / 1e12
             out["roofline_conv_bf16"] = {"kernel": "conv3_bf16_kernel<WM,WN> (dhz_vgg_conv3x3_bf16)", "bound": "mfma",
                                          "achieved": round(tf, 1), "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s",
@@ -382,7 +382,7 @@ def main():
         if timing and timing.get("dhz_ps_attn_fwd"):
             # the stand-alone ProbSparse core (stages the fused kernel does not cover): HBM-bound, 32 KiB / window-head
             ev = timing["dhz_ps_attn_fwd"]
-            ms = sum(a.elapsed_time(b) for a, b, _ in ev)
+            ms = sum(e[0].elapsed_time(e[1]) for e in ev)
             bytes_alg = sum(n for _, _, n in ev)          # Q, K, V in + context out per window-head: 4 * 64 * d * element size
             gbs = bytes_alg / (ms * 1e-3) / 1e9
             traffic = pmc.get("ps_attn_fwd_kernel<32>", {}).get("hbm_bytes_per_launch") if args.dtype == "f32" and args.embed_dim == 32 else None
@@ -422,8 +422,8 @@ def main():
             if ev:
                 # condition (v) of the round-3 ruling: a split kernel is priced on the bf16 FLOPs it ISSUES (six MFMA products per
                 # multiply-add) against the dense bf16 matrix peak - never against the fp32 pipe's 157.3
-                ms = sum(a.elapsed_time(b_) for a, b_, _ in ev)
-                flops = sum(f for _, _, f in ev)
+                ms = sum(e[0].elapsed_time(e[1]) for e in ev)
+                flops = sum(e[2] for e in ev)
                 tf = flops / (ms * 1e-3) / 1e12
                 out[name] = {"kernel": kern, "bound": "mfma", "achieved": round(tf, 1), "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s",
                              "frac": round(tf / MFMA_BF16_PEAK_TF, 4), "flops_counted": "issued bf16 MFMA FLOPs = 6 x algorithmic",

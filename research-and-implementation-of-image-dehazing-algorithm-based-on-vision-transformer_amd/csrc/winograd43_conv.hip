@@ -3,25 +3,34 @@
 // 1.78 x fewer v_mfma_f32_16x16x4_f32 on the same fp32 matrix pipe.
 //
 // Accuracy (profiles/r05_winograd_f43_error_table.txt).  F(4x4) in fp32 with the textbook points (0, +-1, +-2) is 10 x less accurate than
-// F(2x2) and fails the kernel-level tolerance of tests/test_gpu_winograd.py; two measures bring it to ~2 x F(2x2)'s error:
+// F(2x2) and fails the kernel-level tolerance of tests/test_gpu_winograd.py; two measures bring it to ~3 x F(2x2)'s error:
 //   * interpolation points (0, +-3/4, +-3/2, inf): every constant of B^T and A^T is a dyadic rational, the transforms' amplification
 //     is the smallest of the symmetric sets searched (symmetric: B^T d shares the even / odd parts between +-p: 14 packed
 //     operations per 6-point transform);
-//   * the error is dominated by the fp32 ACCUMULATION over input channels of transform-domain values that are larger than the
-//     outputs: every FLUSH_GROUPS channel groups (128 channels) the accumulators are taken through A^T . A into a second, output-
-//     domain accumulator and restart from zero;
+//   * (the remaining error is dominated by the fp32 ACCUMULATION over input channels of transform-domain values that are larger
+//     than the outputs; a flush of the accumulators through A^T . A every 128 channels halves it - measured on the first form of this
+//     kernel - but does not fit the registers of this one);
 //   * the frozen filters are transformed once (G g G^T in double, rounded once).
 //
-// Structure (it differs from the F(2x2) kernel because 36 positions x 16 tiles x 32 output channels = 288 accumulator registers do
-// not leave room for anything else): 256 threads, ONE wave per SIMD with the whole register file; a wave owns a 16 x 16-pixel
-// output block (16 tiles of 4 x 4) x 16 output channels for all 36 positions (144 accumulators + 64 output-domain ones).  Lane
-// (tile i16, channel pair g) transforms ITS OWN tile for ITS OWN two channels, and the MFMA contraction index of lane group g at
-// step s is channel 2 g + s - so the 36 x 2 transformed values a lane computes ARE its B operands: the transformed input never
-// leaves the registers (two sets: one feeds the MFMAs of channel group cb while the other receives the transform of cb + 1).
-// The four waves of a workgroup take four blocks and share the filter slice (16 k x 8 c x 36 positions = 18 KiB per group).
-// Both operands arrive by LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write): the filter slices into a
-// three-slot ring (one barrier per group, placed inside the MFMA stream), the 18 x 18-pixel halo patch of a wave into its own
-// two-slot ring; out-of-image pixels are slots zeroed once that no DMA lane ever writes.
+// Structure.  36 positions x 16 tiles x 32 output channels = 288 accumulator registers: 256 threads, ONE wave per SIMD with the whole
+// register file (256 accumulators in the AGPR half, the rest with everything else in the VGPR half).  A wave owns a 16 x 16-pixel
+// output block (16 tiles of 4 x 4) x 32 output channels for all 36 positions.  Lane (tile i16, channel pair g) transforms ITS OWN tile
+// for ITS OWN two channels, and the MFMA contraction index of lane group g at step s is channel 2 g + s - so the 36 x 2 transformed
+// values a lane computes ARE its B operands: the transformed input never leaves the registers.  Per group of 8 input channels:
+//   (1) transform phase: 36 ds_read_b64 of the lane's 6 x 6 window, B^T d B as 12 six-point transforms of 14 packed operations;
+//   (2) matrix phase: 144 MFMAs (A fragments: one ds_read_b128 per position pair and output-channel half); between them the LDS-DMA
+//       requests of the NEXT group, one per MFMA quad (issued back to back they queue in the address unit: 100 cycles each).
+// The phases are sequential on purpose: vector and fp32 matrix instructions of one wave do not overlap on this part (the first
+// form of this kernel - 16 output channels per wave, the transform of group cb + 1 interleaved with the MFMAs of cb through two
+// register sets - measured its transform and its DMA issue as ADDED to the matrix time and lost to F(2x2); what pays is the ratio:
+// 32 output channels per wave halve the vector work and the operand bytes per MFMA).
+// The four waves of a workgroup take four blocks and share the filter slice (32 k x 8 c x 36 positions = 36 KiB per group) through a
+// two-slot ring (one barrier per group, between the phases); a wave's 18 x 18-pixel halo patch has ONE slot (it is rewritten by DMA during
+// the matrix phase, after the transform has read it); out-of-image pixels are slots zeroed once that no DMA lane ever writes.
+// Rounding: no mid-stream flush fits the register file at this tile (an output-domain accumulator is 128 more registers): with the
+// points above the error is 1.1e-6 rms at 64 input channels .. 2.9e-6 at 512 on O(1) outputs (F(2x2): 3.7e-7 .. 9.4e-7), 0.26 - 0.6
+// of the kernel tolerance on the tested shapes; dehaze_hip/vgg.py therefore keeps the DIFFERENTIATED forward pass on F(2x2) (its
+// roundings decide the ReLU masks of the backward pass) and uses this kernel for the no-gradient passes and the backward-data products.
 #include <stdlib.h>
 #include <type_traits>
 #include "common.h"
@@ -42,6 +51,7 @@ constexpr int NXI = 36;             // transform positions
 constexpr int UF = NXI * CC * KB;   // floats of one (kb, cb) filter slice: 9216 = 36 KiB = 36 DMA runs of 1 KiB
 constexpr int NUBUF = 2;
 constexpr int URUNS = UF / 256;     // 36: nine per wave
+static_assert(URUNS / 4 == 9, "the counted wait at the end of a group (vmcnt(9)) leaves exactly a wave's filter requests in flight");
 // halo patch of a wave: 18 x 18 pixels x 8 channels as 16-byte chunks (4 channels of one pixel), plane hf = channels 4 hf .. 4 hf + 3:
 //   chunk(hf, row, px) = hf * PLANE + row * 18 + px + (row >> 2)
 // the one-chunk skew per four rows makes the ds_read_b64 of the 64 lanes (tile rows 4 ty + a, tile columns 4 tx + p, channel pair g)
@@ -179,6 +189,7 @@ __global__ __launch_bounds__(256, 1) void winograd43_conv3x3_kernel(const float*
 #pragma unroll
                 for (int b = 0; b < 6; ++b) v[a][b] = f32x2{1.f, 1.f};
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // my runs of filter slice cb have landed
         __syncthreads();
         const bool next = cb + 1 < CBn;
         const float* up = ufrag + (cb & 1) * UF;
@@ -200,7 +211,10 @@ __global__ __launch_bounds__(256, 1) void winograd43_conv3x3_kernel(const float*
                 acc[xi + 1][1] = mfma16(ahi[2], v1[0], acc[xi + 1][1]);
             }
             __builtin_amdgcn_sched_barrier(0);
-            if (next && j < URUNS / 4) dma_u_run(cb + 1, j);
+            // the next patch first (two requests per pair-step: it is needed as soon as this group ends), the next filter slice behind it
+            // (needed one transform phase later: the wait at the end of the group leaves those nine requests in flight)
+            if (next && 2 * j < PRUNS) dma_patch_run(cb + 1, 2 * j);
+            if (next && j >= 6 && j - 6 < URUNS / 4) dma_u_run(cb + 1, j - 6);
             __builtin_amdgcn_sched_barrier(0);
             if (!(W43_ABL & 4)) {
                 acc[xi][0] = mfma16(alo[1], v0[1], acc[xi][0]);
@@ -209,11 +223,11 @@ __global__ __launch_bounds__(256, 1) void winograd43_conv3x3_kernel(const float*
                 acc[xi + 1][1] = mfma16(ahi[3], v1[1], acc[xi + 1][1]);
             }
             __builtin_amdgcn_sched_barrier(0);
-            if (next && j < PRUNS) dma_patch_run(cb + 1, j);
+            if (next && 2 * j + 1 < PRUNS) dma_patch_run(cb + 1, 2 * j + 1);
             __builtin_amdgcn_sched_barrier(0);
             alo = nlo; ahi = nhi;
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the next patch and my runs of the next filter slice have landed
+        asm volatile("s_waitcnt vmcnt(9)" ::: "memory");          // the next patch has landed (my nine filter requests may still be in flight)
     }
 
     // ---- epilogue: Y = A^T M A per (k half, accumulator row); lane (tile i16, g) holds output channels 16 kh + 4 g .. + 3 of its 4 x 4 pixels
