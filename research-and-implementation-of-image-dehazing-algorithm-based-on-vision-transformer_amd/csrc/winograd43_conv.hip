@@ -183,6 +183,11 @@ __global__ __launch_bounds__(256, 1) void winograd43_conv3x3_kernel(const float*
             for (int b = 0; b < 6; ++b) bt6(v[0][b], v[1][b], v[2][b], v[3][b], v[4][b], v[5][b]);
 #pragma unroll
             for (int a = 0; a < 6; ++a) bt6(v[a][0], v[a][1], v[a][2], v[a][3], v[a][4], v[a][5]);
+            // pin the transform HERE, as one dense block with six independent chains to interleave: left alone LLVM sinks each row to its
+            // first use inside the matrix phase, where every vector instruction delays the next MFMA (2200 cycles per group measured)
+#pragma unroll
+            for (int a = 0; a < 6; ++a)
+                asm volatile("" : "+v"(v[a][0]), "+v"(v[a][1]), "+v"(v[a][2]), "+v"(v[a][3]), "+v"(v[a][4]), "+v"(v[a][5]));
         } else {
 #pragma unroll
             for (int a = 0; a < 6; ++a)
