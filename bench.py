@@ -112,6 +112,50 @@ def load_pmc_traffic(path, build_id):
     return {k: v for k, v in pmc.items() if not k.startswith("_")}, f"{name} (rocprofv3 --pmc passes of library build {build_id})"
 
 
+def live_pmc_traffic(extra_args, timeout_s=240):
+    """HBM bytes per launch measured IN THIS RUN: two child processes of this same script (2 + 2 steps, nothing but the headline) under
+    `rocprofv3 --pmc FETCH_SIZE` and `rocprofv3 --pmc WRITE_SIZE` - separate passes, no trace domain beside the counters, the interpreter
+    itself behind `--` - summarised as tools/pmc_summary.py does (FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md, KiB
+    units, WRITE_SIZE exact).  Returns (table, source) or ({}, reason)."""
+    import collections
+    import csv
+    import glob
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None:
+        return {}, "rocprofv3 not on this box"
+    tmp = tempfile.mkdtemp(prefix="dhz_pmc_", dir="/tmp")
+    agg = {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, counter)
+            cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__), "--steps", "2",
+                   "--warmup", "2", "--no-cpu-baseline", "--no-kernel-timing", "--no-fp32-pipe", "--no-config4", "--no-live-traffic"] + extra_args
+            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=timeout_s)
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return {}, f"rocprofv3 --pmc {counter} pass failed (rc {r.returncode}): {(r.stderr or '')[-200:].strip()}"
+            per = collections.defaultdict(list)
+            for row in csv.DictReader(open(files[0])):
+                if row["Counter_Name"] == counter:
+                    per[re.sub(r"\(anonymous namespace\)::|^void ", "", row["Kernel_Name"]).split("(")[0]].append(float(row["Counter_Value"]))
+            agg[counter] = per
+    except Exception as e:                                   # a profiler hiccup must never cost the bench line
+        return {}, f"live PMC passes failed ({type(e).__name__}: {e})"
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    table = {}
+    for k, vals in agg["FETCH_SIZE"].items():
+        rd = 2.0 * sum(vals) / len(vals) * 1024.0
+        wv = agg["WRITE_SIZE"].get(k) or [0.0]
+        wr = sum(wv) / len(wv) * 1024.0
+        table[k] = {"launches": len(vals), "read_bytes_per_launch": rd, "write_bytes_per_launch": wr, "hbm_bytes_per_launch": rd + wr}
+    return table, "measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, two child passes of this command (2 + 2 steps)"
+
+
 def run_config4(dev, steps, warmup):
     """BASELINE configs[3] on the driver's clock: E=64, ps=256, per-GPU bs=8, bf16 activations + bf16 weight copies with fp32
     accumulation / master weights, Charbonnier + CR + AdamW.  Same step function, same timing discipline as the headline; the
@@ -193,6 +237,8 @@ def main():
     ap.add_argument("--reserve-cus", type=int, default=None,
                     help="CUs the persistent compute grids leave free (dhz_set_reserved_cus).  N > 1: for RCCL's kernels beside the backward "
                          "pass (default: DHZ_COMM_RESERVE_CUS or 0).  N = 1: applied as given - measures what a reservation costs the step")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="do not measure `roofline.traffic` with two rocprofv3 --pmc child passes; use the stamped profiles/pmc_traffic.json")
     ap.add_argument("--no-fp32-pipe", action="store_true",
                     help="skip the second measurement of the same step on the fp32 matrix pipe (the `fp32_pipe` object)")
     args = ap.parse_args()
@@ -340,6 +386,13 @@ def main():
                                "measured": "ring time is the plan's figure, not a measurement"}
         build_id = _lib.load().dhz_build_id().decode()
         pmc, traffic_source = load_pmc_traffic(os.path.join(ROOT, "profiles", "pmc_traffic.json"), build_id)
+        if world == 1 and timing and not args.no_live_traffic and args.dtype == "f32":
+            extra = ["--batch", str(args.batch), "--embed_dim", str(args.embed_dim), "--ps", str(args.ps)] + (["--no-cr"] if args.no_cr else [])
+            live, why = live_pmc_traffic(extra)
+            if live:
+                pmc, traffic_source = live, why
+            else:
+                traffic_source = f"{traffic_source} (live passes: {why})"
         out["library_build_id"] = build_id
         if timing and timing.get("dhz_linear_bf16"):
             # config 4: the token-Linear GEMMs on v_mfma_f32_16x16x32_bf16 (forward + backward-data launches), against the dense
@@ -385,7 +438,8 @@ def main():
             ms = sum(e[0].elapsed_time(e[1]) for e in ev)
             bytes_alg = sum(n for _, _, n in ev)          # Q, K, V in + context out per window-head: 4 * 64 * d * element size
             gbs = bytes_alg / (ms * 1e-3) / 1e9
-            traffic = pmc.get("ps_attn_fwd_kernel<32>", {}).get("hbm_bytes_per_launch") if args.dtype == "f32" and args.embed_dim == 32 else None
+            traffic = next((v["hbm_bytes_per_launch"] for k, v in pmc.items() if k.startswith("ps_attn_fwd_kernel<32")), None) \
+                if args.dtype == "f32" and args.embed_dim == 32 else None
             entry = {"kernel": "ps_attn_fwd_kernel<d,T> (dhz_ps_attn_fwd)", "bound": "hbm", "achieved": round(gbs, 1),
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
                      "traffic": round(traffic) if traffic else None, "traffic_source": traffic_source, "launches": len(ev),
