@@ -250,6 +250,11 @@ int dhz_linear_dgrad_bf16(const void* dy, int ldy, const void* w, void* dx, int 
 int dhz_linear_wgrad_bf16(const void* dy, int ldy, const void* x, int ldx, int T, int nmat, int nper, int K,
                           float* const* dw, float* const* db, void* stream);
 
+/* K5b Mlp activation (token_mlp = 'ffn', My_model_1.py:442-468 - the constructor default of Uformer; options.py selects 'leff'): y = GELU(u)
+ *     (exact-erf form) over n elements; backward du = dy * GELU'(u) * scale[e / elems_per_scale] (scale NULL = 1: the per-image DropPath
+ *     factor of the branch folded in).  Replaces aten::gelu / aten::gelu_backward between the two token Linears. */
+int dhz_gelu_fwd_dt(const void* u, void* y, int64_t n, int dtype, void* stream);
+int dhz_gelu_bwd_dt(const void* dy, const void* u, void* du, int64_t n, const float* scale, int64_t elems_per_scale, int dtype, void* stream);
 /* dtype-generic forms (dtype = DHZ_F32 / DHZ_BF16 storage of the token tensors, fp32 arithmetic inside) of the streaming
  * kernels around the GEMMs; argument meaning as the fp32 entry points of the same name. */
 int dhz_ln_partition_fwd_dt(const void* x, const float* gamma, const float* beta, void* xw, float* stats, int B, int Hres,

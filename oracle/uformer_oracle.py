@@ -186,6 +186,11 @@ def leff(x, P, pre):
     return F.linear(h, P[pre + "linear2.0.weight"], P[pre + "linear2.0.bias"])
 
 
+def mlp_ffn(x, P, pre):
+    """Mlp.forward - M1:456-468 (token_mlp = 'ffn'): fc1 -> GELU -> fc2 (the Dropouts are identities at drop_rate 0)."""
+    return F.linear(F.gelu(F.linear(x, P[pre + "fc1.weight"], P[pre + "fc1.bias"])), P[pre + "fc2.weight"], P[pre + "fc2.bias"])
+
+
 def _drop_path(x, p, training):
     """timm DropPath semantics: per-sample keep mask, scaled by 1/keep."""
     if p == 0.0 or not training:
@@ -227,7 +232,8 @@ def lewin_block(x, P, pre, heads, win=8, shift=0, variant="probsparse", idx=None
     if shift > 0:
         y = torch.roll(y, shifts=(shift, shift), dims=(1, 2))
     x = shortcut + _drop_path(y.reshape(B, L, C), drop_path, training)
-    z = leff(F.layer_norm(x, (C,), P[pre + "norm2.weight"], P[pre + "norm2.bias"], 1e-5), P, pre + "mlp.")
+    xn2 = F.layer_norm(x, (C,), P[pre + "norm2.weight"], P[pre + "norm2.bias"], 1e-5)
+    z = mlp_ffn(xn2, P, pre + "mlp.") if (pre + "mlp.fc1.weight") in P else leff(xn2, P, pre + "mlp.")      # M1:778-779
     return x + _drop_path(z, drop_path, training)
 
 

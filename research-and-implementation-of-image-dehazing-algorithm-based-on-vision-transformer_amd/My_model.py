@@ -3,7 +3,7 @@
 state_dict matches the reference's dense checkpoints.  Every class exported here defaults to the dense
 attention kernel (dhz_dense_attn_fwd/bwd)."""
 from dehaze_hip import model as _m
-from dehaze_hip.model import (Downsample, DropPath, InputProj, LeFF, LinearProjection, OutputProj, Upsample,  # noqa: F401
+from dehaze_hip.model import (Downsample, DropPath, InputProj, LeFF, LinearProjection, Mlp, OutputProj, Upsample,  # noqa: F401
                               to_2tuple, trunc_normal_, window_partition, window_reverse)
 from dehaze_hip.unet import UNet  # noqa: F401
 

@@ -1,7 +1,7 @@
 """Drop-in for the reference's Uformer_ProbSparse/My_model_1.py (the model `utils.get_arch` builds,
 model_utils.py:81): ProbSparse window attention Uformer on the MI355X HIP kernels.  Same constructor
 signature (M1:961-967), module tree, parameter order and state_dict keys as the reference."""
-from dehaze_hip.model import (AttentionLayer, BasicUformerLayer, Downsample, DropPath, InputProj, LeFF,  # noqa: F401
+from dehaze_hip.model import (AttentionLayer, BasicUformerLayer, Downsample, DropPath, InputProj, LeFF, Mlp,  # noqa: F401
                               LeWinTransformerBlock, LinearProjection, OutputProj, ProbAttention, Upsample,
                               WindowAttention, to_2tuple, trunc_normal_, window_partition, window_reverse)
 from dehaze_hip.model import Uformer as _Uformer

@@ -597,6 +597,29 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
     }
 }
 
+// Mlp's activation (M1:442-468, token_mlp = 'ffn': fc1 -> GELU -> fc2): y = gelu(u) and, for the backward pass, du = dy * gelu'(u) * scale
+// with the DropPath factor of the image the token belongs to (scale[t / rows_per_scale], or 1).  Exact-erf GELU as everywhere (common.h).
+template <typename T>
+__global__ __launch_bounds__(256) void gelu_fwd_kernel(const T* __restrict__ u, T* __restrict__ y, int64_t n4) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const float4 v = ld4(u + 4 * i);
+        f32x4 g, gp;
+        gelu_both4(f32x4{v.x, v.y, v.z, v.w}, g, gp);
+        st4(y + 4 * i, make_float4(g[0], g[1], g[2], g[3]));
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void gelu_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ u, T* __restrict__ du, int64_t n4,
+                                                       const float* __restrict__ scale, int64_t quads_per_scale) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const float4 v = ld4(u + 4 * i), d = ld4(dy + 4 * i);
+        f32x4 g, gp;
+        gelu_both4(f32x4{v.x, v.y, v.z, v.w}, g, gp);
+        const float sc = scale ? scale[i / quads_per_scale] : 1.f;
+        st4(du + 4 * i, make_float4(d.x * gp[0] * sc, d.y * gp[1] * sc, d.z * gp[2] * sc, d.w * gp[3] * sc));
+    }
+}
+
 inline int grid_for(int64_t work_items, int per_block = 256, int cap = 256 * 8) {
     int64_t g = (work_items + per_block - 1) / per_block;
     if (g < 1) g = 1;
@@ -740,6 +763,24 @@ extern "C" int dhz_reverse_residual_bwd_dt(const void* dout, const float* scale,
 extern "C" int dhz_reverse_residual_bwd(const float* dout, const float* scale, float* dyw, int B, int Hres, int Wres,
                                         int C, int shift, int partition, void* stream) {
     return dhz_reverse_residual_bwd_dt(dout, scale, dyw, B, Hres, Wres, C, shift, partition, DHZ_F32, stream);
+}
+
+extern "C" int dhz_gelu_fwd_dt(const void* u, void* y, int64_t n, int dtype, void* stream) {
+    DHZ_REQUIRE(u && y && n > 0 && n % 4 == 0, "dhz_gelu_fwd: bad arguments (n must be a multiple of 4)");
+    DT_SWITCH(dtype, "dhz_gelu_fwd", hipLaunchKernelGGL((gelu_fwd_kernel<T>), dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream,
+                                                        (const T*)u, (T*)y, n / 4));
+    DHZ_CHECK_LAUNCH("dhz_gelu_fwd");
+    return DHZ_OK;
+}
+extern "C" int dhz_gelu_bwd_dt(const void* dy, const void* u, void* du, int64_t n, const float* scale, int64_t elems_per_scale, int dtype,
+                               void* stream) {
+    DHZ_REQUIRE(dy && u && du && n > 0 && n % 4 == 0, "dhz_gelu_bwd: bad arguments (n must be a multiple of 4)");
+    DHZ_REQUIRE(!scale || (elems_per_scale > 0 && elems_per_scale % 4 == 0 && n % elems_per_scale == 0),
+                "dhz_gelu_bwd: elems_per_scale=%lld must be a multiple of 4 that divides n", (long long)elems_per_scale);
+    DT_SWITCH(dtype, "dhz_gelu_bwd", hipLaunchKernelGGL((gelu_bwd_kernel<T>), dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream,
+                                                        (const T*)dy, (const T*)u, (T*)du, n / 4, scale, scale ? elems_per_scale / 4 : 1));
+    DHZ_CHECK_LAUNCH("dhz_gelu_bwd");
+    return DHZ_OK;
 }
 
 extern "C" int dhz_leff_dwconv_fwd_dt(const void* u, const float* w, const float* b, void* t, void* z, int B, int Hres,

@@ -21,6 +21,8 @@ SIGNATURES = {
     "dhz_last_error": [],
     "dhz_build_id": [],
     "dhz_set_reserved_cus": [ctypes.c_int],
+    "dhz_gelu_fwd_dt": [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p],
+    "dhz_gelu_bwd_dt": [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p],
     "dhz_get_reserved_cus": [],
     "dhz_grid_cus": [],
     "dhz_ps_attn_fwd": [c_f, c_f, c_f, c_i, c_p, c_f, c_f, c_f, c_i, c_p, c_i, c_i, c_i, c_i, c_p],

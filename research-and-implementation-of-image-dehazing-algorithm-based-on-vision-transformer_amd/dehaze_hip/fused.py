@@ -410,6 +410,64 @@ class _LeffBranch(Function):
         return (dx, dgamma, dbeta, g_w1, g_b1, g_wd, g_bd, g_w2, g_b2, None, None, None, None)
 
 
+class _FfnBranch(Function):
+    """out = x + drop_scale * fc2(gelu(fc1(LayerNorm(x))))        (M1:873 with token_mlp = 'ffn': M1:442-468)
+    forward : dhz_ln_partition_fwd (plain LN) -> GEMM -> dhz_gelu_fwd -> GEMM -> dhz_reverse_residual_fwd (token order)
+    backward: the mirror sequence, weight gradients in place, the DropPath factor folded into fc2's weight gradient (row scale) and
+              into dhz_gelu_bwd, the shortcut gradient folded into the LayerNorm backward."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, w1, b1, w2, b2, dscale, grad_mode):
+        _require_gpu(x, gamma, beta, w1, w2, dscale)
+        x = x.contiguous()
+        B, L, C = x.shape
+        T = B * L
+        dev = x.device
+        xn = torch.empty((T, C), device=dev, dtype=x.dtype)
+        stats = torch.empty((T, 2), device=dev, dtype=torch.float32)
+        _lib.call("dhz_ln_partition_fwd_dt", _p(x), _p(gamma), _p(beta), _p(xn), _p(stats), B, L, 1, C, 0, 0, ops._dt(x), _stream())
+        u = ops.gemm_fwd(xn, w1, b1)
+        z = torch.empty_like(u)
+        _lib.call("dhz_gelu_fwd_dt", _p(u), _p(z), u.numel(), ops._dt(u), _stream())
+        y = ops.gemm_fwd(z, w2, b2)
+        out = torch.empty_like(x)
+        _lib.call("dhz_reverse_residual_fwd_dt", _p(y), _p(x), _p(dscale), _p(out), B, L, 1, C, 0, 0, ops._dt(x), _stream())
+        if grad_mode and any(ctx.needs_input_grad):
+            ctx.save_for_backward(x, gamma, stats, xn, u, z, dscale, w1, w2)
+            ctx.params = (w1, b1, w2, b2, gamma, beta)
+            ctx.geom = (B, L, C)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, gamma, stats, xn, u, z, dscale, w1_, w2_ = ctx.saved_tensors
+        w1, b1, w2, b2, gamma_p, beta_p = ctx.params
+        B, L, C = ctx.geom
+        T = B * L
+        Ch = u.shape[1]
+        dout = dout.contiguous()
+        fold = dscale is not None and dout.dtype == torch.float32 and L % 32 == 0
+        if dscale is not None and not fold:
+            dy = torch.empty((T, C), device=x.device, dtype=dout.dtype)
+            _lib.call("dhz_reverse_residual_bwd_dt", _p(dout), _p(dscale), _p(dy), B, L, 1, C, 0, 0, ops._dt(dout), _stream())
+        else:
+            dy = dout.view(T, C)
+        dz = ops.gemm_dgrad(dy, w2_)
+        g_w2, g_b2 = _wgrad(dy, 0, z, w2, b2, (dscale, L) if fold else None)
+        du = torch.empty_like(u)
+        _lib.call("dhz_gelu_bwd_dt", _p(dz), _p(u), _p(du), u.numel(), _p(dscale) if fold else None, L * Ch if fold else 0, ops._dt(u),
+                  _stream())
+        dxn = ops.gemm_dgrad(du, w1_)
+        g_w1, g_b1 = _wgrad(du, 0, xn, w1, b1)
+        dx, dgamma, dbeta = _ln_backward(dxn, x, gamma_p, beta_p, gamma, stats, dout, B, L, 1, C, 0, 0)
+        return (dx, dgamma, dbeta, g_w1, g_b1, g_w2, g_b2, None, None)
+
+
+def ffn_branch(x, norm, mlp, dscale):
+    return _FfnBranch.apply(x, norm.weight, norm.bias, mlp.fc1.weight, mlp.fc1.bias, mlp.fc2.weight, mlp.fc2.bias, dscale,
+                            torch.is_grad_enabled())
+
+
 def leff_branch(x, norm, mlp, dscale, Hres, Wres):
     return _LeffBranch.apply(x, norm.weight, norm.bias, mlp.linear1[0].weight, mlp.linear1[0].bias,
                              mlp.dwconv[0].weight, mlp.dwconv[0].bias, mlp.linear2[0].weight, mlp.linear2[0].bias,

@@ -204,6 +204,27 @@ class WindowAttention(nn.Module):
 
 # ----------------------------------------------------------------------------- feed-forward
 
+class Mlp(nn.Module):
+    """M1:442-468 (token_mlp = 'ffn', the constructor default of Uformer; options.py selects 'leff'): fc1 -> GELU -> fc2; the two
+    Dropouts are identities at the model's drop_rate = 0 (kept for the attribute names)."""
+
+    def __init__(self, in_features, hidden_features=None, out_features=None, act_layer=nn.GELU, drop=0.):
+        super().__init__()
+        out_features = out_features or in_features
+        hidden_features = hidden_features or in_features
+        self.fc1 = nn.Linear(in_features, hidden_features)
+        self.act = act_layer()
+        self.fc2 = nn.Linear(hidden_features, out_features)
+        self.drop = nn.Dropout(drop)
+        self.in_features, self.hidden_features, self.out_features = in_features, hidden_features, out_features
+
+    def forward(self, x):
+        B, L, C = x.shape
+        u = ops.linear_tokens(x.reshape(B * L, C), self.fc1.weight, self.fc1.bias)
+        z = ops.gelu_tokens(u)
+        return ops.linear_tokens(z, self.fc2.weight, self.fc2.bias).view(B, L, self.out_features)
+
+
 class LeFF(nn.Module):
     """M1:477-534.  Linear+GELU -> depthwise3x3+GELU -> Linear; the middle stage runs in token (NHWC)
     layout in one HIP kernel, so neither GELU nor the NCHW rearranges touch HBM."""
@@ -234,8 +255,8 @@ class LeWinTransformerBlock(nn.Module):
                  qk_scale=None, drop=0., attn_drop=0., drop_path=0., act_layer=nn.GELU, norm_layer=nn.LayerNorm,
                  token_projection='linear', token_mlp='leff', se_layer=False, variant="probsparse"):
         super().__init__()
-        if token_mlp != 'leff':
-            raise NotImplementedError("only token_mlp='leff' is on the accelerated path (options.py default)")
+        if token_mlp not in ('leff', 'ffn'):
+            raise Exception("FFN error!")                                   # M1:780-781
         self.dim, self.input_resolution, self.num_heads = dim, input_resolution, num_heads
         self.win_size, self.shift_size, self.mlp_ratio, self.token_mlp = win_size, shift_size, mlp_ratio, token_mlp
         if min(self.input_resolution) <= self.win_size:                     # M1:764-766
@@ -248,7 +269,8 @@ class LeWinTransformerBlock(nn.Module):
                                     token_projection=token_projection, se_layer=se_layer, variant=variant)
         self.drop_path = DropPath(drop_path) if drop_path > 0. else nn.Identity()
         self.norm2 = norm_layer(dim)
-        self.mlp = LeFF(dim, int(dim * mlp_ratio), act_layer=act_layer, drop=drop)
+        self.mlp = Mlp(in_features=dim, hidden_features=int(dim * mlp_ratio), act_layer=act_layer, drop=drop) if token_mlp == 'ffn' \
+            else LeFF(dim, int(dim * mlp_ratio), act_layer=act_layer, drop=drop)                              # M1:778-779
         self._mask_cache = {}
         self._staged_idx = None      # set by Uformer.forward (one batched host draw per model forward)
         self._staged_scales = None   # set by Uformer.forward on the GPU: the two DropPath vectors of this block
@@ -299,6 +321,9 @@ class LeWinTransformerBlock(nn.Module):
             xw = ops.ln_partition(x, self.norm1.weight, self.norm1.bias, H, W, self.shift_size)   # LN+roll+partition
             aw = self.attn(xw.view(-1, self.win_size * self.win_size, C), mask=attn_mask, idx=idx)
             x = ops.reverse_residual(aw.reshape(-1, C), x, self._scale(x), H, W, self.shift_size)  # reverse+unroll+res
+        if self.token_mlp == 'ffn':
+            # Mlp branch (norm2 -> fc1 -> GELU -> fc2 -> residual) as one autograd node
+            return fused.ffn_branch(x, self.norm2, self.mlp, self._scale(x))
         # LeFF branch (norm2 -> linear1 -> dwconv -> linear2 -> residual) as one autograd node
         return fused.leff_branch(x, self.norm2, self.mlp, self._scale(x), H, W)
 

@@ -666,6 +666,31 @@ class _LinearTokens(Function):
         return (dx,) + tuple(grads)
 
 
+class _GeluTokens(Function):
+    """GELU between the two Linears of Mlp (M1:460-461) on dhz_gelu_fwd / dhz_gelu_bwd."""
+
+    @staticmethod
+    def forward(ctx, u):
+        _require_gpu(u)
+        u = u.contiguous()
+        y = torch.empty_like(u)
+        _lib.call("dhz_gelu_fwd_dt", _p(u), _p(y), u.numel(), _dt(u), _stream())
+        ctx.save_for_backward(u)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (u,) = ctx.saved_tensors
+        dy = dy.contiguous()
+        du = torch.empty_like(u)
+        _lib.call("dhz_gelu_bwd_dt", _p(dy), _p(u), _p(du), u.numel(), None, 0, _dt(u), _stream())
+        return du
+
+
+def gelu_tokens(u):
+    return _GeluTokens.apply(u)
+
+
 def linear_tokens(x, *wb):
     """x [T,K] (contiguous); wb = W1, b1, W2, b2, ...  ->  [T, sum N_i]."""
     if not torch.is_grad_enabled() or not any(t is not None and t.requires_grad for t in (x,) + wb):

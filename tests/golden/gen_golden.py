@@ -210,6 +210,8 @@ WIDE_BLOCKS = {     # name -> (C, heads, map side, shift): the widths whose bloc
     # 16 wide) and its last decoder stage (C = 32 as TWO heads of 16)
     "block_m1_c16_shift4": (16, 1, 16, 4),
     "block_m1_c32h2_shift4": (32, 2, 16, 4),
+    # round 5: token_mlp = 'ffn' (Mlp, M1:442-468) - the constructor default of Uformer / LeWinTransformerBlock's other branch (M1:778-779)
+    "block_m1_c64_ffn_shift4": (64, 2, 16, 4),
 }
 
 
@@ -219,8 +221,8 @@ def gen_block_wide(M1, name):
     the whole-model golden"""
     C, heads, side, shift = WIDE_BLOCKS[name]
     seed_all(31)
-    blk = M1.LeWinTransformerBlock(dim=C, input_resolution=(side, side), num_heads=heads, win_size=8, shift_size=shift, token_mlp='leff',
-                                   drop_path=0.)
+    blk = M1.LeWinTransformerBlock(dim=C, input_resolution=(side, side), num_heads=heads, win_size=8, shift_size=shift,
+                                   token_mlp='ffn' if "_ffn_" in name else 'leff', drop_path=0.)
     g = torch.Generator().manual_seed(7)
     with torch.no_grad():
         for p in blk.parameters():
@@ -356,6 +358,32 @@ def gen_full_e16(M1, losses):
         y_eval_crop=y_eval[0, :, 40:72, 40:72], y_eval_sum=np.float64(y_eval.double().sum()),
         y_eval_abs=np.float64(y_eval.double().abs().sum()), y_eval_lowres=torch.nn.functional.avg_pool2d(y_eval, 4),
         loss=np.float64(loss.item()), gnorm=gnorm, gsum=gsum, shapes=np.array([str(tuple(v.shape)) for v in sd.values()]))
+
+
+def gen_full_ctor_default(M1, losses):
+    """round 5: M1.Uformer() with the CONSTRUCTOR's defaults (M1:961-967: embed_dim 32, token_mlp = 'ffn' - Mlp blocks instead of LeFF;
+    options.py / get_arch pass 'leff'): state_dict keys / shapes / init stream, eval output, Charbonnier loss and gradient norms"""
+    seed_all(1234)
+    model = M1.Uformer()
+    sd = model.state_dict()
+    stats = np.array([[float(v.double().sum()), float(v.double().abs().sum())] for v in sd.values()])
+    g = torch.Generator().manual_seed(7)
+    gt = torch.rand(1, 3, 128, 128, generator=g)
+    hazy = (0.6 * gt + 0.4 * torch.rand(1, 1, 1, 1, generator=g)).clamp(0, 1)
+    gt, hazy = gt.half().float(), hazy.half().float()
+    model.eval()
+    torch.manual_seed(99)
+    with torch.no_grad():
+        y_eval = model(hazy)
+    torch.manual_seed(99)
+    y = model(hazy)
+    loss = losses.CharbonnierLoss()(torch.clamp(y, 0, 1), gt)
+    loss.backward()
+    gnorm = np.array([float(p.grad.double().norm()) if p.grad is not None else -1.0 for p in model.parameters()])
+    npz("full_m1_ctor_default", keys=np.array(list(sd.keys())), pnames=np.array([n for n, _ in model.named_parameters()]), sd_stats=stats,
+        gt=gt.half(), hazy=hazy.half(), y_eval_crop=y_eval[0, :, 40:72, 40:72], y_eval_sum=np.float64(y_eval.double().sum()),
+        y_eval_abs=np.float64(y_eval.double().abs().sum()), loss=np.float64(loss.item()), gnorm=gnorm,
+        shapes=np.array([str(tuple(v.shape)) for v in sd.values()]))
 
 
 def gen_trajectory(M1, losses):
@@ -503,7 +531,9 @@ def main():
         gen_probattn(M1, ATT, only=("h2_mask_bias_d16",))
         gen_block_wide(M1, "block_m1_c16_shift4")
         gen_block_wide(M1, "block_m1_c32h2_shift4")
+        gen_block_wide(M1, "block_m1_c64_ffn_shift4")
         gen_full_e16(M1, losses)
+        gen_full_ctor_default(M1, losses)
         return
     if len(sys.argv) > 2 and sys.argv[1] == "--only" and sys.argv[2] == "block128":
         install_shims()
@@ -534,6 +564,7 @@ def main():
     gen_misc()
     gen_full(M1, M0, losses)
     gen_full_e16(M1, losses)
+    gen_full_ctor_default(M1, losses)
     gen_trajectory(M1, losses)
     gen_data()
 

@@ -126,7 +126,8 @@ def test_fused_block_vs_reference_golden(golden, dev, name, heads, shift, C):
 
 @pytest.mark.parametrize("name,use_fused", [("block_m1_c128_shift4", True), ("block_m1_c128_shift4", False),
                                             ("block_m1_c256_shift4", False), ("block_m1_c512_shift0", False),
-                                            ("block_m1_c16_shift4", True), ("block_m1_c32h2_shift4", True)])     # head_dim 16 (Uformer16)
+                                            ("block_m1_c16_shift4", True), ("block_m1_c32h2_shift4", True),      # head_dim 16 (Uformer16)
+                                            ("block_m1_c64_ffn_shift4", True), ("block_m1_c64_ffn_shift4", False)])   # token_mlp ffn (Mlp)
 def test_block_wide_vs_reference_golden(golden, dev, name, use_fused):
     """C = 128 (four heads, shifted windows, 16 x 16): the widest instance of the fused window-attention forward - and the kernel chain;
     C = 256 (eight heads) and C = 512 (sixteen heads, the bottleneck's single 8 x 8 window): the kernel chain every block of those widths

@@ -134,6 +134,34 @@ def test_uformer16_vs_reference_golden_and_one_training_step(golden, dev):
         assert torch.isfinite(loss).item() and not torch.equal(w0, model.encoderlayer_0.blocks[0].attn.ProbSpare.query_projection.weight)
 
 
+def test_ctor_default_ffn_model_vs_reference_golden(golden, dev):
+    """M1.Uformer() with the constructor's defaults (token_mlp = 'ffn': Mlp blocks on dhz_gelu_* between two token Linears): eval
+    output, Charbonnier loss and gradient norms vs the REFERENCE's (tests/golden/full_m1_ctor_default.npz)."""
+    import My_model_1 as M1
+    from losses import CharbonnierLoss
+    g = golden("full_m1_ctor_default")
+    seed_all(1234)
+    model = M1.Uformer().to(dev)
+    gt, hazy = T(g["gt"]).float().to(dev), T(g["hazy"]).float().to(dev)
+    model.eval()
+    torch.manual_seed(99)
+    with torch.no_grad():
+        y = model(hazy)
+    crop, ref_crop = y[0, :, 40:72, 40:72].cpu(), T(g["y_eval_crop"])
+    assert torch.allclose(crop, ref_crop, atol=2e-4, rtol=1e-3), (crop - ref_crop).abs().max()
+    assert torch.mean((crop.double() - ref_crop.double()) ** 2).item() < 1e-7
+    torch.manual_seed(99)
+    loss, _ = CharbonnierLoss().forward_clamped(model(hazy), gt)
+    assert abs(loss.item() - float(g["loss"])) < 2e-6
+    loss.backward()
+    gn = np.array([float(p.grad.double().norm()) if p.grad is not None else -1.0 for p in model.parameters()])
+    ref = g["gnorm"]
+    assert np.array_equal(gn < 0, ref < 0)
+    live = ref >= 0
+    rel = np.abs(gn[live] - ref[live]) / (ref[live] + 1e-8)
+    assert rel.max() < 5e-3, rel.max()
+
+
 def test_training_steps_vs_oracle(dev):
     """3 AdamW steps (Charbonnier only, DropPath off so that host and device RNG use is identical):
     product on GPU vs CPU oracle + torch.optim.AdamW, same seeds, same sampled-key stream."""

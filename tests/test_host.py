@@ -67,6 +67,23 @@ def test_state_dict_and_init_stream_match_reference(golden, modname, gname):
         assert sum(p.numel() for _, p in live) == 20628317 and len(list(m.parameters())) - len(live) == 108
 
 
+def test_constructor_default_model_is_the_ffn_variant(golden):
+    """M1.Uformer() with the constructor's own defaults (M1:961-967): token_mlp = 'ffn' - Mlp (fc1 / fc2) blocks instead of LeFF.  Keys,
+    parameter order, shapes and the init RNG stream equal the reference's."""
+    import My_model_1 as M1
+    g = golden("full_m1_ctor_default")
+    random.seed(1234); np.random.seed(1234); torch.manual_seed(1234)
+    m = M1.Uformer()
+    sd = m.state_dict()
+    assert list(sd.keys()) == list(g["keys"]) and any(k.endswith("mlp.fc1.weight") for k in sd) and not any("dwconv" in k for k in sd)
+    assert [n for n, _ in m.named_parameters()] == list(g["pnames"])
+    assert [str(tuple(v.shape)) for v in sd.values()] == list(g["shapes"])
+    stats = np.array([[float(v.double().sum()), float(v.double().abs().sum())] for v in sd.values()])
+    assert np.array_equal(stats, g["sd_stats"])
+    with pytest.raises(Exception, match="FFN error"):
+        M1.LeWinTransformerBlock(dim=32, input_resolution=(16, 16), num_heads=1, token_mlp="mlp")
+
+
 def test_options_match_reference(golden):
     import options
     g = golden("options")

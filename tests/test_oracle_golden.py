@@ -222,12 +222,29 @@ def test_full_model_e16_oracle(golden):
     assert abs(float(y.double().sum()) - float(g["y_eval_sum"])) < 1e-4 * float(g["y_eval_abs"])
 
 
+def test_full_model_ctor_default_oracle(golden):
+    """M1.Uformer() with the constructor defaults (token_mlp = 'ffn'): oracle vs the reference"""
+    import random
+    import My_model_1 as M1
+    g = golden("full_m1_ctor_default")
+    random.seed(1234); np.random.seed(1234); torch.manual_seed(1234)
+    model = M1.Uformer()
+    P = {k: v.detach() for k, v in model.state_dict().items()}
+    hazy = T(g["hazy"]).float()
+    torch.manual_seed(99)
+    with torch.no_grad():
+        y = O.uformer_forward(P, hazy, variant="probsparse")
+    assert torch.allclose(y[0, :, 40:72, 40:72], T(g["y_eval_crop"]), atol=1e-5, rtol=1e-4)
+    assert abs(float(y.double().sum()) - float(g["y_eval_sum"])) < 1e-4 * float(g["y_eval_abs"])
+
+
 WIDE_BLOCKS = {     # tests/golden/gen_golden.py::WIDE_BLOCKS: name -> (C, heads, map side, shift)
     "block_m1_c128_shift4": (128, 4, 16, 4),
     "block_m1_c256_shift4": (256, 8, 16, 4),
     "block_m1_c512_shift0": (512, 16, 8, 0),
     "block_m1_c16_shift4": (16, 1, 16, 4),          # head_dim 16: the embed_dim = 16 model's first stage ...
     "block_m1_c32h2_shift4": (32, 2, 16, 4),        # ... and its last decoder stage (C = 32 as two heads of 16)
+    "block_m1_c64_ffn_shift4": (64, 2, 16, 4),      # token_mlp = 'ffn' (Mlp instead of LeFF, M1:778-779)
 }
 
 
@@ -236,8 +253,8 @@ def _wide_block_inputs(g, M1, name):
     import random
     C, heads, side, shift = WIDE_BLOCKS[name]
     random.seed(31); np.random.seed(31); torch.manual_seed(31)
-    blk = M1.LeWinTransformerBlock(dim=C, input_resolution=(side, side), num_heads=heads, win_size=8, shift_size=shift, token_mlp='leff',
-                                   drop_path=0.)
+    blk = M1.LeWinTransformerBlock(dim=C, input_resolution=(side, side), num_heads=heads, win_size=8, shift_size=shift,
+                                   token_mlp='ffn' if "_ffn_" in name else 'leff', drop_path=0.)
     gen = torch.Generator().manual_seed(7)
     with torch.no_grad():
         for p in blk.parameters():
