@@ -146,6 +146,81 @@ class LinearProjection(nn.Module):
         return q, kv[0], kv[1]
 
 
+# ---- the off-default token projections / squeeze-excite of M1:167-335.  In the ProbSparse model WindowAttention.forward (M1:400-415) calls
+#      ONLY self.ProbSpare: self.qkv, self.proj and self.se_layer are registered, initialised and checkpointed but never run ("dead"
+#      parameters).  So `--token_projection conv | linear_concat` and `se_layer=True` change the state_dict and the init
+#      RNG stream of that model, not its function: the modules below exist for exactly that (same attribute names, shapes, creation
+#      order); their forward() is plain torch and off the accelerated path.  The dense twin (My_model.Uformer) RUNS its qkv / proj
+#      projection: there only token_projection = 'linear' without se_layer is implemented.
+class SELayer(nn.Module):
+    """M1:167-185: channel gate (mean over tokens -> C/16 -> C -> sigmoid)."""
+
+    def __init__(self, channel, reduction=16):
+        super().__init__()
+        self.avg_pool = nn.AdaptiveAvgPool1d(1)
+        self.fc = nn.Sequential(nn.Linear(channel, channel // reduction, bias=False), nn.ReLU(inplace=True),
+                                nn.Linear(channel // reduction, channel, bias=False), nn.Sigmoid())
+
+    def forward(self, x):                                   # [B, N, C]
+        return x * self.fc(x.mean(dim=1)).unsqueeze(1)
+
+
+class SepConv2d(nn.Module):
+    """M1:188-221: depthwise k x k convolution, activation, 1 x 1 convolution."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, act_layer=nn.ReLU):
+        super().__init__()
+        self.depthwise = nn.Conv2d(in_channels, in_channels, kernel_size=kernel_size, stride=stride, padding=padding,
+                                   dilation=dilation, groups=in_channels)
+        self.pointwise = nn.Conv2d(in_channels, out_channels, kernel_size=1)
+        self.act_layer = act_layer() if act_layer is not None else nn.Identity()
+        self.in_channels, self.out_channels, self.kernel_size, self.stride = in_channels, out_channels, kernel_size, stride
+
+    def forward(self, x):
+        return self.pointwise(self.act_layer(self.depthwise(x)))
+
+
+class ConvProjection(nn.Module):
+    """M1:226-254: q / k / v from three separable convolutions over the window's 8 x 8 token map.  (The reference hands `bias` to
+    SepConv2d's sixth positional parameter, which is `dilation`: True -> 1.  Kept.)"""
+
+    def __init__(self, dim, heads=8, dim_head=64, kernel_size=3, q_stride=1, k_stride=1, v_stride=1, dropout=0.,
+                 last_stage=False, bias=True):
+        super().__init__()
+        inner = dim_head * heads
+        self.heads = heads
+        pad = (kernel_size - q_stride) // 2
+        self.to_q = SepConv2d(dim, inner, kernel_size, q_stride, pad, int(bias))
+        self.to_k = SepConv2d(dim, inner, kernel_size, k_stride, pad, int(bias))
+        self.to_v = SepConv2d(dim, inner, kernel_size, v_stride, pad, int(bias))
+
+    def forward(self, x, attn_kv=None):
+        b, n, c = x.shape
+        side = int(math.sqrt(n))
+        kv = x if attn_kv is None else attn_kv
+        to_map = lambda t: t.transpose(1, 2).reshape(b, c, side, side)
+        heads = lambda t: t.flatten(2).reshape(b, self.heads, -1, n).transpose(2, 3)
+        return heads(self.to_q(to_map(x))), heads(self.to_k(to_map(kv))), heads(self.to_v(to_map(kv)))
+
+
+class LinearProjection_Concat_kv(nn.Module):
+    """M1:309-331: q, k, v from one Linear, a second k, v from another, keys / values concatenated along the tokens."""
+
+    def __init__(self, dim, heads=8, dim_head=64, dropout=0., bias=True):
+        super().__init__()
+        inner = dim_head * heads
+        self.heads, self.dim, self.inner_dim = heads, dim, inner
+        self.to_qkv = nn.Linear(dim, inner * 3, bias=bias)
+        self.to_kv = nn.Linear(dim, inner * 2, bias=bias)
+
+    def forward(self, x, attn_kv=None):
+        B_, N, C = x.shape
+        kv_in = x if attn_kv is None else attn_kv
+        q, kd, vd = self.to_qkv(x).reshape(B_, N, 3, self.heads, C // self.heads).permute(2, 0, 3, 1, 4)
+        ke, ve = self.to_kv(kv_in).reshape(B_, N, 2, self.heads, C // self.heads).permute(2, 0, 3, 1, 4)
+        return q, torch.cat((kd, ke), dim=2), torch.cat((vd, ve), dim=2)
+
+
 def relative_position_index(win):
     c = torch.arange(win)
     hh, ww = torch.meshgrid(c, c, indexing="ij")
@@ -160,8 +235,9 @@ class WindowAttention(nn.Module):
     def __init__(self, dim, win_size, num_heads, token_projection='linear', qkv_bias=True, qk_scale=None,
                  attn_drop=0., proj_drop=0., se_layer=False, variant="probsparse"):
         super().__init__()
-        if token_projection != 'linear' or se_layer:
-            raise NotImplementedError("only token_projection='linear', se_layer=False are on the accelerated path")
+        if variant != "probsparse" and (token_projection != 'linear' or se_layer):
+            # the dense twin RUNS qkv / proj / se_layer (M0:428-518): only the options.py defaults are implemented there
+            raise NotImplementedError("My_model (dense attention): only token_projection='linear', se_layer=False are implemented")
         self.dim, self.win_size, self.num_heads, self.variant = dim, win_size, num_heads, variant
         head_dim = dim // num_heads
         self.scale = qk_scale or head_dim ** -0.5
@@ -170,11 +246,16 @@ class WindowAttention(nn.Module):
         self.relative_position_bias_table = nn.Parameter(
             torch.zeros((2 * win_size[0] - 1) * (2 * win_size[1] - 1), num_heads))
         self.register_buffer("relative_position_index", relative_position_index(win_size[0]))
-        self.qkv = LinearProjection(dim, num_heads, dim // num_heads, bias=qkv_bias)
+        if token_projection == 'conv':                                       # M1:384-390 (dead in the ProbSparse forward: see above)
+            self.qkv = ConvProjection(dim, num_heads, dim // num_heads, bias=qkv_bias)
+        elif token_projection == 'linear_concat':
+            self.qkv = LinearProjection_Concat_kv(dim, num_heads, dim // num_heads, bias=qkv_bias)
+        else:
+            self.qkv = LinearProjection(dim, num_heads, dim // num_heads, bias=qkv_bias)
         self.token_projection = token_projection
         self.attn_drop = nn.Dropout(attn_drop)
         self.proj = nn.Linear(dim, dim)
-        self.se_layer = nn.Identity()
+        self.se_layer = SELayer(dim) if se_layer else nn.Identity()          # M1:394
         self.proj_drop = nn.Dropout(proj_drop)
         trunc_normal_(self.relative_position_bias_table, std=.02)
         self.softmax = nn.Softmax(dim=-1)
@@ -597,7 +678,7 @@ class Uformer(nn.Module):
     def live_parameters(self):
         """Parameters that receive gradients (the reference keeps 108 dead tensors - attn.qkv.*, attn.proj.* -
         in parameters() and in the optimizer; they are excluded from gradient buckets)."""
-        dead = ("attn.qkv.", "attn.proj.") if self.variant == "probsparse" else ()
+        dead = ("attn.qkv.", "attn.proj.", "attn.se_layer.") if self.variant == "probsparse" else ()
         return [(n, p) for n, p in self.named_parameters() if not any(d in n for d in dead)]
 
     def _stage_sample_indices(self, device):

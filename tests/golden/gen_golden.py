@@ -386,6 +386,30 @@ def gen_full_ctor_default(M1, losses):
         shapes=np.array([str(tuple(v.shape)) for v in sd.values()]))
 
 
+def gen_dead_branches(M1):
+    """round 5: token_projection = 'conv' / 'linear_concat' and se_layer = True in the ProbSparse model: WindowAttention.forward (M1:400-415)
+    never runs self.qkv / self.proj / self.se_layer, so these switches change the state_dict and the init stream, not the function -
+    keys, shapes, init statistics and the eval output of the (different) initial weights"""
+    g = torch.Generator().manual_seed(7)
+    gt = torch.rand(1, 3, 128, 128, generator=g)
+    hazy = (0.6 * gt + 0.4 * torch.rand(1, 1, 1, 1, generator=g)).clamp(0, 1).half().float()
+    out = {"hazy": hazy.half()}
+    for tag, kw in (("conv_se", dict(token_projection='conv', se_layer=True)), ("concat", dict(token_projection='linear_concat'))):
+        seed_all(1234)
+        model = M1.Uformer(img_size=128, embed_dim=32, win_size=8, token_mlp='leff', **kw)
+        sd = model.state_dict()
+        out[tag + "/keys"] = np.array(list(sd.keys()))
+        out[tag + "/shapes"] = np.array([str(tuple(v.shape)) for v in sd.values()])
+        out[tag + "/sd_stats"] = np.array([[float(v.double().sum()), float(v.double().abs().sum())] for v in sd.values()])
+        model.eval()
+        torch.manual_seed(99)
+        with torch.no_grad():
+            y = model(hazy)
+        out[tag + "/y_eval_crop"] = y[0, :, 40:72, 40:72]
+        out[tag + "/y_eval_sum"] = np.float64(y.double().sum())
+    npz("dead_branches", **out)
+
+
 def gen_trajectory(M1, losses):
     seed_all(1234)
     model = M1.Uformer(img_size=128, embed_dim=32, win_size=8, token_projection='linear', token_mlp='leff')
@@ -534,6 +558,7 @@ def main():
         gen_block_wide(M1, "block_m1_c64_ffn_shift4")
         gen_full_e16(M1, losses)
         gen_full_ctor_default(M1, losses)
+        gen_dead_branches(M1)
         return
     if len(sys.argv) > 2 and sys.argv[1] == "--only" and sys.argv[2] == "block128":
         install_shims()
@@ -565,6 +590,7 @@ def main():
     gen_full(M1, M0, losses)
     gen_full_e16(M1, losses)
     gen_full_ctor_default(M1, losses)
+    gen_dead_branches(M1)
     gen_trajectory(M1, losses)
     gen_data()
 

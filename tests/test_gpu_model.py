@@ -162,6 +162,22 @@ def test_ctor_default_ffn_model_vs_reference_golden(golden, dev):
     assert rel.max() < 5e-3, rel.max()
 
 
+def test_dead_branch_model_vs_reference_golden(golden, dev):
+    """token_projection = 'conv' + se_layer = True: other dead parameters, another init stream, the same function (M1:400-415) - the
+    eval output of that model equals the reference's."""
+    import My_model_1 as M1
+    g = golden("dead_branches")
+    seed_all(1234)
+    model = M1.Uformer(img_size=128, embed_dim=32, win_size=8, token_mlp='leff', token_projection='conv', se_layer=True).to(dev).eval()
+    hazy = T(g["hazy"]).float().to(dev)
+    torch.manual_seed(99)
+    with torch.no_grad():
+        y = model(hazy)
+    crop, ref = y[0, :, 40:72, 40:72].cpu(), T(g["conv_se/y_eval_crop"])
+    assert torch.allclose(crop, ref, atol=2e-4, rtol=1e-3), (crop - ref).abs().max()
+    assert abs(float(y.double().sum()) - float(g["conv_se/y_eval_sum"])) < 1e-3 * float(y.double().abs().sum())
+
+
 def test_training_steps_vs_oracle(dev):
     """3 AdamW steps (Charbonnier only, DropPath off so that host and device RNG use is identical):
     product on GPU vs CPU oracle + torch.optim.AdamW, same seeds, same sampled-key stream."""

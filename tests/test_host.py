@@ -84,6 +84,28 @@ def test_constructor_default_model_is_the_ffn_variant(golden):
         M1.LeWinTransformerBlock(dim=32, input_resolution=(16, 16), num_heads=1, token_mlp="mlp")
 
 
+@pytest.mark.parametrize("tag,kw", [("conv_se", dict(token_projection='conv', se_layer=True)), ("concat", dict(token_projection='linear_concat'))])
+def test_off_default_projections_are_dead_parameters_with_the_reference_layout(golden, tag, kw):
+    """token_projection = 'conv' / 'linear_concat', se_layer = True (M1:384-394): in the ProbSparse model these modules are registered,
+    initialised and checkpointed but never run (M1:400-415) - keys, shapes and init stream equal the reference's, they stay out of the
+    live parameter set; the dense twin, which does run them, refuses."""
+    import My_model as M0
+    import My_model_1 as M1
+    g = golden("dead_branches")
+    random.seed(1234); np.random.seed(1234); torch.manual_seed(1234)
+    m = M1.Uformer(img_size=128, embed_dim=32, win_size=8, token_mlp='leff', **kw)
+    sd = m.state_dict()
+    assert list(sd.keys()) == list(g[tag + "/keys"])
+    assert [str(tuple(v.shape)) for v in sd.values()] == list(g[tag + "/shapes"])
+    stats = np.array([[float(v.double().sum()), float(v.double().abs().sum())] for v in sd.values()])
+    assert np.array_equal(stats, g[tag + "/sd_stats"])
+    live = {n for n, _ in m.live_parameters()}
+    assert not any(".attn.qkv." in n or ".attn.proj." in n or ".attn.se_layer." in n for n in live)
+    assert sum(p.numel() for n, p in m.named_parameters() if n in live) == 20628317           # the same live set as the default model
+    with pytest.raises(NotImplementedError):
+        M0.Uformer(img_size=128, embed_dim=32, win_size=8, token_mlp='leff', **kw)
+
+
 def test_options_match_reference(golden):
     import options
     g = golden("options")
