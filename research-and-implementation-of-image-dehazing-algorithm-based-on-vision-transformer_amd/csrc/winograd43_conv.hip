@@ -27,9 +27,11 @@
 // The four waves of a workgroup take four blocks and share the filter slice (32 k x 8 c x 36 positions = 36 KiB per group) through a
 // two-slot ring (one barrier per group, between the phases); a wave's 18 x 18-pixel halo patch has ONE slot (it is rewritten by DMA during
 // the matrix phase, after the transform has read it); out-of-image pixels are slots zeroed once that no DMA lane ever writes.
-// Rounding: no mid-stream flush fits the register file at this tile (an output-domain accumulator is 128 more registers): with the
-// points above the error is 1.1e-6 rms at 64 input channels .. 2.9e-6 at 512 on O(1) outputs (F(2x2): 3.7e-7 .. 9.4e-7), 0.26 - 0.6
-// of the kernel tolerance on the tested shapes; dehaze_hip/vgg.py therefore keeps the DIFFERENTIATED forward pass on F(2x2) (its
+// Rounding: no mid-stream flush fits the register file at this tile (an output-domain accumulator is 128 more registers; a flush
+// through the output tile inside the channel loop made hipcc spill 100 - 470 registers and cost 30 %): with the points above the
+// error is 1.1e-6 rms at 64 input channels, 2.1e-6 at 256, 2.9e-6 at 512 on O(1) outputs (F(2x2): 3.7e-7 .. 9.4e-7) - 0.26 - 0.7 of the
+// kernel tolerance up to 256 channels, 0.9 - 1.0 at 512.  More than 256 channels therefore run as chains of 256 in separate launches
+// that hand their partial sums over through the output tensor (see the C entry point); dehaze_hip/vgg.py therefore keeps the DIFFERENTIATED forward pass on F(2x2) (its
 // roundings decide the ReLU masks of the backward pass) and uses this kernel for the no-gradient passes and the backward-data products.
 #include <stdlib.h>
 #include <type_traits>
@@ -60,6 +62,10 @@ constexpr int PLANE = 332;
 constexpr int PCHUNKS = 2 * PLANE;                  // 664 chunks = 10.4 KiB
 constexpr int PRUNS = (PCHUNKS + 63) / 64;          // 11 DMA runs
 constexpr int PFLOATS = PRUNS * 256;                // the patch slot (floats), runs are whole KiB
+#ifndef W43_CHAIN
+#define W43_CHAIN 32
+#endif
+constexpr int CHAIN_GROUPS = W43_CHAIN;             // channel groups (of 8) per accumulation chain: 256 channels
 constexpr size_t W43_SMEM = (size_t)(NUBUF * UF + 4 * PFLOATS + KB) * sizeof(float);      // 72 + 44 KiB
 
 // interpolation points 0, +-PA, +-PB, inf
@@ -94,7 +100,10 @@ __global__ __launch_bounds__(256, 1) void winograd43_conv3x3_kernel(const float*
                                                                     const float* __restrict__ bias, int relu,
                                                                     const float* __restrict__ out_mask,
                                                                     const float* __restrict__ out_addend, float* __restrict__ y, int H,
-                                                                    int W, int C, int K, int nblk, int xcd_group) {
+                                                                    int W, int C, int K, int nblk, int xcd_group, int cb0, int ncb,
+                                                                    int chain) {
+    // cb0, ncb: the channel groups [cb0, cb0 + ncb) this launch accumulates; chain bit 0: add the partial sums an earlier launch left
+    // in y, bit 1: leave raw partial sums in y (no bias / ReLU / mask / addend) for a later launch - see dhz_winograd43_conv3x3
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int t = threadIdx.x, lane = t & 63;
     const int w = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -137,8 +146,8 @@ __global__ __launch_bounds__(256, 1) void winograd43_conv3x3_kernel(const float*
         const bool ok = ph < 2 && q < 72 && row < 18 && iy >= 0 && iy < H && ix >= 0 && ix < W;
         poff[r] = ok ? (iy * W + ix) * 8 + ph * 4 : -1;
     }
-    const float* const xbase = x + (size_t)bimg * CBn * plane;
-    const float* const ubase = upack + (size_t)kb * CBn * UF + lane * 4;
+    const float* const xbase = x + ((size_t)bimg * CBn + cb0) * plane;
+    const float* const ubase = upack + ((size_t)kb * CBn + cb0) * UF + lane * 4;
     auto dma_patch_run = [&](int cb, int r) {
         if (W43_ABL & 2) return;
         if (poff[r] >= 0) dma16(xbase + (size_t)cb * plane + poff[r], pw + 256 * r);
@@ -170,7 +179,7 @@ __global__ __launch_bounds__(256, 1) void winograd43_conv3x3_kernel(const float*
     //   (2) barrier (filter slice cb complete for every wave, every wave done with slice cb - 1), 144 MFMAs; in their first half the
     //       DMA of the next group's operands, one request per MFMA pair so that the address unit never queues
 #pragma unroll 1
-    for (int cb = 0; cb < CBn; ++cb) {
+    for (int cb = 0; cb < ncb; ++cb) {
         f32x2 v[6][6];
         if (!(W43_ABL & 1)) {
 #pragma unroll
@@ -196,7 +205,7 @@ __global__ __launch_bounds__(256, 1) void winograd43_conv3x3_kernel(const float*
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // my runs of filter slice cb have landed
         __syncthreads();
-        const bool next = cb + 1 < CBn;
+        const bool next = cb + 1 < ncb;
         const float* up = ufrag + (cb & 1) * UF;
         f32x4 alo = *reinterpret_cast<const f32x4*>(up), ahi = *reinterpret_cast<const f32x4*>(up + 256);
 #pragma unroll
@@ -254,7 +263,7 @@ __global__ __launch_bounds__(256, 1) void winograd43_conv3x3_kernel(const float*
                     yv[j][4 * i + 3]);
         }
         if (live) {
-            const float4 bv = FWD ? *reinterpret_cast<const float4*>(bias_s + 16 * kh + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 bv = (FWD && !(chain & 2)) ? *reinterpret_cast<const float4*>(bias_s + 16 * kh + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
             const size_t obase = (((size_t)bimg * KG + kb * 4 + kh * 2 + hf) * H + oy0 + 4 * ty) * W * 8 + (size_t)(ox0 + 4 * tx) * 8 + sub * 4;
 #pragma unroll
             for (int i = 0; i < 4; ++i)
@@ -263,7 +272,12 @@ __global__ __launch_bounds__(256, 1) void winograd43_conv3x3_kernel(const float*
                     const int p = 4 * i + jx;
                     float4 v4 = make_float4(yv[0][p] + bv.x, yv[1][p] + bv.y, yv[2][p] + bv.z, yv[3][p] + bv.w);
                     const size_t o = obase + ((size_t)i * W + jx) * 8;
-                    if (FWD) {
+                    if (chain & 1) {
+                        const float4 part = *reinterpret_cast<const float4*>(y + o);
+                        v4.x += part.x; v4.y += part.y; v4.z += part.z; v4.w += part.w;
+                    }
+                    if (chain & 2) {
+                    } else if (FWD) {
                         v4.x = fmaxf(v4.x, lo); v4.y = fmaxf(v4.y, lo); v4.z = fmaxf(v4.z, lo); v4.w = fmaxf(v4.w, lo);
                     } else {
                         if (out_addend) {
@@ -339,12 +353,22 @@ extern "C" int dhz_winograd43_conv3x3(const float* x, const float* upack, const 
     const int grid = ((nblk + 3) / 4) * (K / KB);
     const int xcd_group = (grid % 8 == 0) ? 1 : 0;
     hipStream_t s = (hipStream_t)stream;
+    // Accumulation chains: the fp32 rounding of the transform-domain accumulation walks with the square root of the channel count (one
+    // chain of 512 channels sits at 0.9 - 1.0 of the kernel tolerance, 256 at 0.55 - 0.7: profiles/r05_winograd_f43_error_table.txt), and no
+    // second accumulator fits the register file of this tile.  So more than CHAIN_GROUPS channel groups run as several launches on the
+    // stream: all but the last leave raw partial sums in y, all but the first add what they find there (the same lane, the same
+    // addresses), the last applies the epilogue.  One extra read + write of the output per extra chain.
+    const int CBn = C / CC;
 #define GO(F)                                                                                                          \
     do {                                                                                                               \
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&winograd43_conv3x3_kernel<F>),                        \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)W43_SMEM);                          \
-        hipLaunchKernelGGL((winograd43_conv3x3_kernel<F>), dim3(grid), dim3(256), W43_SMEM, s, x, upack, bias, relu,   \
-                           out_mask, out_addend, y, H, W, C, K, nblk, xcd_group);                                      \
+        for (int cb0 = 0; cb0 < CBn; cb0 += CHAIN_GROUPS) {                                                            \
+            const int ncb = CBn - cb0 < CHAIN_GROUPS ? CBn - cb0 : CHAIN_GROUPS;                                       \
+            const int chain = (cb0 > 0 ? 1 : 0) | (cb0 + ncb < CBn ? 2 : 0);                                           \
+            hipLaunchKernelGGL((winograd43_conv3x3_kernel<F>), dim3(grid), dim3(256), W43_SMEM, s, x, upack, bias,     \
+                               relu, out_mask, out_addend, y, H, W, C, K, nblk, xcd_group, cb0, ncb, chain);           \
+        }                                                                                                              \
     } while (0)
     if (fwd) GO(true); else GO(false);
 #undef GO

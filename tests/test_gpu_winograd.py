@@ -81,7 +81,8 @@ def test_maxpool_blocked(B, C, H):
 # F(4x4,3x3) (csrc/winograd43_conv.hip, round 5): the layers of the VGG19 stack it takes (maps of 32 x 32 and more; 64 .. 256 input
 # channels), a 16 x 16 map, a ragged block count - at the SAME tolerances as the F(2x2,3x3) kernel above
 @pytest.mark.parametrize("B,C,K,H", [(2, 64, 64, 32), (1, 64, 128, 64), (2, 128, 128, 32), (1, 128, 256, 32), (1, 256, 256, 32),
-                                     (1, 256, 512, 16), (3, 64, 32, 16), (1, 16, 32, 48), (5, 32, 64, 16)])
+                                     (1, 256, 512, 16), (3, 64, 32, 16), (1, 16, 32, 48), (5, 32, 64, 16),
+                                     (2, 512, 512, 16), (1, 384, 64, 16)])      # > 256 input channels: two accumulation chains (two launches)
 def test_winograd43_forward_and_dgrad(B, C, K, H):
     from dehaze_hip import _lib
     dev = torch.device("cuda:0")
