@@ -473,6 +473,12 @@ class Downsample(nn.Module):
                 and self.out_channel % 64 == 0):
             # config 4: patch matrix + the bf16-MFMA token-Linear GEMMs (csrc/conv_bf16.hip), fp32 master weights
             return ops.conv4s2_tokens(x, conv.weight, conv.bias, s_, s_)
+        ho = s_ // 2
+        if (s_ * s_ == x.shape[1] and x.is_cuda and x.dtype == torch.float32 and self.in_channel % 32 == 16 and self.out_channel % 32 == 0
+                and s_ % 2 == 0 and (not need_grad or ((ho & (ho - 1)) == 0 and (x.shape[0] * ho * ho) % 32 == 0))):
+            # 16 (mod 32) input channels (the embed_dim = 16 model's first down-sampling): the implicit-GEMM kernels tile the contraction in
+            # 32-channel stages, so the tokens and the filters get 16 zero channels (two small copies; autograd slices the gradients back)
+            return ops.conv4s2_tokens(F.pad(x, (0, 16)), F.pad(conv.weight, (0, 0, 0, 0, 0, 16)), conv.bias, s_, s_)
         if x.is_cuda:
             ops.warn_library_fallback("Downsample", (self.in_channel, self.out_channel, tuple(x.shape[1:])))
         if x.dtype == torch.bfloat16:       # shapes the kernels do not tile: library convolution in bf16
@@ -568,6 +574,13 @@ class OutputProj(nn.Module):
 
     def forward(self, x):
         conv = self.proj[0]
+        if (x.is_cuda and len(self.proj) == 1 and self.out_channel == 3 and self.in_channel == 32 and conv.stride == (1, 1)
+                and x.dtype == torch.float32):
+            # 32 input channels (the embed_dim = 16 model): the thin-convolution kernels work in 64-channel chunks - 32 zero channels on the
+            # tokens and the filters (two small copies; autograd slices the gradients back)
+            s_ = int(math.sqrt(x.shape[1]))
+            x = ops.thin_conv3x3(F.pad(x, (0, 32)), F.pad(conv.weight, (0, 0, 0, 0, 0, 32)), conv.bias, s_, s_)
+            return self.norm(x) if self.norm is not None else x
         if (x.is_cuda and len(self.proj) == 1 and self.out_channel == 3 and self.in_channel in (64, 128)
                 and conv.stride == (1, 1) and x.dtype in (torch.float32, torch.bfloat16)):
             # 3 output channels: nothing for the matrix pipe, the library's implicit GEMM runs at 0.6 TB/s - hand-written

@@ -146,7 +146,7 @@ def get_arch(opt):
     if arch == 'Uformer16':
         # model_utils.py:96-98: embed_dim 16 -> head_dim 16 in every block (heads 1, 2, 4, 8, 16, 16, 8, 4, 2).  The window-attention
         # kernels carry head_dim-16 instances, the C = 16 stage's Linears (16 -> 48 / 16 / 64, 64 -> 16) run the 16-wide GEMM /
-        # weight-gradient forms; its two thin convolutions (Downsample 16 -> 32, OutputProj 32 -> 3) go to the library, with a warning
+        # weight-gradient forms; its two thin convolutions (Downsample 16 -> 32, OutputProj 32 -> 3) run the hand-written kernels on zero-padded channels
         return Uformer(img_size=opt.train_ps, embed_dim=16, win_size=8, token_projection='linear', token_mlp='leff')
     if arch == 'Uformer32':
         return Uformer(img_size=opt.train_ps, embed_dim=32, win_size=8, token_projection='linear', token_mlp='leff')

@@ -98,8 +98,10 @@ def test_uformer16_vs_reference_golden_and_one_training_step(golden, dev):
     from losses import CharbonnierLoss
     g = golden("full_m1_e16")
     seed_all(1234)
-    with warnings.catch_warnings():
-        warnings.simplefilter("ignore")
+    from dehaze_hip import ops
+    ops._WARNED.clear()
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
         model = utils.get_arch(argparse.Namespace(arch="Uformer16", train_ps=128, embed_dim=32, win_size=8,
                                                   token_projection="linear", token_mlp="leff")).to(dev)
         assert model.embed_dim == 16 and [b.num_heads for b in (model.encoderlayer_0.blocks[0], model.conv.blocks[0],
@@ -132,6 +134,9 @@ def test_uformer16_vs_reference_golden_and_one_training_step(golden, dev):
         w0 = model.encoderlayer_0.blocks[0].attn.ProbSpare.query_projection.weight.detach().clone()
         loss, lrec, lcr = train_step(model, CharbonnierLoss(), cr, opt, None, hazy, gt)
         assert torch.isfinite(loss).item() and not torch.equal(w0, model.encoderlayer_0.blocks[0].attn.ProbSpare.query_projection.weight)
+    # nothing of this model's step ran on the library convolution (its 16 -> 32 down-sampling and 32 -> 3 output projection take the
+    # hand-written kernels with zero-padded channels)
+    assert not [str(c.message) for c in caught if "library convolution" in str(c.message)], [str(c.message) for c in caught]
 
 
 def test_ctor_default_ffn_model_vs_reference_golden(golden, dev):
