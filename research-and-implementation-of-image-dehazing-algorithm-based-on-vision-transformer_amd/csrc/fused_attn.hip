@@ -79,8 +79,8 @@ struct FusedSmem {
 
 // SAVE: 0 = inference, 1 = every tensor the backward kernel chain consumes, 2 = only the selection ranks (the fused backward of
 // csrc/fused_attn_bwd.hip recomputes the rest)
-template <int C, int SAVE>
-__global__ __launch_bounds__(256, C == 64 ? 3 : (C == 128 ? 1 : 2)) void fused_window_attn_fwd_kernel(
+template <int C, int SAVE, int NW = 1>
+__global__ __launch_bounds__(256 * NW, NW == 2 ? 1 : (C == 64 ? 3 : (C == 128 ? 1 : 2))) void fused_window_attn_fwd_kernel(
     const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
     const float4* __restrict__ wqkv_p, const float* __restrict__ bqkv, const float4* __restrict__ wo_p,
     const float* __restrict__ bo, const uint8_t* __restrict__ idx, const float* __restrict__ bias,
@@ -93,8 +93,11 @@ __global__ __launch_bounds__(256, C == 64 ? 3 : (C == 128 ? 1 : 2)) void fused_w
     constexpr int KS = C / 4;             // k-steps of the QKV GEMM
     constexpr int KS4 = KS / 4;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    FusedSmem<C>& sm = *reinterpret_cast<FusedSmem<C>*>(smem_raw);
-    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    // NW = 2: a 512-thread workgroup carries TWO windows, one per half (threads 0..255 / 256..511), each with its own LDS tiles; the
+    // halves run the same phases in lockstep (the barriers are the workgroup's).  t, w, lane are the indices INSIDE the half.
+    const int half = NW == 2 ? (int)(threadIdx.x >> 8) : 0;
+    FusedSmem<C>& sm = reinterpret_cast<FusedSmem<C>*>(smem_raw)[half];
+    const int t = threadIdx.x & 255, lane = t & 63, w = t >> 6;
     const int i16 = lane & 15, g = lane >> 4;
     const int nWw = Wres >> 3, nW = (Hres >> 3) * nWw;
     // token row / channel quarter of this thread in the row phases = the row / k range of its MFMA A fragment: lane (i16, g) of
@@ -133,14 +136,14 @@ __global__ __launch_bounds__(256, C == 64 ? 3 : (C == 128 ? 1 : 2)) void fused_w
     const float4* const btr = reinterpret_cast<const float4*>(sm.vec + C + qd * CPT);
     const float4* const bor = reinterpret_cast<const float4*>(sm.vec + 2 * C + qd * CPT);
     float4 xv[CPT / 4], xnext[CPT / 4];
-    int win = blockIdx.x;
+    int win = blockIdx.x * NW + half;
     if (win < nwin) {
         const float4* xp = reinterpret_cast<const float4*>(x + src_token(win) * C + qd * CPT);
 #pragma unroll
         for (int i = 0; i < CPT / 4; ++i) xv[i] = xp[i];
     }
 #pragma unroll 1
-    for (; win < nwin; win += gridDim.x) {
+    for (; win < nwin; win += gridDim.x * NW) {
         const int bimg = win / nW, wdx = win % nW;
         const size_t src_tok = src_token(win);
         // ---- 0. LayerNorm of the gathered rows (4 lanes per token); xa = this lane's A fragment for every head's projection
@@ -477,8 +480,8 @@ __global__ __launch_bounds__(256, C == 64 ? 3 : (C == 128 ? 1 : 2)) void fused_w
         if constexpr (WREG) {
 #pragma unroll
             for (int i = 0; i < CPT / 4; ++i) xv[i] = xnext[i];
-        } else if (win + (int)gridDim.x < nwin) {  // (only reached when the grid is smaller than the window count)
-            const float4* xp = reinterpret_cast<const float4*>(x + src_token(win + gridDim.x) * C + qd * CPT);
+        } else if (win + (int)gridDim.x * NW < nwin) {  // (only reached when the grid is smaller than the window count)
+            const float4* xp = reinterpret_cast<const float4*>(x + src_token(win + gridDim.x * NW) * C + qd * CPT);
 #pragma unroll
             for (int i = 0; i < CPT / 4; ++i) xv[i] = xp[i];
         }
@@ -517,14 +520,15 @@ __global__ void prepack_weights_kernel(const float* __restrict__ wq, const float
     }
 }
 
-template <int C, int SAVE>
+template <int C, int SAVE, int NW = 1>
 void launch_fused(hipStream_t s, int nwin, const float* x, const float* gamma, const float* beta, const float* wqkv_p,
                   const float* bqkv, const float* wo_p, const float* bo, const uint8_t* idx, const float* bias,
                   const float* mask, const float* dscale, float* out, float* xn_save, float* qkv_save, float* ctx_save,
                   float* stats_save, uint8_t* rank_save, int Hres, int Wres, int shift) {
-    const size_t smem = sizeof(FusedSmem<C>);
+    const size_t smem = NW * sizeof(FusedSmem<C>);
+    static_assert(sizeof(FusedSmem<C>) % 16 == 0, "the second half's tiles start 16-byte aligned");
     if (smem > 48 * 1024)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_window_attn_fwd_kernel<C, SAVE>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_window_attn_fwd_kernel<C, SAVE, NW>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     // persistent workgroups (only with register-resident weights): exactly as many as are RESIDENT at once - the occupancy
     // the runtime reports for this code object (registers and LDS together: 2 per CU at 222 VGPRs, although 3 would fit the
@@ -537,16 +541,16 @@ void launch_fused(hipStream_t s, int nwin, const float* x, const float* gamma, c
     // resident workgroups per CU of this instantiation: queried once (thread-safe function-local static initialisation)
     static const int occ = [&] {
         int q = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, reinterpret_cast<const void*>(&fused_window_attn_fwd_kernel<C, SAVE>),
-                                                         256, smem) != hipSuccess || q < 1)
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, reinterpret_cast<const void*>(&fused_window_attn_fwd_kernel<C, SAVE, NW>),
+                                                         256 * NW, smem) != hipSuccess || q < 1)
             q = 2;
         return q;
     }();
     const int per_cu = env_wg > 0 ? env_wg : occ;
     const int ncu = dhz_num_cus();
-    int grid = (C == 32 && FUSED_PERSIST_C32) ? ncu * per_cu : nwin;
-    if (grid > nwin) grid = nwin;
-    hipLaunchKernelGGL((fused_window_attn_fwd_kernel<C, SAVE>), dim3(grid), dim3(256), smem, s, x, gamma, beta,
+    int grid = (C == 32 && FUSED_PERSIST_C32) ? ncu * per_cu : nwin / NW;
+    if (grid > nwin / NW) grid = nwin / NW;
+    hipLaunchKernelGGL((fused_window_attn_fwd_kernel<C, SAVE, NW>), dim3(grid), dim3(256 * NW), smem, s, x, gamma, beta,
                        reinterpret_cast<const float4*>(wqkv_p), bqkv, reinterpret_cast<const float4*>(wo_p), bo, idx,
                        bias, mask, dscale, out, xn_save, qkv_save, ctx_save, stats_save, rank_save, Hres, Wres, shift,
                        nwin);
@@ -593,7 +597,22 @@ extern "C" int dhz_fused_window_attn_fwd(const float* x, const float* gamma, con
         else launch_fused<CC, 0>(s, nwin, x, gamma, beta, wqkv_p, bqkv, wo_p, bo, idx, bias, mask, drop_scale, out, \
                                  nullptr, nullptr, nullptr, nullptr, nullptr, Hres, Wres, shift);                \
     } while (0)
-    if (C == 32) GO(32); else if (C == 64) GO(64); else GO(128);
+    // Two windows per 512-thread workgroup (NW = 2) - what the LDS leaves room for beside resident bf16 weight planes - is a DIAGNOSTIC
+    // instance (tools/diag_build.sh + DHZ_FUSED_PAIR=2): measured 320 -> 380 us (inference) / 424 -> 458 (training) at C = 64, 128 x 128 - two
+    // windows in flight instead of three cost what six-term projections could return (profiles/r05_fused_attn_wall.txt).  Not dispatched.
+#ifdef DHZ_DIAG
+    static const int pair_env = getenv("DHZ_FUSED_PAIR") ? atoi(getenv("DHZ_FUSED_PAIR")) : 0;
+#else
+    constexpr int pair_env = 0;
+#endif
+    if (C == 64 && pair_env == 2 && nwin % 2 == 0) {
+        if (save == 1) launch_fused<64, 1, 2>(s, nwin, x, gamma, beta, wqkv_p, bqkv, wo_p, bo, idx, bias, mask, drop_scale, out, xn_save,
+                                              qkv_save, ctx_save, stats_save, rank_save, Hres, Wres, shift);
+        else if (save == 2) launch_fused<64, 2, 2>(s, nwin, x, gamma, beta, wqkv_p, bqkv, wo_p, bo, idx, bias, mask, drop_scale, out,
+                                                   nullptr, nullptr, nullptr, nullptr, rank_save, Hres, Wres, shift);
+        else launch_fused<64, 0, 2>(s, nwin, x, gamma, beta, wqkv_p, bqkv, wo_p, bo, idx, bias, mask, drop_scale, out, nullptr, nullptr,
+                                    nullptr, nullptr, nullptr, Hres, Wres, shift);
+    } else if (C == 32) GO(32); else if (C == 64) GO(64); else GO(128);
 #undef GO
     DHZ_CHECK_LAUNCH("dhz_fused_window_attn_fwd");
     return DHZ_OK;
