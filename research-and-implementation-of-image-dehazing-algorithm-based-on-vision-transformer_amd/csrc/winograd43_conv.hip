@@ -77,6 +77,18 @@ __device__ __forceinline__ void dma16(const float* g, float* l) {
     __builtin_amdgcn_global_load_lds((glb_void*)g, (lds_void*)l, 16, 0, 0);
 }
 
+// 288 accumulator registers against 256 AGPRs: left to itself hipcc keeps 240 in AGPRs, the rest in VGPRs, and SHUTTLES the latter through
+// a[0:15] around every MFMA that touches them (4 v_accvgpr_write, the MFMA, s_nop 9, 4 v_accvgpr_read: 24 of the 144 MFMAs of a group cost
+// twice their time and cannot overlap their neighbours).  The matrix instruction takes its C / D operand from either half of the register
+// file, so the class is pinned per accumulator through the asm constraint: positions 0 .. 31 in AGPRs ("a"), positions 32 .. 35 in VGPRs
+// ("v").  hipcc cannot see that these are matrix instructions: the hazards it would cover are covered by construction - an accumulator
+// is reused four MFMAs (128 pipe cycles) later, and the epilogue waits 2 x s_nop 15 before it reads them.
+__device__ __forceinline__ void mfma_acc_a(f32x4& acc, float a, float b) {
+    asm("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void mfma_acc_v(f32x4& acc, float a, float b) {
+    asm("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+}
 // B^T d for one 6-vector (packed over the lane's two channels): rows for the points 0, +a, -a, +b, -b, inf
 __device__ __forceinline__ void bt6(f32x2& d0, f32x2& d1, f32x2& d2, f32x2& d3, f32x2& d4, f32x2& d5) {
     const f32x2 t0 = A2B2 * d0 - SAB * d2 + d4;
@@ -159,9 +171,13 @@ __global__ __launch_bounds__(256, 1) void winograd43_conv3x3_kernel(const float*
     };
 
     const float* const pread0 = pw + (hf * PLANE + 73 * ty + 4 * tx) * 4 + 2 * sub;
-    f32x4 acc[NXI][2];
+    constexpr int NXA = 32;             // positions whose accumulators live in AGPRs (32 x 2 x 4 = 256 registers); the other four in VGPRs
+    f32x4 acc[NXA][2], accv[NXI - NXA][2];
 #pragma unroll
-    for (int xi = 0; xi < NXI; ++xi) { acc[xi][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[xi][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    for (int xi = 0; xi < NXA; ++xi) { acc[xi][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[xi][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+    for (int xi = 0; xi < NXI - NXA; ++xi) { accv[xi][0] = f32x4{0.f, 0.f, 0.f, 0.f}; accv[xi][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    auto A = [&](int xi, int kh) -> f32x4& { return xi < NXA ? acc[xi][kh] : accv[xi - NXA][kh]; };
 
     // ---- prologue: patch 0 and filter slice 0
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // the zero fill is in LDS before any DMA lane can land on top of it
@@ -219,10 +235,13 @@ __global__ __launch_bounds__(256, 1) void winograd43_conv3x3_kernel(const float*
             const f32x2 v0 = v[xi / 6][xi % 6], v1 = v[(xi + 1) / 6][(xi + 1) % 6];
             __builtin_amdgcn_sched_barrier(0);
             if (!(W43_ABL & 4)) {
-                acc[xi][0] = mfma16(alo[0], v0[0], acc[xi][0]);
-                acc[xi][1] = mfma16(ahi[0], v0[0], acc[xi][1]);
-                acc[xi + 1][0] = mfma16(alo[2], v1[0], acc[xi + 1][0]);
-                acc[xi + 1][1] = mfma16(ahi[2], v1[0], acc[xi + 1][1]);
+                if (xi < NXA) {                                   // (xi is a constant after unrolling; xi and xi + 1 are on the same side)
+                    mfma_acc_a(acc[xi][0], alo[0], v0[0]); mfma_acc_a(acc[xi][1], ahi[0], v0[0]);
+                    mfma_acc_a(acc[xi + 1][0], alo[2], v1[0]); mfma_acc_a(acc[xi + 1][1], ahi[2], v1[0]);
+                } else {
+                    mfma_acc_v(accv[xi - NXA][0], alo[0], v0[0]); mfma_acc_v(accv[xi - NXA][1], ahi[0], v0[0]);
+                    mfma_acc_v(accv[xi + 1 - NXA][0], alo[2], v1[0]); mfma_acc_v(accv[xi + 1 - NXA][1], ahi[2], v1[0]);
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
             // the next patch first (two requests per pair-step: it is needed as soon as this group ends), the next filter slice behind it
@@ -231,10 +250,13 @@ __global__ __launch_bounds__(256, 1) void winograd43_conv3x3_kernel(const float*
             if (next && j >= 6 && j - 6 < URUNS / 4) dma_u_run(cb + 1, j - 6);
             __builtin_amdgcn_sched_barrier(0);
             if (!(W43_ABL & 4)) {
-                acc[xi][0] = mfma16(alo[1], v0[1], acc[xi][0]);
-                acc[xi][1] = mfma16(ahi[1], v0[1], acc[xi][1]);
-                acc[xi + 1][0] = mfma16(alo[3], v1[1], acc[xi + 1][0]);
-                acc[xi + 1][1] = mfma16(ahi[3], v1[1], acc[xi + 1][1]);
+                if (xi < NXA) {
+                    mfma_acc_a(acc[xi][0], alo[1], v0[1]); mfma_acc_a(acc[xi][1], ahi[1], v0[1]);
+                    mfma_acc_a(acc[xi + 1][0], alo[3], v1[1]); mfma_acc_a(acc[xi + 1][1], ahi[3], v1[1]);
+                } else {
+                    mfma_acc_v(accv[xi - NXA][0], alo[1], v0[1]); mfma_acc_v(accv[xi - NXA][1], ahi[1], v0[1]);
+                    mfma_acc_v(accv[xi + 1 - NXA][0], alo[3], v1[1]); mfma_acc_v(accv[xi + 1 - NXA][1], ahi[3], v1[1]);
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
             if (next && 2 * j + 1 < PRUNS) dma_patch_run(cb + 1, 2 * j + 1);
@@ -244,6 +266,8 @@ __global__ __launch_bounds__(256, 1) void winograd43_conv3x3_kernel(const float*
         asm volatile("s_waitcnt vmcnt(9)" ::: "memory");          // the next patch has landed (my nine filter requests may still be in flight)
     }
 
+    // the last matrix instructions (inline asm: hipcc does not know what they are) have written their accumulators before these are read
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
     // ---- epilogue: Y = A^T M A per (k half, accumulator row); lane (tile i16, g) holds output channels 16 kh + 4 g .. + 3 of its 4 x 4 pixels
     const int KG = K / 8;
     const float lo = relu ? 0.f : -__builtin_inff();
@@ -255,7 +279,7 @@ __global__ __launch_bounds__(256, 1) void winograd43_conv3x3_kernel(const float*
             float tm[4][6];
 #pragma unroll
             for (int c = 0; c < 6; ++c)
-                at6(acc[c][kh][j], acc[6 + c][kh][j], acc[12 + c][kh][j], acc[18 + c][kh][j], acc[24 + c][kh][j], acc[30 + c][kh][j],
+                at6(A(c, kh)[j], A(6 + c, kh)[j], A(12 + c, kh)[j], A(18 + c, kh)[j], A(24 + c, kh)[j], A(30 + c, kh)[j],
                     tm[0][c], tm[1][c], tm[2][c], tm[3][c]);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
