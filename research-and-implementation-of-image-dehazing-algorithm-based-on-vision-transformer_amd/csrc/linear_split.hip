@@ -83,6 +83,33 @@ __device__ __forceinline__ void split8x3(const f32x4 a, const f32x4 b, u32x4& hi
     }
 }
 
+// The same split with SCALAR-lane subtractions (11 instructions per pair instead of 9), for loops that multiply on the bf16 matrix pipe
+// while they split: a packed fp32 instruction between two MFMAs costs 7 - 17 cycles of matrix-pipe time, the first two plain vector
+// instructions behind a bf16 MFMA cost nothing and further ones 4 cycles each (tools/ubench/interleave.hip).  Inline asm: left as C,
+// hipcc's SLP vectoriser re-packs the subtractions.
+__device__ __forceinline__ float sub_np(float a, float b) {
+    float r;
+    asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float mul_np(float a, float b) {
+    float r;
+    asm("v_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ void split8x3_np(const f32x4 a, const f32x4 b, u32x4& hi, u32x4& mid, u32x4& lo) {
+    const float x[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float x0 = x[2 * i], x1 = x[2 * i + 1];
+        const float r0 = sub_np(x0, __uint_as_float(__float_as_uint(x0) & 0xffff0000u)), r1 = sub_np(x1, __uint_as_float(__float_as_uint(x1) & 0xffff0000u));
+        const float q0 = sub_np(r0, __uint_as_float(__float_as_uint(r0) & 0xffff0000u)), q1 = sub_np(r1, __uint_as_float(__float_as_uint(r1) & 0xffff0000u));
+        hi[i] = pack_top(x1, x0);
+        mid[i] = pack_top(r1, r0);
+        lo[i] = pack_top(q1, q0);
+    }
+}
+
 // C[M,NF] = A[M,KC] . op(B) (+ bias).  BTR = false: B is [NF][KC] (forward); true: B is [KC][NF] (backward-data).
 template <int WM, int WN, bool BTR, bool SIX>
 __global__ __launch_bounds__(256, 2) void gemm_split_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B,
@@ -505,10 +532,15 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_M * WAVES_N == 4 ? 2 
 #pragma unroll
         for (int b = 0; b < WN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
     f32x4 ra[NA][2], rb[NB][2];
-    float rs[NA];
+    // the per-image factor of dy (rows_per_scale is a multiple of the 32-row stage: one factor per stage, wave-uniform): the image index
+    // walks with the stages in scalar registers - as t / rows_per_scale per chunk it was a 64-bit division, ~75 vector instructions per
+    // chunk and stage between the MFMAs
+    float rs = 1.f;
+    int rs_img = 0, rs_left = 0;                                  // image of the next stage to load, its rows still ahead
+    if (row_scale) { rs_img = (int)(((long long)st0 * BK2) / rows_per_scale); rs_left = rows_per_scale - (int)(((long long)st0 * BK2) % rows_per_scale); }
     if constexpr (DHZ_W6_ABL & 1) {
 #pragma unroll
-        for (int i = 0; i < NA; ++i) { ra[i][0] = ra[i][1] = f32x4{1.f, 1.f, 1.f, 1.f}; rs[i] = 1.f; }
+        for (int i = 0; i < NA; ++i) { ra[i][0] = ra[i][1] = f32x4{1.f, 1.f, 1.f, 1.f}; }
 #pragma unroll
         for (int i = 0; i < NB; ++i) rb[i][0] = rb[i][1] = f32x4{1.f, 1.f, 1.f, 1.f};
     }
@@ -519,35 +551,41 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_M * WAVES_N == 4 ? 2 
         for (int c = 0; c < 8; ++c) dbacc[i][c] = 0.f;
     const bool do_db = (db != nullptr) && (tn == 0);
     int a_off[NA], b_off[NB];                                    // LDS byte offsets of this thread's chunks inside a piece image
-    const float* pa[NA];
-    const float* pb[NB];
+    // global addresses as (wave-uniform stage base) + (32-bit byte offset of the lane): no 64-bit vector arithmetic per load
+    unsigned pa[NA], pb[NB];
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
         const int e = t + NT * i;
         a_off[i] = off_tr<FM>(e / (FM / 8), e % (FM / 8));
-        pa[i] = dy + (size_t)(e / (FM / 8)) * ldy + n0 + 8 * (e % (FM / 8));
+        pa[i] = (unsigned)(((e / (FM / 8)) * ldy + 8 * (e % (FM / 8))) * 4);
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
         const int e = t + NT * i;
         b_off[i] = off_tr<FN>(e / (FN / 8), e % (FN / 8));
-        pb[i] = x + (size_t)(e / (FN / 8)) * ldx + k0 + 8 * (e % (FN / 8));
+        pb[i] = (unsigned)(((e / (FN / 8)) * ldx + 8 * (e % (FN / 8))) * 4);
     }
+    const char* const dyb = reinterpret_cast<const char*>(dy + n0);
+    const char* const xb = reinterpret_cast<const char*>(x + k0);
     auto gload = [&](int st) {
         if constexpr (DHZ_W6_ABL & 1) return;
         const size_t tok0 = (size_t)st * BK2;
+        const char* const da = dyb + tok0 * ldy * 4;
+        const char* const db_ = xb + tok0 * ldx * 4;
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
-            const float* p = pa[i] + tok0 * ldy;
-            ra[i][0] = *reinterpret_cast<const f32x4*>(p);
-            ra[i][1] = *reinterpret_cast<const f32x4*>(p + 4);
-            rs[i] = row_scale ? row_scale[(tok0 + (t + NT * i) / (FM / 8)) / rows_per_scale] : 1.f;
+            ra[i][0] = *reinterpret_cast<const f32x4*>(da + pa[i]);
+            ra[i][1] = *reinterpret_cast<const f32x4*>(da + pa[i] + 16);
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
-            const float* p = pb[i] + tok0 * ldx;
-            rb[i][0] = *reinterpret_cast<const f32x4*>(p);
-            rb[i][1] = *reinterpret_cast<const f32x4*>(p + 4);
+            rb[i][0] = *reinterpret_cast<const f32x4*>(db_ + pb[i]);
+            rb[i][1] = *reinterpret_cast<const f32x4*>(db_ + pb[i] + 16);
+        }
+        if (row_scale) {
+            rs = row_scale[rs_img];
+            rs_left -= BK2;
+            if (rs_left <= 0) { ++rs_img; rs_left += rows_per_scale; }
         }
     };
     auto swrite = [&](int buf) {
@@ -555,10 +593,14 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_M * WAVES_N == 4 ? 2 
         unsigned char* Bs = As + 3 * A_BYTES;
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
-            const f32x4 v0 = ra[i][0] * rs[i], v1 = ra[i][1] * rs[i];
+            f32x4 v0 = ra[i][0], v1 = ra[i][1];
+            if (row_scale) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) { v0[c] = mul_np(v0[c], rs); v1[c] = mul_np(v1[c], rs); }
+            }
             u32x4 hi, mid, lo;
             if constexpr (DHZ_W6_ABL & 2) { hi = __builtin_bit_cast(u32x4, v0); mid = __builtin_bit_cast(u32x4, v1); lo = hi ^ mid; }
-            else split8x3(v0, v1, hi, mid, lo);
+            else split8x3_np(v0, v1, hi, mid, lo);
             if constexpr (DHZ_W6_ABL & 4) { asm volatile("" :: "v"(hi), "v"(mid), "v"(lo)); }
             else {
             *reinterpret_cast<u32x4*>(As + a_off[i]) = hi;
@@ -574,7 +616,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_M * WAVES_N == 4 ? 2 
         for (int i = 0; i < NB; ++i) {
             u32x4 hi, mid, lo;
             if constexpr (DHZ_W6_ABL & 2) { hi = __builtin_bit_cast(u32x4, rb[i][0]); mid = __builtin_bit_cast(u32x4, rb[i][1]); lo = hi ^ mid; }
-            else split8x3(rb[i][0], rb[i][1], hi, mid, lo);
+            else split8x3_np(rb[i][0], rb[i][1], hi, mid, lo);
             if constexpr (DHZ_W6_ABL & 4) { asm volatile("" :: "v"(hi), "v"(mid), "v"(lo)); }
             else {
             *reinterpret_cast<u32x4*>(Bs + b_off[i]) = hi;
@@ -737,7 +779,7 @@ extern "C" int dhz_linear_wgrad_split(const float* dy, int ldy, const float* x, 
     hipStream_t s = (hipStream_t)stream;
     const int rps = rows_per_scale > 0 ? rows_per_scale : 1;
     static const bool old6 = getenv("DHZ_WGRAD6_OLD") != nullptr;       // diagnostics: the round-3 kernel for the six-term form
-    if (terms == 6 && !old6) {
+    if (terms == 6 && !old6 && (!row_scale || rps % BK2 == 0)) {       // (a per-image factor changes between stages, never inside one)
         // pipelined kernel: 128 x 64 / 64 x 128 / 64 x 64 tiles (two piece-image stages of 32 rows: <= 72 KB, two workgroups per CU)
         const int wm6 = nper % 128 == 0 ? 4 : 2, wn6 = (K % 128 == 0 && wm6 == 2) ? 4 : 2;
         // 512-thread tiles (256 x 128 / 128 x 256 / 128 x 128, one workgroup per CU) halve the traffic through L2 and the split work

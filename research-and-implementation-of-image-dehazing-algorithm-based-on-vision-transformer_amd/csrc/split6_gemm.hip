@@ -98,7 +98,30 @@ __device__ __forceinline__ uint32_t pack_top(float x1, float x0) {              
 __device__ __forceinline__ f32x2 top16(f32x2 v) {
     return f32x2{__uint_as_float(__float_as_uint(v[0]) & 0xffff0000u), __uint_as_float(__float_as_uint(v[1]) & 0xffff0000u)};
 }
+#ifndef DHZ_S6_NP
+#define DHZ_S6_NP 1     // 1: the subtractions of the split as scalar-lane v_sub_f32 (inline asm), 0: as v_pk_add_f32
+#endif
+// Between two bf16 MFMAs of a wave the first two plain vector instructions cost nothing and further ones 4 cycles each, a PACKED fp32
+// instruction 7 - 17 cycles of matrix-pipe time (tools/ubench/interleave.hip): the subtractions are therefore issued per lane - 11
+// instructions per pair of elements instead of 9 - through inline asm (left as C, hipcc's SLP vectoriser re-packs them).
+__device__ __forceinline__ float sub_np(float a, float b) {
+    float r;
+    asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 __device__ __forceinline__ void split8x3(const f32x4 a, const f32x4 b, u32x4& hi, u32x4& mid, u32x4& lo) {
+#if DHZ_S6_NP
+    const float x[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float x0 = x[2 * i], x1 = x[2 * i + 1];
+        const float r0 = sub_np(x0, __uint_as_float(__float_as_uint(x0) & 0xffff0000u)), r1 = sub_np(x1, __uint_as_float(__float_as_uint(x1) & 0xffff0000u));
+        const float q0 = sub_np(r0, __uint_as_float(__float_as_uint(r0) & 0xffff0000u)), q1 = sub_np(r1, __uint_as_float(__float_as_uint(r1) & 0xffff0000u));
+        hi[i] = pack_top(x1, x0);
+        mid[i] = pack_top(r1, r0);
+        lo[i] = pack_top(q1, q0);
+    }
+#else
     const f32x2 x[4] = {{a[0], a[1]}, {a[2], a[3]}, {b[0], b[1]}, {b[2], b[3]}};
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -108,6 +131,7 @@ __device__ __forceinline__ void split8x3(const f32x4 a, const f32x4 b, u32x4& hi
         mid[i] = pack_top(r1[1], r1[0]);
         lo[i] = pack_top(r2[1], r2[0]);
     }
+#endif
 }
 
 // Activation loads as inline assembly: hipcc's wait-count pass does not see them, so it cannot answer a use of their registers

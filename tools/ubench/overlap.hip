@@ -32,7 +32,9 @@ typedef short bf16x8 __attribute__((ext_vector_type(8)));
 template <int KIND, int OP>   // KIND 0: v_mfma_f32_16x16x4_f32, 1: v_mfma_f32_16x16x32_bf16
 __global__ __launch_bounds__(512, 1) void k(float* out, int iters, int mode) {
     const int w = threadIdx.x >> 6;
-    const bool isM = w < 4;
+    const bool isM = (mode & 8) ? w >= 4 : w < 4;                  // bit 3: the matrix waves are the younger ones
+    if (mode & 4) { if (isM) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(3); }   // bit 2: vector waves at priority 3
+    if (mode & 16) { if (isM) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0); }  // bit 4: matrix waves at priority 3
     if (isM) {
         if (!(mode & 1)) return;
         f32x4 acc[8];
@@ -94,10 +96,24 @@ void row(float* out, const char* name, int iters) {
            verdict(m0, v0, b0), m1, v1, b1, verdict(m1, v1, b1));
 }
 
+template <int OP>
+void prio(float* out, const char* name, int iters) {
+    for (int kind = 0; kind < 2; ++kind) {
+        printf("%-12s vs %s  M %7.1f V %7.1f | both: equal priority %7.1f, V at prio 3 %7.1f, M at prio 3 %7.1f, M younger %7.1f, M younger + V prio 3 %7.1f\n", name,
+               kind ? "bf16 16x16x32" : "fp32 16x16x4 ", kind ? run<1, OP>(out, iters, 1) : run<0, OP>(out, iters, 1), kind ? run<1, OP>(out, iters, 2) : run<0, OP>(out, iters, 2),
+               kind ? run<1, OP>(out, iters, 3) : run<0, OP>(out, iters, 3), kind ? run<1, OP>(out, iters, 3 | 4) : run<0, OP>(out, iters, 3 | 4),
+               kind ? run<1, OP>(out, iters, 3 | 16) : run<0, OP>(out, iters, 3 | 16), kind ? run<1, OP>(out, iters, 3 | 8) : run<0, OP>(out, iters, 3 | 8),
+               kind ? run<1, OP>(out, iters, 3 | 8 | 4) : run<0, OP>(out, iters, 3 | 8 | 4));
+    }
+}
+
 int main() {
     float* out;
     hipMalloc(&out, 256 * 512 * 4);
     const int iters = 20000;
+    prio<1>(out, "v_fma_f32", iters);
+    prio<8>(out, "v_and_b32", iters);
+    prio<0>(out, "v_pk_fma_f32", iters);
     printf("us per launch; %d iterations x 8 instructions per wave; M = matrix waves alone, V = the other four waves alone (one per SIMD)\n", iters);
 #define X(ID, NAME, ASM, O, I1, I2) row<ID>(out, NAME, iters);
     OPS(X)
