@@ -17,9 +17,13 @@
 // output block (16 tiles of 4 x 4) x 32 output channels for all 36 positions.  Lane (tile i16, channel pair g) transforms ITS OWN tile
 // for ITS OWN two channels, and the MFMA contraction index of lane group g at step s is channel 2 g + s - so the 36 x 2 transformed
 // values a lane computes ARE its B operands: the transformed input never leaves the registers.  Per group of 8 input channels:
-//   (1) transform phase: 36 ds_read_b64 of the lane's 6 x 6 window, B^T d B as 12 six-point transforms of 14 packed operations;
+//   (1) transform phase: B^T d B of the lane's 6 x 6 x 2-channel window as 12 six-point transforms of 12 packed FMAs, in place (the
+//       window was read from LDS - 36 ds_read_b64 - behind the last matrix instructions of the group before, into registers whose
+//       positions were already consumed);
 //   (2) matrix phase: 144 MFMAs (A fragments: one ds_read_b128 per position pair and output-channel half); between them the LDS-DMA
-//       requests of the NEXT group, one per MFMA quad (issued back to back they queue in the address unit: 100 cycles each).
+//       requests of the NEXT group, one per MFMA quad (issued back to back they queue in the address unit: 100 cycles each), each with
+//       its base in SGPRs and a 32-bit lane offset: no vector instruction sits between two MFMAs (one costs 13 - 17 cycles of matrix-pipe
+//       time there: tools/ubench/interleave.hip).
 // The phases are sequential on purpose: vector and fp32 matrix instructions of one wave do not overlap on this part (the first
 // form of this kernel - 16 output channels per wave, the transform of group cb + 1 interleaved with the MFMAs of cb through two
 // register sets - measured its transform and its DMA issue as ADDED to the matrix time and lost to F(2x2); what pays is the ratio:
@@ -37,11 +41,8 @@
 #include <type_traits>
 #include "common.h"
 
-#ifndef W43_FORM
-#define W43_FORM 2      // 2: one wave per SIMD, 32 output channels per wave;  3: two waves per SIMD in opposite phases (the paired form)
-#endif
 #ifndef W43_ABL
-#define W43_ABL 0       // timing diagnostics: 1 no input transform, 2 no DMA, 4 no MFMAs
+#define W43_ABL 0       // timing diagnostics: 1 no input transform, 2 no DMA, 4 no MFMAs, 16 window reads but no transform arithmetic
 #endif
 
 namespace {
@@ -356,301 +357,9 @@ __global__ __launch_bounds__(256, 1) void winograd43_conv3x3_kernel(const float*
 }
 
 
-// ---- the paired form: TWO waves per SIMD that split the 36 positions, in opposite phases ----------------------------------------------
-// The one-wave form above adds its transform (2,000 cycles per group) and its DMA issue to 4,608 cycles of matrix instructions: nothing
-// else is resident on the SIMD to feed the matrix pipe while the wave does vector work.  Here a 512-thread workgroup puts waves w and
-// w + 4 on one SIMD; both own the SAME 16 x 16-pixel block and all 32 output channels, wave w ("role 0") the transform-domain rows
-// 0 .. 2 (positions 0 .. 17) and wave w + 4 ("role 1") the rows 3 .. 5: 18 positions x 2 channel halves x 4 = 144 accumulators each, 36
-// transformed values per lane instead of 72, and HALF a transform each (B^T d for three of the six rows: 8 packed operations per column
-// instead of 14, then three full row transforms: 90 packed operations against 168) - no vector work is duplicated.  Time runs in
-// half-intervals separated by workgroup barriers: role 0 transforms group g in half 2 g and multiplies in half 2 g + 1, role 1 transforms
-// in 2 g + 1 and multiplies in 2 g + 2, so on every SIMD one wave feeds the matrix pipe while the other one does its vector work.
-// Buffers: patch g is read in halves 2 g and 2 g + 1 -> two slots per block; patch g + 1 is requested by the role-0 wave during its
-// transform half 2 g (the vector half has the slack; the matrix halves carry no requests) and awaited at the end of its matrix half
-// 2 g + 1.  Filter slice g is read in halves 2 g + 1 and 2 g + 2 -> two slots; slice g + 1 is requested by the role-1 waves during their
-// transform half 2 g + 1 and awaited at the end of their matrix half 2 g + 2.  Every request has more than a whole half-interval (~1 us) to land.  The output transform Y = A^T M A is a sum over the rows of M: each
-// wave transforms its three rows, the two partial 4 x 4 tiles meet through LDS (role r finishes channel half r).
-constexpr int PSLOT = PCHUNKS * 4;                  // floats of one patch slot (664 chunks; the tail of DMA run 10 is masked)
-constexpr size_t W43P_SMEM = (size_t)(NUBUF * UF + 8 * PSLOT + KB) * sizeof(float);      // 72 + 83 KiB
-static_assert(W43P_SMEM <= 160 * 1024, "LDS of the paired form");
-static_assert(8 * 64 * 64 * sizeof(float) <= (NUBUF * UF + 8 * PSLOT) * sizeof(float), "the partial-tile exchange reuses the operand buffers");
-#ifndef W43P_SKEW
-#define W43P_SKEW 0
-#endif
-#ifndef W43P_PAIR
-#define W43P_PAIR 4      // partner of wave w on its SIMD: w + 4 (the waves of a workgroup go to the four SIMDs round-robin)
-#endif
-
-template <bool FWD>
-__global__ __launch_bounds__(512, 1) void winograd43_pair_kernel(const float* __restrict__ x, const float* __restrict__ upack,
-                                                                 const float* __restrict__ bias, int relu,
-                                                                 const float* __restrict__ out_mask,
-                                                                 const float* __restrict__ out_addend, float* __restrict__ y, int H,
-                                                                 int W, int C, int K, int nblk, int xcd_group, int cb0, int ncb,
-                                                                 int chain) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int t = threadIdx.x, lane = t & 63;
-    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int wb = W43P_PAIR == 4 ? (w & 3) : (w >> 1), role = W43P_PAIR == 4 ? (w >> 2) : (w & 1);
-    const int i16 = lane & 15, g = lane >> 4;
-    const int ty = i16 >> 2, tx = i16 & 3, hf = g >> 1, sub = g & 1;
-    float* const us = smem;                                        // filter ring [2][UF]
-    float* const pw = smem + NUBUF * UF + wb * 2 * PSLOT;          // this block's two patch slots
-    float* const bias_s = smem + NUBUF * UF + 8 * PSLOT;
-    const int KBn = K / KB, CBn = C / CC;
-    int lid = blockIdx.x;
-    if (xcd_group) lid = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
-    const int kb = lid % KBn;
-    int blk = (lid / KBn) * 4 + wb;
-    const bool live = blk < nblk;
-    if (!live) blk = nblk - 1;
-    const int bx_n = W / 16, by_n = H / 16;
-    const int bimg = blk / (bx_n * by_n);
-    const int by = (blk / bx_n) % by_n, bx = blk % bx_n;
-    const int oy0 = by * 16, ox0 = bx * 16;
-    const size_t plane = (size_t)H * W * 8;
-
-    {   // zero both patch slots of the block (its two waves share the work)
-        f32x4* z = reinterpret_cast<f32x4*>(pw);
-        for (int i = role * 64 + lane; i < 2 * PSLOT / 4; i += 128) z[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-    if (FWD && t < KB) bias_s[t] = bias ? bias[kb * KB + t] : 0.f;
-
-    // patch DMA (role 0): run r moves LDS chunks 64 r .. 64 r + 63 of a slot
-    int poff[PRUNS];
-#pragma unroll
-    for (int r = 0; r < PRUNS; ++r) {
-        const int c = 64 * r + lane;
-        const int ph = c / PLANE, rr = c - ph * PLANE;
-        const int k4 = rr / 73;
-        const int q = rr - 73 * k4;
-        const int row = 4 * k4 + q / 18, px = q % 18;
-        const int iy = oy0 - 1 + row, ix = ox0 - 1 + px;
-        const bool ok = ph < 2 && q < 72 && row < 18 && iy >= 0 && iy < H && ix >= 0 && ix < W;
-        poff[r] = ok ? (iy * W + ix) * 8 + ph * 4 : -1;
-    }
-    const float* const xbase = x + ((size_t)bimg * CBn + cb0) * plane;
-    const float* const ubase = upack + ((size_t)kb * CBn + cb0) * UF + lane * 4;
-    auto dma_patch_run = [&](int cb, int r) {
-        if (W43_ABL & 2) return;
-        if (poff[r] >= 0) dma16(xbase + (size_t)cb * plane + poff[r], pw + (cb & 1) * PSLOT + 256 * r);
-    };
-    auto dma_u_run = [&](int cb, int r) {                          // (role 1) run wb + 4 r of slice cb -> ring slot cb & 1
-        if (W43_ABL & 2) return;
-        const int run = wb + 4 * r;
-        dma16(ubase + (size_t)cb * UF + 256 * run, us + (cb & 1) * UF + 256 * run);
-    };
-
-    const float* const pread0 = pw + (hf * PLANE + 73 * ty + 4 * tx) * 4 + 2 * sub;
-    // 18 positions x 2 channel halves: hipcc splits the 256 registers of a wave 128 + 128, so local positions 0 .. 15 sit in the AGPR half,
-    // 16 and 17 in VGPRs
-    constexpr int NPL = 18, NXA = 16;
-    f32x4 acc[NXA][2], accv[NPL - NXA][2];
-#pragma unroll
-    for (int p = 0; p < NXA; ++p) { acc[p][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[p][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-#pragma unroll
-    for (int p = 0; p < NPL - NXA; ++p) { accv[p][0] = f32x4{0.f, 0.f, 0.f, 0.f}; accv[p][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-    auto A = [&](int p, int kh) -> f32x4& { return p < NXA ? acc[p][kh] : accv[p - NXA][kh]; };
-
-    // ---- prologue: patch 0 (role 0), filter slice 0 (role 1)
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __syncthreads();                                               // the zero fill of both waves of the block is in LDS before a DMA lane lands
-    if (!role) {
-#pragma unroll
-        for (int r = 0; r < PRUNS; ++r) dma_patch_run(0, r);
-    } else {
-#pragma unroll
-        for (int r = 0; r < URUNS / 4; ++r) dma_u_run(0, r);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (W43P_SKEW && role) __syncthreads();                        // role 1 runs one half-interval behind (role 0 pays this barrier back after its loop)
-
-    // Both roles run the SAME instruction stream; what differs is data (wave-uniform selects):
-    //   B^T d, the role's three rows:  X = A2B2 x0 - SAB x2 + x4 over window rows (0, 2, 4) [role 0: point 0] or (1, 3, 5) [role 1: infinity];
-    //   e = d4 - Ce d2, o = Co d3 - Cd d1 with (Ce, Co, Cd) = (B2, PA, AB2) [points +-a] or (A2, PB, A2B) [points +-b];  local rows (X, e + o, e - o)
-    //   = transform rows (0, 1, 2) or (5, 3, 4) -> position pairs 3 a + b / 2 of the filter slice
-    const float Ce = role ? A2 : B2, Co = role ? PB : PA, Cd = role ? A2B : AB2;
-    constexpr int RO[6] = {0, 18 * 4, 36 * 4, 54 * 4, (72 + 1) * 4, (90 + 1) * 4};      // window row a -> float offset (a * 18 + (a >> 2)) * 4
-    const float* const px0 = pread0 + (role ? RO[1] : RO[0]);
-    const float* const px2 = pread0 + (role ? RO[3] : RO[2]);
-    const float* const px4 = pread0 + (role ? RO[5] : RO[4]);
-    const float* const ufrag = us + (g * 16 + i16) * 4;
-    const float* const uf0 = ufrag + (role ? 15 : 0) * 512;       // filter fragments of local row 0, 1, 2
-    const float* const uf1 = ufrag + (role ? 9 : 3) * 512;
-    const float* const uf2 = ufrag + (role ? 12 : 6) * 512;
-#pragma unroll 1
-    for (int gi = 0; gi < ncb; ++gi) {
-        // ---- transform half; between its column transforms the requests of the NEXT group's operands (the vector half has the slack, the
-        //      matrix half stays free of them): role 0 the eleven runs of patch gi + 1 (its slot was last read in half 2 gi - 1), role 1 its
-        //      nine runs of filter slice gi + 1 (its slot was last read in half 2 gi) - each has more than a whole half-interval to land
-        f32x2 v[3][6];
-        const bool nx = gi + 1 < ncb;
-        if (!(W43_ABL & 1)) {
-            const int so = (gi & 1) * PSLOT;
-#pragma unroll
-            for (int b = 0; b < 6; ++b) {
-                if (nx) {
-                    if (role == 0) { dma_patch_run(gi + 1, 2 * b); if (2 * b + 1 < PRUNS) dma_patch_run(gi + 1, 2 * b + 1); }
-                    else { dma_u_run(gi + 1, 2 * b); if (2 * b + 1 < URUNS / 4) dma_u_run(gi + 1, 2 * b + 1); }
-                }
-                const f32x2 q1 = *reinterpret_cast<const f32x2*>(pread0 + so + RO[1] + 4 * b);
-                const f32x2 q2 = *reinterpret_cast<const f32x2*>(pread0 + so + RO[2] + 4 * b);
-                const f32x2 q3 = *reinterpret_cast<const f32x2*>(pread0 + so + RO[3] + 4 * b);
-                const f32x2 q4 = *reinterpret_cast<const f32x2*>(pread0 + so + RO[4] + 4 * b);
-                const f32x2 x0 = *reinterpret_cast<const f32x2*>(px0 + so + 4 * b);
-                const f32x2 x2 = *reinterpret_cast<const f32x2*>(px2 + so + 4 * b);
-                const f32x2 x4 = *reinterpret_cast<const f32x2*>(px4 + so + 4 * b);
-                const f32x2 e = q4 - Ce * q2, o = Co * q3 - Cd * q1;
-                v[0][b] = A2B2 * x0 - SAB * x2 + x4;
-                v[1][b] = e + o;
-                v[2][b] = e - o;
-            }
-#pragma unroll
-            for (int a = 0; a < 3; ++a) bt6(v[a][0], v[a][1], v[a][2], v[a][3], v[a][4], v[a][5]);
-#pragma unroll
-            for (int a = 0; a < 3; ++a)
-                asm volatile("" : "+v"(v[a][0]), "+v"(v[a][1]), "+v"(v[a][2]), "+v"(v[a][3]), "+v"(v[a][4]), "+v"(v[a][5]));
-        } else {
-            if (nx) {
-                if (role == 0) {
-#pragma unroll
-                    for (int r = 0; r < PRUNS; ++r) dma_patch_run(gi + 1, r);
-                } else {
-#pragma unroll
-                    for (int r = 0; r < URUNS / 4; ++r) dma_u_run(gi + 1, r);
-                }
-            }
-#pragma unroll
-            for (int a = 0; a < 3; ++a)
-#pragma unroll
-                for (int b = 0; b < 6; ++b) v[a][b] = f32x2{1.f, 1.f};
-        }
-        __syncthreads();
-        // ---- matrix half: 72 MFMAs on this role's half of filter slice gi (fragments one pair-step ahead)
-        const int uo = (gi & 1) * UF;
-        f32x4 alo = *reinterpret_cast<const f32x4*>(uf0 + uo), ahi = *reinterpret_cast<const f32x4*>(uf0 + uo + 256);
-#pragma unroll
-        for (int j = 0; j < 9; ++j) {
-            f32x4 nlo = alo, nhi = ahi;
-            if (j + 1 < 9) {
-                const float* up = ((j + 1) / 3 == 0 ? uf0 : (j + 1) / 3 == 1 ? uf1 : uf2) + uo + ((j + 1) % 3) * 512;
-                nlo = *reinterpret_cast<const f32x4*>(up); nhi = *reinterpret_cast<const f32x4*>(up + 256);
-            }
-            const int p = 2 * j;
-            const f32x2 v0 = v[p / 6][p % 6], v1 = v[(p + 1) / 6][(p + 1) % 6];
-            __builtin_amdgcn_sched_barrier(0);
-            if (!(W43_ABL & 4)) {
-                if (p < NXA) {
-                    mfma_acc_a(acc[p][0], alo[0], v0[0]); mfma_acc_a(acc[p][1], ahi[0], v0[0]);
-                    mfma_acc_a(acc[p + 1][0], alo[2], v1[0]); mfma_acc_a(acc[p + 1][1], ahi[2], v1[0]);
-                } else {
-                    mfma_acc_v(accv[p - NXA][0], alo[0], v0[0]); mfma_acc_v(accv[p - NXA][1], ahi[0], v0[0]);
-                    mfma_acc_v(accv[p + 1 - NXA][0], alo[2], v1[0]); mfma_acc_v(accv[p + 1 - NXA][1], ahi[2], v1[0]);
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            if (!(W43_ABL & 4)) {
-                if (p < NXA) {
-                    mfma_acc_a(acc[p][0], alo[1], v0[1]); mfma_acc_a(acc[p][1], ahi[1], v0[1]);
-                    mfma_acc_a(acc[p + 1][0], alo[3], v1[1]); mfma_acc_a(acc[p + 1][1], ahi[3], v1[1]);
-                } else {
-                    mfma_acc_v(accv[p - NXA][0], alo[1], v0[1]); mfma_acc_v(accv[p - NXA][1], ahi[1], v0[1]);
-                    mfma_acc_v(accv[p + 1 - NXA][0], alo[3], v1[1]); mfma_acc_v(accv[p + 1 - NXA][1], ahi[3], v1[1]);
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            alo = nlo; ahi = nhi;
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the requests of my transform half have landed (long ago)
-        __syncthreads();
-    }
-    if (W43P_SKEW && !role) __syncthreads();
-
-    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
-    // ---- epilogue: Y = A^T M A = sum over the rows a of M of (A^T)[:, a] (M[a, :] A): this wave's three rows give a partial 4 x 4 tile per
-    //      (channel half, accumulator register); the half 1 - role goes to the partner through LDS, the half role is finished here.
-    //      A^T: y0 = m0 + m1 + m2 + m3 + m4;  y1 = PA (m1 - m2) + PB (m3 - m4);  y2 = A2 (m1 + m2) + B2 (m3 + m4);  y3 = A3 (m1 - m2) + B3 (m3 - m4) + m5
-    //      local rows (l0, l1, l2) = (m0, m1, m2) or (m5, m3, m4):  s = l1 + l2, d = l1 - l2;  y0 = s + k0 l0, y1 = c1 d, y2 = c2 s, y3 = c3 d + k3 l0
-    const float c1 = role ? PB : PA, c2 = role ? B2 : A2, c3 = role ? B3 : A3, k0 = role ? 0.f : 1.f, k3 = role ? 1.f : 0.f;
-    float* const xw = smem + (size_t)w * 4096 + lane * 4;          // [wave][16 f32x4][64 lanes]
-    float* const xr = smem + (size_t)(w ^ W43P_PAIR) * 4096 + lane * 4;
-    float yv[4][16];
-#pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
-        float part[4][16];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float tm[4][6];
-#pragma unroll
-            for (int c = 0; c < 6; ++c) {
-                // pass 0: the half that goes to the partner (1 - role), pass 1: the half finished here (role)
-                const float l0 = ((pass != 0) == (role != 0) ? A(c, 1) : A(c, 0))[j];
-                const float l1 = ((pass != 0) == (role != 0) ? A(6 + c, 1) : A(6 + c, 0))[j];
-                const float l2 = ((pass != 0) == (role != 0) ? A(12 + c, 1) : A(12 + c, 0))[j];
-                const float sm = l1 + l2, df = l1 - l2;
-                tm[0][c] = sm + k0 * l0;
-                tm[1][c] = c1 * df;
-                tm[2][c] = c2 * sm;
-                tm[3][c] = c3 * df + k3 * l0;
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                at6(tm[i][0], tm[i][1], tm[i][2], tm[i][3], tm[i][4], tm[i][5], part[j][4 * i], part[j][4 * i + 1], part[j][4 * i + 2],
-                    part[j][4 * i + 3]);
-        }
-        if (pass == 0) {
-#pragma unroll
-            for (int p = 0; p < 16; ++p)
-                *reinterpret_cast<f32x4*>(xw + p * 256) = f32x4{part[0][p], part[1][p], part[2][p], part[3][p]};
-        } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int p = 0; p < 16; ++p) yv[j][p] = part[j][p];
-        }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int p = 0; p < 16; ++p) {
-        const f32x4 o = *reinterpret_cast<const f32x4*>(xr + p * 256);
-        yv[0][p] += o[0]; yv[1][p] += o[1]; yv[2][p] += o[2]; yv[3][p] += o[3];
-    }
-    const int KG = K / 8;
-    const float lo = relu ? 0.f : -__builtin_inff();
-    if (live) {
-        const int kh = role;
-        const float4 bv = (FWD && !(chain & 2)) ? *reinterpret_cast<const float4*>(bias_s + 16 * kh + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
-        const size_t obase = (((size_t)bimg * KG + kb * 4 + kh * 2 + hf) * H + oy0 + 4 * ty) * W * 8 + (size_t)(ox0 + 4 * tx) * 8 + sub * 4;
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int jx = 0; jx < 4; ++jx) {
-                const int p = 4 * i + jx;
-                float4 v4 = make_float4(yv[0][p] + bv.x, yv[1][p] + bv.y, yv[2][p] + bv.z, yv[3][p] + bv.w);
-                const size_t o = obase + ((size_t)i * W + jx) * 8;
-                if (chain & 1) {
-                    const float4 part = *reinterpret_cast<const float4*>(y + o);
-                    v4.x += part.x; v4.y += part.y; v4.z += part.z; v4.w += part.w;
-                }
-                if (chain & 2) {
-                } else if (FWD) {
-                    v4.x = fmaxf(v4.x, lo); v4.y = fmaxf(v4.y, lo); v4.z = fmaxf(v4.z, lo); v4.w = fmaxf(v4.w, lo);
-                } else {
-                    if (out_addend) {
-                        const float4 ad = *reinterpret_cast<const float4*>(out_addend + o);
-                        v4.x += ad.x; v4.y += ad.y; v4.z += ad.z; v4.w += ad.w;
-                    }
-                    if (out_mask) {
-                        const float4 m = *reinterpret_cast<const float4*>(out_mask + o);
-                        v4.x = m.x > 0.f ? v4.x : 0.f; v4.y = m.y > 0.f ? v4.y : 0.f;
-                        v4.z = m.z > 0.f ? v4.z : 0.f; v4.w = m.w > 0.f ? v4.w : 0.f;
-                    }
-                }
-                *reinterpret_cast<float4*>(y + o) = v4;
-            }
-    }
-}
+// (A third form - 512-thread workgroups whose waves w and w + 4 share a block, split the 36 positions and run their transform / matrix halves
+// in opposite phases - was built, correct, and 3 % slower than this one: vector and matrix instructions of different waves of a SIMD
+// serialise on this part, tools/ubench/overlap.hip.  DESIGN 4e; the kernel is in the history at commit 7323fe2.)
 
 // U = G g G^T for every (k, c) in double, rounded once; packed [k / 32][c / 8][xi / 2][(k % 32) / 16][(c % 8) / 2][k % 16][xi % 2][c % 2] (the kernel's
 // LDS order: a slice is copied verbatim).  transposed_rot: the backward-data filters g'[c][k][i][j] = g[k][c][2 - i][2 - j].
@@ -715,15 +424,9 @@ extern "C" int dhz_winograd43_conv3x3(const float* x, const float* upack, const 
     // stream: all but the last leave raw partial sums in y, all but the first add what they find there (the same lane, the same
     // addresses), the last applies the epilogue.  One extra read + write of the output per extra chain.
     const int CBn = C / CC;
-#if W43_FORM == 3
-#define W43_KERNEL winograd43_pair_kernel
-#define W43_THREADS 512
-#define W43_LDS W43P_SMEM
-#else
 #define W43_KERNEL winograd43_conv3x3_kernel
 #define W43_THREADS 256
 #define W43_LDS W43_SMEM
-#endif
 #define GO(F)                                                                                                          \
     do {                                                                                                               \
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&W43_KERNEL<F>),                                       \

@@ -18,7 +18,8 @@ def test_split6_inline_asm_loads_are_not_touched_before_their_wait(capsys):
         assert out.count("ok  ") >= 7 and "FAIL" not in out and "SCRATCH" not in out, out
         # the checker sees what it is meant to see: plant a copy of a destination register right behind one load pair
         lines = open(path).read().splitlines()
-        k = next(i for i, ln in enumerate(lines) if "global_load_dwordx4" in ln and "offset:16" in ln)
+        k0 = next(i for i, ln in enumerate(lines) if ln.startswith("_Z") and "split6_wide_kernel" in ln)      # inside a checked kernel
+        k = next(i for i, ln in enumerate(lines) if i > k0 and "global_load_dwordx4" in ln and "offset:16" in ln)
         import re
         dst = re.search(r"global_load_dwordx4\s+v\[(\d+):", lines[k]).group(1)
         lines.insert(k + 1, f"\tv_mov_b32_e32 v255, v{dst}")
