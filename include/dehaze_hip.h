@@ -325,6 +325,11 @@ int dhz_winograd_conv3x3(const float* x, const float* upack, const float* bias, 
 int dhz_winograd43_prepack(const float* weight, float* upack, int Kout, int Cin, int transposed_rot, void* stream);
 int dhz_winograd43_conv3x3(const float* x, const float* upack, const float* bias, int relu, const float* out_mask,
                            const float* out_addend, float* y, int B, int H, int W, int C, int K, void* stream);
+/* ... + bias + ReLU + 2 x 2 / stride-2 max pooling in the same launch (replaces F.relu(conv2d) followed by nn.MaxPool2d(2, 2) of the VGG19
+ * slices, My_CR.py:60-86, where the un-pooled map is not a tap): ypool [B][K/8][H/2][W/2][8].  scratch: full-resolution map
+ * [B][K/8][H][W][8], needed only for C > 256 (partial sums of the accumulation chains), may be NULL otherwise. */
+int dhz_winograd43_conv3x3_pool(const float* x, const float* upack, const float* bias, float* ypool, float* scratch, int B, int H, int W,
+                                int C, int K, void* stream);
 int dhz_maxpool2x2_blocked_fwd(const float* x, float* y, int N, int H, int W, void* stream);
 int dhz_maxpool2x2_blocked_bwd(const float* gy, const float* act, float* gx, int N, int H, int W, void* stream);
 int dhz_layout_blocked8(const float* src, float* dst, int B, int C, int HW, int to_blocked, const float* bias, int relu,

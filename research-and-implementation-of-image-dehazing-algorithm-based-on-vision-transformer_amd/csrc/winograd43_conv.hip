@@ -127,7 +127,7 @@ __global__ __launch_bounds__(256, 1) void winograd43_conv3x3_kernel(const float*
                                                                     const float* __restrict__ out_mask,
                                                                     const float* __restrict__ out_addend, float* __restrict__ y, int H,
                                                                     int W, int C, int K, int nblk, int xcd_group, int cb0, int ncb,
-                                                                    int chain) {
+                                                                    int chain, float* __restrict__ ypool) {
     // cb0, ncb: the channel groups [cb0, cb0 + ncb) this launch accumulates; chain bit 0: add the partial sums an earlier launch left
     // in y, bit 1: leave raw partial sums in y (no bias / ReLU / mask / addend) for a later launch - see dhz_winograd43_conv3x3
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -325,6 +325,32 @@ __global__ __launch_bounds__(256, 1) void winograd43_conv3x3_kernel(const float*
         if (live) {
             const float4 bv = (FWD && !(chain & 2)) ? *reinterpret_cast<const float4*>(bias_s + 16 * kh + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
             const size_t obase = (((size_t)bimg * KG + kb * 4 + kh * 2 + hf) * H + oy0 + 4 * ty) * W * 8 + (size_t)(ox0 + 4 * tx) * 8 + sub * 4;
+            if (FWD && ypool && !(chain & 2)) {
+                // the layer feeds a 2 x 2 max pooling and nothing else (VGG19 conv1_2 / 2_2 / 3_4 / 4_4 in a no-gradient pass): the lane's
+                // 4 x 4 pixels give 2 x 2 pooled ones - a quarter of the stores, no pooling launch, no full-resolution map
+                const int Hp = H >> 1, Wp = W >> 1;
+                const size_t pbase = (((size_t)bimg * KG + kb * 4 + kh * 2 + hf) * Hp + (oy0 >> 1) + 2 * ty) * Wp * 8 + (size_t)((ox0 >> 1) + 2 * tx) * 8 + sub * 4;
+#pragma unroll
+                for (int pi = 0; pi < 2; ++pi)
+#pragma unroll
+                    for (int pj = 0; pj < 2; ++pj) {
+                        float4 m = make_float4(lo, lo, lo, lo);
+#pragma unroll
+                        for (int a = 0; a < 2; ++a)
+#pragma unroll
+                            for (int b = 0; b < 2; ++b) {
+                                const int p = 4 * (2 * pi + a) + 2 * pj + b;
+                                float4 v4 = make_float4(yv[0][p] + bv.x, yv[1][p] + bv.y, yv[2][p] + bv.z, yv[3][p] + bv.w);
+                                if (chain & 1) {
+                                    const float4 part = *reinterpret_cast<const float4*>(y + obase + ((size_t)(2 * pi + a) * W + 2 * pj + b) * 8);
+                                    v4.x += part.x; v4.y += part.y; v4.z += part.z; v4.w += part.w;
+                                }
+                                m.x = fmaxf(m.x, v4.x); m.y = fmaxf(m.y, v4.y); m.z = fmaxf(m.z, v4.z); m.w = fmaxf(m.w, v4.w);
+                            }
+                        *reinterpret_cast<float4*>(ypool + pbase + ((size_t)pi * Wp + pj) * 8) = m;
+                    }
+                continue;
+            }
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -355,7 +381,6 @@ __global__ __launch_bounds__(256, 1) void winograd43_conv3x3_kernel(const float*
         }
     }
 }
-
 
 // (A third form - 512-thread workgroups whose waves w and w + 4 share a block, split the 36 positions and run their transform / matrix halves
 // in opposite phases - was built, correct, and 3 % slower than this one: vector and matrix instructions of different waves of a SIMD
@@ -406,14 +431,14 @@ extern "C" int dhz_winograd43_prepack(const float* weight, float* upack, int Kou
     return DHZ_OK;
 }
 
-extern "C" int dhz_winograd43_conv3x3(const float* x, const float* upack, const float* bias, int relu, const float* out_mask,
-                                      const float* out_addend, float* y, int B, int H, int W, int C, int K, void* stream) {
-    DHZ_REQUIRE(x && upack && y, "dhz_winograd43_conv3x3: null pointer");
+static int winograd43_launch(const char* who, const float* x, const float* upack, const float* bias, int relu, const float* out_mask,
+                             const float* out_addend, float* y, float* ypool, int B, int H, int W, int C, int K, void* stream) {
+    DHZ_REQUIRE(x && upack && (y || ypool), "%s: null pointer", who);
     DHZ_REQUIRE(B > 0 && H % 16 == 0 && W % 16 == 0 && H >= 16 && W >= 16 && C % 16 == 0 && K % KB == 0,
-                "dhz_winograd43_conv3x3: unsupported shape B=%d H=%d W=%d C=%d K=%d", B, H, W, C, K);
+                "%s: unsupported shape B=%d H=%d W=%d C=%d K=%d", who, B, H, W, C, K);
     const bool fwd = !(out_mask || out_addend);
-    DHZ_REQUIRE(fwd || !(bias || relu), "dhz_winograd43_conv3x3: bias/relu and out_mask/out_addend are exclusive");
-    DHZ_REQUIRE((long long)H * W * 8 * (C / 8) < (1ll << 31), "dhz_winograd43_conv3x3: image too large");
+    DHZ_REQUIRE(fwd || !(bias || relu), "%s: bias/relu and out_mask/out_addend are exclusive", who);
+    DHZ_REQUIRE((long long)H * W * 8 * (C / 8) < (1ll << 31), "%s: image too large", who);
     const int nblk = B * (H / 16) * (W / 16);
     const int grid = ((nblk + 3) / 4) * (K / KB);
     const int xcd_group = (grid % 8 == 0) ? 1 : 0;
@@ -424,22 +449,34 @@ extern "C" int dhz_winograd43_conv3x3(const float* x, const float* upack, const 
     // stream: all but the last leave raw partial sums in y, all but the first add what they find there (the same lane, the same
     // addresses), the last applies the epilogue.  One extra read + write of the output per extra chain.
     const int CBn = C / CC;
-#define W43_KERNEL winograd43_conv3x3_kernel
-#define W43_THREADS 256
-#define W43_LDS W43_SMEM
+    DHZ_REQUIRE(y || CBn <= CHAIN_GROUPS, "%s: %d input channels run as accumulation chains and need the full-resolution scratch y", who, C);
 #define GO(F)                                                                                                          \
     do {                                                                                                               \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&W43_KERNEL<F>),                                       \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)W43_LDS);                           \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&winograd43_conv3x3_kernel<F>),                        \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)W43_SMEM);                          \
         for (int cb0 = 0; cb0 < CBn; cb0 += CHAIN_GROUPS) {                                                            \
             const int ncb = CBn - cb0 < CHAIN_GROUPS ? CBn - cb0 : CHAIN_GROUPS;                                       \
             const int chain = (cb0 > 0 ? 1 : 0) | (cb0 + ncb < CBn ? 2 : 0);                                           \
-            hipLaunchKernelGGL((W43_KERNEL<F>), dim3(grid), dim3(W43_THREADS), W43_LDS, s, x, upack, bias,             \
-                               relu, out_mask, out_addend, y, H, W, C, K, nblk, xcd_group, cb0, ncb, chain);           \
+            hipLaunchKernelGGL((winograd43_conv3x3_kernel<F>), dim3(grid), dim3(256), W43_SMEM, s, x, upack, bias,     \
+                               relu, out_mask, out_addend, y, H, W, C, K, nblk, xcd_group, cb0, ncb, chain, ypool);    \
         }                                                                                                              \
     } while (0)
     if (fwd) GO(true); else GO(false);
 #undef GO
-    DHZ_CHECK_LAUNCH("dhz_winograd43_conv3x3");
+    DHZ_CHECK_LAUNCH(who);
     return DHZ_OK;
+}
+
+extern "C" int dhz_winograd43_conv3x3(const float* x, const float* upack, const float* bias, int relu, const float* out_mask,
+                                      const float* out_addend, float* y, int B, int H, int W, int C, int K, void* stream) {
+    DHZ_REQUIRE(y, "dhz_winograd43_conv3x3: null pointer");
+    return winograd43_launch("dhz_winograd43_conv3x3", x, upack, bias, relu, out_mask, out_addend, y, nullptr, B, H, W, C, K, stream);
+}
+
+// convolution + bias + ReLU + 2 x 2 max pooling in one launch: ypool [B][K/8][H/2][W/2][8].  scratch (full resolution, [B][K/8][H][W][8]) is
+// needed only when C > 256 (the partial sums of the accumulation chains travel through it); may be null otherwise.
+extern "C" int dhz_winograd43_conv3x3_pool(const float* x, const float* upack, const float* bias, float* ypool, float* scratch, int B, int H,
+                                           int W, int C, int K, void* stream) {
+    DHZ_REQUIRE(ypool, "dhz_winograd43_conv3x3_pool: null pointer");
+    return winograd43_launch("dhz_winograd43_conv3x3_pool", x, upack, bias, 1, nullptr, nullptr, scratch, ypool, B, H, W, C, K, stream);
 }

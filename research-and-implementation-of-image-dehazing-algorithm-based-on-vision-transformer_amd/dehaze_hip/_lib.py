@@ -54,6 +54,7 @@ SIGNATURES = {
     "dhz_winograd_conv3x3": [c_f, c_f, c_f, c_i, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_p],
     "dhz_winograd43_prepack": [c_f, c_f, c_i, c_i, c_i, c_p],
     "dhz_winograd43_conv3x3": [c_f, c_f, c_f, c_i, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_p],
+    "dhz_winograd43_conv3x3_pool": [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_p],
     "dhz_maxpool2x2_blocked_fwd": [c_f, c_f, c_i, c_i, c_i, c_p],
     "dhz_maxpool2x2_blocked_bwd": [c_f, c_f, c_f, c_i, c_i, c_i, c_p],
     "dhz_layout_blocked8": [c_f, c_f, c_i, c_i, c_i, c_i, c_f, c_i, c_p],

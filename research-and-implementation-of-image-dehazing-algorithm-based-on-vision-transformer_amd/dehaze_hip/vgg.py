@@ -89,6 +89,9 @@ def _timing_end(ev, B, H, W, Cin, Kout, f43=False):
 F43_ON = os.environ.get("DHZ_WINO_F43", "1") != "0"
 
 
+POOL_FUSED = os.environ.get("DHZ_WINO_POOL", "1") != "0"    # A/B switch: the pooling of the no-gradient pass inside the F(4x4) launch
+
+
 def use_f43(B, H, W, Cin, Kout):
     if not F43_ON or H % 16 or W % 16 or H < 16 or W < 16 or Cin % 16 or Kout % 32:
         return False
@@ -135,17 +138,27 @@ class VggEngine:
         return hit[1], hit[2]
 
     # ---- one Winograd layer
-    def conv(self, i, xb, allow43=True):
+    def conv(self, i, xb, allow43=True, pool=False):
+        """conv i + bias + ReLU; pool=True: + the 2 x 2 max pooling behind it, in the same launch when the layer runs the F(4x4) kernel (the
+        un-pooled map is then never written: only for layers whose output is no tap and is not saved)."""
         B, CG, H, W, _ = xb.shape
         C, K = CONVS[i]
         f43 = allow43 and use_f43(B, H, W, C, K)
         uf, _ = self.packed43(i, xb.device) if f43 else self.packed(i, xb.device)
+        if pool and f43:
+            yp = torch.empty((B, K // 8, H // 2, W // 2, 8), device=xb.device, dtype=torch.float32)
+            scratch = torch.empty((B, K // 8, H, W, 8), device=xb.device, dtype=torch.float32) if C > 256 else None
+            ev = _timing_begin()
+            _lib.call("dhz_winograd43_conv3x3_pool", _p(xb), _p(uf), _p(self.convs[i].bias), _p(yp), _p(scratch) if scratch is not None else None,
+                      B, H, W, C, K, _stream())
+            _timing_end(ev, B, H, W, C, K, f43)
+            return yp
         yb = torch.empty((B, K // 8, H, W, 8), device=xb.device, dtype=torch.float32)
         ev = _timing_begin()
         _lib.call("dhz_winograd43_conv3x3" if f43 else "dhz_winograd_conv3x3", _p(xb), _p(uf), _p(self.convs[i].bias), 1, None, None,
                   _p(yb), B, H, W, C, K, _stream())
         _timing_end(ev, B, H, W, C, K, f43)
-        return yb
+        return pool_fwd(yb) if pool else yb
 
     def conv_dgrad(self, i, gb, below_act=None, addend=None):
         """gb: gradient w.r.t. the pre-activation of conv i.  Returns the gradient w.r.t. conv i's input; with
@@ -190,6 +203,9 @@ class VggEngine:
                 # pass and flip three times as many near-zero units as F(2x2) does (tests/test_gpu_winograd.py::
                 # test_vgg_engine_backward_smooth_loss pins the gradient to 2e-4 of its maximum: ONE flipped first-layer unit is 1.6e-2)
                 # - that pass stays on F(2x2)
+                if POOL_FUSED and save is None and i in POOL_AFTER and i not in TAPS:
+                    cur = self.conv(i, cur, pool=True)          # no-gradient pass, the un-pooled map has no other reader
+                    continue
                 cur = self.conv(i, cur, allow43=(save is None))
             acts[i] = cur
             if i in TAPS:

@@ -118,8 +118,16 @@ def test_winograd43_forward_and_dgrad(B, C, K, H):
         _lib.call("dhz_winograd43_conv3x3", dyb.data_ptr(), upt.data_ptr(), None, 0, None, addb.data_ptr(),
                   dxb.data_ptr(), B, H, H, K, C, s)
         assert torch.allclose(_plain(dxb, C), refdx + add, atol=5e-5, rtol=1e-4)
+    # convolution + bias + ReLU + 2 x 2 max pooling in one launch (the un-pooled map is never written; C > 256: chains through the scratch map)
+    yp = torch.empty(B, K // 8, H // 2, H // 2, 8, device=dev)
+    scratch = torch.empty(B, K // 8, H, H, 8, device=dev) if C > 256 else None
+    _lib.call("dhz_winograd43_conv3x3_pool", xb.data_ptr(), up.data_ptr(), b.data_ptr(), yp.data_ptr(),
+              scratch.data_ptr() if scratch is not None else None, B, H, H, C, K, s)
+    assert torch.allclose(_plain(yp, K), F.max_pool2d(ref, 2, 2), atol=2e-5, rtol=1e-4), (_plain(yp, K) - F.max_pool2d(ref, 2, 2)).abs().max()
     lib = _lib.load()
     assert lib.dhz_winograd43_conv3x3(xb.data_ptr(), up.data_ptr(), None, 0, None, None, yb.data_ptr(), B, 8, 8, C, K, s) == -22
+    if C > 256:
+        assert lib.dhz_winograd43_conv3x3_pool(xb.data_ptr(), up.data_ptr(), b.data_ptr(), yp.data_ptr(), None, B, H, H, C, K, s) == -22
 
 
 @pytest.mark.parametrize("ablation", [False, True])
@@ -286,12 +294,15 @@ def test_vgg_engine_f43_dispatch_at_step_size():
         cl = My_CR.ContrastLoss().to(dev)
     g = torch.Generator().manual_seed(3)
     a0, p, n = (torch.rand(32, 3, 128, 128, generator=g).to(dev) for _ in range(3))
-    calls = []
+    calls, pooled = [], []
     real = _lib.call
 
     def spy(name, *args):
         if name in ("dhz_winograd43_conv3x3", "dhz_winograd_conv3x3"):
             calls.append((name, args[7], args[8], args[10], args[11], args[3] == 0))   # B, H, C, K, backward-data product? (no ReLU)
+        if name == "dhz_winograd43_conv3x3_pool":                                      # convolution + ReLU + pooling in one launch
+            calls.append(("dhz_winograd43_conv3x3", args[5], args[6], args[8], args[9], False))
+            pooled.append((args[5], args[6]))
         return real(name, *args)
 
     res = {}
@@ -300,6 +311,7 @@ def test_vgg_engine_f43_dispatch_at_step_size():
         for on in (False, True):
             V.F43_ON = on
             calls.clear()
+            pooled.clear()
             _lib.call = V._lib.call = spy
             a = a0.clone().requires_grad_()
             loss, ap, an = cl(a, p, n)
@@ -316,6 +328,7 @@ def test_vgg_engine_f43_dispatch_at_step_size():
     assert not any(c[1] == 32 and not c[5] for c in f43)                   # never the forward pass of the 32 differentiated images
     assert any(c[1] == 64 and c[2] == 16 for c in f43)                     # 64 reference images on the 16 x 16 maps: 256 workgroups
     assert not any(c[1] == 32 and c[2] == 16 for c in f43)                 # 32 images there: half a round - stays on F(2x2)
+    assert sorted(pooled) == [(64, 16), (64, 32), (64, 64), (64, 128)]     # the four pooled layers of the no-gradient pass: pooling in the launch
     assert abs(on[0] - off[0]) < 2e-5 * abs(off[0]) and abs(on[1] - off[1]) < 2e-5 * off[1] and abs(on[2] - off[2]) < 2e-5 * off[2]
     d = (on[3] - off[3]).abs()
     # (same ReLU masks in both runs: the differentiated forward pass is F(2x2) either way; sign(fa - fp) may flip where the reference
