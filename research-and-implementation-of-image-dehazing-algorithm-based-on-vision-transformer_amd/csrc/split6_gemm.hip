@@ -41,21 +41,6 @@ typedef const __attribute__((address_space(1))) void glb_void;
 constexpr int BK = 32;          // contraction elements per stage
 constexpr int NT = 512;         // threads per workgroup (8 waves)
 
-#ifdef DHZ_S6_STAMP          // timing diagnostics only (tools/micro/stamp_split6.py builds its own copy): s_memtime at the phase boundaries of
-                             // workgroup DHZ_S6_STAMP, kept in LDS and dumped at the end
-__device__ long long* g_s6_stamp = nullptr;
-constexpr int NSTAMP = 24;
-#define STAMP(slot)                                                                                           \
-    do {                                                                                                      \
-        if (lane == 0 && nstamp < NSTAMP)                                                                     \
-            stamp_lds[(w * NSTAMP + nstamp) * 8 + (slot)] = (unsigned)__builtin_amdgcn_s_memtime();           \
-    } while (0)
-#else
-#define STAMP(slot)
-#endif
-#ifndef DHZ_S6_DBG
-#define DHZ_S6_DBG 0
-#endif
 #ifndef DHZ_S6_ABL
 #define DHZ_S6_ABL 0            // timing diagnostics: 1 = no stores, 2 = no MFMAs, 4 = no activation split, 8 = no weight DMA, 16 = no fragment reads
 #endif
@@ -90,17 +75,11 @@ __device__ __forceinline__ s16x8 tr_frag(const unsigned char* img, int r0, int c
 }
 
 // eight fp32 values -> three bf16 pieces each, by truncation: a bf16 is the top 16 bits of the fp32 pattern, so each piece
-// takes the next eight significant bits of what is left (x - hi and r - mid are exact).  Per pair of elements: two masks and one
-// packed subtraction per level, one v_perm_b32 per piece to pack the two top halves.
+// takes the next eight significant bits of what is left (x - hi and r - mid are exact).  Per pair of elements: two masks and two
+// subtractions per level, one v_perm_b32 per piece to pack the two top halves.
 __device__ __forceinline__ uint32_t pack_top(float x1, float x0) {              // (x1 & 0xffff0000) | (x0 >> 16)
     return __builtin_amdgcn_perm(__float_as_uint(x1), __float_as_uint(x0), 0x07060302u);
 }
-__device__ __forceinline__ f32x2 top16(f32x2 v) {
-    return f32x2{__uint_as_float(__float_as_uint(v[0]) & 0xffff0000u), __uint_as_float(__float_as_uint(v[1]) & 0xffff0000u)};
-}
-#ifndef DHZ_S6_NP
-#define DHZ_S6_NP 1     // 1: the subtractions of the split as scalar-lane v_sub_f32 (inline asm), 0: as v_pk_add_f32
-#endif
 // Between two bf16 MFMAs of a wave the first two plain vector instructions cost nothing and further ones 4 cycles each, a PACKED fp32
 // instruction 7 - 17 cycles of matrix-pipe time (tools/ubench/interleave.hip): the subtractions are therefore issued per lane - 11
 // instructions per pair of elements instead of 9 - through inline asm (left as C, hipcc's SLP vectoriser re-packs them).
@@ -110,7 +89,6 @@ __device__ __forceinline__ float sub_np(float a, float b) {
     return r;
 }
 __device__ __forceinline__ void split8x3(const f32x4 a, const f32x4 b, u32x4& hi, u32x4& mid, u32x4& lo) {
-#if DHZ_S6_NP
     const float x[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -121,17 +99,6 @@ __device__ __forceinline__ void split8x3(const f32x4 a, const f32x4 b, u32x4& hi
         mid[i] = pack_top(r1, r0);
         lo[i] = pack_top(q1, q0);
     }
-#else
-    const f32x2 x[4] = {{a[0], a[1]}, {a[2], a[3]}, {b[0], b[1]}, {b[2], b[3]}};
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const f32x2 r1 = x[i] - top16(x[i]);
-        const f32x2 r2 = r1 - top16(r1);
-        hi[i] = pack_top(x[i][1], x[i][0]);
-        mid[i] = pack_top(r1[1], r1[0]);
-        lo[i] = pack_top(r2[1], r2[0]);
-    }
-#endif
 }
 
 // Activation loads as inline assembly: hipcc's wait-count pass does not see them, so it cannot answer a use of their registers
@@ -189,11 +156,6 @@ __global__ __launch_bounds__(NT, 1) void split6_gemm_kernel(const float* __restr
     unsigned char* const Aring = smem;
     unsigned char* const Bring = smem + 3 * A_SLOT;
     float* const bsm = reinterpret_cast<float*>(smem + 3 * A_SLOT + 3 * B_SLOT);     // the bias vector (zeros without one)
-#ifdef DHZ_S6_STAMP
-    unsigned* const stamp_lds = reinterpret_cast<unsigned*>(bsm + NF);
-    for (int i = threadIdx.x; i < 8 * NSTAMP * 8; i += NT) stamp_lds[i] = 0;
-    int nstamp = 0;
-#endif
 
     const int t = threadIdx.x, lane = t & 63;
     const int w = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -259,7 +221,7 @@ __global__ __launch_bounds__(NT, 1) void split6_gemm_kernel(const float* __restr
 
     f32x4 ra[2][NA][2];                                            // raw activations: stage q in set q & 1
     auto a_addr = [&](const Pos& q, int i) -> const float* {
-        const int m0 = (DHZ_S6_DBG & 32) ? 0 : q.m0, k0 = q.st * BK;
+        const int m0 = q.m0, k0 = q.st * BK;
         return A + (size_t)min(m0 + a_row[i], M - 1) * lda + k0 + 8 * a_kc[i];
     };
     auto a_load = [&](auto set, const Pos& q) {
@@ -287,7 +249,7 @@ __global__ __launch_bounds__(NT, 1) void split6_gemm_kernel(const float* __restr
     };
     auto b_dma = [&](const Pos& q, int slot) {
         if (abl & 8) return;
-        const int n0 = (DHZ_S6_DBG & 64) ? 0 : q.n0, k0 = q.st * BK;
+        const int n0 = q.n0, k0 = q.st * BK;
         const size_t base = BTR ? (size_t)k0 * ldb + n0 : (size_t)n0 * ldb + k0;
         unsigned char* Bs = Bring + slot * B_SLOT;
 #pragma unroll
@@ -407,7 +369,6 @@ __global__ __launch_bounds__(NT, 1) void split6_gemm_kernel(const float* __restr
         using FN = std::integral_constant<int, (R + 1) & 1>;       // fragment set of stage p + 1
         constexpr int S0 = R % 3, S1 = (R + 1) % 3, S2 = (R + 2) % 3;
         const bool have1 = p1.tile >= 0;
-        STAMP(0);
         a_wait(F{}, std::integral_constant<int, DPW + 2 * NA>{});  // stage p + 2's raw activations (set p & 1): older than one DMA set + 2 NA loads
         __builtin_amdgcn_sched_barrier(0);
         // ---- first stream: the lower rows' MFMAs; between them the DMA of stage p + 3 -> slot p % 3, the upper-row fragment
@@ -421,15 +382,12 @@ __global__ __launch_bounds__(NT, 1) void split6_gemm_kernel(const float* __restr
 #pragma unroll
         for (int i = 0; i < NA; ++i) split8x3(ra[R & 1][i][0], ra[R & 1][i][1], sh[i], sm[i], sl[i]);
         mma_rows(F{}, 0, HALF);
-#if !(DHZ_S6_DBG & 16)
 #pragma unroll
         for (int i = 0; i < HALF * WN * 6; ++i) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // one MFMA
             __builtin_amdgcn_sched_group_barrier(0x3b2, 2, 0);     // then up to two vector / LDS / vector-memory instructions
         }
-#endif
         __builtin_amdgcn_sched_barrier(0);
-        STAMP(1);
 #pragma unroll
         for (int i = 0; i < NA; ++i) gload32(pa[i], ra[R & 1][i][0], ra[R & 1][i][1]);      // stage p + 4 -> the set just consumed
         __builtin_amdgcn_sched_barrier(0);
@@ -447,15 +405,12 @@ __global__ __launch_bounds__(NT, 1) void split6_gemm_kernel(const float* __restr
         read_b(FN{}, S1);
         read_a(FN{}, S1, 0, HALF);
         if (HALF < WM) mma_rows(F{}, HALF, WM);
-#if !(DHZ_S6_DBG & 16)
 #pragma unroll
         for (int i = 0; i < (WM - HALF) * WN * 6; ++i) {         // the LDS instructions early: their latency under the rest of the stream
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x382, 2, 0);
         }
-#endif
         __builtin_amdgcn_sched_barrier(0);
-        STAMP(2);
         const bool stored = p0.st == nst - 1;
         bool full = true;
         if (stored) full = epilogue(p0.tile);
@@ -463,17 +418,11 @@ __global__ __launch_bounds__(NT, 1) void split6_gemm_kernel(const float* __restr
         __builtin_amdgcn_sched_barrier(0);
         // the DMA of stage p + 2 (issued one iteration ago) has landed: it is older than 2 NA loads + one DMA set + 2 NA loads and
         // this iteration's stores (vmcnt retires in order); my LDS writes and reads are complete; then everybody's
-        if (DHZ_S6_DBG & 1) wait_vm<0>();
-        else if (!stored) wait_vm<4 * NA + DPW>();
+        if (!stored) wait_vm<4 * NA + DPW>();
         else if (full) wait_vm<4 * NA + DPW + WM * WN>();
         else wait_vm<0>();
-        STAMP(3);
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        STAMP(4);
-#ifdef DHZ_S6_STAMP
-        ++nstamp;
-#endif
         p0 = p1; p1 = p2; p2 = p3; p3 = p4; p4 = next(p4);
     };
     while (true) {
@@ -485,11 +434,6 @@ __global__ __launch_bounds__(NT, 1) void split6_gemm_kernel(const float* __restr
         body(std::integral_constant<int, 5>{}); if (done) break;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // no LDS-DMA may be in flight when the workgroup's LDS is released
-#ifdef DHZ_S6_STAMP
-    __syncthreads();
-    if (g_s6_stamp && blockIdx.x == DHZ_S6_STAMP)
-        for (int i = threadIdx.x; i < 8 * NSTAMP * 8; i += NT) g_s6_stamp[i] = stamp_lds[i];
-#endif
 }
 
 // ---- the wide-tile form: 256 tokens x 128 features per workgroup, 64 x 64 per wave (eight waves as 4 x 2).
@@ -514,11 +458,6 @@ __global__ __launch_bounds__(NT, 1) void split6_wide_kernel(const float* __restr
     static_assert(NDMA % 8 == 0, "whole DMA instructions per wave");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* const bsm = reinterpret_cast<float*>(smem + 2 * SLOT);
-#ifdef DHZ_S6_STAMP
-    unsigned* const stamp_lds = reinterpret_cast<unsigned*>(bsm + NF);
-    for (int i = threadIdx.x; i < 8 * NSTAMP * 8; i += NT) stamp_lds[i] = 0;
-    int nstamp = 0;
-#endif
 
     const int t = threadIdx.x, lane = t & 63;
     const int w = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -681,7 +620,6 @@ __global__ __launch_bounds__(NT, 1) void split6_wide_kernel(const float* __restr
     for (int p = 0;; ++p) {
         const int buf = p & 1;
         const bool have1 = p1.tile >= 0;
-        STAMP(0);
         // ---- stream 1: rows 0, 1 (48 MFMAs); between them the DMA of stage p+1 -> the other slot, the fragment reads of rows 2, 3,
         //      the split of stage p+1's raw activations (loaded during stage p-1) and the address arithmetic of the loads below
         b_dma(valid(p1), buf ^ 1);
@@ -689,7 +627,6 @@ __global__ __launch_bounds__(NT, 1) void split6_wide_kernel(const float* __restr
         read_a(buf, 0, 2);
         a_waitN();                                                 // older than this stage's DMA (and the previous tile's stores)
         __builtin_amdgcn_sched_barrier(0);
-        STAMP(1);
         read_a(buf, 2, 4);
         u32x4 sh[NA], sm[NA], sl[NA];
 #pragma unroll
@@ -704,7 +641,6 @@ __global__ __launch_bounds__(NT, 1) void split6_wide_kernel(const float* __restr
             __builtin_amdgcn_sched_group_barrier(0x382, 2, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
-        STAMP(2);
 #pragma unroll
         for (int i = 0; i < NA; ++i) gload32(pa[i], ra[i][0], ra[i][1]);      // stage p + 2
         __builtin_amdgcn_sched_barrier(0);
@@ -717,7 +653,6 @@ __global__ __launch_bounds__(NT, 1) void split6_wide_kernel(const float* __restr
             __builtin_amdgcn_sched_group_barrier(0x382, 1, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
-        STAMP(3);
         const bool stored = p0.st == nst - 1;
         bool full = true;
         if (stored) full = epilogue(p0.tile);
@@ -727,32 +662,18 @@ __global__ __launch_bounds__(NT, 1) void split6_wide_kernel(const float* __restr
         if (!stored) wait_vm<2 * NA>();
         else if (full) wait_vm<2 * NA + WM * WN>();
         else wait_vm<0>();
-        STAMP(4);
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        STAMP(5);
-#ifdef DHZ_S6_STAMP
-        ++nstamp;
-#endif
         p0 = p1; p1 = p2; p2 = next(p2);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#ifdef DHZ_S6_STAMP
-    __syncthreads();
-    if (g_s6_stamp && blockIdx.x == DHZ_S6_STAMP)
-        for (int i = threadIdx.x; i < 8 * NSTAMP * 8; i += NT) g_s6_stamp[i] = stamp_lds[i];
-#endif
 }
 
 template <bool BTR>
 void launch_wide(const float* A, int lda, const uint16_t* Bh, const uint16_t* Bm, const uint16_t* Bl, int ldb, const float* bias, float* C,
                  int ldc, int M, int NF, int KC, hipStream_t s) {
     constexpr int BM = 256, BN = 128;
-#ifdef DHZ_S6_STAMP
-    const size_t smem = 2 * 3 * (size_t)(BM * 64 + BN * 64) + (size_t)NF * sizeof(float) + 8 * NSTAMP * 8 * 4;
-#else
     const size_t smem = 2 * 3 * (size_t)(BM * 64 + BN * 64) + (size_t)NF * sizeof(float);
-#endif
     const int tiles_n = NF / BN, tiles_m = (M + BM - 1) / BM;
     const int ntiles = tiles_n * tiles_m;
     const int slots = dhz_num_cus();
@@ -766,11 +687,7 @@ template <int WM, int WN, int WAVES_M, bool BTR>
 void launch(const float* A, int lda, const uint16_t* Bh, const uint16_t* Bm, const uint16_t* Bl, int ldb, const float* bias, float* C,
             int ldc, int M, int NF, int KC, hipStream_t s) {
     constexpr int BM = 16 * WM * WAVES_M, BN = 16 * WN * (8 / WAVES_M);
-#ifdef DHZ_S6_STAMP
-    const size_t smem = 3 * 3 * (size_t)(BM * 64 + BN * 64) + (size_t)NF * sizeof(float) + 8 * NSTAMP * 8 * 4;
-#else
     const size_t smem = 3 * 3 * (size_t)(BM * 64 + BN * 64) + (size_t)NF * sizeof(float);     // three ring slots per operand + the bias vector
-#endif
     const int tiles_n = NF / BN, tiles_m = (M + BM - 1) / BM;
     const int ntiles = tiles_n * tiles_m;
     const int slots = dhz_num_cus();
@@ -860,9 +777,6 @@ __global__ __launch_bounds__(256) void split3_planes_t_kernel(const float* __res
 
 }  // namespace
 
-#ifdef DHZ_S6_STAMP
-extern "C" int dhz_debug_s6_stamp(void* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_s6_stamp), &p, sizeof(p)); }
-#endif
 
 extern "C" int dhz_split3_planes_t(const float* src, void* hi, void* mid, void* lo, const int* desc, int nmat, int ntiles, void* stream) {
     const char* who = "dhz_split3_planes_t";
