@@ -30,3 +30,40 @@ def test_split6_inline_asm_loads_are_not_touched_before_their_wait(capsys):
         os.unlink(bad)
     finally:
         os.unlink(path)
+
+
+def test_winograd43_dma_requests_keep_their_base_in_sgprs_and_own_m0():
+    """csrc/winograd43_conv.hip issues its LDS-DMA requests from inline assembly (s_mov_b32 m0 / global_load_lds_dwordx4 v_off, s[base]): the
+    compiler is told that m0 is clobbered but treats it as a reserved register, so the kernel must not contain any compiler-generated use of
+    m0 (none of its own LDS-DMA builtins, no movrel / GWS / sendmsg), every request must be the SGPR-base form (no 64-bit vector address
+    arithmetic between MFMAs), and the 512-register kernel must not touch scratch memory."""
+    import re
+    import isa_check
+    path = isa_check.compile_to_asm(os.path.join(isa_check.CSRC, "winograd43_conv.hip"))
+    try:
+        asm = open(path).read()
+        kernels = re.findall(r"^(_Z\w*winograd43_conv3x3_kernel\w*):[^\n]*\n(.*?)^\.Lfunc_end", asm, re.M | re.S)
+        assert len(kernels) == 2
+        for name, body in kernels:
+            inside, outside_m0, dma, dma_sgpr = False, 0, 0, 0
+            for ln in body.splitlines():
+                t = ln.split(";")[0] if not ln.lstrip().startswith(";;#") else ln
+                if "#ASMSTART" in ln:
+                    inside = True
+                elif "#ASMEND" in ln:
+                    inside = False
+                elif re.search(r"\bm0\b", t) and not inside:
+                    outside_m0 += 1
+                if "global_load_lds_dwordx4" in t:
+                    dma += 1
+                    dma_sgpr += bool(re.search(r"global_load_lds_dwordx4\s+v\d+,\s*s\[\d+:\d+\]", t)) and inside
+            assert outside_m0 == 0, (name, outside_m0)
+            assert dma >= 40 and dma == dma_sgpr, (name, dma, dma_sgpr)
+            assert not re.search(r"^\s*scratch_(load|store)", body, re.M), name
+            import isa_loopmix
+            loop = isa_loopmix.hottest_loop(isa_loopmix.blocks_of(body))
+            ops_ = [i.split()[0] for b in loop for i in b["ins"]]
+            assert ops_.count("v_mfma_f32_16x16x4_f32") == 144, name
+            assert not any(o in ("v_lshl_add_u64", "v_mad_u64_u32", "v_add_co_u32_e32") for o in ops_), name      # no vector address arithmetic in the channel loop
+    finally:
+        os.unlink(path)
