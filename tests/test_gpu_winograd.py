@@ -334,3 +334,30 @@ def test_vgg_engine_f43_dispatch_at_step_size():
     # (same ReLU masks in both runs: the differentiated forward pass is F(2x2) either way; sign(fa - fp) may flip where the reference
     # features moved by their ~1e-6 rounding difference)
     assert d.mean().item() < 2e-3 * off[3].abs().mean().item(), (d.mean().item(), off[3].abs().mean().item())
+
+
+def test_vgg_engine_pooling_in_the_convolution_store_is_bit_identical():
+    """The no-gradient pass with the 2 x 2 max pooling inside the F(4x4) launch (dhz_winograd43_conv3x3_pool) against the same pass with
+    the pooling as its own launch: the five tap features are bit-identical (the maximum of the same four values)."""
+    import warnings
+    import My_CR
+    from dehaze_hip import vgg as V
+    dev = torch.device("cuda:0")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        cl = My_CR.ContrastLoss().to(dev)
+    x = torch.rand(64, 3, 128, 128, generator=torch.Generator().manual_seed(11)).to(dev)
+    eng = cl.vgg.engine_for(x)
+    assert eng is not None
+    old = V.POOL_FUSED
+    try:
+        with torch.no_grad():
+            V.POOL_FUSED = True
+            a = [t.clone() for t in eng.forward_taps(x)]
+            V.POOL_FUSED = False
+            b = eng.forward_taps(x)
+    finally:
+        V.POOL_FUSED = old
+    assert len(a) == len(b) == 5
+    for u, v in zip(a, b):
+        assert torch.equal(u, v)
