@@ -456,8 +456,8 @@ def main():
             tf_issued = issued / (ms * 1e-3) / 1e12
             inst = [v for k, v in pmc.items() if k.startswith("winograd_conv3x3_kernel") or k.startswith("winograd43_conv3x3_kernel")]
             traffic = (sum(v["hbm_bytes_per_launch"] * v["launches"] for v in inst) / sum(v["launches"] for v in inst)) if inst else None
-            out["roofline_dominant"] = {"kernel": "winograd43_conv3x3_kernel<FWD> (dhz_winograd43_conv3x3: F(4x4,3x3), maps >= 32 x 32) + "
-                                                  "winograd_conv3x3_kernel<FWD,Q8> (dhz_winograd_conv3x3: F(2x2,3x3), 16 x 16 and 8 x 8 maps): "
+            out["roofline_dominant"] = {"kernel": "winograd43_conv3x3_kernel<FWD> (dhz_winograd43_conv3x3 / _pool: F(4x4,3x3); the no-gradient passes and the backward-data products on grids of whole rounds) + "
+                                                  "winograd_conv3x3_kernel<FWD,Q8> (dhz_winograd_conv3x3: F(2x2,3x3); the differentiated forward pass, half-round grids, 8 x 8 maps): "
                                                   "the VGG19 convolutions, largest share of the step",
                                         "bound": "mfma", "achieved": round(tf_issued, 2), "peak": MFMA_F32_PEAK_TF,
                                         "unit": "TFLOP/s", "frac": round(tf_issued / MFMA_F32_PEAK_TF, 4),
