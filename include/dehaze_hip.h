@@ -224,6 +224,25 @@ int dhz_linear_fwd_split6(const float* x, int ldx, const void* w_hi, const void*
                           int ldy, int T, int N, int K, void* stream);
 int dhz_linear_dgrad_split6(const float* dy, int ldy, const void* w_hi, const void* w_mid, const void* w_lo, float* dx, int ldx, int T,
                             int N, int K, void* stream);
+/* K4 INSIDE the GEMM (csrc/tok_epilogue.h): the out-projection / linear2 product whose epilogue is the block's residual step -
+ *     out[dst(t), :] = res[dst(t), :] + scale[t / tokens_per_image] * (x[t, :] . w^T + bias)
+ *   windowed = 1: row t of x is a window slot (the order dhz_ln_partition_fwd writes: M1:846-852) and dst(t) is its token-order position
+ *                 after window_reverse + roll(+shift)  =  attn out-projection + M1:859-868 + `shortcut + drop_path(x)` M1:872;
+ *   windowed = 0: dst(t) = t                           =  LeFF linear2 / Mlp fc2 + `x + drop_path(mlp(norm2(x)))` M1:873.
+ *   res == NULL adds nothing (with bias == NULL and windowed = 0 this is the per-image factor of a backward-data product:
+ *   d(ctx) = scale . (d(out) . W_o), the DropPath factor of M1:872 in the backward pass); scale == NULL means 1.
+ *   The GEMM result never exists in HBM in window order: replaces dhz_linear_fwd_split6 + dhz_reverse_residual_fwd.
+ *   res / out: rows of ldo floats in token order; tokens_per_image (= Hres * Wres when windowed) a multiple of 64 dividing T whenever
+ *   scale != NULL or windowed; Hres, Wres multiples of 8, 0 <= shift < 8.  Same shape contract as dhz_linear_fwd_split6 otherwise.
+ *   _split_res / _dgrad_split_scaled: the same epilogue on the kernels of dhz_linear_fwd_split / dhz_linear_dgrad_split (few-tile shapes). */
+int dhz_linear_fwd_split6_res(const float* x, int ldx, const void* w_hi, const void* w_mid, const void* w_lo, const float* bias,
+                              const float* res, const float* scale, float* out, int ldo, int T, int N, int K, int tokens_per_image,
+                              int Hres, int Wres, int shift, int windowed, void* stream);
+int dhz_linear_fwd_split_res(const float* x, int ldx, const float* w, const float* bias, const float* res, const float* scale, float* out,
+                             int ldo, int T, int N, int K, int tokens_per_image, int Hres, int Wres, int shift, int windowed, int terms,
+                             void* stream);
+int dhz_linear_dgrad_split_scaled(const float* dy, int ldy, const float* w, const float* scale, float* dx, int ldx, int T, int N, int K,
+                                  int tokens_per_image, int terms, void* stream);
 /*     hi[i] + mid[i] + lo[i] == src[i] exactly (three bf16 by truncation); n % 8 == 0, 16-byte aligned pointers. */
 int dhz_split3_planes(const float* src, int64_t n, void* hi, void* mid, void* lo, void* stream);
 /*     ... and the planes of the TRANSPOSES of nmat matrices inside one buffer: desc (device, int[nmat][4]) = {offset, rows R, cols C, index
@@ -262,6 +281,14 @@ int dhz_ln_partition_fwd_dt(const void* x, const float* gamma, const float* beta
 int dhz_ln_partition_bwd_dt(const void* dxw, const void* x, const float* gamma, const float* stats, const void* dres, void* dx,
                             float* dgamma, float* dbeta, int B, int Hres, int Wres, int C, int shift, int partition, int dtype,
                             void* stream);
+/* dhz_ln_partition_bwd_dt with the gradient LAYOUTS of a whole LeWin block's backward pass (M1:839-873 under autograd): the LeFF branch's
+ * LayerNorm backward (partition = 0) writes dx in the window order of the attention branch (dx_windowed = 1, dx_shift = its shift) -
+ * exactly the d(out) operand the out-projection's backward-data / weight-gradient products read, so no dhz_reverse_residual_bwd pass
+ * runs - and the attention branch's LayerNorm backward (partition = 1) reads its residual gradient dres in that same order
+ * (dres_windowed = 1).  dx_windowed needs Hres, Wres multiples of 8 and dx != dres. */
+int dhz_ln_partition_bwd_lay(const void* dxw, const void* x, const float* gamma, const float* stats, const void* dres, void* dx,
+                             float* dgamma, float* dbeta, int B, int Hres, int Wres, int C, int shift, int partition, int dres_windowed,
+                             int dx_windowed, int dx_shift, int dtype, void* stream);
 int dhz_reverse_residual_fwd_dt(const void* yw, const void* shortcut, const float* scale, void* out, int B, int Hres, int Wres,
                                 int C, int shift, int partition, int dtype, void* stream);
 int dhz_reverse_residual_bwd_dt(const void* dout, const float* scale, void* dyw, int B, int Hres, int Wres, int C, int shift,

@@ -81,7 +81,9 @@ __global__ __launch_bounds__(256) void ln_partition_bwd_kernel(const T* __restri
                                                                const T* dres, T* dx,
                                                                float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                                int ntok, int Hres, int Wres, int C, int shift, int lpt,
-                                                               int partition) {
+                                                               int partition, int lay) {
+    // lay (dhz_ln_partition_bwd_lay): bit 0 - dres lies in the window order of (shift, partition) like dxw; bit 1 - dx is WRITTEN in
+    // the window order of shift (lay >> 8) on the same map: the layout the consumer (the attention branch's backward) reads
     __shared__ float red[2 * 1024];                            // dgamma | dbeta  (C <= 1024)
     const int tpw = 64 / lpt;
     const int lane = threadIdx.x & 63;
@@ -104,7 +106,7 @@ __global__ __launch_bounds__(256) void ln_partition_bwd_kernel(const T* __restri
     struct Group {
         float4 xh[VPL], dy[VPL], rs[VPL];
         float mean, rstd;
-        int tok;
+        int tok, drow;
         bool ok;
     };
     auto load = [&](int base, Group& G) {
@@ -113,12 +115,15 @@ __global__ __launch_bounds__(256) void ln_partition_bwd_kernel(const T* __restri
         G.mean = 0.f; G.rstd = 0.f;
         if (G.ok) {
             const int bimg = G.tok / HW, p = G.tok % HW;
-            const size_t src = partition ? (size_t)bimg * HW + window_slot(p / Wres, p % Wres, Hres, Wres, shift) : (size_t)G.tok;
+            const int hh = p / Wres, ww = p - hh * Wres;
+            const size_t src = partition ? (size_t)bimg * HW + window_slot(hh, ww, Hres, Wres, shift) : (size_t)G.tok;
+            const size_t rsrc = (lay & 1) ? src : (size_t)G.tok;
+            G.drow = (lay & 2) ? bimg * HW + window_slot(hh, ww, Hres, Wres, lay >> 8) : G.tok;
 #pragma unroll
             for (int v = 0; v < VPL; ++v) {
                 G.xh[v] = ld4(x + (size_t)G.tok * C + quad_col<WIDE>(li, v, lpt));
                 G.dy[v] = ld4(dxw + src * C + quad_col<WIDE>(li, v, lpt));
-                if (dres) G.rs[v] = ld4(dres + (size_t)G.tok * C + quad_col<WIDE>(li, v, lpt));
+                if (dres) G.rs[v] = ld4(dres + rsrc * C + quad_col<WIDE>(li, v, lpt));
             }
             const float2 st = *reinterpret_cast<const float2*>(stats + 2 * (size_t)G.tok);
             G.mean = st.x; G.rstd = st.y;
@@ -154,7 +159,7 @@ __global__ __launch_bounds__(256) void ln_partition_bwd_kernel(const T* __restri
                 r.z = rstd * (G.dy[v].z - s1 - G.xh[v].z * s2);
                 r.w = rstd * (G.dy[v].w - s1 - G.xh[v].w * s2);
                 if (dres) { r.x += G.rs[v].x; r.y += G.rs[v].y; r.z += G.rs[v].z; r.w += G.rs[v].w; }
-                st4(dx + (size_t)G.tok * C + quad_col<WIDE>(li, v, lpt), r);
+                st4(dx + (size_t)G.drow * C + quad_col<WIDE>(li, v, lpt), r);
             }
         }
     };
@@ -691,12 +696,17 @@ extern "C" int dhz_ln_partition_fwd(const float* x, const float* gamma, const fl
     return dhz_ln_partition_fwd_dt(x, gamma, beta, xw, stats, B, Hres, Wres, C, shift, partition, DHZ_F32, stream);
 }
 
-extern "C" int dhz_ln_partition_bwd_dt(const void* dxw, const void* x, const float* gamma, const float* stats,
-                                       const void* dres, void* dx, float* dgamma, float* dbeta, int B, int Hres, int Wres,
-                                       int C, int shift, int partition, int dtype, void* stream) {
+extern "C" int dhz_ln_partition_bwd_lay(const void* dxw, const void* x, const float* gamma, const float* stats,
+                                        const void* dres, void* dx, float* dgamma, float* dbeta, int B, int Hres, int Wres,
+                                        int C, int shift, int partition, int dres_windowed, int dx_windowed, int dx_shift, int dtype,
+                                        void* stream) {
     DHZ_REQUIRE(dxw && x && gamma && stats && dx && dgamma && dbeta, "dhz_ln_partition_bwd: null pointer");
     DHZ_REQUIRE(B > 0 && Hres > 0 && Wres > 0 && (!partition || (Hres % 8 == 0 && Wres % 8 == 0 && shift >= 0 && shift < 8)),
                 "dhz_ln_partition_bwd: bad shape");
+    DHZ_REQUIRE(!dres_windowed || partition, "dhz_ln_partition_bwd_lay: a window-ordered dres needs partition = 1");
+    DHZ_REQUIRE(!dx_windowed || (Hres % 8 == 0 && Wres % 8 == 0 && dx_shift >= 0 && dx_shift < 8 && dx != dres),
+                "dhz_ln_partition_bwd_lay: a window-ordered dx needs an Hres x Wres map of multiples of 8, a shift in [0, 8) and dx != dres");
+    const int lay = (dres_windowed ? 1 : 0) | (dx_windowed ? 2 | (dx_shift << 8) : 0);
     int lpt, vpl;
     DHZ_REQUIRE(ln_geometry(C, &lpt, &vpl) == 0, "dhz_ln_partition_bwd: unsupported C=%d", C);
     const int ntok = B * Hres * Wres;
@@ -710,18 +720,23 @@ extern "C" int dhz_ln_partition_bwd_dt(const void* dxw, const void* x, const flo
     grid = grid < 64 ? 64 : (grid > cap ? cap : grid);
     hipStream_t s = (hipStream_t)stream;
     if (wide) {
-#define LAUNCHW(V) hipLaunchKernelGGL((ln_partition_bwd_kernel<V, bf16s, true>), dim3(grid), dim3(256), 0, s, (const bf16s*)dxw, (const bf16s*)x, gamma, stats, (const bf16s*)dres, (bf16s*)dx, dgamma, dbeta, ntok, Hres, Wres, C, shift, lpt, partition)
+#define LAUNCHW(V) hipLaunchKernelGGL((ln_partition_bwd_kernel<V, bf16s, true>), dim3(grid), dim3(256), 0, s, (const bf16s*)dxw, (const bf16s*)x, gamma, stats, (const bf16s*)dres, (bf16s*)dx, dgamma, dbeta, ntok, Hres, Wres, C, shift, lpt, partition, lay)
         if (vpw == 2) LAUNCHW(2); else LAUNCHW(4);
 #undef LAUNCHW
         DHZ_CHECK_LAUNCH("dhz_ln_partition_bwd");
         return DHZ_OK;
     }
-#define LAUNCH(V) hipLaunchKernelGGL((ln_partition_bwd_kernel<V, T>), dim3(grid), dim3(256), 0, s, (const T*)dxw, (const T*)x, gamma, stats, (const T*)dres, (T*)dx, dgamma, dbeta, ntok, Hres, Wres, C, shift, lpt, partition)
+#define LAUNCH(V) hipLaunchKernelGGL((ln_partition_bwd_kernel<V, T>), dim3(grid), dim3(256), 0, s, (const T*)dxw, (const T*)x, gamma, stats, (const T*)dres, (T*)dx, dgamma, dbeta, ntok, Hres, Wres, C, shift, lpt, partition, lay)
     DT_SWITCH(dtype, "dhz_ln_partition_bwd",
               switch (vpl) { case 1: LAUNCH(1); break; case 2: LAUNCH(2); break; case 3: LAUNCH(3); break; default: LAUNCH(4); });
 #undef LAUNCH
     DHZ_CHECK_LAUNCH("dhz_ln_partition_bwd");
     return DHZ_OK;
+}
+extern "C" int dhz_ln_partition_bwd_dt(const void* dxw, const void* x, const float* gamma, const float* stats,
+                                       const void* dres, void* dx, float* dgamma, float* dbeta, int B, int Hres, int Wres,
+                                       int C, int shift, int partition, int dtype, void* stream) {
+    return dhz_ln_partition_bwd_lay(dxw, x, gamma, stats, dres, dx, dgamma, dbeta, B, Hres, Wres, C, shift, partition, 0, 0, 0, dtype, stream);
 }
 extern "C" int dhz_ln_partition_bwd(const float* dxw, const float* x, const float* gamma, const float* stats,
                                     const float* dres, float* dx, float* dgamma, float* dbeta, int B, int Hres, int Wres,

@@ -17,6 +17,7 @@
 // fp32 in HBM.
 #include <stdlib.h>
 #include "common.h"
+#include "tok_epilogue.h"
 
 namespace {
 
@@ -114,7 +115,7 @@ __device__ __forceinline__ void split8x3_np(const f32x4 a, const f32x4 b, u32x4&
 template <int WM, int WN, bool BTR, bool SIX>
 __global__ __launch_bounds__(256, 2) void gemm_split_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B,
                                                             int ldb, const float* __restrict__ bias, float* __restrict__ C, int ldc,
-                                                            int M, int NF, int KC, int tiles_n, int ntiles) {
+                                                            int M, int NF, int KC, int tiles_n, int ntiles, const TokEpi epi, int epi_on) {
     constexpr int BM = 32 * WM, BN = 32 * WN;
     constexpr int A_BYTES = BM * 128;
     constexpr int B_BYTES = BTR ? BK * BN * 2 : BN * 128;
@@ -261,6 +262,25 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(const float* __restr
         {   // acc[a][b][j] = C[token 16 a + i16][feature 16 b + 4 g + j]: one 16-byte store per block and lane
             const int m0 = tm * BM + wm * WM * 16 + i16, n0 = tn * BN + wn * WN * 16 + 4 * g;
             float* c0 = C + (size_t)m0 * ldc + n0;
+            if (epi_on) {                                                    // the block's residual step (csrc/tok_epilogue.h)
+                const int mbw = __builtin_amdgcn_readfirstlane(tm * BM + wm * WM * 16);
+                int dst[WM];
+                float sc;
+                tok_epi_rows<WM>(epi, mbw < M ? mbw : 0, i16, dst, sc);
+#pragma unroll
+                for (int a = 0; a < WM; ++a) {
+                    if (m0 + 16 * a < M) {
+#pragma unroll
+                        for (int b = 0; b < WN; ++b) {
+                            f32x4 v = acc[a][b];
+                            if (bias) v += *reinterpret_cast<const f32x4*>(bias + n0 + 16 * b);
+                            v *= sc;
+                            if (epi.res) v += *reinterpret_cast<const f32x4*>(epi.res + (size_t)dst[a] * ldc + n0 + 16 * b);
+                            *reinterpret_cast<f32x4*>(C + (size_t)dst[a] * ldc + n0 + 16 * b) = v;
+                        }
+                    }
+                }
+            } else
 #pragma unroll
             for (int a = 0; a < WM; ++a) {
                 if (m0 + 16 * a < M) {
@@ -285,7 +305,7 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(const float* __restr
 
 template <int WM, int WN, bool BTR, bool SIX>
 void launch_split(const float* A, int lda, const float* B, int ldb, const float* bias, float* C, int ldc, int M, int NF, int KC,
-                  hipStream_t s) {
+                  const TokEpi& epi, int epi_on, hipStream_t s) {
     constexpr int BM = 32 * WM, BN = 32 * WN;
     constexpr size_t smem = (SIX ? 3 : 2) * ((size_t)(BM * 128) + (size_t)(BTR ? BK * BN * 2 : BN * 128));
     const int tiles_n = NF / BN, tiles_m = (M + BM - 1) / BM;
@@ -296,12 +316,12 @@ void launch_split(const float* A, int lda, const float* B, int ldb, const float*
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_split_kernel<WM, WN, BTR, SIX>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     hipLaunchKernelGGL((gemm_split_kernel<WM, WN, BTR, SIX>), dim3(grid), dim3(256), smem, s, A, lda, B, ldb, bias, C, ldc, M, NF, KC,
-                       tiles_n, ntiles);
+                       tiles_n, ntiles, epi, epi_on);
 }
 
 template <bool BTR>
 int dispatch_split(const char* who, const float* A, int lda, const float* B, int ldb, const float* bias, float* C, int ldc, int M,
-                   int NF, int KC, int terms, hipStream_t s) {
+                   int NF, int KC, int terms, hipStream_t s, const TokEpi& epi = TokEpi{}, int epi_on = 0) {
     DHZ_REQUIRE(terms == 3 || terms == 6, "%s: terms=%d (3 or 6)", who, terms);
     DHZ_REQUIRE(A && B && C, "%s: null pointer", who);
     DHZ_REQUIRE(M > 0 && NF > 0 && KC > 0 && NF % 64 == 0 && KC % 64 == 0, "%s: T=%d features=%d contraction=%d (multiples of 64)", who,
@@ -309,13 +329,18 @@ int dispatch_split(const char* who, const float* A, int lda, const float* B, int
     DHZ_REQUIRE(lda % 4 == 0 && ldb % 4 == 0 && ldc % 4 == 0 && ldc >= NF && lda >= KC, "%s: bad leading dimensions", who);
     DHZ_REQUIRE((((uintptr_t)A | (uintptr_t)B | (uintptr_t)C | (uintptr_t)bias) & 15) == 0, "%s: operands must be 16-byte aligned", who);
     // six-term form: three LDS images per operand - 64-column tiles keep two workgroups per CU (72 KB)
+    if (epi_on) {
+        const char* bad = tok_epi_check(epi, M);
+        DHZ_REQUIRE(!bad, "%s: %s", who, bad);
+        DHZ_REQUIRE(((uintptr_t)epi.res & 15) == 0, "%s: the shortcut must be 16-byte aligned", who);
+    }
     const int wn = (NF % 128 == 0 && terms == 3) ? 4 : 2;      // (128-column tiles at 96 KB / one workgroup per CU: slower, measured)
     const long blocks128 = (long)((M + 127) / 128) * (NF / (32 * wn));
     const int wm = blocks128 >= dhz_num_cus() ? 4 : 2;
 #define CASE(a, b) \
     if (wm == a && wn == b) {                                                                              \
-        if (terms == 3) launch_split<a, b, BTR, false>(A, lda, B, ldb, bias, C, ldc, M, NF, KC, s);        \
-        else launch_split<a, b, BTR, true>(A, lda, B, ldb, bias, C, ldc, M, NF, KC, s);                    \
+        if (terms == 3) launch_split<a, b, BTR, false>(A, lda, B, ldb, bias, C, ldc, M, NF, KC, epi, epi_on, s);        \
+        else launch_split<a, b, BTR, true>(A, lda, B, ldb, bias, C, ldc, M, NF, KC, epi, epi_on, s);                    \
     }
     CASE(4, 4) CASE(4, 2) CASE(2, 4) CASE(2, 2)
 #undef CASE
@@ -752,6 +777,19 @@ extern "C" int dhz_linear_fwd_split(const float* x, int ldx, const float* w, con
 extern "C" int dhz_linear_dgrad_split(const float* dy, int ldy, const float* w, float* dx, int ldx, int T, int N, int K, int terms,
                                       void* stream) {
     return dispatch_split<true>("dhz_linear_dgrad_split", dy, ldy, w, K, nullptr, dx, ldx, T, K, N, terms, (hipStream_t)stream);
+}
+
+extern "C" int dhz_linear_fwd_split_res(const float* x, int ldx, const float* w, const float* bias, const float* res, const float* scale,
+                                        float* out, int ldo, int T, int N, int K, int tokens_per_image, int Hres, int Wres, int shift,
+                                        int windowed, int terms, void* stream) {
+    const TokEpi epi{res, scale, tokens_per_image, Hres, Wres, shift, windowed};
+    return dispatch_split<false>("dhz_linear_fwd_split_res", x, ldx, w, K, bias, out, ldo, T, N, K, terms, (hipStream_t)stream, epi, 1);
+}
+
+extern "C" int dhz_linear_dgrad_split_scaled(const float* dy, int ldy, const float* w, const float* scale, float* dx, int ldx, int T, int N,
+                                             int K, int tokens_per_image, int terms, void* stream) {
+    const TokEpi epi{nullptr, scale, tokens_per_image, 0, 0, 0, 0};
+    return dispatch_split<true>("dhz_linear_dgrad_split_scaled", dy, ldy, w, K, nullptr, dx, ldx, T, K, N, terms, (hipStream_t)stream, epi, 1);
 }
 
 extern "C" int dhz_linear_wgrad_split(const float* dy, int ldy, const float* x, int ldx, int T, int nmat, int nper, int K,

@@ -27,6 +27,7 @@
 #include <stdlib.h>
 #include <type_traits>
 #include "common.h"
+#include "tok_epilogue.h"
 
 namespace {
 
@@ -135,11 +136,12 @@ template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_wai
 //     barrier(p)
 // so every global access has two stages of matrix time to land, no fragment read waits on a barrier, and the barrier is only
 // the hand-over of ring slots.  The loop is unrolled six times (ring slots, register sets and fragment sets are compile-time).
-template <int WM, int WN, int WAVES_M, bool BTR>
+// EPI: the epilogue is the block's residual step (csrc/tok_epilogue.h): C[dst(m)] = res[dst(m)] + scale[img(m)] (acc + bias).
+template <int WM, int WN, int WAVES_M, bool BTR, bool EPI>
 __global__ __launch_bounds__(NT, 1) void split6_gemm_kernel(const float* __restrict__ A, int lda, const uint16_t* __restrict__ Bh,
                                                             const uint16_t* __restrict__ Bm, const uint16_t* __restrict__ Bl,
                                                             int ldb, const float* __restrict__ bias, float* __restrict__ C, int ldc,
-                                                            int M, int NF, int KC, int tiles_n, int ntiles) {
+                                                            int M, int NF, int KC, int tiles_n, int ntiles, const TokEpi epi) {
     constexpr int WAVES_N = 8 / WAVES_M;
     constexpr int BM = 16 * WM * WAVES_M, BN = 16 * WN * WAVES_N;
     constexpr int A_BYTES = BM * 64, B_BYTES = BN * 64;            // one piece of one stage
@@ -310,6 +312,35 @@ __global__ __launch_bounds__(NT, 1) void split6_gemm_kernel(const float* __restr
         f32x4 bv[WN];
 #pragma unroll
         for (int b = 0; b < WN; ++b) bv[b] = *reinterpret_cast<const f32x4*>(bsm + n0 + 16 * b);
+        if constexpr (EPI) {
+            // the shortcut values are requested here, behind this iteration's operand requests: the wait in front of the stores
+            // drains those too (vmcnt retires in order) - about one memory latency per tile, a few per cent of its matrix time
+            const int mbw = tm * BM + wm * WM * 16;                  // wave-uniform
+            int dst[WM];
+            float sc;
+            tok_epi_rows<WM>(epi, mbw < M ? mbw : 0, i16, dst, sc);
+            const int nn = tn * BN + wn * WN * 16 + 4 * g;
+            f32x4 rv[WM][WN];
+#pragma unroll
+            for (int a = 0; a < WM; ++a)
+#pragma unroll
+                for (int b = 0; b < WN; ++b)
+                    rv[a][b] = epi.res ? *reinterpret_cast<const f32x4*>(epi.res + (size_t)min(dst[a], M - 1) * ldc + nn + 16 * b)
+                                       : f32x4{0.f, 0.f, 0.f, 0.f};
+            const bool efull = tm * BM + BM <= M;                    // wave-uniform; WM * WN stores when true (the caller counts them)
+#pragma unroll
+            for (int a = 0; a < WM; ++a)
+                if (efull || m0 + 16 * a < M) {
+#pragma unroll
+                    for (int b = 0; b < WN; ++b)
+                        *reinterpret_cast<f32x4*>(C + (size_t)dst[a] * ldc + nn + 16 * b) = rv[a][b] + sc * (acc[a][b] + bv[b]);
+                }
+#pragma unroll
+            for (int a = 0; a < WM; ++a)
+#pragma unroll
+                for (int b = 0; b < WN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+            return efull;
+        }
         const bool full = tm * BM + BM <= M;                      // wave-uniform
         if (full) {
 #pragma unroll
@@ -444,11 +475,11 @@ __global__ __launch_bounds__(NT, 1) void split6_gemm_kernel(const float* __restr
 // per product) and a 256 x 128 workgroup tile 0.7 x the L2 bytes per product; a stage then carries 96 MFMAs per wave (two
 // waves per SIMD: ~3000 cycles), long enough for a plain two-slot ring: the DMA of stage p+1 and the split of its activations
 // go into the other slot during stage p and have the whole stage to land.
-template <bool BTR>
+template <bool BTR, bool EPI>
 __global__ __launch_bounds__(NT, 1) void split6_wide_kernel(const float* __restrict__ A, int lda, const uint16_t* __restrict__ Bh,
                                                             const uint16_t* __restrict__ Bm, const uint16_t* __restrict__ Bl,
                                                             int ldb, const float* __restrict__ bias, float* __restrict__ C, int ldc,
-                                                            int M, int NF, int KC, int tiles_n, int ntiles) {
+                                                            int M, int NF, int KC, int tiles_n, int ntiles, const TokEpi epi) {
     constexpr int WM = 4, WN = 4, WAVES_N = 2;
     constexpr int BM = 256, BN = 128;
     constexpr int A_BYTES = BM * 64, B_BYTES = BN * 64;            // one piece of one stage
@@ -576,6 +607,35 @@ __global__ __launch_bounds__(NT, 1) void split6_wide_kernel(const float* __restr
         f32x4 bv[WN];
 #pragma unroll
         for (int b = 0; b < WN; ++b) bv[b] = *reinterpret_cast<const f32x4*>(bsm + n0 + 16 * b);
+        if constexpr (EPI) {
+            // the shortcut values are requested here, behind this iteration's operand requests: the wait in front of the stores
+            // drains those too (vmcnt retires in order) - about one memory latency per tile, a few per cent of its matrix time
+            const int mbw = tm * BM + wm * WM * 16;                  // wave-uniform
+            int dst[WM];
+            float sc;
+            tok_epi_rows<WM>(epi, mbw < M ? mbw : 0, i16, dst, sc);
+            const int nn = tn * BN + wn * WN * 16 + 4 * g;
+            f32x4 rv[WM][WN];
+#pragma unroll
+            for (int a = 0; a < WM; ++a)
+#pragma unroll
+                for (int b = 0; b < WN; ++b)
+                    rv[a][b] = epi.res ? *reinterpret_cast<const f32x4*>(epi.res + (size_t)min(dst[a], M - 1) * ldc + nn + 16 * b)
+                                       : f32x4{0.f, 0.f, 0.f, 0.f};
+            const bool efull = tm * BM + BM <= M;                    // wave-uniform; WM * WN stores when true (the caller counts them)
+#pragma unroll
+            for (int a = 0; a < WM; ++a)
+                if (efull || m0 + 16 * a < M) {
+#pragma unroll
+                    for (int b = 0; b < WN; ++b)
+                        *reinterpret_cast<f32x4*>(C + (size_t)dst[a] * ldc + nn + 16 * b) = rv[a][b] + sc * (acc[a][b] + bv[b]);
+                }
+#pragma unroll
+            for (int a = 0; a < WM; ++a)
+#pragma unroll
+                for (int b = 0; b < WN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+            return efull;
+        }
         const bool full = tm * BM + BM <= M;
         if (full) {
 #pragma unroll
@@ -669,38 +729,38 @@ __global__ __launch_bounds__(NT, 1) void split6_wide_kernel(const float* __restr
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-template <bool BTR>
+template <bool BTR, bool EPI>
 void launch_wide(const float* A, int lda, const uint16_t* Bh, const uint16_t* Bm, const uint16_t* Bl, int ldb, const float* bias, float* C,
-                 int ldc, int M, int NF, int KC, hipStream_t s) {
+                 int ldc, int M, int NF, int KC, const TokEpi& epi, hipStream_t s) {
     constexpr int BM = 256, BN = 128;
     const size_t smem = 2 * 3 * (size_t)(BM * 64 + BN * 64) + (size_t)NF * sizeof(float);
     const int tiles_n = NF / BN, tiles_m = (M + BM - 1) / BM;
     const int ntiles = tiles_n * tiles_m;
     const int slots = dhz_num_cus();
     const int grid = ntiles < slots ? ntiles : slots;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&split6_wide_kernel<BTR>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    hipLaunchKernelGGL((split6_wide_kernel<BTR>), dim3(grid), dim3(NT), smem, s, A, lda, Bh, Bm, Bl, ldb, bias, C, ldc, M, NF, KC, tiles_n,
-                       ntiles);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&split6_wide_kernel<BTR, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipLaunchKernelGGL((split6_wide_kernel<BTR, EPI>), dim3(grid), dim3(NT), smem, s, A, lda, Bh, Bm, Bl, ldb, bias, C, ldc, M, NF, KC, tiles_n,
+                       ntiles, epi);
 }
 
-template <int WM, int WN, int WAVES_M, bool BTR>
+template <int WM, int WN, int WAVES_M, bool BTR, bool EPI>
 void launch(const float* A, int lda, const uint16_t* Bh, const uint16_t* Bm, const uint16_t* Bl, int ldb, const float* bias, float* C,
-            int ldc, int M, int NF, int KC, hipStream_t s) {
+            int ldc, int M, int NF, int KC, const TokEpi& epi, hipStream_t s) {
     constexpr int BM = 16 * WM * WAVES_M, BN = 16 * WN * (8 / WAVES_M);
     const size_t smem = 3 * 3 * (size_t)(BM * 64 + BN * 64) + (size_t)NF * sizeof(float);     // three ring slots per operand + the bias vector
     const int tiles_n = NF / BN, tiles_m = (M + BM - 1) / BM;
     const int ntiles = tiles_n * tiles_m;
     const int slots = dhz_num_cus();
     const int grid = ntiles < slots ? ntiles : slots;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&split6_gemm_kernel<WM, WN, WAVES_M, BTR>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&split6_gemm_kernel<WM, WN, WAVES_M, BTR, EPI>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    hipLaunchKernelGGL((split6_gemm_kernel<WM, WN, WAVES_M, BTR>), dim3(grid), dim3(NT), smem, s, A, lda, Bh, Bm, Bl, ldb, bias, C, ldc,
-                       M, NF, KC, tiles_n, ntiles);
+    hipLaunchKernelGGL((split6_gemm_kernel<WM, WN, WAVES_M, BTR, EPI>), dim3(grid), dim3(NT), smem, s, A, lda, Bh, Bm, Bl, ldb, bias, C, ldc,
+                       M, NF, KC, tiles_n, ntiles, epi);
 }
 
-template <bool BTR>
+template <bool BTR, bool EPI = false>
 int dispatch(const char* who, const float* A, int lda, const uint16_t* Bh, const uint16_t* Bm, const uint16_t* Bl, int ldb,
-             const float* bias, float* C, int ldc, int M, int NF, int KC, hipStream_t s) {
+             const float* bias, float* C, int ldc, int M, int NF, int KC, hipStream_t s, const TokEpi& epi = TokEpi{}) {
     DHZ_REQUIRE(A && Bh && Bm && Bl && C, "%s: null pointer", who);
     DHZ_REQUIRE(M > 0 && NF > 0 && KC > 0 && NF % (BTR ? 64 : 32) == 0 && KC % 32 == 0,
                 "%s: T=%d features=%d contraction=%d (contraction a multiple of 32, features of %d)", who, M, NF, KC, BTR ? 64 : 32);
@@ -714,10 +774,15 @@ int dispatch(const char* who, const float* A, int lda, const uint16_t* Bh, const
     const int cus = dhz_num_cus();
     int bn = NF % 128 == 0 ? 128 : NF % 64 == 0 ? 64 : 32;
     if (bn == 128 && (long)((M + 127) / 128) * (NF / 128) < cus && (long)((M + 127) / 128) * (NF / 64) >= cus / 2) bn = 64;
-#define GO(WM_, WN_, WV_) launch<WM_, WN_, WV_, BTR>(A, lda, Bh, Bm, Bl, ldb, bias, C, ldc, M, NF, KC, s)
+    if (EPI) {
+        const char* bad = tok_epi_check(epi, M);
+        DHZ_REQUIRE(!bad, "%s: %s", who, bad);
+        DHZ_REQUIRE(((uintptr_t)epi.res & 15) == 0, "%s: the shortcut must be 16-byte aligned", who);
+    }
+#define GO(WM_, WN_, WV_) launch<WM_, WN_, WV_, BTR, EPI>(A, lda, Bh, Bm, Bl, ldb, bias, C, ldc, M, NF, KC, epi, s)
     static const int force = getenv("DHZ_S6_TILE") ? atoi(getenv("DHZ_S6_TILE")) : 0;          // diagnostics: 1 = never wide, 2 = always wide
     const bool wide = bn == 128 && force != 1 && (force == 2 || (long)((M + 255) / 256) * (NF / 128) >= cus);
-    if (wide) launch_wide<BTR>(A, lda, Bh, Bm, Bl, ldb, bias, C, ldc, M, NF, KC, s);        // 256 x 128
+    if (wide) launch_wide<BTR, EPI>(A, lda, Bh, Bm, Bl, ldb, bias, C, ldc, M, NF, KC, epi, s);        // 256 x 128
     else if (bn == 128) GO(4, 2, 2);                              // 128 x 128
     else if (bn == 64) GO(2, 2, 4);                               // 128 x 64
     else if constexpr (!BTR) GO(1, 2, 8);                         // 128 x 32
@@ -813,4 +878,12 @@ extern "C" int dhz_linear_dgrad_split6(const float* dy, int ldy, const void* w_h
     // dx[T,K] = dy[T,N] w[N,K]: the contraction runs over the N rows of w (transposed reads), the output features are its K columns
     return dispatch<true>("dhz_linear_dgrad_split6", dy, ldy, (const uint16_t*)w_hi, (const uint16_t*)w_mid, (const uint16_t*)w_lo, K,
                           nullptr, dx, ldx, T, K, N, (hipStream_t)stream);
+}
+
+extern "C" int dhz_linear_fwd_split6_res(const float* x, int ldx, const void* w_hi, const void* w_mid, const void* w_lo, const float* bias,
+                                         const float* res, const float* scale, float* out, int ldo, int T, int N, int K, int tokens_per_image,
+                                         int Hres, int Wres, int shift, int windowed, void* stream) {
+    const TokEpi epi{res, scale, tokens_per_image, Hres, Wres, shift, windowed};
+    return dispatch<false, true>("dhz_linear_fwd_split6_res", x, ldx, (const uint16_t*)w_hi, (const uint16_t*)w_mid, (const uint16_t*)w_lo, K,
+                                 bias, out, ldo, T, N, K, (hipStream_t)stream, epi);
 }

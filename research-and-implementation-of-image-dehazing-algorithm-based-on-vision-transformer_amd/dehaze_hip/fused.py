@@ -1,10 +1,17 @@
-"""Fused attention branch of a LeWin block: ONE forward kernel (dhz_fused_window_attn_fwd) and a hand-sequenced
-backward over the existing kernels, wrapped as a single autograd node.
+"""The two branches of a LeWin block (M1:839-873) as hand-sequenced kernel chains behind autograd nodes.
 
-forward  : out = x + drop_scale * OutProj(ProbAttn(QKV(partition(roll(LN(x))))))           (M1:839-872)
-backward : reverse_residual_bwd -> out-proj dgrad (library GEMM) + wgrad (dhz_linear_wgrad, in place)
-           -> dhz_ps_attn_bwd (+ bias table gradient) -> QKV dgrad + wgrad -> dhz_ln_partition_bwd with the
-           shortcut gradient folded in (dx = dout + dLN) - no autograd-side accumulation kernels at all.
+attention branch : out = x + drop_scale * OutProj(ProbAttn(QKV(partition(roll(LN(x))))))           (M1:839-872)
+    forward  : ONE kernel (dhz_fused_window_attn_fwd) where it wins, else dhz_ln_partition_fwd -> QKV GEMM -> dhz_ps_attn_fwd ->
+               out-projection GEMM whose EPILOGUE is window reverse + un-roll + DropPath factor + residual (ops.gemm_fwd_res)
+    backward : out-proj dgrad + wgrad -> dhz_ps_attn_bwd (+ bias table gradient) -> QKV dgrad + wgrad -> dhz_ln_partition_bwd with
+               the shortcut gradient folded in (dx = dout + dLN) - no autograd-side accumulation kernels at all
+LeFF / Mlp branch: out = x + drop_scale * linear2(gelu(dwconv(gelu(linear1(LN(x))))))                (M1:873)
+whole block      : block() runs both branches as ONE node, so that the gradient between them can live in the layout its consumer
+                   reads: the LeFF branch's LayerNorm backward writes d(x1) in the attention branch's WINDOW order
+                   (dhz_ln_partition_bwd_lay), the out-projection's backward products read it as it lies (the DropPath factor as a
+                   row factor inside them), the attention LayerNorm backward reads its residual gradient in the same order -
+                   dhz_reverse_residual_bwd never runs.
+Each branch's forward / backward is a plain function over a record (`_Rec`); the autograd nodes only store and replay records.
 """
 import torch
 from torch.autograd import Function
@@ -82,20 +89,30 @@ def _ready(*params):
             ops.GRAD_READY(p)
 
 
-def _ln_backward(dxn, x, gamma_p, beta_p, gamma, stats, dres, B, Hres, Wres, C, shift, partition):
+def _ln_backward(dxn, x, gamma_p, beta_p, gamma, stats, dres, B, Hres, Wres, C, shift, partition, dres_windowed=False, dx_window=None):
     """LayerNorm backward with the shortcut gradient folded in; d(gamma), d(beta) accumulated in place when the
-    parameters are leaves (returns (dx, dgamma, dbeta) with None for gradients already accumulated)."""
+    parameters are leaves (returns (dx, dgamma, dbeta) with None for gradients already accumulated).
+    dres_windowed: dres lies in this call's window order; dx_window = shift: dx is WRITTEN in the window order of that shift."""
     dx = torch.empty_like(x)
     gg, gb = _grad_buf(gamma_p), _grad_buf(beta_p)
+    lay = (1 if dres_windowed else 0, 0 if dx_window is None else 1, 0 if dx_window is None else int(dx_window))
     if gg is not None and gb is not None:
-        _lib.call("dhz_ln_partition_bwd_dt", _p(dxn), _p(x), _p(gamma), _p(stats), _p(dres), _p(dx), _p(gg), _p(gb),
-                  B, Hres, Wres, C, shift, partition, ops._dt(x), _stream())
+        _lib.call("dhz_ln_partition_bwd_lay", _p(dxn), _p(x), _p(gamma), _p(stats), _p(dres), _p(dx), _p(gg), _p(gb),
+                  B, Hres, Wres, C, shift, partition, *lay, ops._dt(x), _stream())
         _ready(gamma_p, beta_p)
         return dx, None, None
     dgb = torch.zeros((2, C), device=x.device, dtype=torch.float32)
-    _lib.call("dhz_ln_partition_bwd_dt", _p(dxn), _p(x), _p(gamma), _p(stats), _p(dres), _p(dx), dgb[0].data_ptr(),
-              dgb[1].data_ptr(), B, Hres, Wres, C, shift, partition, ops._dt(x), _stream())
+    _lib.call("dhz_ln_partition_bwd_lay", _p(dxn), _p(x), _p(gamma), _p(stats), _p(dres), _p(dx), dgb[0].data_ptr(),
+              dgb[1].data_ptr(), B, Hres, Wres, C, shift, partition, *lay, ops._dt(x), _stream())
     return dx, dgb[0], dgb[1]
+
+
+class _Rec:
+    """what one branch's forward leaves for its backward: tensors (through ctx.save_for_backward), parameters, geometry"""
+    __slots__ = ("saved", "params", "geom", "kind")
+
+    def __init__(self, kind=None, saved=(), params=None, geom=None):
+        self.kind, self.saved, self.params, self.geom = kind, tuple(saved), params, geom
 
 
 def _table_backward(dpart, parts, table_p, H, dev):
@@ -109,310 +126,324 @@ def _table_backward(dpart, parts, table_p, H, dev):
     return dtable
 
 
-class _FusedAttnBranch(Function):
-    @staticmethod
-    def forward(ctx, x, gamma, beta, wq, bq, wk, bk, wv, bv, wo, bo, table, idx, mask, dscale, Hres, Wres, shift, H, grad_mode):
-        _require_gpu(x, gamma, beta, wq, wo, table, idx, mask, dscale)
-        x = x.contiguous()
-        B, L, C = x.shape
-        assert L == Hres * Wres and C == 32 * H and C in SUPPORTED_C
-        dev = x.device
-        T = B * L
-        f32 = dict(device=dev, dtype=torch.float32)
-        wqkv_p = torch.empty(3 * C * C, **f32)
-        wo_p = torch.empty(C * C, **f32)
-        _lib.call("dhz_fused_attn_prepack", _p(wq), _p(wk), _p(wv), _p(wo), _p(wqkv_p), _p(wo_p), C, _stream())
-        bqkv = ops.cat_rows([bq.detach(), bk.detach(), bv.detach()])
-        bias = None
-        if table is not None:
-            bias = torch.empty((H, NTOK, NTOK), **f32)
-            _lib.call("dhz_bias_gather", _p(table.contiguous()), _p(bias), H, _stream())
-        out = torch.empty_like(x)
-        train = grad_mode and any(ctx.needs_input_grad)
-        fused_bwd = train and C in ATTN_FUSED_BWD_C and x.dtype == torch.float32
-        xn = qkv = cx = stats = rank = None
-        if train:
-            if not fused_bwd:
-                xn = torch.empty((T, C), **f32)
-                qkv = torch.empty((T, 3 * C), **f32)
-                cx = torch.empty((T, C), **f32)
-                stats = torch.empty((T, 2), **f32)
-            rank = torch.empty(((T // NTOK) * H * NTOK,), device=dev, dtype=torch.uint8)
-        timing = ops.KERNEL_TIMING.get("dhz_fused_window_attn_fwd") if ops.KERNEL_TIMING is not None else None
-        if timing is not None:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-        _lib.call("dhz_fused_window_attn_fwd", _p(x), _p(gamma), _p(beta), _p(wqkv_p), _p(bqkv), _p(wo_p), _p(bo), _p(idx),
-                  _p(bias), _p(mask), _p(dscale), _p(out), _p(xn), _p(qkv), _p(cx), _p(stats), _p(rank), B, Hres, Wres, C,
-                  shift, _stream())
-        if timing is not None:
-            e1.record()
-            timing.append((e0, e1, T // NTOK, C))
-        ctx.fused_bwd = fused_bwd
-        if fused_bwd:
-            wt = torch.empty(4096, **f32)
-            _lib.call("dhz_fused_attn_bwd_prepack", _p(wq), _p(wk), _p(wv), _p(wo), _p(wt), C, _stream())
-            ctx.save_for_backward(x, gamma, beta, rank, bias, mask, dscale, wqkv_p, bqkv, wt)
-            ctx.params = (wq, bq, wk, bk, wv, bv, wo, bo, gamma, beta, table)
-            ctx.geom = (B, Hres, Wres, C, shift, H)
-        elif train:
-            ctx.save_for_backward(x, gamma, stats, xn, qkv, cx, rank, bias, mask, dscale, wq, wk, wv, wo)
-            ctx.params = (wq, bq, wk, bk, wv, bv, wo, bo, gamma, beta, table)
-            ctx.geom = (B, Hres, Wres, C, shift, H)
-        return out
+# ----------------------------------------------------------------------------- attention branch: forward / backward as functions
+def _attn_fused_fwd(train, x, gamma, beta, wq, bq, wk, bk, wv, bv, wo, bo, table, idx, mask, dscale, Hres, Wres, shift, H):
+    """one kernel: LN, roll, partition, QKV, ProbSparse core, out-projection, reverse, residual (csrc/fused_attn.hip)"""
+    _require_gpu(x, gamma, beta, wq, wo, table, idx, mask, dscale)
+    x = x.contiguous()
+    B, L, C = x.shape
+    assert L == Hres * Wres and C == 32 * H and C in SUPPORTED_C
+    dev = x.device
+    T = B * L
+    f32 = dict(device=dev, dtype=torch.float32)
+    wqkv_p = torch.empty(3 * C * C, **f32)
+    wo_p = torch.empty(C * C, **f32)
+    _lib.call("dhz_fused_attn_prepack", _p(wq), _p(wk), _p(wv), _p(wo), _p(wqkv_p), _p(wo_p), C, _stream())
+    bqkv = ops.cat_rows([bq.detach(), bk.detach(), bv.detach()])
+    bias = None
+    if table is not None:
+        bias = torch.empty((H, NTOK, NTOK), **f32)
+        _lib.call("dhz_bias_gather", _p(table.contiguous()), _p(bias), H, _stream())
+    out = torch.empty_like(x)
+    fused_bwd = train and C in ATTN_FUSED_BWD_C and x.dtype == torch.float32
+    xn = qkv = cx = stats = rank = None
+    if train:
+        if not fused_bwd:
+            xn = torch.empty((T, C), **f32)
+            qkv = torch.empty((T, 3 * C), **f32)
+            cx = torch.empty((T, C), **f32)
+            stats = torch.empty((T, 2), **f32)
+        rank = torch.empty(((T // NTOK) * H * NTOK,), device=dev, dtype=torch.uint8)
+    timing = ops.KERNEL_TIMING.get("dhz_fused_window_attn_fwd") if ops.KERNEL_TIMING is not None else None
+    if timing is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    _lib.call("dhz_fused_window_attn_fwd", _p(x), _p(gamma), _p(beta), _p(wqkv_p), _p(bqkv), _p(wo_p), _p(bo), _p(idx),
+              _p(bias), _p(mask), _p(dscale), _p(out), _p(xn), _p(qkv), _p(cx), _p(stats), _p(rank), B, Hres, Wres, C,
+              shift, _stream())
+    if timing is not None:
+        e1.record()
+        timing.append((e0, e1, T // NTOK, C))
+    rec = None
+    params = (wq, bq, wk, bk, wv, bv, wo, bo, gamma, beta, table)
+    geom = (B, Hres, Wres, C, shift, H)
+    if fused_bwd:
+        wt = torch.empty(4096, **f32)
+        _lib.call("dhz_fused_attn_bwd_prepack", _p(wq), _p(wk), _p(wv), _p(wo), _p(wt), C, _stream())
+        rec = _Rec("attn_fused_bwd", (x, gamma, beta, rank, bias, mask, dscale, wqkv_p, bqkv, wt), params, geom)
+    elif train:
+        rec = _Rec("attn_chain_bwd", (x, gamma, stats, xn, qkv, cx, rank, bias, mask, dscale, wq, wk, wv, wo), params, geom)
+    return out, rec
 
-    @staticmethod
-    def _backward_fused(ctx, dout):
-        """One kernel from d(out) to dx and every parameter gradient (csrc/fused_attn_bwd.hip)."""
-        x, gamma, beta, rank, bias, mask, dscale, wqkv_p, bqkv, wt = ctx.saved_tensors
-        wq, bq, wk, bk, wv, bv, wo, bo, gamma_p, beta_p, table_p = ctx.params
-        B, Hres, Wres, C, shift, H = ctx.geom
-        dev = x.device
-        f32 = dict(device=dev, dtype=torch.float32)
-        plist = (wq, wk, wv, bq, bk, bv, wo, bo, gamma_p, beta_p)
-        bufs = [_grad_buf(p) if p is not None else None for p in plist]
-        inplace = all(b is not None or p is None for b, p in zip(bufs, plist))
-        if not inplace:
-            bufs = [torch.zeros_like(p, memory_format=torch.contiguous_format) if p is not None else None for p in plist]
-        gwq, gwk, gwv, gbq, gbk, gbv, gwo, gbo, gg, gb = bufs
-        nwin = B * (Hres // 8) * (Wres // 8)
-        parts = _lib.load().dhz_fused_attn_bwd_parts(nwin)
-        dpart = torch.empty((parts, NTOK, NTOK), **f32) if bias is not None else None
-        dx = torch.empty_like(x)
-        _lib.call("dhz_fused_window_attn_bwd", _p(x), _p(dout.contiguous()), _p(gamma), _p(beta), _p(wqkv_p), _p(bqkv), _p(wt),
-                  _p(bias), _p(mask), _p(dscale), _p(rank), _p(dx), _p(gwq), _p(gwk), _p(gwv), _p(gbq), _p(gbk), _p(gbv), _p(gwo),
-                  _p(gbo), _p(gg), _p(gb), _p(dpart), B, Hres, Wres, C, shift, _stream())
-        dtable = _table_backward(dpart, parts, table_p, H, dev) if bias is not None else None
-        if inplace:
-            _ready(*[p for p in plist if p is not None])
-            return (dx, None, None, None, None, None, None, None, None, None, None, dtable,
-                    None, None, None, None, None, None, None, None)
-        return (dx, gg, gb, gwq, gbq, gwk, gbk, gwv, gbv, gwo, gbo, dtable, None, None, None, None, None, None, None, None)
 
-    @staticmethod
-    def backward(ctx, dout):
-        if getattr(ctx, "fused_bwd", False):
-            return _FusedAttnBranch._backward_fused(ctx, dout)
-        x, gamma, stats, xn, qkv, cx, rank, bias, mask, dscale, wq_, wk_, wv_, wo_ = ctx.saved_tensors
-        wq, bq, wk, bk, wv, bv, wo, bo, gamma_p, beta_p, table_p = ctx.params
-        B, Hres, Wres, C, shift, H = ctx.geom
-        dout = dout.contiguous()
-        dev = x.device
-        T = B * Hres * Wres
-        B_ = T // NTOK
-        f32 = dict(device=dev, dtype=torch.float32)
+def _attn_chain_fwd(train, x, gamma, beta, wq, bq, wk, bk, wv, bv, wo, bo, table, idx, mask, dscale, Hres, Wres, shift, H):
+    """dhz_ln_partition_fwd -> QKV GEMM -> dhz_ps_attn_fwd -> out-projection GEMM with the residual epilogue (K4 inside the GEMM)"""
+    _require_gpu(x, gamma, beta, wq, wo, table, idx, mask, dscale)
+    x = x.contiguous()
+    B, L, C = x.shape
+    d = C // H
+    dev = x.device
+    T = B * L
+    f32 = dict(device=dev, dtype=torch.float32)
+    xn = torch.empty((T, C), device=dev, dtype=x.dtype)
+    stats = torch.empty((T, 2), **f32)
+    _lib.call("dhz_ln_partition_fwd_dt", _p(x), _p(gamma), _p(beta), _p(xn), _p(stats), B, Hres, Wres, C, shift, 1,
+              ops._dt(x), _stream())
+    wcat = ops.cat_rows([wq.detach(), wk.detach(), wv.detach()])
+    qkv = ops.gemm_fwd(xn, wcat, ops.cat_rows([bq.detach(), bk.detach(), bv.detach()]))
+    bias = None
+    if table is not None:
+        bias = torch.empty((H, NTOK, NTOK), **f32)
+        _lib.call("dhz_bias_gather", _p(table.contiguous()), _p(bias), H, _stream())
+    cx = torch.empty((T, C), device=dev, dtype=x.dtype)
+    rank = torch.empty(((T // NTOK) * H * NTOK,), device=dev, dtype=torch.uint8)
+    nW = mask.shape[0] if mask is not None else 1
+    base = qkv.data_ptr()
+    timing = ops.KERNEL_TIMING.get("dhz_ps_attn_fwd") if ops.KERNEL_TIMING is not None else None
+    if timing is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    es = qkv.element_size()
+    _lib.call("dhz_ps_attn_fwd_dt", base, base + es * C, base + 2 * es * C, 3 * C, _p(idx), _p(bias), _p(mask), _p(cx), C,
+              _p(rank), T // NTOK, H, nW, d, ops._dt(qkv), _stream())
+    if timing is not None:
+        e1.record()
+        timing.append((e0, e1, (T // NTOK) * H * 4 * NTOK * d * qkv.element_size()))
+    out = ops.gemm_fwd_res(cx, wo, bo, x.view(T, C), dscale, B, Hres, Wres, shift, True).view(B, L, C)
+    rec = None
+    if train:
+        rec = _Rec("attn_chain_bwd", (x, gamma, stats, xn, qkv, cx, rank, bias, mask, dscale, wq, wk, wv, wo),
+                   (wq, bq, wk, bk, wv, bv, wo, bo, gamma, beta, table), (B, Hres, Wres, C, shift, H))
+    return out, rec
+
+
+def _attn_bwd_fused(rec, dout):
+    """One kernel from d(out) to dx and every parameter gradient (csrc/fused_attn_bwd.hip)."""
+    x, gamma, beta, rank, bias, mask, dscale, wqkv_p, bqkv, wt = rec.saved
+    wq, bq, wk, bk, wv, bv, wo, bo, gamma_p, beta_p, table_p = rec.params
+    B, Hres, Wres, C, shift, H = rec.geom
+    dev = x.device
+    f32 = dict(device=dev, dtype=torch.float32)
+    plist = (wq, wk, wv, bq, bk, bv, wo, bo, gamma_p, beta_p)
+    bufs = [_grad_buf(p) if p is not None else None for p in plist]
+    inplace = all(b is not None or p is None for b, p in zip(bufs, plist))
+    if not inplace:
+        bufs = [torch.zeros_like(p, memory_format=torch.contiguous_format) if p is not None else None for p in plist]
+    gwq, gwk, gwv, gbq, gbk, gbv, gwo, gbo, gg, gb = bufs
+    nwin = B * (Hres // 8) * (Wres // 8)
+    parts = _lib.load().dhz_fused_attn_bwd_parts(nwin)
+    dpart = torch.empty((parts, NTOK, NTOK), **f32) if bias is not None else None
+    dx = torch.empty_like(x)
+    _lib.call("dhz_fused_window_attn_bwd", _p(x), _p(dout.contiguous()), _p(gamma), _p(beta), _p(wqkv_p), _p(bqkv), _p(wt),
+              _p(bias), _p(mask), _p(dscale), _p(rank), _p(dx), _p(gwq), _p(gwk), _p(gwv), _p(gbq), _p(gbk), _p(gbv), _p(gwo),
+              _p(gbo), _p(gg), _p(gb), _p(dpart), B, Hres, Wres, C, shift, _stream())
+    dtable = _table_backward(dpart, parts, table_p, H, dev) if bias is not None else None
+    if inplace:
+        _ready(*[p for p in plist if p is not None])
+        return (dx, None, None, None, None, None, None, None, None, None, None, dtable)
+    return (dx, gg, gb, gwq, gbq, gwk, gbk, gwv, gbv, gwo, gbo, dtable)
+
+
+def _attn_bwd(rec, dout, windowed=False):
+    """backward of the attention branch from d(out): (dx, dgamma, dbeta, dWq, dbq, dWk, dbk, dWv, dbv, dWo, dbo, dtable), None for
+    gradients accumulated in place.  windowed: dout arrives in this branch's window order, WITHOUT the DropPath factor (written by
+    the LeFF branch's LayerNorm backward, block()): no dhz_reverse_residual_bwd pass - the factor rides in the out-projection's
+    backward-data epilogue and as the row factor of its weight gradient."""
+    if rec.kind == "attn_fused_bwd":
+        assert not windowed
+        return _attn_bwd_fused(rec, dout)
+    x, gamma, stats, xn, qkv, cx, rank, bias, mask, dscale, wq_, wk_, wv_, wo_ = rec.saved
+    wq, bq, wk, bk, wv, bv, wo, bo, gamma_p, beta_p, table_p = rec.params
+    B, Hres, Wres, C, shift, H = rec.geom
+    d = C // H
+    dout = dout.contiguous()
+    dev = x.device
+    T = B * Hres * Wres
+    B_ = T // NTOK
+    f32 = dict(device=dev, dtype=torch.float32)
+    if windowed:
+        daw = dout.view(T, C)
+        rs = (dscale, Hres * Wres) if dscale is not None else None
+        dctx = ops.gemm_dgrad(daw, wo_, rs)
+        g_wo, g_bo = _wgrad(daw, 0, cx, wo, bo, rs)
+    else:
         # (1) gradient of the window-ordered out-projection output
-        daw = torch.empty((T, C), **f32)
+        daw = torch.empty((T, C), device=dev, dtype=dout.dtype)
         _lib.call("dhz_reverse_residual_bwd_dt", _p(dout), _p(dscale), _p(daw), B, Hres, Wres, C, shift, 1, ops._dt(dout), _stream())
         # (2) out-projection
         dctx = ops.gemm_dgrad(daw, wo_)
         g_wo, g_bo = _wgrad(daw, 0, cx, wo, bo)
-        # (3) attention core
-        dqkv = torch.empty_like(qkv)
-        parts = _lib.load().dhz_ps_attn_bwd_parts_d(B_, H, C // H)
-        dpart = torch.empty((parts, NTOK, NTOK), **f32) if bias is not None else None
-        nW = mask.shape[0] if mask is not None else 1
-        base, gb = qkv.data_ptr(), dqkv.data_ptr()
-        _lib.call("dhz_ps_attn_bwd", base, base + 4 * C, base + 8 * C, 3 * C, _p(bias), _p(mask), _p(rank), _p(dctx), C,
-                  gb, gb + 4 * C, gb + 8 * C, 3 * C, _p(dpart), B_, H, nW, 32, _stream())
-        dtable = _table_backward(dpart, parts, table_p, H, dev) if bias is not None else None
-        # (4) QKV projection
-        dxn = ops.gemm_dgrad(dqkv, ops.cat_rows([wq_.detach(), wk_.detach(), wv_.detach()]))
-        g_wq, g_bq, g_wk, g_bk, g_wv, g_bv = _wgrad_qkv(dqkv, xn, C, [(wq, bq), (wk, bk), (wv, bv)])
-        # (5) LayerNorm backward + shortcut gradient in one pass
-        dx, dgamma, dbeta = _ln_backward(dxn, x, gamma_p, beta_p, gamma, stats, dout, B, Hres, Wres, C, shift, 1)
-        return (dx, dgamma, dbeta, g_wq, g_bq, g_wk, g_bk, g_wv, g_bv, g_wo, g_bo, dtable,
-                None, None, None, None, None, None, None, None)
+    # (3) attention core
+    dqkv = torch.empty_like(qkv)
+    parts = _lib.load().dhz_ps_attn_bwd_parts_d(B_, H, d)
+    dpart = torch.empty((parts, NTOK, NTOK), **f32) if bias is not None else None
+    nW = mask.shape[0] if mask is not None else 1
+    base, gb = qkv.data_ptr(), dqkv.data_ptr()
+    es = qkv.element_size()
+    _lib.call("dhz_ps_attn_bwd_dt", base, base + es * C, base + 2 * es * C, 3 * C, _p(bias), _p(mask), _p(rank), _p(dctx), C,
+              gb, gb + es * C, gb + 2 * es * C, 3 * C, _p(dpart), B_, H, nW, d, ops._dt(qkv), _stream())
+    dtable = _table_backward(dpart, parts, table_p, H, dev) if bias is not None else None
+    # (4) QKV projection
+    dxn = ops.gemm_dgrad(dqkv, ops.cat_rows([wq_.detach(), wk_.detach(), wv_.detach()]))
+    g_wq, g_bq, g_wk, g_bk, g_wv, g_bv = _wgrad_qkv(dqkv, xn, C, [(wq, bq), (wk, bk), (wv, bv)])
+    # (5) LayerNorm backward + shortcut gradient in one pass
+    dx, dgamma, dbeta = _ln_backward(dxn, x, gamma_p, beta_p, gamma, stats, dout, B, Hres, Wres, C, shift, 1, dres_windowed=windowed)
+    return (dx, dgamma, dbeta, g_wq, g_bq, g_wk, g_bk, g_wv, g_bv, g_wo, g_bo, dtable)
+
+
+def _use_fused_attn(x, heads, Hres, Wres):
+    C = x.shape[-1]
+    return ENABLED and x.dtype == torch.float32 and C == 32 * heads and (C in (32, 64) or (C == 128 and Hres * Wres <= ATTN_FUSED_C128_MAX_HW))
+
+
+class _AttnNode(Function):
+    """the attention branch as one autograd node; FUSED selects the forward (the backward follows the record)"""
+
+    @staticmethod
+    def forward(ctx, fused, x, gamma, beta, wq, bq, wk, bk, wv, bv, wo, bo, table, idx, mask, dscale, Hres, Wres, shift, H, grad_mode):
+        train = grad_mode and any(ctx.needs_input_grad)      # grad mode reads False inside Function.forward: passed in
+        out, rec = (_attn_fused_fwd if fused else _attn_chain_fwd)(train, x, gamma, beta, wq, bq, wk, bk, wv, bv, wo, bo, table, idx, mask,
+                                                                   dscale, Hres, Wres, shift, H)
+        if rec is not None:
+            ctx.save_for_backward(*rec.saved)
+            rec.saved = ()
+        ctx.rec = rec
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        rec = ctx.rec
+        rec.saved = ctx.saved_tensors
+        g = _attn_bwd(rec, dout)
+        rec.saved = ()
+        return (None,) + g + (None,) * 8
 
 
 def fused_attn_branch(x, norm, layer, table, idx, mask, dscale, Hres, Wres, shift, heads):
     """x: [B,L,C]; norm: nn.LayerNorm; layer: AttentionLayer (query/key/value/out projections)."""
     q, k, v, o = layer.query_projection, layer.key_projection, layer.value_projection, layer.out_projection
-    return _FusedAttnBranch.apply(x, norm.weight, norm.bias, q.weight, q.bias, k.weight, k.bias, v.weight, v.bias,
-                                  o.weight, o.bias, table, idx, mask, dscale, Hres, Wres, shift, heads, torch.is_grad_enabled())
-
-
-# ----------------------------------------------------------------------------- unfused forward, same hand-sequenced backward
-class _AttnBranchChain(Function):
-    """Attention branch for the widths the fused kernel does not cover (C >= 256) or where the kernel chain is
-    faster: forward = dhz_ln_partition_fwd -> library GEMM -> dhz_ps_attn_fwd -> library GEMM ->
-    dhz_reverse_residual_fwd, as ONE autograd node whose backward is the same sequence as _FusedAttnBranch's
-    (shortcut gradient folded into the LayerNorm backward, weight gradients accumulated in place)."""
-
-    @staticmethod
-    def forward(ctx, x, gamma, beta, wq, bq, wk, bk, wv, bv, wo, bo, table, idx, mask, dscale, Hres, Wres, shift, H, grad_mode):
-        _require_gpu(x, gamma, beta, wq, wo, table, idx, mask, dscale)
-        x = x.contiguous()
-        B, L, C = x.shape
-        d = C // H
-        dev = x.device
-        T = B * L
-        f32 = dict(device=dev, dtype=torch.float32)
-        xn = torch.empty((T, C), device=dev, dtype=x.dtype)
-        stats = torch.empty((T, 2), **f32)
-        _lib.call("dhz_ln_partition_fwd_dt", _p(x), _p(gamma), _p(beta), _p(xn), _p(stats), B, Hres, Wres, C, shift, 1,
-                  ops._dt(x), _stream())
-        wcat = ops.cat_rows([wq.detach(), wk.detach(), wv.detach()])
-        qkv = ops.gemm_fwd(xn, wcat, ops.cat_rows([bq.detach(), bk.detach(), bv.detach()]))
-        bias = None
-        if table is not None:
-            bias = torch.empty((H, NTOK, NTOK), **f32)
-            _lib.call("dhz_bias_gather", _p(table.contiguous()), _p(bias), H, _stream())
-        cx = torch.empty((T, C), device=dev, dtype=x.dtype)
-        rank = torch.empty(((T // NTOK) * H * NTOK,), device=dev, dtype=torch.uint8)
-        nW = mask.shape[0] if mask is not None else 1
-        base = qkv.data_ptr()
-        timing = ops.KERNEL_TIMING.get("dhz_ps_attn_fwd") if ops.KERNEL_TIMING is not None else None
-        if timing is not None:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-        es = qkv.element_size()
-        _lib.call("dhz_ps_attn_fwd_dt", base, base + es * C, base + 2 * es * C, 3 * C, _p(idx), _p(bias), _p(mask), _p(cx), C,
-                  _p(rank), T // NTOK, H, nW, d, ops._dt(qkv), _stream())
-        if timing is not None:
-            e1.record()
-            timing.append((e0, e1, (T // NTOK) * H * 4 * NTOK * d * qkv.element_size()))
-        aw = ops.gemm_fwd(cx, wo, bo)
-        out = torch.empty_like(x)
-        _lib.call("dhz_reverse_residual_fwd_dt", _p(aw), _p(x), _p(dscale), _p(out), B, Hres, Wres, C, shift, 1, ops._dt(x), _stream())
-        if grad_mode and any(ctx.needs_input_grad):
-            ctx.save_for_backward(x, gamma, stats, xn, qkv, cx, rank, bias, mask, dscale, wq, wk, wv, wo)
-            ctx.params = (wq, bq, wk, bk, wv, bv, wo, bo, gamma, beta, table)
-            ctx.geom = (B, Hres, Wres, C, shift, H)
-        return out
-
-    @staticmethod
-    def backward(ctx, dout):
-        x, gamma, stats, xn, qkv, cx, rank, bias, mask, dscale, wq_, wk_, wv_, wo_ = ctx.saved_tensors
-        wq, bq, wk, bk, wv, bv, wo, bo, gamma_p, beta_p, table_p = ctx.params
-        B, Hres, Wres, C, shift, H = ctx.geom
-        d = C // H
-        dout = dout.contiguous()
-        dev = x.device
-        T = B * Hres * Wres
-        B_ = T // NTOK
-        f32 = dict(device=dev, dtype=torch.float32)
-        daw = torch.empty((T, C), device=dev, dtype=dout.dtype)
-        _lib.call("dhz_reverse_residual_bwd_dt", _p(dout), _p(dscale), _p(daw), B, Hres, Wres, C, shift, 1, ops._dt(dout), _stream())
-        dctx = ops.gemm_dgrad(daw, wo_)
-        g_wo, g_bo = _wgrad(daw, 0, cx, wo, bo)
-        dqkv = torch.empty_like(qkv)
-        parts = _lib.load().dhz_ps_attn_bwd_parts_d(B_, H, C // H)
-        dpart = torch.empty((parts, NTOK, NTOK), **f32) if bias is not None else None
-        nW = mask.shape[0] if mask is not None else 1
-        base, gb = qkv.data_ptr(), dqkv.data_ptr()
-        es = qkv.element_size()
-        _lib.call("dhz_ps_attn_bwd_dt", base, base + es * C, base + 2 * es * C, 3 * C, _p(bias), _p(mask), _p(rank), _p(dctx), C,
-                  gb, gb + es * C, gb + 2 * es * C, 3 * C, _p(dpart), B_, H, nW, d, ops._dt(qkv), _stream())
-        dtable = _table_backward(dpart, parts, table_p, H, dev) if bias is not None else None
-        dxn = ops.gemm_dgrad(dqkv, ops.cat_rows([wq_.detach(), wk_.detach(), wv_.detach()]))
-        g_wq, g_bq, g_wk, g_bk, g_wv, g_bv = _wgrad_qkv(dqkv, xn, C, [(wq, bq), (wk, bk), (wv, bv)])
-        dx, dgamma, dbeta = _ln_backward(dxn, x, gamma_p, beta_p, gamma, stats, dout, B, Hres, Wres, C, shift, 1)
-        return (dx, dgamma, dbeta, g_wq, g_bq, g_wk, g_bk, g_wv, g_bv, g_wo, g_bo, dtable,
-                None, None, None, None, None, None, None, None)
+    return _AttnNode.apply(True, x, norm.weight, norm.bias, q.weight, q.bias, k.weight, k.bias, v.weight, v.bias,
+                           o.weight, o.bias, table, idx, mask, dscale, Hres, Wres, shift, heads, torch.is_grad_enabled())
 
 
 def attn_branch(x, norm, layer, table, idx, mask, dscale, Hres, Wres, shift, heads):
     """Dispatch: fused kernel where it wins (measured, tools/bench_fused.py), kernel chain elsewhere."""
-    C = x.shape[-1]
     q, k, v, o = layer.query_projection, layer.key_projection, layer.value_projection, layer.out_projection
-    args = (x, norm.weight, norm.bias, q.weight, q.bias, k.weight, k.bias, v.weight, v.bias, o.weight, o.bias, table, idx,
-            mask, dscale, Hres, Wres, shift, heads, torch.is_grad_enabled())
-    use_fused = ENABLED and x.dtype == torch.float32 and C == 32 * heads and (C in (32, 64) or (C == 128 and Hres * Wres <= ATTN_FUSED_C128_MAX_HW))
-    return (_FusedAttnBranch if use_fused else _AttnBranchChain).apply(*args)
+    return _AttnNode.apply(_use_fused_attn(x, heads, Hres, Wres), x, norm.weight, norm.bias, q.weight, q.bias, k.weight, k.bias, v.weight,
+                           v.bias, o.weight, o.bias, table, idx, mask, dscale, Hres, Wres, shift, heads, torch.is_grad_enabled())
 
 
-# ----------------------------------------------------------------------------- LeFF branch as one autograd node
-class _LeffBranch(Function):
+# ----------------------------------------------------------------------------- LeFF branch
+def _leff_fwd(train, x, gamma, beta, w1, b1, wd, bd, w2, b2, dscale, Hres, Wres):
     """out = x + drop_scale * linear2(gelu(dwconv3x3(gelu(linear1(LayerNorm(x))))))       (M1:873 + M1:496-534)
-    forward : dhz_ln_partition_fwd (plain LN) -> library GEMM -> dhz_leff_dwconv_fwd -> library GEMM ->
-              dhz_reverse_residual_fwd (token order)
-    backward: the mirror sequence with in-place weight gradients and the shortcut gradient folded into the
-              LayerNorm backward (no autograd accumulation kernels)."""
+    one kernel (csrc/leff_fused.hip) at C = 32 / 64, else dhz_ln_partition_fwd (plain LN) -> GEMM -> dhz_leff_dwconv_fwd -> GEMM with
+    the residual epilogue (token order)"""
+    _require_gpu(x, gamma, beta, w1, wd, w2, dscale)
+    x = x.contiguous()
+    B, L, C = x.shape
+    Ch = w1.shape[0]
+    T = B * L
+    dev = x.device
+    f32 = dict(device=dev, dtype=torch.float32)
+    wdc = wd.contiguous()
+    tiled = Hres % 8 == 0 and Wres % 16 == 0
+    fp32 = x.dtype == torch.float32                      # the fused LeFF kernels are fp32-only
+    if LEFF_FUSED and C in LEFF_FUSED_C and tiled and fp32 and not (C == 64 and T > LEFF_FUSED_C64_MAX_T and ops.SPLIT_BF16 == 6):
+        # one kernel: norm2, linear1, GELU, depthwise 3x3, GELU, linear2, DropPath scale, residual (csrc/leff_fused.hip)
+        out = torch.empty_like(x)
+        xn = stats = u = tg = z = None
+        if train:
+            xn = torch.empty((T, C), **f32)
+            stats = torch.empty((T, 2), **f32)
+            u = torch.empty((T, Ch), **f32)
+            tg = torch.empty((T, Ch), **f32)
+            z = torch.empty((T, Ch), **f32)
+        _lib.call("dhz_leff_fused_fwd", _p(x), _p(gamma), _p(beta), _p(w1), _p(b1), _p(wdc), _p(bd), _p(w2), _p(b2),
+                  _p(dscale), _p(out), _p(xn), _p(stats), _p(u), _p(tg), _p(z), B, Hres, Wres, C, _stream())
+    else:
+        xn = torch.empty((T, C), device=dev, dtype=x.dtype)
+        stats = torch.empty((T, 2), **f32)
+        _lib.call("dhz_ln_partition_fwd_dt", _p(x), _p(gamma), _p(beta), _p(xn), _p(stats), B, L, 1, C, 0, 0, ops._dt(x), _stream())
+        u = ops.gemm_fwd(xn, w1, b1)
+        z = torch.empty_like(u)
+        tg = torch.empty_like(u) if train else None
+        _lib.call("dhz_leff_dwconv_fwd_dt", _p(u), _p(wdc), _p(bd), _p(tg), _p(z), B, Hres, Wres, Ch, ops._dt(u), _stream())
+        out = ops.gemm_fwd_res(z, w2, b2, x.view(T, C), dscale, B, L, 1, 0, False).view(B, L, C)
+    rec = None
+    if train:
+        rec = _Rec("leff", (x, gamma, stats, xn, u, tg, z, dscale, w1, wdc, w2), (w1, b1, wd, bd, w2, b2, gamma, beta), (B, L, C, Ch, Hres, Wres))
+    return out, rec
+
+
+def _leff_bwd(rec, dout, dx_window=None):
+    """the mirror sequence with in-place weight gradients and the shortcut gradient folded into the LayerNorm backward (no autograd
+    accumulation kernels): (dx, dgamma, dbeta, dW1, db1, dWd, dbd, dW2, db2).  dx_window = shift: dx is written in the window order
+    of that shift on the Hres x Wres map (block(): what the attention branch's backward reads)."""
+    x, gamma, stats, xn, u, tg, z, dscale, w1_, wdc, w2_ = rec.saved
+    w1, b1, wd, bd, w2, b2, gamma_p, beta_p = rec.params
+    B, L, C, Ch, Hres, Wres = rec.geom
+    T = B * L
+    dout = dout.contiguous()
+    dev = x.device
+    f32 = dict(device=dev, dtype=torch.float32)
+    gwd, gbd = _grad_buf(wd), _grad_buf(bd)
+    # DropPath scale of the branch output (per image): in fp32 it is folded into the consumers - linear2's weight gradient scales
+    # the rows of dout as it stages them, the depthwise backward scales dz - instead of a scaled copy of dout (one pass over
+    # [T, C] per block less); bf16 keeps the copy
+    fold = dscale is not None and dout.dtype == torch.float32 and L % 32 == 0
+    zscale = dscale if fold else None
+    if dscale is not None and not fold:
+        dy = torch.empty((T, C), device=dev, dtype=dout.dtype)
+        _lib.call("dhz_reverse_residual_bwd_dt", _p(dout), _p(dscale), _p(dy), B, L, 1, C, 0, 0, ops._dt(dout), _stream())
+    else:
+        dy = dout.view(T, C)
+    dz = ops.gemm_dgrad(dy, w2_)
+    g_w2, g_b2 = _wgrad(dy, 0, z, w2, b2, (dscale, L) if fold else None)
+    du = torch.empty_like(u)
+    if gwd is not None and gbd is not None:          # depthwise weight / bias gradients straight into .grad
+        _lib.call("dhz_leff_dwconv_bwd_scaled_dt", _p(dz), _p(u), _p(tg), _p(wdc), _p(du), _p(gwd), _p(gbd), _p(zscale), B, Hres,
+                  Wres, Ch, ops._dt(u), _stream())
+        _ready(wd, bd)
+        g_wd = g_bd = None
+    else:
+        dwb = torch.zeros((Ch * 10,), **f32)
+        _lib.call("dhz_leff_dwconv_bwd_scaled_dt", _p(dz), _p(u), _p(tg), _p(wdc), _p(du), dwb.data_ptr(),
+                  dwb.data_ptr() + 4 * Ch * 9, _p(zscale), B, Hres, Wres, Ch, ops._dt(u), _stream())
+        g_wd, g_bd = dwb[:Ch * 9].view(Ch, 1, 3, 3), dwb[Ch * 9:]
+    dxn = ops.gemm_dgrad(du, w1_)
+    g_w1, g_b1 = _wgrad(du, 0, xn, w1, b1)
+    if dx_window is None:
+        dx, dgamma, dbeta = _ln_backward(dxn, x, gamma_p, beta_p, gamma, stats, dout, B, L, 1, C, 0, 0)
+    else:
+        dx, dgamma, dbeta = _ln_backward(dxn, x, gamma_p, beta_p, gamma, stats, dout, B, Hres, Wres, C, 0, 0, dx_window=dx_window)
+    return (dx, dgamma, dbeta, g_w1, g_b1, g_wd, g_bd, g_w2, g_b2)
+
+
+class _LeffBranch(Function):
+    """the LeFF branch as one autograd node"""
 
     @staticmethod
     def forward(ctx, x, gamma, beta, w1, b1, wd, bd, w2, b2, dscale, Hres, Wres, grad_mode):
-        _require_gpu(x, gamma, beta, w1, wd, w2, dscale)
-        x = x.contiguous()
-        B, L, C = x.shape
-        Ch = w1.shape[0]
-        T = B * L
-        dev = x.device
-        f32 = dict(device=dev, dtype=torch.float32)
         train = grad_mode and any(ctx.needs_input_grad)      # grad mode reads False inside Function.forward: passed in
-        wdc = wd.contiguous()
-        out = torch.empty_like(x)
-        tiled = Hres % 8 == 0 and Wres % 16 == 0
-        fp32 = x.dtype == torch.float32                      # the fused LeFF kernels are fp32-only
-        if LEFF_FUSED and C in LEFF_FUSED_C and tiled and fp32 and not (C == 64 and T > LEFF_FUSED_C64_MAX_T and ops.SPLIT_BF16 == 6):
-            # one kernel: norm2, linear1, GELU, depthwise 3x3, GELU, linear2, DropPath scale, residual (csrc/leff_fused.hip)
-            xn = stats = u = tg = z = None
-            if train:
-                xn = torch.empty((T, C), **f32)
-                stats = torch.empty((T, 2), **f32)
-                u = torch.empty((T, Ch), **f32)
-                tg = torch.empty((T, Ch), **f32)
-                z = torch.empty((T, Ch), **f32)
-            _lib.call("dhz_leff_fused_fwd", _p(x), _p(gamma), _p(beta), _p(w1), _p(b1), _p(wdc), _p(bd), _p(w2), _p(b2),
-                      _p(dscale), _p(out), _p(xn), _p(stats), _p(u), _p(tg), _p(z), B, Hres, Wres, C, _stream())
-        else:
-            xn = torch.empty((T, C), device=dev, dtype=x.dtype)
-            stats = torch.empty((T, 2), **f32)
-            _lib.call("dhz_ln_partition_fwd_dt", _p(x), _p(gamma), _p(beta), _p(xn), _p(stats), B, L, 1, C, 0, 0, ops._dt(x), _stream())
-            u = ops.gemm_fwd(xn, w1, b1)
-            z = torch.empty_like(u)
-            tg = torch.empty_like(u) if train else None
-            _lib.call("dhz_leff_dwconv_fwd_dt", _p(u), _p(wdc), _p(bd), _p(tg), _p(z), B, Hres, Wres, Ch, ops._dt(u), _stream())
-            y = ops.gemm_fwd(z, w2, b2)
-            _lib.call("dhz_reverse_residual_fwd_dt", _p(y), _p(x), _p(dscale), _p(out), B, L, 1, C, 0, 0, ops._dt(x), _stream())
-        if train:
-            ctx.save_for_backward(x, gamma, stats, xn, u, tg, z, dscale, w1, wdc, w2)
-            ctx.params = (w1, b1, wd, bd, w2, b2, gamma, beta)
-            ctx.geom = (B, L, C, Ch, Hres, Wres)
+        out, rec = _leff_fwd(train, x, gamma, beta, w1, b1, wd, bd, w2, b2, dscale, Hres, Wres)
+        if rec is not None:
+            ctx.save_for_backward(*rec.saved)
+            rec.saved = ()
+        ctx.rec = rec
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        x, gamma, stats, xn, u, tg, z, dscale, w1_, wdc, w2_ = ctx.saved_tensors
-        w1, b1, wd, bd, w2, b2, gamma_p, beta_p = ctx.params
-        B, L, C, Ch, Hres, Wres = ctx.geom
-        T = B * L
-        dout = dout.contiguous()
-        dev = x.device
-        f32 = dict(device=dev, dtype=torch.float32)
-        gwd, gbd = _grad_buf(wd), _grad_buf(bd)
-        # DropPath scale of the branch output (per image): in fp32 it is folded into the consumers - linear2's weight gradient scales
-        # the rows of dout as it stages them, the depthwise backward scales dz - instead of a scaled copy of dout (one pass over
-        # [T, C] per block less); bf16 keeps the copy
-        fold = dscale is not None and dout.dtype == torch.float32 and L % 32 == 0
-        zscale = dscale if fold else None
-        if dscale is not None and not fold:
-            dy = torch.empty((T, C), device=dev, dtype=dout.dtype)
-            _lib.call("dhz_reverse_residual_bwd_dt", _p(dout), _p(dscale), _p(dy), B, L, 1, C, 0, 0, ops._dt(dout), _stream())
-        else:
-            dy = dout.view(T, C)
-        dz = ops.gemm_dgrad(dy, w2_)
-        g_w2, g_b2 = _wgrad(dy, 0, z, w2, b2, (dscale, L) if fold else None)
-        du = torch.empty_like(u)
-        if gwd is not None and gbd is not None:          # depthwise weight / bias gradients straight into .grad
-            _lib.call("dhz_leff_dwconv_bwd_scaled_dt", _p(dz), _p(u), _p(tg), _p(wdc), _p(du), _p(gwd), _p(gbd), _p(zscale), B, Hres,
-                      Wres, Ch, ops._dt(u), _stream())
-            _ready(wd, bd)
-            g_wd = g_bd = None
-        else:
-            dwb = torch.zeros((Ch * 10,), **f32)
-            _lib.call("dhz_leff_dwconv_bwd_scaled_dt", _p(dz), _p(u), _p(tg), _p(wdc), _p(du), dwb.data_ptr(),
-                      dwb.data_ptr() + 4 * Ch * 9, _p(zscale), B, Hres, Wres, Ch, ops._dt(u), _stream())
-            g_wd, g_bd = dwb[:Ch * 9].view(Ch, 1, 3, 3), dwb[Ch * 9:]
-        dxn = ops.gemm_dgrad(du, w1_)
-        g_w1, g_b1 = _wgrad(du, 0, xn, w1, b1)
-        dx, dgamma, dbeta = _ln_backward(dxn, x, gamma_p, beta_p, gamma, stats, dout, B, L, 1, C, 0, 0)
-        return (dx, dgamma, dbeta, g_w1, g_b1, g_wd, g_bd, g_w2, g_b2, None, None, None, None)
+        rec = ctx.rec
+        rec.saved = ctx.saved_tensors
+        g = _leff_bwd(rec, dout)
+        rec.saved = ()
+        return g + (None, None, None, None)
 
 
 class _FfnBranch(Function):
     """out = x + drop_scale * fc2(gelu(fc1(LayerNorm(x))))        (M1:873 with token_mlp = 'ffn': M1:442-468)
-    forward : dhz_ln_partition_fwd (plain LN) -> GEMM -> dhz_gelu_fwd -> GEMM -> dhz_reverse_residual_fwd (token order)
+    forward : dhz_ln_partition_fwd (plain LN) -> GEMM -> dhz_gelu_fwd -> GEMM with the residual epilogue (token order)
     backward: the mirror sequence, weight gradients in place, the DropPath factor folded into fc2's weight gradient (row scale) and
               into dhz_gelu_bwd, the shortcut gradient folded into the LayerNorm backward."""
 
@@ -429,9 +460,7 @@ class _FfnBranch(Function):
         u = ops.gemm_fwd(xn, w1, b1)
         z = torch.empty_like(u)
         _lib.call("dhz_gelu_fwd_dt", _p(u), _p(z), u.numel(), ops._dt(u), _stream())
-        y = ops.gemm_fwd(z, w2, b2)
-        out = torch.empty_like(x)
-        _lib.call("dhz_reverse_residual_fwd_dt", _p(y), _p(x), _p(dscale), _p(out), B, L, 1, C, 0, 0, ops._dt(x), _stream())
+        out = ops.gemm_fwd_res(z, w2, b2, x.view(T, C), dscale, B, L, 1, 0, False).view(B, L, C)
         if grad_mode and any(ctx.needs_input_grad):
             ctx.save_for_backward(x, gamma, stats, xn, u, z, dscale, w1, w2)
             ctx.params = (w1, b1, w2, b2, gamma, beta)
@@ -472,3 +501,52 @@ def leff_branch(x, norm, mlp, dscale, Hres, Wres):
     return _LeffBranch.apply(x, norm.weight, norm.bias, mlp.linear1[0].weight, mlp.linear1[0].bias,
                              mlp.dwconv[0].weight, mlp.dwconv[0].bias, mlp.linear2[0].weight, mlp.linear2[0].bias,
                              dscale, Hres, Wres, torch.is_grad_enabled())
+
+
+# ----------------------------------------------------------------------------- the whole block as one node
+BLOCK_NODE = True       # False: two nodes per block (attn_branch, leff_branch) with a token-order gradient between them
+
+
+class _BlockNode(Function):
+    """attention branch + LeFF branch of one LeWin block (M1:839-873).  Forward = the two branch forwards; backward = the two branch
+    backwards with the gradient between them in the attention branch's window order whenever that branch runs the kernel chain
+    backward (module docstring).  Argument layout: (fused, x, 18 attention arguments, 11 LeFF arguments, grad_mode)."""
+    NA, NL = 18, 11
+
+    @staticmethod
+    def forward(ctx, fused, x, *args):
+        a, l, grad_mode = args[:_BlockNode.NA], args[_BlockNode.NA:_BlockNode.NA + _BlockNode.NL], args[-1]
+        train = grad_mode and any(ctx.needs_input_grad)
+        x1, ra = (_attn_fused_fwd if fused else _attn_chain_fwd)(train, x, *a)
+        out, rl = _leff_fwd(train, x1, *l)
+        if train:
+            ctx.na = len(ra.saved)
+            ctx.save_for_backward(*ra.saved, *rl.saved)
+            ra.saved = rl.saved = ()
+        ctx.recs = (ra, rl)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        ra, rl = ctx.recs
+        sv = ctx.saved_tensors
+        ra.saved, rl.saved = sv[:ctx.na], sv[ctx.na:]
+        B, Hres, Wres, C, shift, H = ra.geom
+        # window-order hand-over: chain backward, fp32 storage (the row-factor forms of the products), whole 64-token images
+        windowed = ra.kind == "attn_chain_bwd" and dout.dtype == torch.float32 and rl.geom[4:] == (Hres, Wres) and (Hres * Wres) % 64 == 0
+        gl = _leff_bwd(rl, dout, dx_window=shift if windowed else None)
+        ga = _attn_bwd(ra, gl[0], windowed=windowed)
+        ra.saved = rl.saved = ()
+        #      fused   x       attention parameters (11)   idx, mask, dscale, Hres, Wres, shift, H      LeFF parameters (8)   dscale, Hres, Wres, grad_mode
+        return (None, ga[0]) + ga[1:] + (None,) * 7 + gl[1:] + (None,) * 4
+
+
+def block(x, norm1, layer, table, idx, mask, dscale_attn, Hres, Wres, shift, heads, norm2, mlp, dscale_mlp):
+    """both branches of a LeWin block with a LeFF token mixer as one autograd node"""
+    q, k, v, o = layer.query_projection, layer.key_projection, layer.value_projection, layer.out_projection
+    return _BlockNode.apply(_use_fused_attn(x, heads, Hres, Wres), x,
+                            norm1.weight, norm1.bias, q.weight, q.bias, k.weight, k.bias, v.weight, v.bias, o.weight, o.bias, table, idx,
+                            mask, dscale_attn, Hres, Wres, shift, heads,
+                            norm2.weight, norm2.bias, mlp.linear1[0].weight, mlp.linear1[0].bias, mlp.dwconv[0].weight, mlp.dwconv[0].bias,
+                            mlp.linear2[0].weight, mlp.linear2[0].bias, dscale_mlp, Hres, Wres,
+                            torch.is_grad_enabled())

@@ -396,6 +396,10 @@ class LeWinTransformerBlock(nn.Module):
                 idx = draw_sample_index(1, ops.NTOK)[0]
             if idx.device != x.device or idx.dtype != torch.uint8:
                 idx = idx.to(device=x.device, dtype=torch.uint8)
+            if fused.BLOCK_NODE and self.token_mlp == 'leff':
+                # both branches as one node: the gradient between them never takes the token-order detour (fused.block)
+                return fused.block(x, self.norm1, self.attn.ProbSpare, table, idx.contiguous(), attn_mask, self._scale(x), H, W,
+                                   self.shift_size, self.num_heads, self.norm2, self.mlp, self._scale(x))
             x = fused.attn_branch(x, self.norm1, self.attn.ProbSpare, table, idx.contiguous(), attn_mask,
                                   self._scale(x), H, W, self.shift_size, self.num_heads)
         else:

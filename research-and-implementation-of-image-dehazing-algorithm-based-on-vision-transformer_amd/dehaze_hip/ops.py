@@ -318,13 +318,72 @@ def gemm_fwd(x, W, b=None):
     return y
 
 
-def gemm_dgrad(dy, W):
-    """dx[T,K] = dy[T,N] W[N,K] (dhz_linear_dgrad)."""
+RES_EPILOGUE = not os.environ.get("DHZ_NO_RES_EPILOGUE")        # A/B switch: K4 as a pass of its own (the pre-round-6 chain)
+
+
+def gemm_fwd_res(x, W, b, res, scale, B, Hres, Wres, shift, windowed):
+    """out = res + scale[image] * (x W^T + b) with the rows stored at their token-order position: K4 (window reverse, un-roll,
+    DropPath factor, residual; M1:859-873) as the EPILOGUE of the out-projection / linear2 GEMM (dhz_linear_fwd_split6_res,
+    csrc/tok_epilogue.h).  x: [T, K] (window order when `windowed`, the order dhz_ln_partition_fwd writes); res: [T, N] in token
+    order; scale: [B] or None.  Shapes / arithmetic the epilogue kernels do not cover (bf16 storage, the fp32 matrix pipe) run
+    the GEMM and dhz_reverse_residual_fwd as two launches."""
+    _require_gpu(x, W, b, res, scale)
+    T, K = x.shape
+    N = W.shape[0]
+    HW = Hres * Wres
+    assert x.stride(1) == 1 and W.shape[1] == K and res.is_contiguous() and T == B * HW
+    route = "f32"
+    if RES_EPILOGUE and x.dtype == torch.float32 and SPLIT_BF16 == 6 and x.stride(0) % 4 == 0 and HW % 64 == 0 and W.is_contiguous():
+        route = _route6(T, K, N, False)
+    if route == "f32":
+        y = gemm_fwd(x, W, b)
+        out = torch.empty_like(res)
+        _lib.call("dhz_reverse_residual_fwd_dt", _p(y), _p(res), _p(scale), _p(out), B, Hres, Wres, N, shift, 1 if windowed else 0,
+                  _dt(res), _stream())
+        return out
+    out = torch.empty_like(res)
+    ev = _timed("dhz_linear_split6")
+    if route == "new":
+        hi, mid, lo = split_planes(W)
+        _lib.call("dhz_linear_fwd_split6_res", _p(x), x.stride(0), _p(hi), _p(mid), _p(lo), _p(b), _p(res), _p(scale), _p(out), N, T, N, K,
+                  HW, Hres, Wres, shift, 1 if windowed else 0, _stream())
+    else:
+        _lib.call("dhz_linear_fwd_split_res", _p(x), x.stride(0), _p(W), _p(b), _p(res), _p(scale), _p(out), N, T, N, K, HW, Hres, Wres,
+                  shift, 1 if windowed else 0, 6, _stream())
+    _timed_end(ev, 12.0 * T * N * K)
+    return out
+
+
+def gemm_dgrad(dy, W, row_scale=None):
+    """dx[T,K] = dy[T,N] W[N,K] (dhz_linear_dgrad).  row_scale = (scale[B], rows_per_image): dx rows carry the per-image factor
+    (the DropPath factor of the branch in the backward pass) - in the epilogue of the six-term kernels, a pass of its own elsewhere."""
     _require_gpu(dy, W)
     T, N = dy.shape
     K = W.shape[1]
     assert dy.stride(1) == 1 and W.shape[0] == N
     W = W if W.is_contiguous() else W.contiguous()
+    if row_scale is not None:
+        sc, rows = row_scale
+        assert T % rows == 0
+        f32ok = RES_EPILOGUE and dy.dtype == torch.float32 and SPLIT_BF16 == 6 and dy.stride(0) % 4 == 0 and rows % 64 == 0
+        if f32ok and _route6(T, N, K, False) == "new" and not _NO_TPLANES and split_planes_t(W) is not None:
+            hi, mid, lo = split_planes_t(W)
+            dx = torch.empty((T, K), device=dy.device, dtype=dy.dtype)
+            ev = _timed("dhz_linear_split6")
+            _lib.call("dhz_linear_fwd_split6_res", _p(dy), dy.stride(0), _p(hi), _p(mid), _p(lo), None, None, _p(sc), _p(dx), K, T, K, N,
+                      rows, 0, 0, 0, 0, _stream())
+            _timed_end(ev, 12.0 * T * N * K)
+            return dx
+        if f32ok and _route6(T, N, K, True) == "old":
+            dx = torch.empty((T, K), device=dy.device, dtype=dy.dtype)
+            ev = _timed("dhz_linear_split6")
+            _lib.call("dhz_linear_dgrad_split_scaled", _p(dy), dy.stride(0), _p(W), _p(sc), _p(dx), K, T, N, K, rows, 6, _stream())
+            _timed_end(ev, 12.0 * T * N * K)
+            return dx
+        dx = gemm_dgrad(dy, W)
+        out = torch.empty_like(dx)
+        _lib.call("dhz_reverse_residual_bwd_dt", _p(dx), _p(sc), _p(out), T // rows, rows, 1, K, 0, 0, _dt(dx), _stream())
+        return out
     dx = torch.empty((T, K), device=dy.device, dtype=dy.dtype)
     if dy.dtype == BF16:
         Wt = None if _NO_TPLANES else bf16_copy_t(W)

@@ -1,0 +1,212 @@
+"""-m gpu: K4 inside the GEMMs (round 6).  The out-projection / linear2 product whose epilogue is window reverse + un-roll + DropPath
+factor + residual (dhz_linear_fwd_split6_res / dhz_linear_fwd_split_res, csrc/tok_epilogue.h; M1:859-873), the row-factor form of
+the backward-data product, the gradient layouts of dhz_ln_partition_bwd_lay, and the whole-block autograd node (fused.block)
+against the two-node form it replaces.  References are float64 restatements in torch of the reference's own op sequence
+(window_reverse M1:577-601, torch.roll M1:866, shortcut + drop_path M1:872)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+BOUND6 = 2.0 ** -21          # same elementwise bound as tests/test_gpu_split.py (relative to sum |a||b|)
+
+
+def _window_reverse_roll(yw, B, H, W, shift):
+    """[B*nW*64, C] window-ordered rows -> [B*H*W, C] token order: window_reverse (M1:577-601) then roll(+shift) (M1:866)"""
+    C = yw.shape[1]
+    y = yw.view(B, H // 8, W // 8, 8, 8, C).permute(0, 1, 3, 2, 4, 5).reshape(B, H, W, C)
+    if shift:
+        y = torch.roll(y, shifts=(shift, shift), dims=(1, 2))
+    return y.reshape(B * H * W, C)
+
+
+# (B, H, W, K, N): shapes that reach each kernel of the dispatch - 256 x 128 tiles (wide), 128 x 128, 128 x 64, 128 x 32, and the
+# few-tile kernel of csrc/linear_split.hip (through its own entry point)
+SHAPES = [(8, 64, 64, 128, 128),      # T = 32768: wide
+          (2, 32, 32, 512, 128),      # T = 2048, N = 128: 128 x 64 tiles (few tiles), long contraction (LeFF linear2 shape)
+          (8, 16, 16, 256, 256),      # T = 2048: 128 x 64
+          (32, 16, 16, 512, 512),     # T = 8192, N = 512: 128 x 128
+          (4, 24, 40, 64, 96),        # N = 96: 128 x 32 tiles; a non-square, non-power-of-two map
+          (3, 8, 8, 128, 64)]         # a partial last tile (T = 192)
+
+
+@pytest.mark.parametrize("windowed,shift,scaled", [(1, 0, False), (1, 4, True), (1, 3, True), (0, 0, True), (0, 0, False)])
+@pytest.mark.parametrize("B,H,W,K,N", SHAPES)
+def test_residual_epilogue_vs_fp64(B, H, W, K, N, windowed, shift, scaled):
+    from dehaze_hip import _lib, ops
+    dev = torch.device("cuda:0")
+    s = torch.cuda.current_stream().cuda_stream
+    T = B * H * W
+    g = torch.Generator().manual_seed(T + K + N + shift)
+    x = torch.randn(T, K, generator=g).to(dev)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(dev)
+    b = torch.randn(N, generator=g).to(dev)
+    res = torch.randn(T, N, generator=g).to(dev)
+    sc = torch.tensor([0.0 if i % 3 == 1 else 1.0 / 0.9 for i in range(B)]).to(dev) if scaled else None   # DropPath: 0 or 1 / keep
+    y64 = x.double() @ w.double().t() + b.double()
+    mag = x.double().abs() @ w.double().abs().t() + b.double().abs()
+    f = sc.double().repeat_interleave(H * W)[:, None] if scaled else 1.0
+    if windowed:
+        ref = res.double() + _window_reverse_roll(f * y64, B, H, W, shift)
+        mag = _window_reverse_roll(f * mag, B, H, W, shift) + res.double().abs()
+    else:
+        ref = res.double() + f * y64
+        mag = f * mag + res.double().abs()
+    hi, mid, lo = ops.split_planes(w)
+    out = torch.full((T, N), float("nan"), device=dev)
+    _lib.call("dhz_linear_fwd_split6_res", x.data_ptr(), K, hi.data_ptr(), mid.data_ptr(), lo.data_ptr(), b.data_ptr(), res.data_ptr(),
+              sc.data_ptr() if scaled else None, out.data_ptr(), N, T, N, K, H * W, H, W, shift, windowed, s)
+    err = (out.double() - ref).abs()
+    assert torch.isfinite(out).all()
+    assert (err <= BOUND6 * mag + 1e-7).all(), (err / mag).max().item()
+    # dropped images return the shortcut bit for bit
+    if scaled:
+        rows = torch.arange(T, device=dev).view(B, H * W)[1]
+        assert torch.equal(out[rows], res[rows])
+    if K % 64 == 0 and N % 64 == 0:
+        out2 = torch.full((T, N), float("nan"), device=dev)
+        _lib.call("dhz_linear_fwd_split_res", x.data_ptr(), K, w.data_ptr(), b.data_ptr(), res.data_ptr(), sc.data_ptr() if scaled else None,
+                  out2.data_ptr(), N, T, N, K, H * W, H, W, shift, windowed, 6, s)
+        err = (out2.double() - ref).abs()
+        assert torch.isfinite(out2).all()
+        assert (err <= BOUND6 * mag + 1e-7).all(), (err / mag).max().item()
+
+
+def test_residual_epilogue_equals_the_two_launch_form():
+    """the epilogue form against the GEMM + dhz_reverse_residual_fwd pair it replaces, same kernels' products: equal to the last
+    fp32 rounding of the final add"""
+    from dehaze_hip import ops
+    dev = torch.device("cuda:0")
+    B, H, W, C = 4, 32, 32, 128
+    T = B * H * W
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(T, C, generator=g).to(dev)
+    w = (torch.randn(C, C, generator=g) / C ** 0.5).to(dev)
+    b = torch.randn(C, generator=g).to(dev)
+    res = torch.randn(T, C, generator=g).to(dev)
+    sc = torch.tensor([1.25, 0.0, 1.25, 1.25]).to(dev)
+    old = ops.RES_EPILOGUE
+    try:
+        ops.RES_EPILOGUE = True
+        a = ops.gemm_fwd_res(x, w, b, res, sc, B, H, W, 4, True)
+        ops.RES_EPILOGUE = False
+        r = ops.gemm_fwd_res(x, w, b, res, sc, B, H, W, 4, True)
+    finally:
+        ops.RES_EPILOGUE = old
+    assert (a - r).abs().max().item() <= 2e-6 * (1.0 + r.abs().max().item())
+
+
+def test_epilogue_argument_checks():
+    from dehaze_hip import _lib
+    dev = torch.device("cuda:0")
+    x = torch.zeros(192, 64, device=dev)
+    pl = torch.zeros(3, 64 * 64, device=dev, dtype=torch.bfloat16)
+    out = torch.zeros(192, 64, device=dev)
+    args = lambda hw, Hm, Wm, sh: (x.data_ptr(), 64, pl[0].data_ptr(), pl[1].data_ptr(), pl[2].data_ptr(), None, out.data_ptr(), None,
+                                   out.data_ptr(), 64, 192, 64, 64, hw, Hm, Wm, sh, 1, None)
+    for bad in ((60, 6, 10, 0), (64, 8, 8, 9), (64, 4, 16, 0), (128, 8, 16, 0)):       # HW % 64, shift range, H % 8, T % HW
+        with pytest.raises(_lib.DehazeHipError):
+            _lib.call("dhz_linear_fwd_split6_res", *args(*bad))
+
+
+@pytest.mark.parametrize("T,N,K,rows", [(8192, 256, 256, 1024), (32768, 128, 128, 4096), (2048, 512, 512, 64), (4096, 64, 64, 1024)])
+def test_scaled_dgrad_vs_fp64(T, N, K, rows):
+    """dx = scale[image] * (dy . W): ops.gemm_dgrad(row_scale=...) on every route (the forward kernel on the planes of W^T, the few-tile
+    kernel, the extra-pass fallback)"""
+    from dehaze_hip import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(T + N)
+    dy = torch.randn(T, N, generator=g).to(dev)
+    w = (torch.randn(N, K, generator=g) / N ** 0.5).to(dev)
+    sc = (0.5 + torch.rand(T // rows, generator=g)).to(dev)
+    sc[0] = 0.0
+    dx = ops.gemm_dgrad(dy, w, (sc, rows))
+    f = sc.double().repeat_interleave(rows)[:, None]
+    ref = f * (dy.double() @ w.double())
+    mag = f * (dy.double().abs() @ w.double().abs())
+    err = (dx.double() - ref).abs()
+    assert (err <= BOUND6 * mag + 1e-7).all(), (err / (mag + 1e-30)).max().item()
+
+
+@pytest.mark.parametrize("C", [64, 128, 512])
+@pytest.mark.parametrize("shift,dshift", [(0, 4), (4, 0)])
+def test_ln_backward_layouts(C, shift, dshift):
+    """dhz_ln_partition_bwd_lay: (a) dx written in the window order of dshift == the plain call followed by the partition permutation;
+    (b) dres read in the call's own window order == the plain call on the un-permuted dres."""
+    from dehaze_hip import _lib
+    dev = torch.device("cuda:0")
+    s = torch.cuda.current_stream().cuda_stream
+    B, H, W = 3, 16, 24
+    T = B * H * W
+    g = torch.Generator().manual_seed(C + shift)
+    x = torch.randn(T, C, generator=g).to(dev)
+    gamma = (1.0 + 0.1 * torch.randn(C, generator=g)).to(dev)
+    beta = (0.1 * torch.randn(C, generator=g)).to(dev)
+    xn = torch.empty_like(x)
+    stats = torch.empty(T, 2, device=dev)
+    dy = torch.randn(T, C, generator=g).to(dev)
+    dres = torch.randn(T, C, generator=g).to(dev)
+
+    def perm(t, sh):        # token order -> window order of shift sh (roll(-sh) + window_partition, M1:846-852)
+        m = t.view(B, H, W, C)
+        if sh:
+            m = torch.roll(m, shifts=(-sh, -sh), dims=(1, 2))
+        return m.view(B, H // 8, 8, W // 8, 8, C).permute(0, 1, 3, 2, 4, 5).reshape(T, C).contiguous()
+
+    def run(part, sh, dresw, dxw, dxs, dres_t):
+        dx = torch.empty_like(x)
+        dg, db = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+        _lib.call("dhz_ln_partition_bwd_lay", dy.data_ptr(), x.data_ptr(), gamma.data_ptr(), stats.data_ptr(), dres_t.data_ptr(), dx.data_ptr(),
+                  dg.data_ptr(), db.data_ptr(), B, H, W, C, sh, part, dresw, dxw, dxs, 0, s)
+        return dx, dg, db
+
+    for part, sh in ((0, 0), (1, shift)):
+        _lib.call("dhz_ln_partition_fwd_dt", x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), xn.data_ptr(), stats.data_ptr(), B, H, W, C, sh,
+                  part, 0, s)
+        base = run(part, sh, 0, 0, 0, dres)
+        a = run(part, sh, 0, 1, dshift, dres)
+        assert torch.equal(a[0], perm(base[0], dshift))
+        for u, v in ((a[1], base[1]), (a[2], base[2])):                 # d(gamma), d(beta): atomic sums, order varies run to run
+            assert torch.allclose(u, v, rtol=1e-4, atol=1e-3)
+        if part:
+            bres = run(part, sh, 1, 0, 0, perm(dres, sh))
+            assert torch.equal(bres[0], base[0])
+
+
+def _block_grads(use_block, C, heads, res, shift, drop, seed=3):
+    import My_model_1 as M1
+    from dehaze_hip import fused
+    dev = torch.device("cuda:0")
+    torch.manual_seed(seed)
+    blk = M1.LeWinTransformerBlock(dim=C, input_resolution=(res, res), num_heads=heads, win_size=8, shift_size=shift, mlp_ratio=4.,
+                                   drop_path=drop, token_projection='linear', token_mlp='leff').to(dev)
+    blk.train()
+    B = 4
+    x = torch.randn(B, res * res, C, generator=torch.Generator().manual_seed(seed + 1)).to(dev).requires_grad_(True)
+    gy = torch.randn(B, res * res, C, generator=torch.Generator().manual_seed(seed + 2)).to(dev)
+    old = fused.BLOCK_NODE
+    fused.BLOCK_NODE = use_block
+    try:
+        torch.manual_seed(99)                 # the ProbSparse sample and the DropPath draws
+        y = blk(x)
+        y.backward(gy)
+    finally:
+        fused.BLOCK_NODE = old
+    return [y.detach(), x.grad.detach()] + [p.grad.detach() for p in blk.parameters() if p.grad is not None]
+
+
+@pytest.mark.parametrize("C,heads,res,shift,drop", [(128, 4, 32, 4, 0.3),      # chain forward + chain backward, DropPath live
+                                                    (256, 8, 16, 0, 0.0),      # no DropPath factor
+                                                    (64, 2, 16, 4, 0.3),       # fused forward, chain backward
+                                                    (32, 1, 16, 4, 0.3),       # fused forward AND backward: token-order hand-over stays
+                                                    (512, 16, 8, 0, 0.3)])     # single-window map, few-tile kernels
+def test_block_node_equals_two_nodes(C, heads, res, shift, drop):
+    """fused.block (window-order gradient hand-over, row-factor products) against attn_branch + leff_branch: same forward bits, the
+    gradients equal up to the regrouping of the DropPath factor (s * (g . W) against (s * g) . W: one fp32 rounding per product)"""
+    a = _block_grads(True, C, heads, res, shift, drop)
+    b = _block_grads(False, C, heads, res, shift, drop)
+    assert len(a) == len(b)
+    assert torch.equal(a[0], b[0])
+    for i, (u, v) in enumerate(zip(a[1:], b[1:])):
+        tol = 2e-5 * v.abs().max().item() + 1e-7          # (+ absolute floor: d(b_k) is zero in exact arithmetic, ~1e-9 of rounding noise)
+        assert (u - v).abs().max().item() <= tol, (i, (u - v).abs().max().item(), tol)
