@@ -36,28 +36,32 @@ MFMA_F32_PEAK_TF = 157.3       # fp32-input MFMA dense peak
 MFMA_BF16_PEAK_TF = 2500.0     # bf16 MFMA dense peak (MI355X_MICROARCH.md: ~2.5 PF dense)
 
 
-def _cpu_steps(P, params, opt, hazy, gt, vggW, w_cr, steps):
+def _cpu_steps(P, params, opt, hazy, gt, vggW, w_cr, steps, warm=1):
+    """median seconds per step over `steps` timed steps after `warm` untimed ones"""
     from oracle import uformer_oracle as O
     times = []
-    for i in range(steps + 1):
+    for i in range(steps + warm):
         t0 = time.perf_counter()
         opt.zero_grad()
         loss, _ = O.train_step_loss(P, hazy, gt, w_char=1.0, w_cr=w_cr, vggW=vggW, training=True)
         loss.backward()
         opt.step()
-        if i > 0:
+        if i >= warm:
             times.append(time.perf_counter() - t0)
     times.sort()
     return times[len(times) // 2]
 
 
+CPU_STEPS = 5            # BASELINE.md section 4: >= 5 timed steps after 1 warm-up, at one thread and at every core
+
+
 def cpu_baseline(bs=2):
-    """CPU oracle (kind 'port') on this node's host cores, bounded sample.  `value` is the HEADLINE's
-    recipe - BASELINE configs[1]: E=32, ps=128, fp32, Charbonnier + VGG19 contrastive loss, AdamW - at the fastest thread count
-    found; the config-1 recipe (Charbonnier only: what the reference's own CPU path was timed with in the survey container,
-    1.98 patches/s at 8 threads, 0.40 at 1 thread) is timed at every core, at 8 threads and at one thread and kept as side
-    fields.  os.cpu_count() and the load average are recorded: the GPU hosts of the pool are shared, and a many-core run that is
-    slower than an 8-thread one is a busy host, not a property of the code."""
+    """CPU oracle (kind 'port') on this node's host cores, bounded sample (>= 5 timed steps after one warm-up
+    step, at 1 thread and at the many-thread setting).  `value` is the HEADLINE's recipe - BASELINE configs[1]: E=32, ps=128, fp32,
+    Charbonnier + VGG19 contrastive loss, AdamW - at 8 threads (the survey container's core count; the GPU hosts of this pool are
+    shared 256-thread machines, where an every-core run measures the neighbours).  Side fields: the same recipe at 1 thread, the
+    config-1 recipe (Charbonnier only: what the reference's own CPU path was timed with in the survey container, 1.98 patches/s at 8
+    threads, 0.40 at 1 thread) at 8 and 1 threads, the every-core figure (2 timed steps) with the load average."""
     from oracle import uformer_oracle as O
     import My_model_1 as M1
     from dehaze_hip.train import synthetic_batch
@@ -69,29 +73,35 @@ def cpu_baseline(bs=2):
     gt, hazy = synthetic_batch(bs, 128, seed=99)
     cores = torch.get_num_threads()
     load0 = os.getloadavg() if hasattr(os, "getloadavg") else (None, None, None)
-    med = {}
-    med[cores] = _cpu_steps(P, params, opt, hazy, gt, None, 0.0, 3)
+    vggW = O.seeded_vgg_weights()
+    many = min(8, cores)
+    t_cr, t_c1 = {}, {}
     try:
-        for n in (8, 1):                                 # the survey container's 8 threads, and one thread
-            if n < cores:
-                torch.set_num_threads(n)
-                med[n] = _cpu_steps(P, params, opt, hazy, gt, None, 0.0, 2 if n > 1 else 1)
-        best = min(med, key=med.get)                      # a shared many-core host can be slower at every core than at eight
-        torch.set_num_threads(best)
-        med_cr = _cpu_steps(P, params, opt, hazy, gt, O.seeded_vgg_weights(), 1.0, 2)      # the headline's recipe
+        for n in sorted({many, 1}, reverse=True):
+            torch.set_num_threads(n)
+            t_cr[n] = _cpu_steps(P, params, opt, hazy, gt, vggW, 1.0, CPU_STEPS)          # the headline's recipe
+            t_c1[n] = _cpu_steps(P, params, opt, hazy, gt, None, 0.0, CPU_STEPS)          # config 1: Charbonnier only
+        all_cores = None
+        if cores > many:
+            torch.set_num_threads(cores)
+            all_cores = _cpu_steps(P, params, opt, hazy, gt, vggW, 1.0, 2)
     finally:
         torch.set_num_threads(cores)
-    per_threads = {str(n): round(bs / t, 4) for n, t in sorted(med.items())}
-    return {"value": round(bs / med_cr, 4), "unit": "patches/s", "cores": best, "kind": "port",
+    load1 = os.getloadavg() if hasattr(os, "getloadavg") else (None, None, None)
+    rnd = lambda d: {str(n): round(bs / t, 4) for n, t in sorted(d.items())}
+    return {"value": round(bs / t_cr[many], 4), "unit": "patches/s", "cores": many, "kind": "port",
             "sample": f"CPU oracle, BASELINE configs[1] recipe (E=32 ps=128 fp32, Charbonnier + VGG19 contrastive loss, AdamW) at bs={bs}, "
-                      f"{best} thread{'s' if best > 1 else ''} (the fastest of the thread counts tried on the config-1 recipe), median of 2 "
-                      f"steps after 1 warm-up: {med_cr:.3f} s/step; config-1 recipe (Charbonnier only), median s/step: "
-                      + ", ".join(f"{t:.3f} at {n} thread{'s' if n > 1 else ''}" for n, t in sorted(med.items())),
-            "value_config1_charbonnier_only": round(bs / med[best], 4), "patches_per_s_by_threads_config1": per_threads,
+                      f"{many} threads, median of {CPU_STEPS} timed steps after 1 warm-up: {t_cr[many]:.3f} s/step "
+                      f"(1 thread: {t_cr[1]:.3f} s/step); config-1 recipe (Charbonnier only), same protocol: "
+                      + ", ".join(f"{t:.3f} s/step at {n} thread{'s' if n > 1 else ''}" for n, t in sorted(t_c1.items())),
+            "patches_per_s_by_threads": rnd(t_cr), "value_1_thread": round(bs / t_cr[1], 4),
+            "value_config1_charbonnier_only": round(bs / t_c1[many], 4), "patches_per_s_by_threads_config1": rnd(t_c1),
+            "all_cores": None if all_cores is None else {"threads": cores, "patches_per_s": round(bs / all_cores, 4), "timed_steps": 2,
+                                                          "note": "shared host: this figure measures the neighbours' load as much as the code"},
+            "protocol": f"{CPU_STEPS} timed steps after 1 warm-up per (recipe, thread count); median",
             "host": {"os_cpu_count": os.cpu_count(), "torch_threads_default": cores,
                      "loadavg_1_5_15_before": [round(x, 2) if x is not None else None for x in load0],
-                     "note": "the GPU hosts of this pool are shared: a load average near the core count means the many-thread figures "
-                             "measure the neighbours"},
+                     "loadavg_1_5_15_after": [round(x, 2) if x is not None else None for x in load1]},
             "survey_container_reference": {"patches_per_s_8_threads": 1.98, "patches_per_s_1_thread": 0.40,
                                            "note": "the reference's own My_model_1.Uformer, config-1 recipe, BASELINE.md section 2"}}
 
@@ -122,6 +132,7 @@ def live_pmc_traffic(extra_args, timeout_s=240):
     import glob
     import re
     import shutil
+    import signal
     import subprocess
     import tempfile
     exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
@@ -133,11 +144,22 @@ def live_pmc_traffic(extra_args, timeout_s=240):
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             d = os.path.join(tmp, counter)
             cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__), "--steps", "2",
-                   "--warmup", "2", "--no-cpu-baseline", "--no-kernel-timing", "--no-fp32-pipe", "--no-config4", "--no-live-traffic"] + extra_args
-            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=timeout_s)
+                   "--warmup", "2", "--no-cpu-baseline", "--no-kernel-timing", "--no-fp32-pipe", "--no-config4", "--no-config5", "--no-live-traffic"] + extra_args
+            # own session: on a timeout the WHOLE group goes (rocprofv3 and the interpreter under it), nothing keeps running on the GPU
+            proc = subprocess.Popen(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.PIPE,
+                                    text=True, start_new_session=True)
+            try:
+                _, err = proc.communicate(timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                try:
+                    os.killpg(proc.pid, signal.SIGKILL)
+                except ProcessLookupError:
+                    pass
+                proc.wait()
+                return {}, f"rocprofv3 --pmc {counter} pass exceeded {timeout_s} s (process group killed)"
             files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
-            if r.returncode != 0 or not files:
-                return {}, f"rocprofv3 --pmc {counter} pass failed (rc {r.returncode}): {(r.stderr or '')[-200:].strip()}"
+            if proc.returncode != 0 or not files:
+                return {}, f"rocprofv3 --pmc {counter} pass failed (rc {proc.returncode}): {(err or '')[-200:].strip()}"
             per = collections.defaultdict(list)
             for row in csv.DictReader(open(files[0])):
                 if row["Counter_Name"] == counter:
@@ -213,6 +235,51 @@ def run_config4(dev, steps, warmup):
     return out
 
 
+def run_config5(dev, forwards=10, warm=2):
+    """BASELINE configs[4] on the driver's clock: whole-image restoration as the reference's test_long_GPU.py does it (:72-93) - a
+    1200 x 1600 image wrap-padded to L = 1664, ONE eval forward on [1, 3, 1664, 1664] (43,264 windows per full-resolution block), crop,
+    clamp.  s/image over `forwards` timed forwards after `warm`; the window-attention kernel of the north star is timed with HIP events
+    in a separate pass (its inference regime: no training saves)."""
+    import My_model_1 as M1
+    import test_long_GPU as TL
+    from dehaze_hip import ops
+    from dehaze_hip.train import synthetic_batch
+    torch.manual_seed(1234)
+    model = M1.Uformer(img_size=128, embed_dim=32, win_size=8, token_projection='linear', token_mlp='leff').to(dev).eval()
+    _, hazy = synthetic_batch(1, (1200, 1600), seed=900, device=dev)
+    L = TL.padded_size(1200, 1600, 128)
+    with torch.no_grad():
+        for _ in range(warm):
+            out = TL.restore_image(model, hazy, 128)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(forwards):
+            out = TL.restore_image(model, hazy, 128)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        peak = torch.cuda.max_memory_allocated(dev)
+        ops.KERNEL_TIMING = {"dhz_fused_window_attn_fwd": []}
+        for _ in range(3):
+            TL.restore_image(model, hazy, 128)
+        torch.cuda.synchronize()
+        ev, ops.KERNEL_TIMING = ops.KERNEL_TIMING["dhz_fused_window_attn_fwd"], None
+    res = {"workload": f"Uformer_ProbSparse whole-image eval forward E=32, 1200x1600 image wrap-padded to [1,3,{L},{L}], fp32 "
+                       "(BASELINE configs[4]: test_long_GPU.py pad + one forward + crop + clamp), random-init weights",
+           "value": round(el / forwards, 5), "unit": "s/image", "higher_is_better": False, "images_per_s": round(forwards / el, 3),
+           "forwards": forwards, "warmup": warm, "padded_side": L, "windows_per_full_res_block": (L // 8) ** 2,
+           "peak_hbm_gb": round(peak / 2 ** 30, 2), "output_finite": bool(torch.isfinite(out).all().item()),
+           "psnr_ssim": "not a bench quantity (random-init weights, synthetic image); parity of this path: tests/test_gpu_data_eval.py"}
+    if ev:
+        ms = sum(a.elapsed_time(b) for a, b, _, _ in ev)
+        flops = sum(n * 2 * 64 * (4 * c * c + 75 * c) for _, _, n, c in ev)
+        tf = flops / (ms * 1e-3) / 1e12
+        res["roofline"] = {"kernel": "fused_window_attn_fwd_kernel<C,SAVE=0> (dhz_fused_window_attn_fwd, inference: no training saves), C in {32,64,128}",
+                           "bound": "mfma", "achieved": round(tf, 2), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
+                           "frac": round(tf / MFMA_F32_PEAK_TF, 4), "traffic": None, "launches": len(ev),
+                           "avg_launch_us": round(1e3 * ms / len(ev), 2), "alg_flops_per_launch": flops // len(ev)}
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -231,6 +298,8 @@ def main():
     ap.add_argument("--no-config4", action="store_true",
                     help="skip the BASELINE configs[3] measurement (E=64 ps=256 bs=8 bf16) that the default configs[1] run appends as the "
                          "`config4` object")
+    ap.add_argument("--no-config5", action="store_true",
+                    help="skip the BASELINE configs[4] measurement (whole-image eval forward on [1,3,1664,1664]) appended as the `config5` object")
     ap.add_argument("--no-overlap", action="store_true",
                     help="N > 1 diagnostics: launch every gradient bucket's all-reduce AFTER backward instead of from the hooks (separates "
                          "'RCCL starved by the persistent compute grids' from 'RCCL slow')")
@@ -353,7 +422,27 @@ def main():
                      "arithmetic": "every product on the fp32 matrix pipe (v_mfma_f32_16x16x4_f32); same process, model, optimizer "
                                    "state and batch as the headline, measured after it",
                      "loss_last_step": round(float(loss_s), 6)}
+    extras = {}
     if rank == 0:
+        # every TIMED measurement first (the other single-GPU BASELINE configurations, the CPU baseline); the counter passes of
+        # `roofline.traffic` - two profiler child processes on the same GPU - run after the last of them
+        plan = reducer.plan() if reducer is not None else None
+        reserve = reducer.reserve_cus if reducer is not None else None
+        if world == 1 and not args.no_config4 and (args.dtype, args.embed_dim, args.ps, args.batch) == ("f32", 32, 128, 32) \
+                and not args.no_cr:
+            # on the same clock: free the config-2 state first
+            model = opt = cr = reducer = None
+            import gc
+            gc.collect()
+            torch.cuda.empty_cache()
+            extras["config4"] = run_config4(dev, args.steps, min(args.warmup, 5))
+            if not args.no_config5:
+                gc.collect()
+                torch.cuda.empty_cache()
+                torch.cuda.reset_peak_memory_stats(dev)
+                extras["config5"] = run_config5(dev)
+        if world == 1 and not args.no_cpu_baseline:
+            extras["cpu_baseline"] = cpu_baseline()
         total = args.batch * world * args.steps
         out = {
             "metric": f"train patches/sec ({args.ps}x{args.ps}, embed_dim={args.embed_dim})", "value": round(total / elapsed, 3),
@@ -375,11 +464,10 @@ def main():
                 "fp32 storage/accumulate; products on the fp32 matrix pipe" if headline_terms == 0 else
                 "EXPERIMENT (not a product setting): fp32 storage/accumulate; products 3xbf16 MFMA (~16 mantissa bits per product)")
             out["config"]["split_terms"] = headline_terms
-        if reducer is not None:
+        if plan is not None:
             # the exchange of one step as performed (bucket byte ranges in launch order, single-ring xGMI time): makes a
             # scaling run diagnosable from its JSON line alone
-            plan = reducer.plan()
-            out["exchange"] = {"backend": backend, "bucket_mb": args.bucket_mb, "overlap_with_backward": not args.no_overlap, "reserve_cus": reducer.reserve_cus,
+            out["exchange"] = {"backend": backend, "bucket_mb": args.bucket_mb, "overlap_with_backward": not args.no_overlap, "reserve_cus": reserve,
                                "grid_cus": _lib.load().dhz_grid_cus(), "payload_bytes": plan["payload_bytes"],
                                "n_buckets": len(plan["buckets"]), "bucket_bytes": [b["bytes"] for b in plan["buckets"]],
                                "ring_time_ms_single_link": round(plan["ring_time_ms"], 3),
@@ -485,16 +573,7 @@ def main():
                              "avg_launch_us": round(1e3 * ms / len(ev), 2), "issued_flops_per_launch": int(flops / len(ev))}
         if fp32_pipe is not None:
             out["fp32_pipe"] = fp32_pipe
-        if world == 1 and not args.no_config4 and (args.dtype, args.embed_dim, args.ps, args.batch) == ("f32", 32, 128, 32) \
-                and not args.no_cr:
-            # the other single-GPU BASELINE configuration, on the same clock: free the config-2 state first
-            model = opt = cr = reducer = None
-            import gc
-            gc.collect()
-            torch.cuda.empty_cache()
-            out["config4"] = run_config4(dev, args.steps, min(args.warmup, 5))
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
+        out.update(extras)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

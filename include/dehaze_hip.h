@@ -347,8 +347,11 @@ int dhz_winograd_conv3x3(const float* x, const float* upack, const float* bias, 
 /* K11b The same convolution as Winograd F(4x4,3x3) (round 5; csrc/winograd43_conv.hip): 36 transform-domain products per 16 outputs
  *      instead of 16 per 4.  Same tensors, same epilogues, same argument meaning as the two entry points above; upack holds
  *      36*Kout*Cin floats.  H % 16 == 0, W % 16 == 0 (maps of 16 x 16 and more: the 8 x 8 layer stays on dhz_winograd_conv3x3),
- *      C % 16 == 0, K % 16 == 0.  Interpolation points (0, +-3/4, +-3/2, inf), filters transformed in double, accumulation flushed to
- *      the output domain every 128 input channels: ~2x the rounding error of F(2x2,3x3), inside the same test tolerances. */
+ *      C % 16 == 0, K % 32 == 0 (a workgroup owns 32 output channels; other K: DHZ_EINVAL).  Interpolation points (0, +-3/4, +-3/2, inf),
+ *      filters transformed in double.  Input channels are accumulated in the transform domain in chains of 256: C <= 256 is one launch;
+ *      C > 256 runs as chained launches over 256-channel slices in which y carries the partial sums (READ and written by every launch
+ *      but the first; bias / relu / out_mask / out_addend applied by the last) - ~2x the rounding error of F(2x2,3x3), inside the same
+ *      test tolerances. */
 int dhz_winograd43_prepack(const float* weight, float* upack, int Kout, int Cin, int transposed_rot, void* stream);
 int dhz_winograd43_conv3x3(const float* x, const float* upack, const float* bias, int relu, const float* out_mask,
                            const float* out_addend, float* y, int B, int H, int W, int C, int K, void* stream);

@@ -92,12 +92,17 @@ __device__ __forceinline__ void dma16s(const char* sbase, unsigned voff, float* 
 // twice their time and cannot overlap their neighbours).  The matrix instruction takes its C / D operand from either half of the register
 // file, so the class is pinned per accumulator through the asm constraint: positions 0 .. 31 in AGPRs ("a"), positions 32 .. 35 in VGPRs
 // ("v").  hipcc cannot see that these are matrix instructions: the hazards it would cover are covered by construction - an accumulator
-// is reused four MFMAs (128 pipe cycles) later, and the epilogue waits 2 x s_nop 15 before it reads them.
+// is reused four MFMAs (128 pipe cycles) later, and the epilogue waits 2 x s_nop 15 before it reads them.  The statements are VOLATILE:
+// volatile asm statements keep their program order among themselves, so no matrix instruction can sink behind the s_nop pair that ends
+// the loop nest (same generated loop as the non-volatile form, instruction for instruction).  What the compiler could still do - copy or
+// split the live range of a "v"-class accumulator next to its MFMA - is excluded per code object by tests/test_isa.py: no instruction of the
+// channel loop other than the MFMAs touches an accumulator register, and the two s_nop 15 sit between the last MFMA and the first
+// accumulator read.
 __device__ __forceinline__ void mfma_acc_a(f32x4& acc, float a, float b) {
-    asm("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+    asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
 }
 __device__ __forceinline__ void mfma_acc_v(f32x4& acc, float a, float b) {
-    asm("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+    asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
 }
 // B^T d for one 6-vector (packed over the lane's two channels): rows for the points 0, +a, -a, +b, -b, inf.  Twelve fused operations: the odd
 // parts PA d3 - PA B2 d1 = PA (d3 - B2 d1) and PB (d3 - A2 d1) take their factor in the FMA that forms the +- rows (written as sums of
@@ -302,8 +307,15 @@ __global__ __launch_bounds__(256, 1) void winograd43_conv3x3_kernel(const float*
         }
     }
 
-    // the last matrix instructions (inline asm: hipcc does not know what they are) have written their accumulators before these are read
-    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    // the last matrix instructions (inline asm: hipcc does not know what they are) have written their accumulators before these are read.
+    // The fence CARRIES the accumulators of the last two pair-steps (positions 32 .. 35: the VGPR-class ones, sixteen matrix instructions) as
+    // in / out operands: no read or copy of them can be placed in front of the s_nop pair.  The AGPR-class accumulators are at least those
+    // sixteen matrix instructions (512 pipe cycles) old at this point - the compiler may, and does, start shuffling them before the fence.
+    static_assert(NXI - NXA == 4, "the fence below names the four VGPR-class accumulator positions");
+    asm volatile("s_nop 15\n\ts_nop 15"
+                 : "+v"(accv[0][0]), "+v"(accv[0][1]), "+v"(accv[1][0]), "+v"(accv[1][1]), "+v"(accv[2][0]), "+v"(accv[2][1]), "+v"(accv[3][0]),
+                   "+v"(accv[3][1])
+                 :: "memory");
     // ---- epilogue: Y = A^T M A per (k half, accumulator row); lane (tile i16, g) holds output channels 16 kh + 4 g .. + 3 of its 4 x 4 pixels
     const int KG = K / 8;
     const float lo = relu ? 0.f : -__builtin_inff();

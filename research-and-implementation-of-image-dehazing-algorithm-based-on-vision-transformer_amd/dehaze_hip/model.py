@@ -298,6 +298,11 @@ class Mlp(nn.Module):
         self.fc2 = nn.Linear(hidden_features, out_features)
         self.drop = nn.Dropout(drop)
         self.in_features, self.hidden_features, self.out_features = in_features, hidden_features, out_features
+        # the HIP path of this branch (fused._FfnBranch, Mlp.forward) evaluates exact-erf GELU and no dropout: what the reference runs at
+        # the model's defaults.  Anything else would silently diverge from M1:442-468 - refuse it
+        if drop > 0. or act_layer is not nn.GELU:
+            raise NotImplementedError(f"Mlp(act_layer={getattr(act_layer, '__name__', act_layer)}, drop={drop}): the HIP Mlp branch implements "
+                                      "nn.GELU with drop = 0 (the reference's defaults) only")
 
     def forward(self, x):
         B, L, C = x.shape

@@ -342,6 +342,20 @@ class GradReducer:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
             ops.GRAD_READY = self._on_grad_inplace      # wgrad kernels accumulate in place, bypassing autograd hooks
 
+    def close(self):
+        """give the reserved compute units back (dhz_set_reserved_cus is process-global: single-rank work that follows in the same
+        process would otherwise keep the shrunken grids)"""
+        if getattr(self, "reserve_cus", 0):
+            try:
+                from . import _lib
+                _lib.call("dhz_set_reserved_cus", 0)
+            except Exception:
+                pass
+            self.reserve_cus = 0
+
+    def __del__(self):
+        self.close()
+
     def plan(self, world=None, link_gbs=153.0):
         """The exchange this reducer performs per step, without performing it: bucket byte ranges in launch (= backward)
         order and the ring all-reduce time they imply on xGMI.  A ring over N GPUs moves 2 (N - 1) / N of the payload over

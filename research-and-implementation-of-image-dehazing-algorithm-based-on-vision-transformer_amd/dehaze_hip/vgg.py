@@ -96,7 +96,7 @@ def use_f43(B, H, W, Cin, Kout):
     if not F43_ON or H % 16 or W % 16 or H < 16 or W < 16 or Cin % 16 or Kout % 32:
         return False
     wgs = (B * (H // 16) * (W // 16) + 3) // 4 * (Kout // 32)
-    cus = _lib.load().dhz_grid_cus()
+    cus = _lib.load().dhz_grid_cus() + _lib.load().dhz_get_reserved_cus()      # PHYSICAL CUs: this grid is not persistent, a reservation does not shrink it
     rounds = (wgs + cus - 1) // cus
     return wgs >= 0.92 * rounds * cus          # the last round of workgroups nearly full
 

@@ -67,3 +67,95 @@ def test_winograd43_dma_requests_keep_their_base_in_sgprs_and_own_m0():
             assert not any(o in ("v_lshl_add_u64", "v_mad_u64_u32", "v_add_co_u32_e32") for o in ops_), name      # no vector address arithmetic in the channel loop
     finally:
         os.unlink(path)
+
+
+def test_winograd43_accumulator_hazards_are_covered_by_the_code_shape():
+    """The 288 accumulators of csrc/winograd43_conv.hip are written by inline-asm MFMAs the compiler's hazard recogniser cannot see
+    (ADVICE round 5).  Per code object: (1) inside the channel loop no instruction other than those MFMAs reads or writes an
+    accumulator register (no v_mov / v_accvgpr copy or live-range split next to a matrix instruction that is still in flight);
+    (2) the channel loop ENDS with the sixteen matrix instructions of the VGPR-class accumulators, so an AGPR-class accumulator is
+    at least 16 matrix instructions old when the loop is left, and on every path from the loop's exits two `s_nop 15` come before
+    the first instruction that touches a VGPR-class accumulator (the fence carries them as operands)."""
+    import re
+    import isa_check
+    import isa_loopmix
+    areg = re.compile(r"\b([av])\[(\d+):(\d+)\]|\b([av])(\d+)\b")
+
+    def regs(text):
+        out = set()
+        for m in areg.finditer(text):
+            if m.group(1):
+                out.update((m.group(1), i) for i in range(int(m.group(2)), int(m.group(3)) + 1))
+            else:
+                out.add((m.group(4), int(m.group(5))))
+        return out
+
+    path = isa_check.compile_to_asm(os.path.join(isa_check.CSRC, "winograd43_conv.hip"))
+    try:
+        asm = open(path).read()
+        kernels = re.findall(r"^(_Z\w*winograd43_conv3x3_kernel\w*):[^\n]*\n(.*?)^\.Lfunc_end", asm, re.M | re.S)
+        assert len(kernels) == 2
+        for name, body in kernels:
+            loop = [i for b in isa_loopmix.hottest_loop(isa_loopmix.blocks_of(body)) for i in b["ins"]]
+            mf = [i for i in loop if i.startswith("v_mfma_f32_16x16x4_f32")]
+            assert len(mf) == 144, name
+            accs = set()
+            for i in mf:
+                accs |= regs(i.split(None, 1)[1].split(",")[0])
+            assert len(accs) == 288 and sum(1 for c, _ in accs if c == "a") == 256, (name, len(accs))
+            vaccs = {r for r in accs if r[0] == "v"}
+            for i in mf[-16:]:                         # the loop's tail: the VGPR-class positions 32 .. 35
+                assert regs(i.split(None, 1)[1].split(",")[0]) <= vaccs, (name, i)
+            # (1) nothing but the matrix instructions touches an accumulator inside the loop
+            for i in loop:
+                if i.startswith("v_mfma") or " " not in i:
+                    continue
+                hit = regs(i.split(None, 1)[1]) & accs
+                assert not hit, (name, i, sorted(hit)[:4])
+            # (2) control flow: from the exits of the channel loop, every path reaches the `s_nop 15` pair before it reaches an instruction
+            #     that touches a VGPR-class accumulator register (block layout is not program order: walk the labels and branches)
+            blocks = isa_loopmix.blocks_of(body)
+            label_at = {b["label"]: k for k, b in enumerate(blocks) if b["label"].startswith(".LBB")}
+            hdr = next(b for b in blocks if any(i.startswith("v_mfma") for i in b["ins"]) and "Inner Loop Header" in b["comment"])
+            hl = hdr["label"].replace(".L", "")
+            in_loop = {k for k, b in enumerate(blocks) if b is hdr or re.search(r"Header=%s\b" % hl, b["comment"])}
+
+            def succ(k):
+                out, ins = [], blocks[k]["ins"]
+                for t in ins:
+                    m = re.match(r"s_cbranch_\w+\s+(\.LBB\d+_\d+)|s_branch\s+(\.LBB\d+_\d+)", t)
+                    if m:
+                        out.append(label_at[m.group(1) or m.group(2)])
+                if not (ins and (ins[-1].startswith("s_branch") or ins[-1].startswith("s_endpgm"))) and k + 1 < len(blocks):
+                    out.append(k + 1)
+                return out
+
+            def scan(k):
+                """-> 'nops' (the pair comes first), 'acc' (an accumulator access comes first) or None (neither in this block)"""
+                n = 0
+                for t in blocks[k]["ins"]:
+                    if t.startswith("s_nop") and t.split()[1] == "15":
+                        n += 1
+                        if n == 2:
+                            return "nops"
+                    elif " " in t and not t.startswith("v_mfma") and regs(t.split(None, 1)[1]) & vaccs:
+                        return "acc"
+                return None
+
+            todo = [t for k in in_loop for t in succ(k) if t not in in_loop]
+            assert todo, name
+            seen, protected = set(), 0
+            while todo:
+                k = todo.pop()
+                if k in seen:
+                    continue
+                seen.add(k)
+                r = scan(k)
+                assert r != "acc", (name, blocks[k]["label"], "an accumulator is touched before the s_nop pair")
+                if r == "nops":
+                    protected += 1
+                    continue
+                todo += [t for t in succ(k) if t not in in_loop]
+            assert protected >= 1, name
+    finally:
+        os.unlink(path)
