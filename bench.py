@@ -396,6 +396,36 @@ def main():
         torch.cuda.synchronize()
     timing = ops.KERNEL_TIMING
     ops.KERNEL_TIMING = None
+    exchange_diag = None
+    if reducer is not None:
+        # N > 1 self-diagnosis (the 8-GPU run is the driver's, not the builder's): (a) how long the compute stream sits in
+        # reducer.wait() per step - the exchange time NOT hidden behind the backward pass; (b) the same step with every bucket
+        # launched after backward (no overlap at all).  (a) near 0 and (b) - headline near the ring time: the overlap works;
+        # (a) near the ring time: RCCL's kernels did not get CUs beside the persistent grids (try --reserve-cus 8).
+        n_diag = min(args.steps, 5)
+        reducer.timing = []
+        for _ in range(n_diag):
+            step()
+        torch.cuda.synchronize()
+        exposed = [a.elapsed_time(b) for a, b in reducer.timing]
+        reducer.timing = None
+        was = reducer.overlap
+        reducer.overlap = False
+        step()
+        dist.barrier()
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        for _ in range(n_diag):
+            step()
+        torch.cuda.synchronize()
+        dist.barrier()
+        el2 = time.perf_counter() - t2
+        reducer.overlap = was
+        tm2 = torch.tensor([el2, sum(exposed) / max(len(exposed), 1)], device=dev, dtype=torch.float64)
+        dist.all_reduce(tm2, op=dist.ReduceOp.MAX)
+        exchange_diag = {"exposed_wait_ms_per_step": round(tm2[1].item(), 3), "no_overlap_ms_per_step": round(1e3 * tm2[0].item() / n_diag, 3),
+                         "steps": n_diag, "how": "HIP events around the joins of GradReducer.wait() on the compute stream (max over ranks); "
+                                                 "then the same step with every bucket's all-reduce launched after backward"}
     fp32_pipe = None
     if headline_terms and not args.no_fp32_pipe:
         # the same model / optimizer state / batch with every product on the fp32 matrix pipe (v_mfma_f32_16x16x4_f32)
@@ -471,7 +501,8 @@ def main():
                                "grid_cus": _lib.load().dhz_grid_cus(), "payload_bytes": plan["payload_bytes"],
                                "n_buckets": len(plan["buckets"]), "bucket_bytes": [b["bytes"] for b in plan["buckets"]],
                                "ring_time_ms_single_link": round(plan["ring_time_ms"], 3),
-                               "measured": "ring time is the plan's figure, not a measurement"}
+                               "measured": "ring time is the plan's figure, not a measurement",
+                               **(exchange_diag or {})}
         build_id = _lib.load().dhz_build_id().decode()
         pmc, traffic_source = load_pmc_traffic(os.path.join(ROOT, "profiles", "pmc_traffic.json"), build_id)
         if world == 1 and timing and not args.no_live_traffic and args.dtype == "f32":

@@ -243,6 +243,10 @@ int dhz_linear_fwd_split_res(const float* x, int ldx, const float* w, const floa
                              void* stream);
 int dhz_linear_dgrad_split_scaled(const float* dy, int ldy, const float* w, const float* scale, float* dx, int ldx, int T, int N, int K,
                                   int tokens_per_image, int terms, void* stream);
+/*   ... and on the bf16 kernels of BASELINE config 4 (dhz_linear_fwd_bf16): x, w, res, out in bf16, bias / scale fp32, fp32 accumulation;
+ *   out = bf16(res + scale (x . w^T + bias)) - one rounding less than the two-launch form (the product is not rounded to bf16 first). */
+int dhz_linear_fwd_bf16_res(const void* x, int ldx, const void* w, const float* bias, const void* res, const float* scale, void* out, int ldo,
+                            int T, int N, int K, int tokens_per_image, int Hres, int Wres, int shift, int windowed, void* stream);
 /*     hi[i] + mid[i] + lo[i] == src[i] exactly (three bf16 by truncation); n % 8 == 0, 16-byte aligned pointers. */
 int dhz_split3_planes(const float* src, int64_t n, void* hi, void* mid, void* lo, void* stream);
 /*     ... and the planes of the TRANSPOSES of nmat matrices inside one buffer: desc (device, int[nmat][4]) = {offset, rows R, cols C, index

@@ -18,6 +18,7 @@
 //     permuted order, so a lane owns 8 consecutive features of a token: 16-byte bf16 stores (as csrc/linear_bf16.hip).
 #include <stdlib.h>
 #include "common.h"
+#include "tok_epilogue.h"
 
 #ifndef BFP_ABL
 #define BFP_ABL 0        // timing diagnostics (tools/variants.sh): 1 no stores, 2 no MFMAs, 4 no DMA, 8 no fragment reads
@@ -71,7 +72,8 @@ template <int NLOAD, bool NTS>
 __global__ __launch_bounds__(64 * (NCOMP + NLOAD), 1) void gemm_bf16_pipe_kernel(const uint16_t* __restrict__ A, int lda,
                                                                                  const uint16_t* __restrict__ B, int ldb,
                                                                                  const float* __restrict__ bias, uint16_t* __restrict__ C,
-                                                                                 int ldc, int M, int NF, int KC, int tiles_n, int ntiles) {
+                                                                                 int ldc, int M, int NF, int KC, int tiles_n, int ntiles,
+                                                                                 const TokEpi epi, int epi_on) {
     constexpr int NT = 64 * (NCOMP + NLOAD);
     constexpr int SPL = NSUB / NLOAD;                  // 16-row groups per loading wave
     constexpr int DPL = 2 * SPL;                       // its DMA instructions per stage
@@ -183,6 +185,21 @@ __global__ __launch_bounds__(64 * (NCOMP + NLOAD), 1) void gemm_bf16_pipe_kernel
         const int m0 = q.m0 + wm * WM * 16 + i16, n0 = q.n0 + wn * WN * 16 + 8 * g;
         uint16_t* c0 = C + (size_t)m0 * ldc + n0;
         const bool full = q.m0 + BM <= M;                                          // wave-uniform
+        if (epi_on) {                                                              // the block's residual step (csrc/tok_epilogue.h)
+            const int mbw = q.m0 + wm * WM * 16;
+            int dst[WM];
+            float sc;
+            tok_epi_rows<WM>(epi, mbw < M ? mbw : 0, i16, dst, sc);
+#pragma unroll
+            for (int a = 0; a < WM; ++a)
+                if (full || m0 + 16 * a < M) {
+#pragma unroll
+                    for (int h = 0; h < WN / 2; ++h)
+                        tok_epi_store8_bf16(epi, C, (size_t)dst[a] * ldc + n0 + 32 * h, sc,
+                                            acc[a][2 * h] + *reinterpret_cast<const f32x4*>(bsm + n0 + 32 * h),
+                                            acc[a][2 * h + 1] + *reinterpret_cast<const f32x4*>(bsm + n0 + 32 * h + 4));
+                }
+        } else
 #pragma unroll
         for (int a = 0; a < WM; ++a)
 #pragma unroll
@@ -255,12 +272,12 @@ __global__ __launch_bounds__(64 * (NCOMP + NLOAD), 1) void gemm_bf16_pipe_kernel
 }
 
 template <int NLOAD, bool NTS>
-void launch_pipe(const uint16_t* A, int lda, const uint16_t* B, int ldb, const float* bias, uint16_t* C, int ldc, int M, int NF, int KC,
+void launch_pipe(const TokEpi& epi, int epi_on, const uint16_t* A, int lda, const uint16_t* B, int ldb, const float* bias, uint16_t* C, int ldc, int M, int NF, int KC,
                  int tiles_n, int ntiles, int grid, size_t smem, hipStream_t s) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_pipe_kernel<NLOAD, NTS>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)smem);
     hipLaunchKernelGGL((gemm_bf16_pipe_kernel<NLOAD, NTS>), dim3(grid), dim3(64 * (NCOMP + NLOAD)), smem, s, A, lda, B, ldb, bias, C, ldc, M, NF,
-                       KC, tiles_n, ntiles);
+                       KC, tiles_n, ntiles, epi, epi_on);
 }
 
 }  // namespace
@@ -302,7 +319,9 @@ extern "C" int dhz_bf16_transpose_batched(const float* src, void* dst, const int
 
 // Called by csrc/linear_bf16.hip's forward dispatch for the shapes this kernel takes; returns false when it does not apply.
 bool dhz_gemm_bf16_pipe_try(const uint16_t* A, int lda, const uint16_t* B, int ldb, const float* bias, uint16_t* C, int ldc, int M, int NF,
-                            int KC, hipStream_t s) {
+                            int KC, hipStream_t s, const TokEpi* epi) {
+    const int epi_on = epi != nullptr;
+    const TokEpi e = epi ? *epi : TokEpi{};
     static const int mode = getenv("DHZ_BF16_PIPE") ? atoi(getenv("DHZ_BF16_PIPE")) : 1;     // diagnostics: 0 = never, 2 = whenever legal
     if (!mode || NF % BN || KC % BKS || NF > 2048 || (long)ldb * NF >= (1L << 31)) return false;
     const int tiles_n = NF / BN, tiles_m = (M + BM - 1) / BM;
@@ -313,8 +332,9 @@ bool dhz_gemm_bf16_pipe_try(const uint16_t* A, int lda, const uint16_t* B, int l
     const int grid = ntiles < cus ? ntiles : cus;
     static const int nt_env = (getenv("DHZ_BF16_PIPE_NT") && *getenv("DHZ_BF16_PIPE_NT")) ? atoi(getenv("DHZ_BF16_PIPE_NT")) : -1;       // diagnostics: 0 / 1 force
     const int nt_store = nt_env >= 0 ? nt_env : ((double)M * NF * 2 >= 192e6);
-    if (nt_store) launch_pipe<2, true>(A, lda, B, ldb, bias, C, ldc, M, NF, KC, tiles_n, ntiles, grid, smem, s);
-    else launch_pipe<2, false>(A, lda, B, ldb, bias, C, ldc, M, NF, KC, tiles_n, ntiles, grid, smem, s);
+    // (the residual epilogue's output is the next kernel's input and its shortcut: never a non-temporal store)
+    if (nt_store && !epi_on) launch_pipe<2, true>(e, epi_on, A, lda, B, ldb, bias, C, ldc, M, NF, KC, tiles_n, ntiles, grid, smem, s);
+    else launch_pipe<2, false>(e, epi_on, A, lda, B, ldb, bias, C, ldc, M, NF, KC, tiles_n, ntiles, grid, smem, s);
     return true;
 }
 

@@ -15,13 +15,14 @@
 //     (lane & 15), rows r0 .. r0 + 3.
 // Forward / backward-data: persistent workgroups pipelined across tiles (as csrc/linear_gemm.hip); outputs leave as bf16.
 #include "common.h"
+#include "tok_epilogue.h"
 
 #ifndef BF_ABL
 #define BF_ABL 0        // timing diagnostics (tools/variants.sh): 1 no epilogue stores, 2 no MFMAs, 4 no global operand loads, 8 weight gradient: no atomics
 #endif
 
 bool dhz_gemm_bf16_pipe_try(const uint16_t* A, int lda, const uint16_t* B, int ldb, const float* bias, uint16_t* C, int ldc, int M, int NF,
-                            int KC, hipStream_t s);          // csrc/gemm_bf16_pipe.hip
+                            int KC, hipStream_t s, const TokEpi* epi);          // csrc/gemm_bf16_pipe.hip (epi: residual epilogue or null)
 
 namespace {
 
@@ -67,7 +68,7 @@ template <int WM, int WN, bool BTR>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(const uint16_t* __restrict__ A, int lda,
                                                         const uint16_t* __restrict__ B, int ldb,
                                                         const float* __restrict__ bias, uint16_t* __restrict__ C, int ldc,
-                                                        int M, int N, int K, int tiles_n, int ntiles) {
+                                                        int M, int N, int K, int tiles_n, int ntiles, const TokEpi epi, int epi_on) {
     constexpr int BM = 32 * WM, BN = 32 * WN;
     constexpr int A_BYTES = BM * 128;
     constexpr int B_BYTES = BTR ? BK * BN * 2 : BN * 128;
@@ -205,7 +206,19 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const uint16_t* __restri
                 r[3] = (uint32_t)f32_to_bf16(v1[2]) | ((uint32_t)f32_to_bf16(v1[3]) << 16);
                 return r;
             };
-            if (tm * BM + BM <= M) {                                     // wave-uniform
+            if (epi_on) {                                                // the block's residual step (csrc/tok_epilogue.h)
+                const int mbw = __builtin_amdgcn_readfirstlane(tm * BM + wm * WM * 16);
+                int dst[WM];
+                float sc;
+                tok_epi_rows<WM>(epi, mbw < M ? mbw : 0, i16, dst, sc);
+#pragma unroll
+                for (int a = 0; a < WM; ++a)
+                    if (m0 + 16 * a < M) {
+#pragma unroll
+                        for (int h = 0; h < WN / 2; ++h)
+                            tok_epi_store8_bf16(epi, C, (size_t)dst[a] * ldc + n0 + 32 * h, sc, acc[a][2 * h] + bv[2 * h], acc[a][2 * h + 1] + bv[2 * h + 1]);
+                    }
+            } else if (tm * BM + BM <= M) {                              // wave-uniform
 #pragma unroll
                 for (int a = 0; a < WM; ++a)
 #pragma unroll
@@ -232,7 +245,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const uint16_t* __restri
 
 template <int WM, int WN, bool BTR>
 void launch_gemm(const uint16_t* A, int lda, const uint16_t* B, int ldb, const float* bias, uint16_t* C, int ldc, int M, int N,
-                 int K, hipStream_t s) {
+                 int K, const TokEpi& epi, int epi_on, hipStream_t s) {
     constexpr int BM = 32 * WM, BN = 32 * WN;
     constexpr size_t smem = 2 * (size_t)(BM * 128 + (BTR ? BK * BN * 2 : BN * 128));
     const int tiles_n = N / BN, tiles_m = (M + BM - 1) / BM;
@@ -243,12 +256,19 @@ void launch_gemm(const uint16_t* A, int lda, const uint16_t* B, int ldb, const f
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<WM, WN, BTR>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     hipLaunchKernelGGL((gemm_bf16_kernel<WM, WN, BTR>), dim3(grid), dim3(256), smem, s, A, lda, B, ldb, bias, C, ldc, M, N, K,
-                       tiles_n, ntiles);
+                       tiles_n, ntiles, epi, epi_on);
 }
 
 template <bool BTR>
 int dispatch_gemm(const char* who, const uint16_t* A, int lda, const uint16_t* B, int ldb, const float* bias, uint16_t* C, int ldc,
-                  int M, int N, int K, hipStream_t s) {
+                  int M, int N, int K, hipStream_t s, const TokEpi* epi = nullptr) {
+    const int epi_on = epi != nullptr;
+    const TokEpi e = epi ? *epi : TokEpi{};
+    if (epi_on) {
+        const char* bad = tok_epi_check(e, M);
+        DHZ_REQUIRE(!bad, "%s: %s", who, bad);
+        DHZ_REQUIRE(((uintptr_t)e.res & 15) == 0, "%s: the shortcut must be 16-byte aligned", who);
+    }
     DHZ_REQUIRE(A && B && C, "%s: null pointer", who);
     DHZ_REQUIRE(M > 0 && N > 0 && K > 0 && N % 64 == 0 && K % 64 == 0, "%s: T=%d N=%d K=%d (N, K must be multiples of 64)", who, M, N,
                 K);
@@ -256,7 +276,7 @@ int dispatch_gemm(const char* who, const uint16_t* A, int lda, const uint16_t* B
     DHZ_REQUIRE((((uintptr_t)A | (uintptr_t)B | (uintptr_t)C) & 15) == 0, "%s: operands must be 16-byte aligned", who);
     if constexpr (!BTR) {
         // the software-pipelined 256 x 128 kernel (csrc/gemm_bf16_pipe.hip) where the problem has a tile per CU
-        if (dhz_gemm_bf16_pipe_try(A, lda, B, ldb, bias, C, ldc, M, N, K, s)) {
+        if (dhz_gemm_bf16_pipe_try(A, lda, B, ldb, bias, C, ldc, M, N, K, s, epi)) {
             DHZ_CHECK_LAUNCH(who);
             return DHZ_OK;
         }
@@ -265,7 +285,7 @@ int dispatch_gemm(const char* who, const uint16_t* A, int lda, const uint16_t* B
     const long blocks128 = (long)((M + 127) / 128) * (N / (32 * wn));
     const int wm = blocks128 >= 256 ? 4 : 2;
 #define CASE(a, b) \
-    if (wm == a && wn == b) launch_gemm<a, b, BTR>(A, lda, B, ldb, bias, C, ldc, M, N, K, s);
+    if (wm == a && wn == b) launch_gemm<a, b, BTR>(A, lda, B, ldb, bias, C, ldc, M, N, K, e, epi_on, s);
     CASE(4, 4) CASE(4, 2) CASE(2, 4) CASE(2, 2)
 #undef CASE
     DHZ_CHECK_LAUNCH(who);
@@ -447,6 +467,14 @@ extern "C" int dhz_linear_fwd_bf16(const void* x, int ldx, const void* w, const 
                                    void* stream) {
     return dispatch_gemm<false>("dhz_linear_fwd_bf16", (const uint16_t*)x, ldx, (const uint16_t*)w, K, bias, (uint16_t*)y, ldy, T, N, K,
                                 (hipStream_t)stream);
+}
+
+extern "C" int dhz_linear_fwd_bf16_res(const void* x, int ldx, const void* w, const float* bias, const void* res, const float* scale, void* out,
+                                       int ldo, int T, int N, int K, int tokens_per_image, int Hres, int Wres, int shift, int windowed,
+                                       void* stream) {
+    const TokEpi epi{res, scale, tokens_per_image, Hres, Wres, shift, windowed};
+    return dispatch_gemm<false>("dhz_linear_fwd_bf16_res", (const uint16_t*)x, ldx, (const uint16_t*)w, K, bias, (uint16_t*)out, ldo, T, N, K,
+                                (hipStream_t)stream, &epi);
 }
 
 extern "C" int dhz_linear_dgrad_bf16(const void* dy, int ldy, const void* w, void* dx, int ldx, int T, int N, int K, void* stream) {

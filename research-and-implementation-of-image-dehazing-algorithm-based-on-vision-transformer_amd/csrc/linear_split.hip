@@ -275,7 +275,7 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(const float* __restr
                             f32x4 v = acc[a][b];
                             if (bias) v += *reinterpret_cast<const f32x4*>(bias + n0 + 16 * b);
                             v *= sc;
-                            if (epi.res) v += *reinterpret_cast<const f32x4*>(epi.res + (size_t)dst[a] * ldc + n0 + 16 * b);
+                            if (epi.res) v += *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(epi.res) + (size_t)dst[a] * ldc + n0 + 16 * b);
                             *reinterpret_cast<f32x4*>(C + (size_t)dst[a] * ldc + n0 + 16 * b) = v;
                         }
                     }

@@ -325,7 +325,7 @@ __global__ __launch_bounds__(NT, 1) void split6_gemm_kernel(const float* __restr
             for (int a = 0; a < WM; ++a)
 #pragma unroll
                 for (int b = 0; b < WN; ++b)
-                    rv[a][b] = epi.res ? *reinterpret_cast<const f32x4*>(epi.res + (size_t)min(dst[a], M - 1) * ldc + nn + 16 * b)
+                    rv[a][b] = epi.res ? *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(epi.res) + (size_t)min(dst[a], M - 1) * ldc + nn + 16 * b)
                                        : f32x4{0.f, 0.f, 0.f, 0.f};
             const bool efull = tm * BM + BM <= M;                    // wave-uniform; WM * WN stores when true (the caller counts them)
 #pragma unroll
@@ -620,7 +620,7 @@ __global__ __launch_bounds__(NT, 1) void split6_wide_kernel(const float* __restr
             for (int a = 0; a < WM; ++a)
 #pragma unroll
                 for (int b = 0; b < WN; ++b)
-                    rv[a][b] = epi.res ? *reinterpret_cast<const f32x4*>(epi.res + (size_t)min(dst[a], M - 1) * ldc + nn + 16 * b)
+                    rv[a][b] = epi.res ? *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(epi.res) + (size_t)min(dst[a], M - 1) * ldc + nn + 16 * b)
                                        : f32x4{0.f, 0.f, 0.f, 0.f};
             const bool efull = tm * BM + BM <= M;                    // wave-uniform; WM * WN stores when true (the caller counts them)
 #pragma unroll

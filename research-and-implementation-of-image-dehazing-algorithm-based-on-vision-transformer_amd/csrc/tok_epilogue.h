@@ -8,7 +8,7 @@
 #include "common.h"
 
 struct TokEpi {
-    const float* res;      // shortcut, [images * HW] rows of ldc floats in TOKEN order, or null (nothing added)
+    const void* res;       // shortcut, [images * HW] rows of ldc elements (fp32, or bf16 in the bf16 kernels) in TOKEN order, or null
     const float* scale;    // per-image factor (DropPath), or null (1)
     int HW;                // tokens per image (a multiple of 64 whenever scale or win is set)
     int Hres, Wres, shift; // map geometry of the window layout (win != 0)
@@ -38,6 +38,23 @@ __device__ __forceinline__ void tok_epi_rows(const TokEpi& e, int mb, int i16, i
         if (ww >= e.Wres) ww -= e.Wres;
         dst[a] = img * e.HW + hh * e.Wres + ww;
     }
+}
+
+// bf16 kernels: a lane's 8 consecutive features of one row: out = bf16(res + sc * v)   (v = acc + bias in fp32)
+__device__ __forceinline__ void tok_epi_store8_bf16(const TokEpi& e, uint16_t* C, size_t off, float sc, const f32x4 v0, const f32x4 v1) {
+    typedef uint32_t u32x4_ __attribute__((ext_vector_type(4)));
+    f32x4 r0 = sc * v0, r1 = sc * v1;
+    if (e.res) {
+        const u32x4_ q = *reinterpret_cast<const u32x4_*>(reinterpret_cast<const uint16_t*>(e.res) + off);
+        r0 += f32x4{__uint_as_float(q[0] << 16), __uint_as_float(q[0] & 0xffff0000u), __uint_as_float(q[1] << 16), __uint_as_float(q[1] & 0xffff0000u)};
+        r1 += f32x4{__uint_as_float(q[2] << 16), __uint_as_float(q[2] & 0xffff0000u), __uint_as_float(q[3] << 16), __uint_as_float(q[3] & 0xffff0000u)};
+    }
+    u32x4_ r;
+    r[0] = (uint32_t)f32_to_bf16(r0[0]) | ((uint32_t)f32_to_bf16(r0[1]) << 16);
+    r[1] = (uint32_t)f32_to_bf16(r0[2]) | ((uint32_t)f32_to_bf16(r0[3]) << 16);
+    r[2] = (uint32_t)f32_to_bf16(r1[0]) | ((uint32_t)f32_to_bf16(r1[1]) << 16);
+    r[3] = (uint32_t)f32_to_bf16(r1[2]) | ((uint32_t)f32_to_bf16(r1[3]) << 16);
+    *reinterpret_cast<u32x4_*>(C + off) = r;
 }
 
 // host-side argument check shared by the entry points; returns nullptr or the complaint

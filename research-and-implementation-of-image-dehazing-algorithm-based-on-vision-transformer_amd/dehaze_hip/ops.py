@@ -335,6 +335,14 @@ def gemm_fwd_res(x, W, b, res, scale, B, Hres, Wres, shift, windowed):
     route = "f32"
     if RES_EPILOGUE and x.dtype == torch.float32 and SPLIT_BF16 == 6 and x.stride(0) % 4 == 0 and HW % 64 == 0 and W.is_contiguous():
         route = _route6(T, K, N, False)
+    if RES_EPILOGUE and x.dtype == BF16 and res.dtype == BF16 and HW % 64 == 0 and N % 64 == 0 and K % 64 == 0 and x.stride(0) % 8 == 0:
+        Wb = bf16_copy(W if W.is_contiguous() else W.contiguous())
+        out = torch.empty_like(res)
+        ev = _timed("dhz_linear_bf16")
+        _lib.call("dhz_linear_fwd_bf16_res", _p(x), x.stride(0), _p(Wb), _p(b), _p(res), _p(scale), _p(out), N, T, N, K, HW, Hres, Wres, shift,
+                  1 if windowed else 0, _stream())
+        _timed_end(ev, 2.0 * T * N * K)
+        return out
     if route == "f32":
         y = gemm_fwd(x, W, b)
         out = torch.empty_like(res)

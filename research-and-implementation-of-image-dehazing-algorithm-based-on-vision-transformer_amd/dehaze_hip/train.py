@@ -337,6 +337,7 @@ class GradReducer:
         self._hooks = []
         self._seen = set()            # parameters already announced in this backward pass
         self.calls = None             # diagnostics: set to {} to count announcements per parameter id
+        self.timing = None            # diagnostics: set to [] and wait() appends a HIP-event pair around its joins (bench.py: exposed exchange)
         if self.world > 1:
             for p, _, _ in slices:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
@@ -396,8 +397,16 @@ class GradReducer:
                 if 0 < self._pending[b] < n or (self._pending[b] == 0 and n > 0) or (not self.overlap and n > 0):
                     self._handles.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group,
                                                          async_op=True))
+            ev = None
+            if self.timing is not None and torch.cuda.is_available() and self.flat.is_cuda:
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                ev[0].record()
             for h in self._handles:
                 h.wait()
+            if ev is not None:
+                # between the two records the compute stream does nothing but wait for the collectives: the EXPOSED exchange time
+                ev[1].record()
+                self.timing.append(ev)
         self._handles = []
         self._pending = [0] * len(self.buckets)
         self._seen = set()

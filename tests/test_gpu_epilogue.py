@@ -210,3 +210,34 @@ def test_block_node_equals_two_nodes(C, heads, res, shift, drop):
     for i, (u, v) in enumerate(zip(a[1:], b[1:])):
         tol = 2e-5 * v.abs().max().item() + 1e-7          # (+ absolute floor: d(b_k) is zero in exact arithmetic, ~1e-9 of rounding noise)
         assert (u - v).abs().max().item() <= tol, (i, (u - v).abs().max().item(), tol)
+
+@pytest.mark.parametrize("windowed,shift,scaled", [(1, 4, True), (0, 0, True), (1, 0, False)])
+@pytest.mark.parametrize("B,H,W,K,N", [(8, 64, 64, 128, 128),     # 256 x 128 tiles of the software-pipelined kernel
+                                       (2, 32, 32, 512, 128),     # few tiles: csrc/linear_bf16.hip's kernel
+                                       (4, 16, 24, 64, 64),       # 64-wide output
+                                       (3, 8, 8, 128, 192)])      # partial last tile
+def test_residual_epilogue_bf16_vs_fp64(B, H, W, K, N, windowed, shift, scaled):
+    """config 4's form (dhz_linear_fwd_bf16_res): bf16 operands / shortcut / result, fp32 accumulation; the result is ONE bf16 rounding of
+    res + scale (x . w^T + bias) evaluated in fp32"""
+    from dehaze_hip import _lib
+    dev = torch.device("cuda:0")
+    s = torch.cuda.current_stream().cuda_stream
+    T = B * H * W
+    g = torch.Generator().manual_seed(T + K + N + shift)
+    x = torch.randn(T, K, generator=g).to(dev).bfloat16()
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(dev).bfloat16()
+    b = torch.randn(N, generator=g).to(dev)
+    res = torch.randn(T, N, generator=g).to(dev).bfloat16()
+    sc = torch.tensor([0.0 if i % 3 == 1 else 1.0 / 0.9 for i in range(B)]).to(dev) if scaled else None
+    y64 = x.double() @ w.double().t() + b.double()
+    f = sc.double().repeat_interleave(H * W)[:, None] if scaled else 1.0
+    ref = res.double() + (_window_reverse_roll(f * y64, B, H, W, shift) if windowed else f * y64)
+    out = torch.full((T, N), float("nan"), device=dev, dtype=torch.bfloat16)
+    _lib.call("dhz_linear_fwd_bf16_res", x.data_ptr(), K, w.data_ptr(), b.data_ptr(), res.data_ptr(), sc.data_ptr() if scaled else None,
+              out.data_ptr(), N, T, N, K, H * W, H, W, shift, windowed, s)
+    assert torch.isfinite(out.float()).all()
+    err = (out.double() - ref).abs()
+    assert (err <= 2.0 ** -8 * ref.abs() + 1e-3).all(), (err / (ref.abs() + 1e-3)).max().item()      # half an ulp of bf16 + fp32 accumulation
+    if scaled:
+        rows = torch.arange(T, device=dev).view(B, H * W)[1]
+        assert torch.equal(out[rows], res[rows])
