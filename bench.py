@@ -306,6 +306,9 @@ def main():
     ap.add_argument("--reserve-cus", type=int, default=None,
                     help="CUs the persistent compute grids leave free (dhz_set_reserved_cus).  N > 1: for RCCL's kernels beside the backward "
                          "pass (default: DHZ_COMM_RESERVE_CUS or 0).  N = 1: applied as given - measures what a reservation costs the step")
+    ap.add_argument("--side-stream", type=int, choices=[0, 1], default=int(os.environ.get("DHZ_SIDE_STREAM", "0")),
+                    help="1: the no-gradient VGG19 passes of the contrastive loss (target, hazy input) run on a second HIP stream beside the "
+                         "model's forward (train_step(side=SideStream)); same work, same results")
     ap.add_argument("--no-live-traffic", action="store_true",
                     help="do not measure `roofline.traffic` with two rocprofv3 --pmc child passes; use the stamped profiles/pmc_traffic.json")
     ap.add_argument("--no-fp32-pipe", action="store_true",
@@ -359,8 +362,13 @@ def main():
     target, input_ = synthetic_batch(args.batch, args.ps, seed=1234 + rank, device=dev)
     torch.manual_seed(4321 + rank)                # per-rank sampling / DropPath streams
 
+    side = None
+    if args.side_stream and not args.no_cr:
+        from dehaze_hip.train import SideStream
+        side = SideStream(dev)
+
     def step():
-        return train_step(model, char, cr, opt, reducer, input_, target, 1.0, 0.0 if args.no_cr else 1.0)
+        return train_step(model, char, cr, opt, reducer, input_, target, 1.0, 0.0 if args.no_cr else 1.0, side=side)
 
     # The headline runs the product's DEFAULT arithmetic (dehaze_hip.ops.SPLIT_BF16 = 6 unless the environment overrides it): fp32
     # storage and accumulation, the products of the GEMM-shaped kernels as six bf16 MFMA passes over operands cut into three bf16

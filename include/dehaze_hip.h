@@ -95,6 +95,10 @@ int dhz_ps_attn_bwd(const float* q, const float* k, const float* v, int ld, cons
  *     dhz_ln_partition_bwd consume.  Inference mode: pass NULL for all five. */
 int dhz_fused_attn_prepack(const float* wq, const float* wk, const float* wv, const float* wo,
                            float* wqkv_p, float* wo_p, int C, void* stream);
+/* ... for n <= 16 blocks in ONE launch (host arrays of device pointers; C[i] in {32, 64, 128}).  Same values as n calls of
+ * dhz_fused_attn_prepack. */
+int dhz_fused_attn_prepack_multi(const float* const* wq, const float* const* wk, const float* const* wv, const float* const* wo,
+                                 float* const* wqkv_p, float* const* wo_p, const int* C, int n, void* stream);
 int dhz_fused_window_attn_fwd(const float* x, const float* gamma, const float* beta, const float* wqkv_p,
                               const float* bqkv, const float* wo_p, const float* bo, const uint8_t* idx,
                               const float* bias, const float* mask, const float* drop_scale, float* out,
@@ -135,6 +139,9 @@ int dhz_dense_attn_bwd(const float* q, const float* k, const float* v, int ld, c
 /* K7  relative-position bias:  bias[h,i,j] = table[rel_index(i,j), h]   (M1:408-410, win = 8).
  * table: [225, H].  bias: [H,64,64]. */
 int dhz_bias_gather(const float* table, float* bias, int H, void* stream);
+/* ... for every block of one model forward in ONE launch (host arrays of n <= 32 device pointers / head counts; entry i: biases[i][H_i,64,64]
+ * from tables[i][225,H_i]).  Same values as n calls of dhz_bias_gather. */
+int dhz_bias_gather_multi(const float* const* tables, float* const* biases, const int* heads, int n, void* stream);
 /* dtable[t,h] (+)= sum_p sum_{(i,j): rel_index(i,j)=t} dbias_part[p,i,j] over parts p with p%H==h.
  * dtable: [225,H], overwritten when accumulate == 0. */
 int dhz_bias_table_grad(const float* dbias_part, int parts, float* dtable, int H, int accumulate,

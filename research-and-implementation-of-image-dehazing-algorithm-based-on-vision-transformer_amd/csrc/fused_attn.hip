@@ -520,6 +520,35 @@ __global__ void prepack_weights_kernel(const float* __restrict__ wq, const float
     }
 }
 
+// the prepack of every fused block of one model forward in ONE launch: entry = blockIdx.y
+constexpr int PREPACK_MULTI_MAX = 16;
+struct PrepackMulti { const float* wq[PREPACK_MULTI_MAX]; const float* wk[PREPACK_MULTI_MAX]; const float* wv[PREPACK_MULTI_MAX];
+                      const float* wo[PREPACK_MULTI_MAX]; float* wqkv_p[PREPACK_MULTI_MAX]; float* wo_p[PREPACK_MULTI_MAX]; int C[PREPACK_MULTI_MAX]; };
+__global__ void prepack_weights_multi_kernel(const PrepackMulti d) {
+    const int m = blockIdx.y, C = d.C[m];
+    const float* wq = d.wq[m]; const float* wk = d.wk[m]; const float* wv = d.wv[m]; const float* wo = d.wo[m];
+    const int H = C / 32, KS4 = C / 16;
+    const int nq = H * 6 * KS4 * 64 * 4, no = H * (C / 16) * 2 * 64 * 4;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < nq) {
+        const int r = e & 3, lane = (e >> 2) & 63;
+        int rest = e >> 8;
+        const int s4 = rest % KS4; rest /= KS4;
+        const int j = rest % 6, h = rest / 6;
+        const int i16 = lane & 15, g = lane >> 4;
+        const float* W = (j >> 1) == 0 ? wq : ((j >> 1) == 1 ? wk : wv);
+        d.wqkv_p[m][e] = W[(size_t)(32 * h + 16 * (j & 1) + i16) * C + g * (C / 4) + 4 * s4 + r];
+    } else if (e < nq + no) {
+        const int f = e - nq;
+        const int r = f & 3, lane = (f >> 2) & 63;
+        int rest = f >> 8;
+        const int s4 = rest & 1; rest >>= 1;
+        const int tn = rest % (C / 16), h = rest / (C / 16);
+        const int i16 = lane & 15, g = lane >> 4;
+        d.wo_p[m][f] = wo[(size_t)(16 * tn + i16) * C + 32 * h + 8 * g + 4 * s4 + r];
+    }
+}
+
 template <int C, int SAVE, int NW = 1>
 void launch_fused(hipStream_t s, int nwin, const float* x, const float* gamma, const float* beta, const float* wqkv_p,
                   const float* bqkv, const float* wo_p, const float* bo, const uint8_t* idx, const float* bias,
@@ -566,6 +595,23 @@ extern "C" int dhz_fused_attn_prepack(const float* wq, const float* wk, const fl
     hipLaunchKernelGGL(prepack_weights_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, wq, wk, wv, wo,
                        wqkv_p, wo_p, C);
     DHZ_CHECK_LAUNCH("dhz_fused_attn_prepack");
+    return DHZ_OK;
+}
+
+extern "C" int dhz_fused_attn_prepack_multi(const float* const* wq, const float* const* wk, const float* const* wv, const float* const* wo,
+                                            float* const* wqkv_p, float* const* wo_p, const int* C, int n, void* stream) {
+    DHZ_REQUIRE(wq && wk && wv && wo && wqkv_p && wo_p && C && n > 0 && n <= PREPACK_MULTI_MAX,
+                "dhz_fused_attn_prepack_multi: null pointer or n=%d outside 1..%d", n, PREPACK_MULTI_MAX);
+    PrepackMulti d = {};
+    int cmax = 0;
+    for (int i = 0; i < n; ++i) {
+        DHZ_REQUIRE(wq[i] && wk[i] && wv[i] && wo[i] && wqkv_p[i] && wo_p[i], "dhz_fused_attn_prepack_multi: entry %d: null pointer", i);
+        DHZ_REQUIRE(C[i] == 32 || C[i] == 64 || C[i] == 128, "dhz_fused_attn_prepack_multi: entry %d: C=%d unsupported (32, 64, 128)", i, C[i]);
+        d.wq[i] = wq[i]; d.wk[i] = wk[i]; d.wv[i] = wv[i]; d.wo[i] = wo[i]; d.wqkv_p[i] = wqkv_p[i]; d.wo_p[i] = wo_p[i]; d.C[i] = C[i];
+        cmax = C[i] > cmax ? C[i] : cmax;
+    }
+    hipLaunchKernelGGL(prepack_weights_multi_kernel, dim3((4 * cmax * cmax + 255) / 256, n), dim3(256), 0, (hipStream_t)stream, d);
+    DHZ_CHECK_LAUNCH("dhz_fused_attn_prepack_multi");
     return DHZ_OK;
 }
 

@@ -598,6 +598,18 @@ __global__ void bias_gather_kernel(const float* __restrict__ table, float* __res
     bias[e] = table[rel * H + h];
 }
 
+// every block's bias gather of one model forward in ONE launch (18 launches of ~4 us otherwise): entry = blockIdx.y
+constexpr int BIAS_MULTI_MAX = 32;
+struct BiasMulti { const float* table[BIAS_MULTI_MAX]; float* bias[BIAS_MULTI_MAX]; int H[BIAS_MULTI_MAX]; };
+__global__ void bias_gather_multi_kernel(const BiasMulti d) {
+    const int H = d.H[blockIdx.y];
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;   // over H*64*64
+    if (e >= H * NT * NT) return;
+    const int h = e / (NT * NT), i = (e / NT) % NT, j = e % NT;
+    const int rel = ((i >> 3) - (j >> 3) + 7) * 15 + ((i & 7) - (j & 7) + 7);
+    d.bias[blockIdx.y][e] = d.table[blockIdx.y][rel * H + h];
+}
+
 // one workgroup per head: sum the per-workgroup partials, then fold (i,j) pairs onto the 225 table rows
 // grid = (16 element-chunks, H heads, Z part-slices): every thread sums one (i,j) element over its slice of
 // the per-workgroup partials (coalesced across the 256 threads) and adds it onto the table row rel(i,j).
@@ -766,6 +778,21 @@ extern "C" int dhz_bias_gather(const float* table, float* bias, int H, void* str
     const int n = H * NT * NT;
     hipLaunchKernelGGL(bias_gather_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, table, bias, H);
     DHZ_CHECK_LAUNCH("dhz_bias_gather");
+    return DHZ_OK;
+}
+
+extern "C" int dhz_bias_gather_multi(const float* const* tables, float* const* biases, const int* heads, int n, void* stream) {
+    DHZ_REQUIRE(tables && biases && heads && n > 0 && n <= BIAS_MULTI_MAX, "dhz_bias_gather_multi: null pointer or n=%d outside 1..%d", n,
+                BIAS_MULTI_MAX);
+    BiasMulti d = {};
+    int hmax = 0;
+    for (int i = 0; i < n; ++i) {
+        DHZ_REQUIRE(tables[i] && biases[i] && heads[i] > 0, "dhz_bias_gather_multi: entry %d: null pointer or H=%d", i, heads[i]);
+        d.table[i] = tables[i]; d.bias[i] = biases[i]; d.H[i] = heads[i];
+        hmax = heads[i] > hmax ? heads[i] : hmax;
+    }
+    hipLaunchKernelGGL(bias_gather_multi_kernel, dim3((hmax * NT * NT + 255) / 256, n), dim3(256), 0, (hipStream_t)stream, d);
+    DHZ_CHECK_LAUNCH("dhz_bias_gather_multi");
     return DHZ_OK;
 }
 

@@ -126,6 +126,63 @@ def _table_backward(dpart, parts, table_p, H, dev):
     return dtable
 
 
+# ----------------------------------------------------------------------------- per-forward staging of parameter-derived operands
+# Uformer.forward derives, in ONE launch each for the whole model, what every block would otherwise derive for itself in a launch
+# of a few microseconds: the relative-position bias tiles (dhz_bias_gather_multi) and the fragment-ordered weight copies of the
+# fused attention kernel (dhz_fused_attn_prepack_multi).  The branch forwards take a staged operand when there is one for their
+# parameter (consumed on use: a second forward without a new staging derives its own again) and derive it themselves otherwise.
+STAGED_BIAS = {}        # id(table parameter) -> [H, 64, 64]
+STAGED_PREPACK = {}     # id(query weight)    -> (wqkv_p, wo_p)
+
+
+def stage_block_operands(entries, device):
+    """entries: [(table or None, H, (wq, wk, wv, wo) or None, C)] in execution order (Uformer.forward builds it)."""
+    import ctypes
+    STAGED_BIAS.clear()
+    STAGED_PREPACK.clear()
+    arr = lambda ptrs: ctypes.cast((ctypes.c_void_p * len(ptrs))(*ptrs), ctypes.c_void_p)
+    tabs = [(t, H) for t, H, _, _ in entries if t is not None]
+    if tabs:
+        flat = torch.empty((sum(H for _, H in tabs) * NTOK * NTOK,), device=device, dtype=torch.float32)
+        outs, off = [], 0
+        for t, H in tabs:
+            outs.append(flat[off: off + H * NTOK * NTOK].view(H, NTOK, NTOK))
+            off += H * NTOK * NTOK
+        for i0 in range(0, len(tabs), 32):
+            part = list(zip(tabs, outs))[i0: i0 + 32]
+            tcs = [t.contiguous() for (t, _), _ in part]
+            _lib.call("dhz_bias_gather_multi", arr([_p(t) for t in tcs]), arr([_p(o) for _, o in part]),
+                      ctypes.cast((ctypes.c_int * len(part))(*[H for (_, H), _ in part]), ctypes.c_void_p), len(part), _stream())
+        for (t, _), o in zip(tabs, outs):
+            STAGED_BIAS[id(t)] = (t, o)          # (the parameter itself rides along: its id cannot be reused while the entry lives)
+    packs = [(w, C) for _, _, w, C in entries if w is not None]
+    if packs:
+        flat = torch.empty((sum(4 * C * C for _, C in packs),), device=device, dtype=torch.float32)
+        outs, off = [], 0
+        for _, C in packs:
+            outs.append((flat[off: off + 3 * C * C], flat[off + 3 * C * C: off + 4 * C * C]))
+            off += 4 * C * C
+        for i0 in range(0, len(packs), 16):
+            part = list(zip(packs, outs))[i0: i0 + 16]
+            ws = [[_p(w[k].contiguous()) for (w, _), _ in part] for k in range(4)]
+            _lib.call("dhz_fused_attn_prepack_multi", arr(ws[0]), arr(ws[1]), arr(ws[2]), arr(ws[3]), arr([_p(o[0]) for _, o in part]),
+                      arr([_p(o[1]) for _, o in part]), ctypes.cast((ctypes.c_int * len(part))(*[C for (_, C), _ in part]), ctypes.c_void_p),
+                      len(part), _stream())
+        for (w, _), o in zip(packs, outs):
+            STAGED_PREPACK[id(w[0])] = (w[0], o)
+
+
+def _bias_tile(table, H, dev):
+    if table is None:
+        return None
+    hit = STAGED_BIAS.pop(id(table), None)
+    if hit is not None and hit[0] is table and hit[1].shape[0] == H and hit[1].device == dev:
+        return hit[1]
+    bias = torch.empty((H, NTOK, NTOK), device=dev, dtype=torch.float32)
+    _lib.call("dhz_bias_gather", _p(table.contiguous()), _p(bias), H, _stream())
+    return bias
+
+
 # ----------------------------------------------------------------------------- attention branch: forward / backward as functions
 def _attn_fused_fwd(train, x, gamma, beta, wq, bq, wk, bk, wv, bv, wo, bo, table, idx, mask, dscale, Hres, Wres, shift, H):
     """one kernel: LN, roll, partition, QKV, ProbSparse core, out-projection, reverse, residual (csrc/fused_attn.hip)"""
@@ -136,14 +193,15 @@ def _attn_fused_fwd(train, x, gamma, beta, wq, bq, wk, bk, wv, bv, wo, bo, table
     dev = x.device
     T = B * L
     f32 = dict(device=dev, dtype=torch.float32)
-    wqkv_p = torch.empty(3 * C * C, **f32)
-    wo_p = torch.empty(C * C, **f32)
-    _lib.call("dhz_fused_attn_prepack", _p(wq), _p(wk), _p(wv), _p(wo), _p(wqkv_p), _p(wo_p), C, _stream())
+    hit = STAGED_PREPACK.pop(id(wq), None)
+    if hit is not None and hit[0] is wq and hit[1][0].numel() == 3 * C * C and hit[1][0].device == dev:
+        wqkv_p, wo_p = hit[1]
+    else:
+        wqkv_p = torch.empty(3 * C * C, **f32)
+        wo_p = torch.empty(C * C, **f32)
+        _lib.call("dhz_fused_attn_prepack", _p(wq), _p(wk), _p(wv), _p(wo), _p(wqkv_p), _p(wo_p), C, _stream())
     bqkv = ops.cat_rows([bq.detach(), bk.detach(), bv.detach()])
-    bias = None
-    if table is not None:
-        bias = torch.empty((H, NTOK, NTOK), **f32)
-        _lib.call("dhz_bias_gather", _p(table.contiguous()), _p(bias), H, _stream())
+    bias = _bias_tile(table, H, dev)
     out = torch.empty_like(x)
     fused_bwd = train and C in ATTN_FUSED_BWD_C and x.dtype == torch.float32
     xn = qkv = cx = stats = rank = None
@@ -191,10 +249,7 @@ def _attn_chain_fwd(train, x, gamma, beta, wq, bq, wk, bk, wv, bv, wo, bo, table
               ops._dt(x), _stream())
     wcat = ops.cat_rows([wq.detach(), wk.detach(), wv.detach()])
     qkv = ops.gemm_fwd(xn, wcat, ops.cat_rows([bq.detach(), bk.detach(), bv.detach()]))
-    bias = None
-    if table is not None:
-        bias = torch.empty((H, NTOK, NTOK), **f32)
-        _lib.call("dhz_bias_gather", _p(table.contiguous()), _p(bias), H, _stream())
+    bias = _bias_tile(table, H, dev)
     cx = torch.empty((T, C), device=dev, dtype=x.dtype)
     rank = torch.empty(((T // NTOK) * H * NTOK,), device=dev, dtype=torch.uint8)
     nW = mask.shape[0] if mask is not None else 1

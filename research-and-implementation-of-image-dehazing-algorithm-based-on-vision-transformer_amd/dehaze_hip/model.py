@@ -739,10 +739,34 @@ class Uformer(nn.Module):
         for i, b in enumerate(live):
             b._staged_scales = [r[2 * i], r[2 * i + 1]]
 
+    def _stage_block_operands(self, x, mask):
+        """The relative-position bias tiles of all blocks and the fragment-ordered weights of the fused attention blocks of this forward in
+        ONE launch each (fused.stage_block_operands) - 26 launches of ~4.5 us per training step otherwise."""
+        if not x.is_cuda or self.variant != "probsparse":
+            return
+        import options
+        rel = options.is_relative_position_bias
+        Himg, Wimg = x.shape[-2], x.shape[-1]
+        scales = [1, 2, 4, 8, 16, 8, 4, 2]
+        entries = []
+        for st, sc in zip(self.stages(), scales + [1]):
+            for b in st.blocks:
+                if b.attn.variant != "probsparse" or b.win_size != 8 or b.dim != 32 * b.num_heads or mask is not None:
+                    continue
+                lay = b.attn.ProbSpare
+                fused_fwd = self.act_dtype != torch.bfloat16 and fused.ENABLED and \
+                    (b.dim in (32, 64) or (b.dim == 128 and (Himg // sc) * (Wimg // sc) <= fused.ATTN_FUSED_C128_MAX_HW))
+                w = (lay.query_projection.weight, lay.key_projection.weight, lay.value_projection.weight, lay.out_projection.weight) \
+                    if fused_fwd else None
+                entries.append((b.attn.relative_position_bias_table if rel else None, b.num_heads, w, b.dim))
+        if entries:
+            fused.stage_block_operands(entries, x.device)
+
     def forward(self, x, mask=None):
         ops.sync_shadows()          # derived weight copies (bf16 / split planes) follow parameters written outside the optimizer
         self._stage_sample_indices(x.device)
         self._stage_drop_path(x)
+        self._stage_block_operands(x, mask)
         self.input_proj.out_dtype = self.act_dtype if x.is_cuda else torch.float32
         y = self.pos_drop(self.input_proj(x))
         if self.act_dtype == torch.bfloat16 and y.is_cuda and y.dtype != torch.bfloat16:
