@@ -48,6 +48,34 @@ __device__ __forceinline__ float r4sum(float v) { v += dpp<0xB1>(v); return v + 
 __device__ __forceinline__ float r8max(float v) { v = r4max(v); return fmaxf(v, dpp<0x141>(v)); }
 __device__ __forceinline__ float r8sum(float v) { v = r4sum(v); return v + dpp<0x141>(v); }
 
+// ---- six-term projections (P6): the QKV product of a head on the bf16 matrix pipe, fp32-class (csrc/split6_gemm.hip's arithmetic:
+// three bf16 truncation pieces per operand value, products hh hm mh hl lh mm, dropped terms <= 2^-24 relative, fp32 accumulation)
+typedef __bf16 bf16x8_ __attribute__((ext_vector_type(8)));
+typedef short s16x8_ __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4_ __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void lds_void_;
+typedef const __attribute__((address_space(1))) void glb_void_;
+__device__ __forceinline__ f32x4 mfma_b16(u32x4_ a, u32x4_ b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_, a), __builtin_bit_cast(bf16x8_, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ uint32_t pack_top_(float x1, float x0) {              // (x1 & 0xffff0000) | (x0 >> 16)
+    return __builtin_amdgcn_perm(__float_as_uint(x1), __float_as_uint(x0), 0x07060302u);
+}
+// eight fp32 values -> their three bf16 pieces (hi + mid + lo == x exactly), packed as MFMA operands
+__device__ __forceinline__ void split8x3_(const float* x, u32x4_& hi, u32x4_& mid, u32x4_& lo) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float x0 = x[2 * i], x1 = x[2 * i + 1];
+        const float r0 = x0 - __uint_as_float(__float_as_uint(x0) & 0xffff0000u), r1 = x1 - __uint_as_float(__float_as_uint(x1) & 0xffff0000u);
+        const float q0 = r0 - __uint_as_float(__float_as_uint(r0) & 0xffff0000u), q1 = r1 - __uint_as_float(__float_as_uint(r1) & 0xffff0000u);
+        hi[i] = pack_top_(x1, x0);
+        mid[i] = pack_top_(r1, r0);
+        lo[i] = pack_top_(q1, q0);
+    }
+}
+constexpr int P6_RUNS = 36;            // 1 KiB runs (one per wave-wide 16-byte fragment read) of a head's QKV planes per 64 channels:
+                                       // 6 column tiles x 2 k-blocks of 32 x 3 pieces
+
 // v_writelane_b32: lane LANE of `old` := the wave-uniform value (this compiler has no builtin for it).  The lane select is an
 // inline constant - a second SGPR would exceed the one-scalar-operand (constant bus) limit of a VALU instruction; the value is a
 // SALU result, which the hardware interlocks (no manual wait states).
@@ -79,7 +107,11 @@ struct FusedSmem {
 
 // SAVE: 0 = inference, 1 = every tensor the backward kernel chain consumes, 2 = only the selection ranks (the fused backward of
 // csrc/fused_attn_bwd.hip recomputes the rest)
-template <int C, int SAVE, int NW = 1>
+// P6: wqkv_p holds the six-term planes of dhz_fused_attn_prepack6 instead of fp32 fragments; the QKV product of a head runs on the bf16
+// matrix pipe with its weight planes brought ONCE per workgroup by LDS-DMA into the Q / K / V / S tiles (dead at that point: 36 KiB per 64
+// channels), shared by the four waves - not 4 x through L1 per wave (the round-4 attempt), three workgroups per CU kept (not the
+// resident-planes form of round 5).
+template <int C, int SAVE, int NW = 1, bool P6 = false>
 __global__ __launch_bounds__(256 * NW, NW == 2 ? 1 : (C == 64 ? 3 : (C == 128 ? 1 : 2))) void fused_window_attn_fwd_kernel(
     const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
     const float4* __restrict__ wqkv_p, const float* __restrict__ bqkv, const float4* __restrict__ wo_p,
@@ -175,6 +207,13 @@ __global__ __launch_bounds__(256 * NW, NW == 2 ? 1 : (C == 64 ? 3 : (C == 128 ? 
             }
             if (SAVE == 1 && !(abl & 128) && qd == 0) *reinterpret_cast<float2*>(stats_save + 2 * src_tok) = make_float2(mean, rstd);
         }
+        // P6: the lane's A fragments as bf16 pieces; k-block kb (32 channels of the contraction, 8 per lane group) <-> channels
+        // g C/4 + 8 kb + e - the same (arbitrary, consistent) order the planes are packed in
+        u32x4_ a6[P6 ? KS / 8 : 1][3];
+        if constexpr (P6) {
+#pragma unroll
+            for (int kb = 0; kb < KS / 8; ++kb) split8x3_(&xa[8 * kb], a6[kb][0], a6[kb][1], a6[kb][2]);
+        }
         f32x4 oacc[C / 16];                    // out-projection accumulators: rows 16w.., all C columns
 #pragma unroll
         for (int i = 0; i < C / 16; ++i) oacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -190,7 +229,40 @@ __global__ __launch_bounds__(256 * NW, NW == 2 ? 1 : (C == 64 ? 3 : (C == 128 ? 
                     const float bj = sm.vec[3 * C + (j >> 1) * C + 32 * h + 16 * (j & 1) + i16];
                     acc[j] = f32x4{bj, bj, bj, bj};
                 }
-                if constexpr (WREG) {
+                if constexpr (P6) {
+                    unsigned char* const Bimg = reinterpret_cast<unsigned char*>(sm.q);       // q | k | v | s: 45 KiB contiguous, dead here
+                    const unsigned char* const planes = reinterpret_cast<const unsigned char*>(wqkv_p);
+                    if (h == 0) __syncthreads();           // the previous window's epilogue staged through S (wave-local, no barrier of its own)
+#pragma unroll 1
+                    for (int ch = 0; ch < C / 64; ++ch) {
+                        if (ch > 0) __syncthreads();       // every wave has read the previous 64 channels' planes
+                        const unsigned char* src = planes + ((size_t)(h * (C / 64) + ch) * P6_RUNS) * 1024 + lane * 16;
+#pragma unroll
+                        for (int r = 0; r < P6_RUNS / 4; ++r)
+                            __builtin_amdgcn_global_load_lds((glb_void_*)(src + (w + 4 * r) * 1024), (lds_void_*)(Bimg + (w + 4 * r) * 1024), 16, 0, 0);
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        __syncthreads();
+#pragma unroll
+                        for (int kbl = 0; kbl < 2; ++kbl) {
+                            const int kb = 2 * ch + kbl;
+#pragma unroll
+                            for (int jg = 0; jg < 6; jg += 3) {                        // three column tiles at a time: 9 fragment reads, 18 MFMAs,
+                                u32x4_ bq[3][3];                                       // term-major (an accumulator is reused three MFMAs later)
+#pragma unroll
+                                for (int jj = 0; jj < 3; ++jj)
+#pragma unroll
+                                    for (int pc = 0; pc < 3; ++pc)
+                                        bq[jj][pc] = *reinterpret_cast<const u32x4_*>(Bimg + (((jg + jj) * 2 + kbl) * 3 + pc) * 1024 + lane * 16);
+                                constexpr int TA[6] = {2, 0, 1, 0, 1, 0}, TB[6] = {0, 2, 1, 1, 0, 0};      // (token piece, weight piece): lh hl mm hm mh hh
+#pragma unroll
+                                for (int term = 0; term < 6; ++term)
+#pragma unroll
+                                    for (int jj = 0; jj < 3; ++jj) acc[jg + jj] = mfma_b16(a6[kb][TA[term]], bq[jj][TB[term]], acc[jg + jj]);
+                            }
+                        }
+                    }
+                    __syncthreads();                       // the planes are read: the results below overwrite them
+                } else if constexpr (WREG) {
 #pragma unroll
                     for (int s4 = 0; s4 < 2; ++s4) {
 #pragma unroll
@@ -520,6 +592,32 @@ __global__ void prepack_weights_kernel(const float* __restrict__ wq, const float
     }
 }
 
+// six-term planes of the Q / K / V weights in the fragment order of the P6 kernel: run (1 KiB = 64 lanes x 8 bf16) index
+//   ((h (C/64) + ch) 36 + (j 2 + kbl) 3 + piece),   element (lane = 16 g + i16, e) = piece of W_m[32 h + 16 (j & 1) + i16][g C/4 + 8 (2 ch + kbl) + e],
+// m = j >> 1 (Q, K, V), pieces by truncation (hi + mid + lo == W exactly).  One thread per (run without piece, lane, e).
+__global__ void prepack6_kernel(const float* __restrict__ wq, const float* __restrict__ wk, const float* __restrict__ wv,
+                                uint16_t* __restrict__ out, int C) {
+    const int n = (C / 32) * (C / 64) * 12 * 512;              // (h, ch, j, kbl) x 64 lanes x 8 elements
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const int e = t & 7, lane = (t >> 3) & 63;
+    int rest = t >> 9;
+    const int kbl = rest & 1; rest >>= 1;
+    const int j = rest % 6; rest /= 6;
+    const int ch = rest % (C / 64), h = rest / (C / 64);
+    const int i16 = lane & 15, g = lane >> 4;
+    const float* W = (j >> 1) == 0 ? wq : ((j >> 1) == 1 ? wk : wv);
+    const float x = W[(size_t)(32 * h + 16 * (j & 1) + i16) * C + g * (C / 4) + 8 * (2 * ch + kbl) + e];
+    const float hi = __uint_as_float(__float_as_uint(x) & 0xffff0000u);
+    const float r1 = x - hi;
+    const float mid = __uint_as_float(__float_as_uint(r1) & 0xffff0000u);
+    const float r2 = r1 - mid;
+    const size_t run = ((size_t)(h * (C / 64) + ch) * 12 + (j * 2 + kbl)) * 3;
+    out[(run + 0) * 512 + lane * 8 + e] = (uint16_t)(__float_as_uint(x) >> 16);
+    out[(run + 1) * 512 + lane * 8 + e] = (uint16_t)(__float_as_uint(r1) >> 16);
+    out[(run + 2) * 512 + lane * 8 + e] = (uint16_t)(__float_as_uint(r2) >> 16);
+}
+
 // the prepack of every fused block of one model forward in ONE launch: entry = blockIdx.y
 constexpr int PREPACK_MULTI_MAX = 16;
 struct PrepackMulti { const float* wq[PREPACK_MULTI_MAX]; const float* wk[PREPACK_MULTI_MAX]; const float* wv[PREPACK_MULTI_MAX];
@@ -549,7 +647,7 @@ __global__ void prepack_weights_multi_kernel(const PrepackMulti d) {
     }
 }
 
-template <int C, int SAVE, int NW = 1>
+template <int C, int SAVE, int NW = 1, bool P6 = false>
 void launch_fused(hipStream_t s, int nwin, const float* x, const float* gamma, const float* beta, const float* wqkv_p,
                   const float* bqkv, const float* wo_p, const float* bo, const uint8_t* idx, const float* bias,
                   const float* mask, const float* dscale, float* out, float* xn_save, float* qkv_save, float* ctx_save,
@@ -557,7 +655,7 @@ void launch_fused(hipStream_t s, int nwin, const float* x, const float* gamma, c
     const size_t smem = NW * sizeof(FusedSmem<C>);
     static_assert(sizeof(FusedSmem<C>) % 16 == 0, "the second half's tiles start 16-byte aligned");
     if (smem > 48 * 1024)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_window_attn_fwd_kernel<C, SAVE, NW>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_window_attn_fwd_kernel<C, SAVE, NW, P6>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     // persistent workgroups (only with register-resident weights): exactly as many as are RESIDENT at once - the occupancy
     // the runtime reports for this code object (registers and LDS together: 2 per CU at 222 VGPRs, although 3 would fit the
@@ -570,7 +668,7 @@ void launch_fused(hipStream_t s, int nwin, const float* x, const float* gamma, c
     // resident workgroups per CU of this instantiation: queried once (thread-safe function-local static initialisation)
     static const int occ = [&] {
         int q = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, reinterpret_cast<const void*>(&fused_window_attn_fwd_kernel<C, SAVE, NW>),
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, reinterpret_cast<const void*>(&fused_window_attn_fwd_kernel<C, SAVE, NW, P6>),
                                                          256 * NW, smem) != hipSuccess || q < 1)
             q = 2;
         return q;
@@ -579,7 +677,7 @@ void launch_fused(hipStream_t s, int nwin, const float* x, const float* gamma, c
     const int ncu = dhz_num_cus();
     int grid = (C == 32 && FUSED_PERSIST_C32) ? ncu * per_cu : nwin / NW;
     if (grid > nwin / NW) grid = nwin / NW;
-    hipLaunchKernelGGL((fused_window_attn_fwd_kernel<C, SAVE, NW>), dim3(grid), dim3(256 * NW), smem, s, x, gamma, beta,
+    hipLaunchKernelGGL((fused_window_attn_fwd_kernel<C, SAVE, NW, P6>), dim3(grid), dim3(256 * NW), smem, s, x, gamma, beta,
                        reinterpret_cast<const float4*>(wqkv_p), bqkv, reinterpret_cast<const float4*>(wo_p), bo, idx,
                        bias, mask, dscale, out, xn_save, qkv_save, ctx_save, stats_save, rank_save, Hres, Wres, shift,
                        nwin);
@@ -615,11 +713,11 @@ extern "C" int dhz_fused_attn_prepack_multi(const float* const* wq, const float*
     return DHZ_OK;
 }
 
-extern "C" int dhz_fused_window_attn_fwd(const float* x, const float* gamma, const float* beta, const float* wqkv_p,
-                                         const float* bqkv, const float* wo_p, const float* bo, const uint8_t* idx,
-                                         const float* bias, const float* mask, const float* drop_scale, float* out,
-                                         float* xn_save, float* qkv_save, float* ctx_save, float* stats_save,
-                                         uint8_t* rank_save, int B, int Hres, int Wres, int C, int shift, void* stream) {
+static int fused_fwd_impl(bool p6, const float* x, const float* gamma, const float* beta, const float* wqkv_p,
+                          const float* bqkv, const float* wo_p, const float* bo, const uint8_t* idx,
+                          const float* bias, const float* mask, const float* drop_scale, float* out,
+                          float* xn_save, float* qkv_save, float* ctx_save, float* stats_save,
+                          uint8_t* rank_save, int B, int Hres, int Wres, int C, int shift, void* stream) {
     DHZ_REQUIRE(x && gamma && beta && wqkv_p && bqkv && wo_p && bo && idx && out, "dhz_fused_window_attn_fwd: null pointer");
     DHZ_REQUIRE(C == 32 || C == 64 || C == 128, "dhz_fused_window_attn_fwd: C=%d unsupported (32, 64, 128)", C);
     DHZ_REQUIRE(B > 0 && Hres % 8 == 0 && Wres % 8 == 0 && Hres >= 8 && Wres >= 8 && shift >= 0 && shift < 8,
@@ -658,8 +756,43 @@ extern "C" int dhz_fused_window_attn_fwd(const float* x, const float* gamma, con
                                                    nullptr, nullptr, nullptr, nullptr, rank_save, Hres, Wres, shift);
         else launch_fused<64, 0, 2>(s, nwin, x, gamma, beta, wqkv_p, bqkv, wo_p, bo, idx, bias, mask, drop_scale, out, nullptr, nullptr,
                                     nullptr, nullptr, nullptr, Hres, Wres, shift);
+    } else if (p6) {
+        DHZ_REQUIRE(C == 64, "dhz_fused_window_attn_fwd6: C=%d (the six-term projection form exists for C = 64)", C);
+        if (save == 1) launch_fused<64, 1, 1, true>(s, nwin, x, gamma, beta, wqkv_p, bqkv, wo_p, bo, idx, bias, mask, drop_scale, out, xn_save,
+                                                    qkv_save, ctx_save, stats_save, rank_save, Hres, Wres, shift);
+        else if (save == 2) launch_fused<64, 2, 1, true>(s, nwin, x, gamma, beta, wqkv_p, bqkv, wo_p, bo, idx, bias, mask, drop_scale, out,
+                                                         nullptr, nullptr, nullptr, nullptr, rank_save, Hres, Wres, shift);
+        else launch_fused<64, 0, 1, true>(s, nwin, x, gamma, beta, wqkv_p, bqkv, wo_p, bo, idx, bias, mask, drop_scale, out, nullptr, nullptr,
+                                          nullptr, nullptr, nullptr, Hres, Wres, shift);
     } else if (C == 32) GO(32); else if (C == 64) GO(64); else GO(128);
 #undef GO
     DHZ_CHECK_LAUNCH("dhz_fused_window_attn_fwd");
+    return DHZ_OK;
+}
+
+extern "C" int dhz_fused_window_attn_fwd(const float* x, const float* gamma, const float* beta, const float* wqkv_p,
+                                         const float* bqkv, const float* wo_p, const float* bo, const uint8_t* idx,
+                                         const float* bias, const float* mask, const float* drop_scale, float* out,
+                                         float* xn_save, float* qkv_save, float* ctx_save, float* stats_save,
+                                         uint8_t* rank_save, int B, int Hres, int Wres, int C, int shift, void* stream) {
+    return fused_fwd_impl(false, x, gamma, beta, wqkv_p, bqkv, wo_p, bo, idx, bias, mask, drop_scale, out, xn_save, qkv_save, ctx_save,
+                          stats_save, rank_save, B, Hres, Wres, C, shift, stream);
+}
+
+extern "C" int dhz_fused_window_attn_fwd6(const float* x, const float* gamma, const float* beta, const void* wqkv6_p,
+                                          const float* bqkv, const float* wo_p, const float* bo, const uint8_t* idx,
+                                          const float* bias, const float* mask, const float* drop_scale, float* out,
+                                          float* xn_save, float* qkv_save, float* ctx_save, float* stats_save,
+                                          uint8_t* rank_save, int B, int Hres, int Wres, int C, int shift, void* stream) {
+    return fused_fwd_impl(true, x, gamma, beta, (const float*)wqkv6_p, bqkv, wo_p, bo, idx, bias, mask, drop_scale, out, xn_save, qkv_save,
+                          ctx_save, stats_save, rank_save, B, Hres, Wres, C, shift, stream);
+}
+
+extern "C" int dhz_fused_attn_prepack6(const float* wq, const float* wk, const float* wv, void* wqkv6_p, int C, void* stream) {
+    DHZ_REQUIRE(wq && wk && wv && wqkv6_p, "dhz_fused_attn_prepack6: null pointer");
+    DHZ_REQUIRE(C == 64 || C == 128, "dhz_fused_attn_prepack6: C=%d unsupported (64, 128)", C);
+    const int n = (C / 32) * (C / 64) * 12 * 512;
+    hipLaunchKernelGGL(prepack6_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, wq, wk, wv, (uint16_t*)wqkv6_p, C);
+    DHZ_CHECK_LAUNCH("dhz_fused_attn_prepack6");
     return DHZ_OK;
 }

@@ -30,6 +30,10 @@ ATTN_FUSED_C128_MAX_HW = 1024   # C = 128 takes the fused attention forward up t
 # Fused attention BACKWARD (csrc/fused_attn_bwd.hip, C = 32): the forward then saves only the selection ranks.  A/B against the
 # backward kernel chain: tools/bench_fused.py, profiles/r03_fused_attn_bwd_ab.txt.
 ATTN_FUSED_BWD_C = (32,)
+# Six-term QKV projections inside the fused forward (csrc/fused_attn.hip, P6): weight planes brought once per workgroup by LDS-DMA into
+# the dead Q / K / V / S tiles.  DHZ_FUSED_P6=0 selects the fp32-pipe projections (A/B: tools/bench_fused.py).
+ATTN_FUSED_P6 = __import__("os").environ.get("DHZ_FUSED_P6", "1") != "0"
+ATTN_FUSED_P6_C = (64,)
 LEFF_FUSED = True           # False forces the kernel chain everywhere
 LEFF_FUSED_C = (32, 64)     # widths that take the fused forward
 # ... C = 64 only below this many tokens when the chain's GEMMs run in the six-term form (tools/bench_leff.py, bs 32, forward with the
@@ -212,11 +216,17 @@ def _attn_fused_fwd(train, x, gamma, beta, wq, bq, wk, bk, wv, bv, wo, bo, table
             cx = torch.empty((T, C), **f32)
             stats = torch.empty((T, 2), **f32)
         rank = torch.empty(((T // NTOK) * H * NTOK,), device=dev, dtype=torch.uint8)
+    entry = "dhz_fused_window_attn_fwd"
+    if ATTN_FUSED_P6 and C in ATTN_FUSED_P6_C:
+        # the QKV product of every head on the bf16 matrix pipe (six-term, fp32-class): planes in the kernel's fragment order
+        w6 = torch.empty((C // 32) * (C // 64) * 36 * 512, device=dev, dtype=torch.bfloat16)
+        _lib.call("dhz_fused_attn_prepack6", _p(wq), _p(wk), _p(wv), _p(w6), C, _stream())
+        wqkv_p, entry = w6, "dhz_fused_window_attn_fwd6"
     timing = ops.KERNEL_TIMING.get("dhz_fused_window_attn_fwd") if ops.KERNEL_TIMING is not None else None
     if timing is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    _lib.call("dhz_fused_window_attn_fwd", _p(x), _p(gamma), _p(beta), _p(wqkv_p), _p(bqkv), _p(wo_p), _p(bo), _p(idx),
+    _lib.call(entry, _p(x), _p(gamma), _p(beta), _p(wqkv_p), _p(bqkv), _p(wo_p), _p(bo), _p(idx),
               _p(bias), _p(mask), _p(dscale), _p(out), _p(xn), _p(qkv), _p(cx), _p(stats), _p(rank), B, Hres, Wres, C,
               shift, _stream())
     if timing is not None:
