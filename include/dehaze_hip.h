@@ -107,14 +107,17 @@ int dhz_fused_window_attn_fwd(const float* x, const float* gamma, const float* b
                               void* stream);
 /* The same kernel with the Q / K / V product of every head on the bf16 matrix pipe in the six-term form of dhz_linear_fwd_split6 (three bf16
  * truncation pieces per operand value, products hh hm mh hl lh mm, dropped terms <= 2^-24 relative, fp32 accumulation: fp32-class results).
- * wqkv6_p: the planes of the three weights in the kernel's fragment order (dhz_fused_attn_prepack6: (C/32) (C/64) 36 KiB of bf16), brought ONCE
- * per workgroup and head by LDS-DMA into tiles that are dead during the projection - not once per wave through L1.  Every other argument as
- * dhz_fused_window_attn_fwd (wo_p from dhz_fused_attn_prepack).  C = 64. */
+ * So is the out-projection (its planes in the S tile while P V runs).  wqkv6_p: the planes of the four weights in the kernel's fragment order
+ * (dhz_fused_attn_prepack6: (C/32) ((C/64) 36 + (C/16) 3) KiB of bf16), brought ONCE per workgroup and head by LDS-DMA into tiles that are dead
+ * at that point - not once per wave through L1.  Every other argument as dhz_fused_window_attn_fwd (wo_p is not read).  C = 64. */
 int dhz_fused_window_attn_fwd6(const float* x, const float* gamma, const float* beta, const void* wqkv6_p, const float* bqkv,
                                const float* wo_p, const float* bo, const uint8_t* idx, const float* bias, const float* mask,
                                const float* drop_scale, float* out, float* xn_save, float* qkv_save, float* ctx_save, float* stats_save,
                                uint8_t* rank_save, int B, int Hres, int Wres, int C, int shift, void* stream);
-int dhz_fused_attn_prepack6(const float* wq, const float* wk, const float* wv, void* wqkv6_p, int C, void* stream);
+int dhz_fused_attn_prepack6(const float* wq, const float* wk, const float* wv, const float* wo, void* wqkv6_p, int C, void* stream);
+/* ... for n <= 16 blocks in ONE launch (host arrays of device pointers). */
+int dhz_fused_attn_prepack6_multi(const float* const* wq, const float* const* wk, const float* const* wv, const float* const* wo,
+                                  void* const* wqkv6_p, const int* C, int n, void* stream);
 
 /* Fused BACKWARD of the same branch at C = 32 (one head): given d(out) it recomputes LayerNorm, Q/K/V, the selected scores, both
  *     softmaxes and P V per window from x and the 64 selection ranks the forward saved (rank_save of dhz_fused_window_attn_fwd

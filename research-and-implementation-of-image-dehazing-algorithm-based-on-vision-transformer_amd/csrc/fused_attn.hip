@@ -124,6 +124,9 @@ __global__ __launch_bounds__(256 * NW, NW == 2 ? 1 : (C == 64 ? 3 : (C == 128 ? 
     constexpr int CPT = C / 4;            // floats per thread in the token-row phases (4 threads per token)
     constexpr int KS = C / 4;             // k-steps of the QKV GEMM
     constexpr int KS4 = KS / 4;
+    constexpr int P6_QKV_BYTES = (C / 32) * (C / 64 > 0 ? C / 64 : 1) * P6_RUNS * 1024;     // the Q / K / V planes; the out-projection's follow
+    constexpr int P6O_RUNS = (C / 16) * 3;                                                    // 1 KiB runs of one head's out-projection planes
+    constexpr bool P6O = P6 && P6O_RUNS * 1024 <= (int)sizeof(float) * NT * SS && P6O_RUNS % 4 == 0;   // ... fit the S tile (C <= 64)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     // NW = 2: a 512-thread workgroup carries TWO windows, one per half (threads 0..255 / 256..511), each with its own LDS tiles; the
     // halves run the same phases in lockstep (the barriers are the workgroup's).  t, w, lane are the indices INSIDE the half.
@@ -458,6 +461,15 @@ __global__ __launch_bounds__(256 * NW, NW == 2 ? 1 : (C == 64 ? 3 : (C == 128 ? 
                 for (int i = 0; i < CPT / 4; ++i) xnext[i] = xp[i];
             }
             __syncthreads();                       // P complete
+            if constexpr (P6O) {
+                // the out-projection's weight planes of this head (C/16 column tiles x 3 pieces, 1 KiB each) into the S tile - dead since
+                // the softmax read it - while P V runs; they are waited for in front of the next barrier
+                const unsigned char* src = reinterpret_cast<const unsigned char*>(wqkv_p) + P6_QKV_BYTES + (size_t)h * P6O_RUNS * 1024 + lane * 16;
+#pragma unroll
+                for (int r = 0; r < P6O_RUNS / 4; ++r)
+                    __builtin_amdgcn_global_load_lds((glb_void_*)(src + (w + 4 * r) * 1024),
+                                                     (lds_void_*)(reinterpret_cast<unsigned char*>(sm.s) + (w + 4 * r) * 1024), 16, 0, 0);
+            }
             // ---- 2e. O_h = P V_h (32 x 32): one 16x16 tile per wave, into the dead Q tile
             float* O = sm.q;                       // 32 x HS (Q_h was last read before the first barrier of this head)
             if (!(abl & 32)) {
@@ -471,7 +483,8 @@ __global__ __launch_bounds__(256 * NW, NW == 2 ? 1 : (C == 64 ? 3 : (C == 128 ? 
 #pragma unroll
                 for (int r = 0; r < 4; ++r) O[(16 * tr + 4 * g + r) * HS + 16 * tc + i16] = acc[r];
             }
-            __syncthreads();                       // O complete
+            if constexpr (P6O) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();                       // O complete (P6O: and the out-projection planes)
             // ---- 3. out-projection partial: oacc += ctx_h Wo[:, 32h:32h+32]^T ; ctx row = selected row or mean row
             if (!(abl & 64)) {
                 const int rk = __shfl(myrank, 16 * w + i16);
@@ -479,7 +492,21 @@ __global__ __launch_bounds__(256 * NW, NW == 2 ? 1 : (C == 64 ? 3 : (C == 128 ? 
                 float a[8];
                 ld4(&O[srow * HS + 8 * g], &a[0]);
                 ld4(&O[srow * HS + 8 * g + 4], &a[4]);
-                if constexpr (WREG) {
+                if constexpr (P6O) {
+                    u32x4_ ao[3];
+                    split8x3_(a, ao[0], ao[1], ao[2]);                 // the lane's 8 consecutive k of its context row ARE a bf16 A fragment
+                    const unsigned char* const Wimg = reinterpret_cast<const unsigned char*>(sm.s);
+                    u32x4_ bo6[C / 16][3];
+#pragma unroll
+                    for (int tn = 0; tn < C / 16; ++tn)
+#pragma unroll
+                        for (int pc = 0; pc < 3; ++pc) bo6[tn][pc] = *reinterpret_cast<const u32x4_*>(Wimg + (tn * 3 + pc) * 1024 + lane * 16);
+                    constexpr int TA[6] = {2, 0, 1, 0, 1, 0}, TB[6] = {0, 2, 1, 1, 0, 0};
+#pragma unroll
+                    for (int term = 0; term < 6; ++term)
+#pragma unroll
+                        for (int tn = 0; tn < C / 16; ++tn) oacc[tn] = mfma_b16(ao[TA[term]], bo6[tn][TB[term]], oacc[tn]);
+                } else if constexpr (WREG) {
 #pragma unroll
                     for (int s4 = 0; s4 < 2; ++s4) {
 #pragma unroll
@@ -595,27 +622,49 @@ __global__ void prepack_weights_kernel(const float* __restrict__ wq, const float
 // six-term planes of the Q / K / V weights in the fragment order of the P6 kernel: run (1 KiB = 64 lanes x 8 bf16) index
 //   ((h (C/64) + ch) 36 + (j 2 + kbl) 3 + piece),   element (lane = 16 g + i16, e) = piece of W_m[32 h + 16 (j & 1) + i16][g C/4 + 8 (2 ch + kbl) + e],
 // m = j >> 1 (Q, K, V), pieces by truncation (hi + mid + lo == W exactly).  One thread per (run without piece, lane, e).
-__global__ void prepack6_kernel(const float* __restrict__ wq, const float* __restrict__ wk, const float* __restrict__ wv,
-                                uint16_t* __restrict__ out, int C) {
+// Behind them the out-projection's planes: run ((h C/16 + tn) 3 + piece), element = piece of Wo[16 tn + i16][32 h + 8 g + e].
+__device__ __forceinline__ void prepack6_element(const float* __restrict__ wq, const float* __restrict__ wk, const float* __restrict__ wv,
+                                                 const float* __restrict__ wo, uint16_t* __restrict__ out, int C, int t) {
     const int n = (C / 32) * (C / 64) * 12 * 512;              // (h, ch, j, kbl) x 64 lanes x 8 elements
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n) return;
-    const int e = t & 7, lane = (t >> 3) & 63;
-    int rest = t >> 9;
-    const int kbl = rest & 1; rest >>= 1;
-    const int j = rest % 6; rest /= 6;
-    const int ch = rest % (C / 64), h = rest / (C / 64);
-    const int i16 = lane & 15, g = lane >> 4;
-    const float* W = (j >> 1) == 0 ? wq : ((j >> 1) == 1 ? wk : wv);
-    const float x = W[(size_t)(32 * h + 16 * (j & 1) + i16) * C + g * (C / 4) + 8 * (2 * ch + kbl) + e];
+    const int no = (C / 32) * (C / 16) * 512;                  // (h, tn) x 64 lanes x 8 elements
+    if (t >= n + no) return;
+    float x;
+    uint16_t* o;
+    if (t >= n) {
+        const int f = t - n;
+        const int e = f & 7, lane = (f >> 3) & 63;
+        const int rest = f >> 9;
+        const int tn = rest % (C / 16), h = rest / (C / 16);
+        const int i16 = lane & 15, g = lane >> 4;
+        x = wo[(size_t)(16 * tn + i16) * C + 32 * h + 8 * g + e];
+        o = out + (size_t)3 * n + ((size_t)(h * (C / 16) + tn) * 3) * 512 + lane * 8 + e;
+    } else {
+        const int e = t & 7, lane = (t >> 3) & 63;
+        int rest = t >> 9;
+        const int kbl = rest & 1; rest >>= 1;
+        const int j = rest % 6; rest /= 6;
+        const int ch = rest % (C / 64), h = rest / (C / 64);
+        const int i16 = lane & 15, g = lane >> 4;
+        const float* W = (j >> 1) == 0 ? wq : ((j >> 1) == 1 ? wk : wv);
+        x = W[(size_t)(32 * h + 16 * (j & 1) + i16) * C + g * (C / 4) + 8 * (2 * ch + kbl) + e];
+        o = out + (((size_t)(h * (C / 64) + ch) * 12 + (j * 2 + kbl)) * 3) * 512 + lane * 8 + e;
+    }
     const float hi = __uint_as_float(__float_as_uint(x) & 0xffff0000u);
     const float r1 = x - hi;
     const float mid = __uint_as_float(__float_as_uint(r1) & 0xffff0000u);
     const float r2 = r1 - mid;
-    const size_t run = ((size_t)(h * (C / 64) + ch) * 12 + (j * 2 + kbl)) * 3;
-    out[(run + 0) * 512 + lane * 8 + e] = (uint16_t)(__float_as_uint(x) >> 16);
-    out[(run + 1) * 512 + lane * 8 + e] = (uint16_t)(__float_as_uint(r1) >> 16);
-    out[(run + 2) * 512 + lane * 8 + e] = (uint16_t)(__float_as_uint(r2) >> 16);
+    o[0] = (uint16_t)(__float_as_uint(x) >> 16);
+    o[512] = (uint16_t)(__float_as_uint(r1) >> 16);
+    o[1024] = (uint16_t)(__float_as_uint(r2) >> 16);
+}
+__global__ void prepack6_kernel(const float* __restrict__ wq, const float* __restrict__ wk, const float* __restrict__ wv,
+                                const float* __restrict__ wo, uint16_t* __restrict__ out, int C) {
+    prepack6_element(wq, wk, wv, wo, out, C, blockIdx.x * blockDim.x + threadIdx.x);
+}
+struct Prepack6Multi { const float* wq[16]; const float* wk[16]; const float* wv[16]; const float* wo[16]; uint16_t* out[16]; int C[16]; };
+__global__ void prepack6_multi_kernel(const Prepack6Multi d) {
+    const int m = blockIdx.y;
+    prepack6_element(d.wq[m], d.wk[m], d.wv[m], d.wo[m], d.out[m], d.C[m], blockIdx.x * blockDim.x + threadIdx.x);
 }
 
 // the prepack of every fused block of one model forward in ONE launch: entry = blockIdx.y
@@ -770,6 +819,23 @@ static int fused_fwd_impl(bool p6, const float* x, const float* gamma, const flo
     return DHZ_OK;
 }
 
+extern "C" int dhz_fused_attn_prepack6_multi(const float* const* wq, const float* const* wk, const float* const* wv, const float* const* wo,
+                                             void* const* wqkv6_p, const int* C, int n, void* stream) {
+    DHZ_REQUIRE(wq && wk && wv && wo && wqkv6_p && C && n > 0 && n <= 16, "dhz_fused_attn_prepack6_multi: null pointer or n=%d outside 1..16", n);
+    Prepack6Multi d = {};
+    int tmax = 0;
+    for (int i = 0; i < n; ++i) {
+        DHZ_REQUIRE(wq[i] && wk[i] && wv[i] && wo[i] && wqkv6_p[i], "dhz_fused_attn_prepack6_multi: entry %d: null pointer", i);
+        DHZ_REQUIRE(C[i] == 64 || C[i] == 128, "dhz_fused_attn_prepack6_multi: entry %d: C=%d unsupported (64, 128)", i, C[i]);
+        d.wq[i] = wq[i]; d.wk[i] = wk[i]; d.wv[i] = wv[i]; d.wo[i] = wo[i]; d.out[i] = (uint16_t*)wqkv6_p[i]; d.C[i] = C[i];
+        const int t = (C[i] / 32) * (C[i] / 64) * 12 * 512 + (C[i] / 32) * (C[i] / 16) * 512;
+        tmax = t > tmax ? t : tmax;
+    }
+    hipLaunchKernelGGL(prepack6_multi_kernel, dim3((tmax + 255) / 256, n), dim3(256), 0, (hipStream_t)stream, d);
+    DHZ_CHECK_LAUNCH("dhz_fused_attn_prepack6_multi");
+    return DHZ_OK;
+}
+
 extern "C" int dhz_fused_window_attn_fwd(const float* x, const float* gamma, const float* beta, const float* wqkv_p,
                                          const float* bqkv, const float* wo_p, const float* bo, const uint8_t* idx,
                                          const float* bias, const float* mask, const float* drop_scale, float* out,
@@ -788,11 +854,11 @@ extern "C" int dhz_fused_window_attn_fwd6(const float* x, const float* gamma, co
                           ctx_save, stats_save, rank_save, B, Hres, Wres, C, shift, stream);
 }
 
-extern "C" int dhz_fused_attn_prepack6(const float* wq, const float* wk, const float* wv, void* wqkv6_p, int C, void* stream) {
-    DHZ_REQUIRE(wq && wk && wv && wqkv6_p, "dhz_fused_attn_prepack6: null pointer");
+extern "C" int dhz_fused_attn_prepack6(const float* wq, const float* wk, const float* wv, const float* wo, void* wqkv6_p, int C, void* stream) {
+    DHZ_REQUIRE(wq && wk && wv && wo && wqkv6_p, "dhz_fused_attn_prepack6: null pointer");
     DHZ_REQUIRE(C == 64 || C == 128, "dhz_fused_attn_prepack6: C=%d unsupported (64, 128)", C);
-    const int n = (C / 32) * (C / 64) * 12 * 512;
-    hipLaunchKernelGGL(prepack6_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, wq, wk, wv, (uint16_t*)wqkv6_p, C);
+    const int n = (C / 32) * (C / 64) * 12 * 512 + (C / 32) * (C / 16) * 512;
+    hipLaunchKernelGGL(prepack6_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, wq, wk, wv, wo, (uint16_t*)wqkv6_p, C);
     DHZ_CHECK_LAUNCH("dhz_fused_attn_prepack6");
     return DHZ_OK;
 }

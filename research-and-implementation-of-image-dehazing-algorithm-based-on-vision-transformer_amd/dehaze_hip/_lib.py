@@ -34,7 +34,8 @@ SIGNATURES = {
                                   c_i, c_i, c_i, c_i, c_i, c_p],
     "dhz_fused_window_attn_fwd6": [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_p, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_p,
                                    c_i, c_i, c_i, c_i, c_i, c_p],
-    "dhz_fused_attn_prepack6": [c_f, c_f, c_f, c_p, c_i, c_p],
+    "dhz_fused_attn_prepack6": [c_f, c_f, c_f, c_f, c_p, c_i, c_p],
+    "dhz_fused_attn_prepack6_multi": [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p],
     "dhz_fused_attn_bwd_parts": [c_i],
     "dhz_fused_attn_bwd_prepack": [c_f, c_f, c_f, c_f, c_f, c_i, c_p],
     "dhz_fused_window_attn_bwd": [c_f] * 11 + [c_f] * 12 + [c_i, c_i, c_i, c_i, c_i, c_p],

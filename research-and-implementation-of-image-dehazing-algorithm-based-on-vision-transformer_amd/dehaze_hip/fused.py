@@ -159,7 +159,23 @@ def stage_block_operands(entries, device):
                       ctypes.cast((ctypes.c_int * len(part))(*[H for (_, H), _ in part]), ctypes.c_void_p), len(part), _stream())
         for (t, _), o in zip(tabs, outs):
             STAGED_BIAS[id(t)] = (t, o)          # (the parameter itself rides along: its id cannot be reused while the entry lives)
-    packs = [(w, C) for _, _, w, C in entries if w is not None]
+    p6 = lambda C: ATTN_FUSED_P6 and C in ATTN_FUSED_P6_C
+    packs6 = [(w, C) for _, _, w, C in entries if w is not None and p6(C)]
+    if packs6:
+        n6 = lambda C: (C // 32) * ((C // 64) * 36 + (C // 16) * 3) * 512
+        flat = torch.empty((sum(n6(C) for _, C in packs6),), device=device, dtype=torch.bfloat16)
+        outs, off = [], 0
+        for _, C in packs6:
+            outs.append(flat[off: off + n6(C)])
+            off += n6(C)
+        for i0 in range(0, len(packs6), 16):
+            part = list(zip(packs6, outs))[i0: i0 + 16]
+            ws = [[_p(w[k].contiguous()) for (w, _), _ in part] for k in range(4)]
+            _lib.call("dhz_fused_attn_prepack6_multi", arr(ws[0]), arr(ws[1]), arr(ws[2]), arr(ws[3]), arr([_p(o) for _, o in part]),
+                      ctypes.cast((ctypes.c_int * len(part))(*[C for (_, C), _ in part]), ctypes.c_void_p), len(part), _stream())
+        for (w, _), o in zip(packs6, outs):
+            STAGED_PREPACK[id(w[0])] = (w[0], o)
+    packs = [(w, C) for _, _, w, C in entries if w is not None and not p6(C)]
     if packs:
         flat = torch.empty((sum(4 * C * C for _, C in packs),), device=device, dtype=torch.float32)
         outs, off = [], 0
@@ -197,8 +213,20 @@ def _attn_fused_fwd(train, x, gamma, beta, wq, bq, wk, bk, wv, bv, wo, bo, table
     dev = x.device
     T = B * L
     f32 = dict(device=dev, dtype=torch.float32)
+    use6 = ATTN_FUSED_P6 and C in ATTN_FUSED_P6_C
+    n6 = (C // 32) * ((C // 64) * 36 + (C // 16) * 3) * 512
     hit = STAGED_PREPACK.pop(id(wq), None)
-    if hit is not None and hit[0] is wq and hit[1][0].numel() == 3 * C * C and hit[1][0].device == dev:
+    if hit is not None and hit[0] is not wq:
+        hit = None
+    if use6:
+        # the QKV and out-projection products of every head on the bf16 matrix pipe (six-term, fp32-class): planes in the kernel's fragment order
+        if hit is not None and torch.is_tensor(hit[1]) and hit[1].numel() == n6 and hit[1].device == dev:
+            wqkv_p = hit[1]
+        else:
+            wqkv_p = torch.empty(n6, device=dev, dtype=torch.bfloat16)
+            _lib.call("dhz_fused_attn_prepack6", _p(wq), _p(wk), _p(wv), _p(wo), _p(wqkv_p), C, _stream())
+        wo_p = wqkv_p                                           # (not read by the six-term kernel; a valid pointer for the argument check)
+    elif hit is not None and not torch.is_tensor(hit[1]) and hit[1][0].numel() == 3 * C * C and hit[1][0].device == dev:
         wqkv_p, wo_p = hit[1]
     else:
         wqkv_p = torch.empty(3 * C * C, **f32)
@@ -216,12 +244,7 @@ def _attn_fused_fwd(train, x, gamma, beta, wq, bq, wk, bk, wv, bv, wo, bo, table
             cx = torch.empty((T, C), **f32)
             stats = torch.empty((T, 2), **f32)
         rank = torch.empty(((T // NTOK) * H * NTOK,), device=dev, dtype=torch.uint8)
-    entry = "dhz_fused_window_attn_fwd"
-    if ATTN_FUSED_P6 and C in ATTN_FUSED_P6_C:
-        # the QKV product of every head on the bf16 matrix pipe (six-term, fp32-class): planes in the kernel's fragment order
-        w6 = torch.empty((C // 32) * (C // 64) * 36 * 512, device=dev, dtype=torch.bfloat16)
-        _lib.call("dhz_fused_attn_prepack6", _p(wq), _p(wk), _p(wv), _p(w6), C, _stream())
-        wqkv_p, entry = w6, "dhz_fused_window_attn_fwd6"
+    entry = "dhz_fused_window_attn_fwd6" if use6 else "dhz_fused_window_attn_fwd"
     timing = ops.KERNEL_TIMING.get("dhz_fused_window_attn_fwd") if ops.KERNEL_TIMING is not None else None
     if timing is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
