@@ -313,6 +313,11 @@ int dhz_ln_partition_bwd_dt(const void* dxw, const void* x, const float* gamma, 
 int dhz_ln_partition_bwd_lay(const void* dxw, const void* x, const float* gamma, const float* stats, const void* dres, void* dx,
                              float* dgamma, float* dbeta, int B, int Hres, int Wres, int C, int shift, int partition, int dres_windowed,
                              int dx_windowed, int dx_shift, int dtype, void* stream);
+/* ... with a SECOND output: dx2 (may be NULL) receives scale2[image] * dx in the window order of dx_shift (scale2 NULL = 1) - the scaled,
+ * window-ordered d(out) operand of the out-projection's backward products for storage types whose GEMMs take no row factor (bf16). */
+int dhz_ln_partition_bwd_lay2(const void* dxw, const void* x, const float* gamma, const float* stats, const void* dres, void* dx,
+                              float* dgamma, float* dbeta, int B, int Hres, int Wres, int C, int shift, int partition, int dres_windowed,
+                              int dx_windowed, int dx_shift, void* dx2, const float* scale2, int dtype, void* stream);
 int dhz_reverse_residual_fwd_dt(const void* yw, const void* shortcut, const float* scale, void* out, int B, int Hres, int Wres,
                                 int C, int shift, int partition, int dtype, void* stream);
 int dhz_reverse_residual_bwd_dt(const void* dout, const float* scale, void* dyw, int B, int Hres, int Wres, int C, int shift,

@@ -81,9 +81,12 @@ __global__ __launch_bounds__(256) void ln_partition_bwd_kernel(const T* __restri
                                                                const T* dres, T* dx,
                                                                float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                                int ntok, int Hres, int Wres, int C, int shift, int lpt,
-                                                               int partition, int lay) {
+                                                               int partition, int lay, T* __restrict__ dx2,
+                                                               const float* __restrict__ scale2) {
     // lay (dhz_ln_partition_bwd_lay): bit 0 - dres lies in the window order of (shift, partition) like dxw; bit 1 - dx is WRITTEN in
-    // the window order of shift (lay >> 8) on the same map: the layout the consumer (the attention branch's backward) reads
+    // the window order of shift (lay >> 8) on the same map: the layout the consumer (the attention branch's backward) reads.
+    // dx2 (optional): a SECOND copy of dx in that window order, times scale2[image] - the scaled, window-ordered d(out) operand of the
+    // out-projection's backward products where their kernels take no row factor (bf16 storage)
     __shared__ float red[2 * 1024];                            // dgamma | dbeta  (C <= 1024)
     const int tpw = 64 / lpt;
     const int lane = threadIdx.x & 63;
@@ -105,8 +108,8 @@ __global__ __launch_bounds__(256) void ln_partition_bwd_kernel(const T* __restri
     // atomics (<= 2 workgroups per CU) a single group left only ~24 KB per CU in flight.
     struct Group {
         float4 xh[VPL], dy[VPL], rs[VPL];
-        float mean, rstd;
-        int tok, drow;
+        float mean, rstd, sc2;
+        int tok, drow, drow2;
         bool ok;
     };
     auto load = [&](int base, Group& G) {
@@ -119,6 +122,10 @@ __global__ __launch_bounds__(256) void ln_partition_bwd_kernel(const T* __restri
             const size_t src = partition ? (size_t)bimg * HW + window_slot(hh, ww, Hres, Wres, shift) : (size_t)G.tok;
             const size_t rsrc = (lay & 1) ? src : (size_t)G.tok;
             G.drow = (lay & 2) ? bimg * HW + window_slot(hh, ww, Hres, Wres, lay >> 8) : G.tok;
+            if (dx2) {
+                G.drow2 = bimg * HW + window_slot(hh, ww, Hres, Wres, lay >> 8);
+                G.sc2 = scale2 ? scale2[bimg] : 1.f;
+            }
 #pragma unroll
             for (int v = 0; v < VPL; ++v) {
                 G.xh[v] = ld4(x + (size_t)G.tok * C + quad_col<WIDE>(li, v, lpt));
@@ -160,6 +167,7 @@ __global__ __launch_bounds__(256) void ln_partition_bwd_kernel(const T* __restri
                 r.w = rstd * (G.dy[v].w - s1 - G.xh[v].w * s2);
                 if (dres) { r.x += G.rs[v].x; r.y += G.rs[v].y; r.z += G.rs[v].z; r.w += G.rs[v].w; }
                 st4(dx + (size_t)G.drow * C + quad_col<WIDE>(li, v, lpt), r);
+                if (dx2) st4(dx2 + (size_t)G.drow2 * C + quad_col<WIDE>(li, v, lpt), make_float4(G.sc2 * r.x, G.sc2 * r.y, G.sc2 * r.z, G.sc2 * r.w));
             }
         }
     };
@@ -696,17 +704,19 @@ extern "C" int dhz_ln_partition_fwd(const float* x, const float* gamma, const fl
     return dhz_ln_partition_fwd_dt(x, gamma, beta, xw, stats, B, Hres, Wres, C, shift, partition, DHZ_F32, stream);
 }
 
-extern "C" int dhz_ln_partition_bwd_lay(const void* dxw, const void* x, const float* gamma, const float* stats,
-                                        const void* dres, void* dx, float* dgamma, float* dbeta, int B, int Hres, int Wres,
-                                        int C, int shift, int partition, int dres_windowed, int dx_windowed, int dx_shift, int dtype,
-                                        void* stream) {
+extern "C" int dhz_ln_partition_bwd_lay2(const void* dxw, const void* x, const float* gamma, const float* stats,
+                                         const void* dres, void* dx, float* dgamma, float* dbeta, int B, int Hres, int Wres,
+                                         int C, int shift, int partition, int dres_windowed, int dx_windowed, int dx_shift, void* dx2,
+                                         const float* scale2, int dtype, void* stream) {
+    DHZ_REQUIRE(!dx2 || (Hres % 8 == 0 && Wres % 8 == 0 && dx_shift >= 0 && dx_shift < 8 && dx2 != dres && dx2 != dx),
+                "dhz_ln_partition_bwd_lay2: the second (window-ordered) output needs an Hres x Wres map of multiples of 8, a shift in [0, 8) and its own buffer");
     DHZ_REQUIRE(dxw && x && gamma && stats && dx && dgamma && dbeta, "dhz_ln_partition_bwd: null pointer");
     DHZ_REQUIRE(B > 0 && Hres > 0 && Wres > 0 && (!partition || (Hres % 8 == 0 && Wres % 8 == 0 && shift >= 0 && shift < 8)),
                 "dhz_ln_partition_bwd: bad shape");
     DHZ_REQUIRE(!dres_windowed || partition, "dhz_ln_partition_bwd_lay: a window-ordered dres needs partition = 1");
     DHZ_REQUIRE(!dx_windowed || (Hres % 8 == 0 && Wres % 8 == 0 && dx_shift >= 0 && dx_shift < 8 && dx != dres),
                 "dhz_ln_partition_bwd_lay: a window-ordered dx needs an Hres x Wres map of multiples of 8, a shift in [0, 8) and dx != dres");
-    const int lay = (dres_windowed ? 1 : 0) | (dx_windowed ? 2 | (dx_shift << 8) : 0);
+    const int lay = (dres_windowed ? 1 : 0) | (dx_windowed ? 2 : 0) | ((dx_windowed || dx2) ? (dx_shift << 8) : 0);
     int lpt, vpl;
     DHZ_REQUIRE(ln_geometry(C, &lpt, &vpl) == 0, "dhz_ln_partition_bwd: unsupported C=%d", C);
     const int ntok = B * Hres * Wres;
@@ -720,18 +730,25 @@ extern "C" int dhz_ln_partition_bwd_lay(const void* dxw, const void* x, const fl
     grid = grid < 64 ? 64 : (grid > cap ? cap : grid);
     hipStream_t s = (hipStream_t)stream;
     if (wide) {
-#define LAUNCHW(V) hipLaunchKernelGGL((ln_partition_bwd_kernel<V, bf16s, true>), dim3(grid), dim3(256), 0, s, (const bf16s*)dxw, (const bf16s*)x, gamma, stats, (const bf16s*)dres, (bf16s*)dx, dgamma, dbeta, ntok, Hres, Wres, C, shift, lpt, partition, lay)
+#define LAUNCHW(V) hipLaunchKernelGGL((ln_partition_bwd_kernel<V, bf16s, true>), dim3(grid), dim3(256), 0, s, (const bf16s*)dxw, (const bf16s*)x, gamma, stats, (const bf16s*)dres, (bf16s*)dx, dgamma, dbeta, ntok, Hres, Wres, C, shift, lpt, partition, lay, (bf16s*)dx2, scale2)
         if (vpw == 2) LAUNCHW(2); else LAUNCHW(4);
 #undef LAUNCHW
         DHZ_CHECK_LAUNCH("dhz_ln_partition_bwd");
         return DHZ_OK;
     }
-#define LAUNCH(V) hipLaunchKernelGGL((ln_partition_bwd_kernel<V, T>), dim3(grid), dim3(256), 0, s, (const T*)dxw, (const T*)x, gamma, stats, (const T*)dres, (T*)dx, dgamma, dbeta, ntok, Hres, Wres, C, shift, lpt, partition, lay)
+#define LAUNCH(V) hipLaunchKernelGGL((ln_partition_bwd_kernel<V, T>), dim3(grid), dim3(256), 0, s, (const T*)dxw, (const T*)x, gamma, stats, (const T*)dres, (T*)dx, dgamma, dbeta, ntok, Hres, Wres, C, shift, lpt, partition, lay, (T*)dx2, scale2)
     DT_SWITCH(dtype, "dhz_ln_partition_bwd",
               switch (vpl) { case 1: LAUNCH(1); break; case 2: LAUNCH(2); break; case 3: LAUNCH(3); break; default: LAUNCH(4); });
 #undef LAUNCH
     DHZ_CHECK_LAUNCH("dhz_ln_partition_bwd");
     return DHZ_OK;
+}
+extern "C" int dhz_ln_partition_bwd_lay(const void* dxw, const void* x, const float* gamma, const float* stats,
+                                        const void* dres, void* dx, float* dgamma, float* dbeta, int B, int Hres, int Wres,
+                                        int C, int shift, int partition, int dres_windowed, int dx_windowed, int dx_shift, int dtype,
+                                        void* stream) {
+    return dhz_ln_partition_bwd_lay2(dxw, x, gamma, stats, dres, dx, dgamma, dbeta, B, Hres, Wres, C, shift, partition, dres_windowed, dx_windowed,
+                                     dx_shift, nullptr, nullptr, dtype, stream);
 }
 extern "C" int dhz_ln_partition_bwd_dt(const void* dxw, const void* x, const float* gamma, const float* stats,
                                        const void* dres, void* dx, float* dgamma, float* dbeta, int B, int Hres, int Wres,

@@ -94,6 +94,7 @@ SIGNATURES = {
     "dhz_linear_fwd_split_res": [c_f, c_i, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
     "dhz_linear_fwd_bf16_res": [c_f, c_i, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
     "dhz_linear_dgrad_split_scaled": [c_f, c_i, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
+    "dhz_ln_partition_bwd_lay2": [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_i, c_p],
     "dhz_ln_partition_bwd_lay": [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
     "dhz_split3_planes": [c_f, c_l, c_p, c_p, c_p, c_p],
     "dhz_split3_planes_t": [c_f, c_p, c_p, c_p, c_p, c_i, c_i, c_p],

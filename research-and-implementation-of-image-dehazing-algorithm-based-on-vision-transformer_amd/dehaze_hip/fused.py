@@ -93,21 +93,30 @@ def _ready(*params):
             ops.GRAD_READY(p)
 
 
-def _ln_backward(dxn, x, gamma_p, beta_p, gamma, stats, dres, B, Hres, Wres, C, shift, partition, dres_windowed=False, dx_window=None):
+def _ln_backward(dxn, x, gamma_p, beta_p, gamma, stats, dres, B, Hres, Wres, C, shift, partition, dres_windowed=False, dx_window=None,
+                 dx2=None):
     """LayerNorm backward with the shortcut gradient folded in; d(gamma), d(beta) accumulated in place when the
     parameters are leaves (returns (dx, dgamma, dbeta) with None for gradients already accumulated).
     dres_windowed: dres lies in this call's window order; dx_window = shift: dx is WRITTEN in the window order of that shift."""
     dx = torch.empty_like(x)
     gg, gb = _grad_buf(gamma_p), _grad_buf(beta_p)
     lay = (1 if dres_windowed else 0, 0 if dx_window is None else 1, 0 if dx_window is None else int(dx_window))
+    # dx2 = (shift, scale or None): a second copy of dx in the window order of that shift, times the per-image factor; returned as dx[1]
+    d2 = None
+    if dx2 is not None:
+        d2 = torch.empty_like(x)
+        lay = (lay[0], lay[1], int(dx2[0]))
+        dx = (dx, d2)
+    tail = (_p(d2), _p(dx2[1]) if dx2 is not None else None)
+    dx0 = dx[0] if d2 is not None else dx
     if gg is not None and gb is not None:
-        _lib.call("dhz_ln_partition_bwd_lay", _p(dxn), _p(x), _p(gamma), _p(stats), _p(dres), _p(dx), _p(gg), _p(gb),
-                  B, Hres, Wres, C, shift, partition, *lay, ops._dt(x), _stream())
+        _lib.call("dhz_ln_partition_bwd_lay2", _p(dxn), _p(x), _p(gamma), _p(stats), _p(dres), _p(dx0), _p(gg), _p(gb),
+                  B, Hres, Wres, C, shift, partition, *lay, *tail, ops._dt(x), _stream())
         _ready(gamma_p, beta_p)
         return dx, None, None
     dgb = torch.zeros((2, C), device=x.device, dtype=torch.float32)
-    _lib.call("dhz_ln_partition_bwd_lay", _p(dxn), _p(x), _p(gamma), _p(stats), _p(dres), _p(dx), dgb[0].data_ptr(),
-              dgb[1].data_ptr(), B, Hres, Wres, C, shift, partition, *lay, ops._dt(x), _stream())
+    _lib.call("dhz_ln_partition_bwd_lay2", _p(dxn), _p(x), _p(gamma), _p(stats), _p(dres), _p(dx0), dgb[0].data_ptr(),
+              dgb[1].data_ptr(), B, Hres, Wres, C, shift, partition, *lay, *tail, ops._dt(x), _stream())
     return dx, dgb[0], dgb[1]
 
 
@@ -332,7 +341,7 @@ def _attn_bwd_fused(rec, dout):
     return (dx, gg, gb, gwq, gbq, gwk, gbk, gwv, gbv, gwo, gbo, dtable)
 
 
-def _attn_bwd(rec, dout, windowed=False):
+def _attn_bwd(rec, dout, windowed=False, daw_pre=None):
     """backward of the attention branch from d(out): (dx, dgamma, dbeta, dWq, dbq, dWk, dbk, dWv, dbv, dWo, dbo, dtable), None for
     gradients accumulated in place.  windowed: dout arrives in this branch's window order, WITHOUT the DropPath factor (written by
     the LeFF branch's LayerNorm backward, block()): no dhz_reverse_residual_bwd pass - the factor rides in the out-projection's
@@ -349,7 +358,12 @@ def _attn_bwd(rec, dout, windowed=False):
     T = B * Hres * Wres
     B_ = T // NTOK
     f32 = dict(device=dev, dtype=torch.float32)
-    if windowed:
+    if daw_pre is not None:
+        # (bf16 storage) the LeFF branch's LayerNorm backward wrote the scaled, window-ordered copy beside the token-order gradient
+        daw = daw_pre.view(T, C)
+        dctx = ops.gemm_dgrad(daw, wo_)
+        g_wo, g_bo = _wgrad(daw, 0, cx, wo, bo)
+    elif windowed:
         daw = dout.view(T, C)
         rs = (dscale, Hres * Wres) if dscale is not None else None
         dctx = ops.gemm_dgrad(daw, wo_, rs)
@@ -463,7 +477,7 @@ def _leff_fwd(train, x, gamma, beta, w1, b1, wd, bd, w2, b2, dscale, Hres, Wres)
     return out, rec
 
 
-def _leff_bwd(rec, dout, dx_window=None):
+def _leff_bwd(rec, dout, dx_window=None, dx2=None):
     """the mirror sequence with in-place weight gradients and the shortcut gradient folded into the LayerNorm backward (no autograd
     accumulation kernels): (dx, dgamma, dbeta, dW1, db1, dWd, dbd, dW2, db2).  dx_window = shift: dx is written in the window order
     of that shift on the Hres x Wres map (block(): what the attention branch's backward reads)."""
@@ -500,7 +514,9 @@ def _leff_bwd(rec, dout, dx_window=None):
         g_wd, g_bd = dwb[:Ch * 9].view(Ch, 1, 3, 3), dwb[Ch * 9:]
     dxn = ops.gemm_dgrad(du, w1_)
     g_w1, g_b1 = _wgrad(du, 0, xn, w1, b1)
-    if dx_window is None:
+    if dx2 is not None:       # dx in token order AND a scaled window-ordered copy (block(), bf16 storage): dx = (dx, copy)
+        dx, dgamma, dbeta = _ln_backward(dxn, x, gamma_p, beta_p, gamma, stats, dout, B, Hres, Wres, C, 0, 0, dx2=dx2)
+    elif dx_window is None:
         dx, dgamma, dbeta = _ln_backward(dxn, x, gamma_p, beta_p, gamma, stats, dout, B, L, 1, C, 0, 0)
     else:
         dx, dgamma, dbeta = _ln_backward(dxn, x, gamma_p, beta_p, gamma, stats, dout, B, Hres, Wres, C, 0, 0, dx_window=dx_window)
@@ -592,6 +608,7 @@ def leff_branch(x, norm, mlp, dscale, Hres, Wres):
 
 
 # ----------------------------------------------------------------------------- the whole block as one node
+DUAL_BF16 = True        # bf16 storage: window-ordered scaled gradient copy from the LeFF LayerNorm backward (False: dhz_reverse_residual_bwd)
 BLOCK_NODE = True       # False: two nodes per block (attn_branch, leff_branch) with a token-order gradient between them
 
 
@@ -622,8 +639,16 @@ class _BlockNode(Function):
         B, Hres, Wres, C, shift, H = ra.geom
         # window-order hand-over: chain backward, fp32 storage (the row-factor forms of the products), whole 64-token images
         windowed = ra.kind == "attn_chain_bwd" and dout.dtype == torch.float32 and rl.geom[4:] == (Hres, Wres) and (Hres * Wres) % 64 == 0
-        gl = _leff_bwd(rl, dout, dx_window=shift if windowed else None)
-        ga = _attn_bwd(ra, gl[0], windowed=windowed)
+        # bf16 storage (the row-factor forms do not exist there): the same LayerNorm backward writes the scaled window-ordered copy
+        # beside the token-order gradient - one more store instead of the dhz_reverse_residual_bwd pass
+        dual = (not windowed) and ra.kind == "attn_chain_bwd" and dout.dtype == ops.BF16 and rl.geom[4:] == (Hres, Wres) \
+            and Hres % 8 == 0 and Wres % 8 == 0 and DUAL_BF16
+        if dual:
+            gl = _leff_bwd(rl, dout, dx2=(shift, ra.saved[9]))          # ra.saved[9]: the attention branch's DropPath factor (or None)
+            ga = _attn_bwd(ra, gl[0][0], daw_pre=gl[0][1])
+        else:
+            gl = _leff_bwd(rl, dout, dx_window=shift if windowed else None)
+            ga = _attn_bwd(ra, gl[0], windowed=windowed)
         ra.saved = rl.saved = ()
         #      fused   x       attention parameters (11)   idx, mask, dscale, Hres, Wres, shift, H      LeFF parameters (8)   dscale, Hres, Wres, grad_mode
         return (None, ga[0]) + ga[1:] + (None,) * 7 + gl[1:] + (None,) * 4

@@ -44,14 +44,15 @@ class DropPath(nn.Module):
         if self.drop_prob == 0. or not self.training:
             return None
         keep = 1 - self.drop_prob
-        r = x.new_empty((x.shape[0],)).bernoulli_(keep)
+        # always fp32 (the kernels read `const float* scale`; with bf16 token storage x.new_empty would hand them a bf16 vector)
+        r = torch.empty((x.shape[0],), device=x.device, dtype=torch.float32).bernoulli_(keep)
         if keep > 0 and self.scale_by_keep:
             r.div_(keep)
         return r
 
     def forward(self, x):
         s = self.sample_scale(x)
-        return x if s is None else x * s.view((-1,) + (1,) * (x.ndim - 1))
+        return x if s is None else x * s.to(x.dtype).view((-1,) + (1,) * (x.ndim - 1))
 
 
 def n_top(L, factor=5):

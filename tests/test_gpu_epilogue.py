@@ -241,3 +241,34 @@ def test_residual_epilogue_bf16_vs_fp64(B, H, W, K, N, windowed, shift, scaled):
     if scaled:
         rows = torch.arange(T, device=dev).view(B, H * W)[1]
         assert torch.equal(out[rows], res[rows])
+
+
+def test_bf16_block_dual_gradient_copy():
+    """bf16 storage (config 4): the LeFF LayerNorm backward writes the scaled, window-ordered gradient copy for the attention branch's
+    backward (dhz_ln_partition_bwd_lay2) instead of a dhz_reverse_residual_bwd pass: same gradients up to one bf16 rounding (the copy is
+    rounded once from fp32, not from the rounded token-order gradient)."""
+    import My_model_1 as M1
+    from dehaze_hip import fused
+    dev = torch.device("cuda:0")
+    res = {}
+    for dual in (True, False):
+        torch.manual_seed(5)
+        blk = M1.LeWinTransformerBlock(dim=128, input_resolution=(32, 32), num_heads=4, win_size=8, shift_size=4, mlp_ratio=4., drop_path=0.3,
+                                       token_projection='linear', token_mlp='leff').to(dev).train()
+        x = torch.randn(4, 1024, 128, generator=torch.Generator().manual_seed(6)).to(dev).bfloat16().requires_grad_(True)
+        gy = torch.randn(4, 1024, 128, generator=torch.Generator().manual_seed(7)).to(dev).bfloat16()
+        old = fused.DUAL_BF16
+        fused.DUAL_BF16 = dual
+        try:
+            torch.manual_seed(99)
+            y = blk(x)
+            y.backward(gy)
+        finally:
+            fused.DUAL_BF16 = old
+        res[dual] = [y.detach().float(), x.grad.detach().float()] + [p.grad.detach().float() for p in blk.parameters() if p.grad is not None]
+    assert torch.equal(res[True][0], res[False][0])
+    for i, (u, v) in enumerate(zip(res[True][1:], res[False][1:])):
+        # bf16 has 8 significant bits: one rounding more or less per element of the hand-over is 2^-9 relative per element
+        # (absolute floors: d(b_k) is zero in exact arithmetic - bf16 rounding noise of ~1e-4 against gradients of O(1))
+        assert (u - v).abs().max().item() <= 5e-2 * v.abs().max().item() + 1e-3, (i, (u - v).abs().max().item(), v.abs().max().item())
+        assert (u - v).abs().mean().item() <= 1e-2 * v.abs().mean().item() + 1e-4, i
