@@ -54,8 +54,9 @@ def _wgrad(dy, off, x, w, b, row_scale=None):
         ops._accumulate_param_grads(dy, off, x, [(w, b)], row_scale)
         return None, None
     if mine:
-        dw = torch.zeros_like(w, memory_format=torch.contiguous_format)
-        db = torch.zeros_like(b) if b is not None else None
+        fp = w.dtype == torch.float32
+        dw = ops.zeros_f32(tuple(w.shape), w.device) if fp else torch.zeros_like(w, memory_format=torch.contiguous_format)
+        db = (ops.zeros_f32(tuple(b.shape), b.device) if fp else torch.zeros_like(b)) if b is not None else None
         ops.wgrad_into(dy, off, x, N, dw, db, row_scale)
         return dw, db
     raise RuntimeError(f"dehaze_hip: Linear weight gradient for T={T}, N={N}, K={K}: the HIP kernel needs multiples of 16 "

@@ -559,6 +559,24 @@ def shift_mask(Hres, Wres, shift, device):
 # AccumulateGrad - and therefore its post-accumulate hooks - is bypassed for those); the gradient reducer
 # installs itself here to keep its bucket bookkeeping.
 GRAD_READY = None
+# [zeroed fp32 tensor, bump offset, weakref(owner)]: FlatAdamW.zero_grad() zeroes it together with the flat gradient buffer and resets the
+# offset; zeros_f32 carves accumulation targets of the backward pass out of it (valid until the next zero_grad)
+ZERO_SCRATCH = None
+
+
+def zeros_f32(shape, device):
+    """torch.zeros(shape, fp32) - from the optimizer's pre-zeroed scratch region when one is registered for this device and has room
+    (no fill launch), else a fresh allocation.  Only for temporaries of ONE backward pass."""
+    n = 1
+    for d in shape:
+        n *= int(d)
+    zs = ZERO_SCRATCH
+    if zs is not None and zs[2]() is not None and zs[0].device == device:
+        off = (zs[1] + 7) // 8 * 8
+        if off + n <= zs[0].numel():
+            zs[1] = off + n
+            return zs[0][off: off + n].view(shape)
+    return torch.zeros(shape, device=device, dtype=torch.float32)
 
 
 def _accumulate_param_grads(dy, ldy_off, x, params, row_scale=None):
@@ -722,8 +740,9 @@ class _LinearTokens(Function):
                 _accumulate_param_grads(dy, off, x, [(w, b)])
                 grads += [None, None]
             elif mine:
-                dw = torch.zeros_like(w, memory_format=torch.contiguous_format)
-                db = torch.zeros_like(b) if b is not None else None
+                fp = w.dtype == torch.float32           # (accumulation targets of this backward pass: from the optimizer's zeroed scratch, no fill launch)
+                dw = zeros_f32(tuple(w.shape), w.device) if fp else torch.zeros_like(w, memory_format=torch.contiguous_format)
+                db = (zeros_f32(tuple(b.shape), b.device) if b.dtype == torch.float32 else torch.zeros_like(b)) if b is not None else None
                 wgrad_into(dy, off, x, N, dw, db)
                 grads += [dw, db]
             else:
@@ -885,7 +904,7 @@ class _CharbonnierClamped(Function):
         x = x.contiguous()
         y = y.contiguous()
         n = x.numel()
-        acc = torch.zeros((), device=x.device, dtype=torch.float32)
+        acc = zeros_f32((), x.device)
         clamped = torch.empty_like(x) if clamp01 else None
         _lib.call("dhz_charbonnier_fwd", _p(x), _p(y), _p(clamped), _p(acc), n, float(eps), int(clamp01), _stream())
         ctx.save_for_backward(x, y)
@@ -1023,7 +1042,7 @@ class _Conv4s2(Function):
             _lib.call("dhz_conv4s2_dgrad", _p(dy), _p(wq), _p(dx), B, H, W, Cin, Cout, _stream())
         gw = gb = None
         if w.requires_grad or (b is not None and b.requires_grad):
-            dwp = torch.zeros((Cout, 16 * Cin), device=x.device, dtype=torch.float32)
+            dwp = zeros_f32((Cout, 16 * Cin), x.device)
             inplace_b = b is not None and b.is_leaf and b.requires_grad
             if inplace_b and b.grad is None:
                 b.grad = torch.zeros_like(b)

@@ -59,7 +59,12 @@ class FlatAdamW(torch.optim.Optimizer):
         n = sum((p.numel() + 7) // 8 * 8 for p in order)
         npad = n
         fp = torch.zeros(npad, device=dev, dtype=torch.float32)
-        fg = torch.zeros(npad, device=dev, dtype=torch.float32)
+        # behind the gradients: a zeroed scratch region for the accumulation targets of the backward pass that are NOT parameter gradients
+        # in parameter layout (the resampling convolutions' weight gradients in GEMM layout, bias gradients of derived biases): zeroed by
+        # the same launch as the gradients (zero_grad), handed out by ops.zeros_f32 - a dozen fill launches per step otherwise
+        nscr = (sum(p.numel() for p in order if p.dim() == 4) + 65536 + 7) // 8 * 8
+        fg_all = torch.zeros(npad + nscr, device=dev, dtype=torch.float32)
+        fg = fg_all[:npad]
         self._offsets = {}
         off = 0
         for p in order:
@@ -72,7 +77,7 @@ class FlatAdamW(torch.optim.Optimizer):
             p.grad = fg[off:off + k].view_as(p)
             self._offsets[id(p)] = (off, k)
             off += k
-        self._flat = dict(p=fp, g=fg, m=torch.zeros_like(fp), v=torch.zeros_like(fp), n=n)
+        self._flat = dict(p=fp, g=fg, g_all=fg_all, scratch=fg_all[npad:], m=torch.zeros_like(fp), v=torch.zeros_like(fp), n=n)
 
     def _qkv_adjacent(self, order):
         """Within every attention layer put the three projection weights back to back (Wq, Wk, Wv) and the three biases
@@ -106,7 +111,8 @@ class FlatAdamW(torch.optim.Optimizer):
 
     def zero_grad(self, set_to_none=False):
         self._ensure_flat()
-        self._flat["g"].zero_()
+        self._flat["g_all"].zero_()                       # the gradients and the scratch region behind them: one launch
+        ops.ZERO_SCRATCH = [self._flat["scratch"], 0, weakref.ref(self)]
         for p in self._all:
             if id(p) not in self._offsets:
                 p.grad = None

@@ -487,7 +487,7 @@ class _ContrastTaps(Function):
             _TAP_CONST[key] = (torch.tensor([1.0 / f.numel() for f in a], dtype=torch.float32).view(k, 1).to(dev),
                                torch.tensor(list(weights), dtype=torch.float32).to(dev))
         inv_cnt, w = _TAP_CONST[key]
-        sums = torch.zeros((k, 2), device=dev, dtype=torch.float32)
+        sums = ops.zeros_f32((k, 2), dev)          # (accumulation target of this pass: the optimizer's zeroed scratch when there is one)
         ps, ns = [], []
         for i in range(k):
             p = feats[k + i][:B].contiguous()
