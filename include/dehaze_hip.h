@@ -159,6 +159,8 @@ int dhz_bias_gather_multi(const float* const* tables, float* const* biases, cons
  * dtable: [225,H], overwritten when accumulate == 0. */
 int dhz_bias_table_grad(const float* dbias_part, int parts, float* dtable, int H, int accumulate,
                         void* stream);
+/* ... for n <= 32 blocks in ONE launch, ACCUMULATING into dtable[i] (host arrays; the accumulate = 1 form of dhz_bias_table_grad per entry). */
+int dhz_bias_table_grad_multi(const float* const* dbias_part, const int* parts, float* const* dtable, const int* heads, int n, void* stream);
 
 /* K9  InputProj: Conv2d(3, E, 3x3, padding 1) + LeakyReLU(slope) from the NCHW image into the token layout, M1:659-682
  *     (replaces aten::convolution + aten::leaky_relu_ + the NCHW -> token copy), E = 32 or 64.

@@ -637,6 +637,35 @@ __global__ __launch_bounds__(256) void bias_table_grad_kernel(const float* __res
     if (t < 225) atomicAdd(dtable + t * H + h, tab[t]);
 }
 
+// every block's table gradient of one backward pass in ONE launch (single-process runs: fused.py defers them to the end of backward)
+constexpr int TGRAD_MULTI_MAX = 32;
+struct TableGradMulti { const float* part[TGRAD_MULTI_MAX]; float* dtable[TGRAD_MULTI_MAX]; int parts[TGRAD_MULTI_MAX]; int H[TGRAD_MULTI_MAX]; };
+__global__ __launch_bounds__(256) void bias_table_grad_multi_kernel(const TableGradMulti d) {
+    __shared__ float tab[225];
+    const int m = blockIdx.z, H = d.H[m], parts = d.parts[m];
+    const int h = blockIdx.y, t = threadIdx.x;
+    if (h >= H) return;
+    const int z = min(max(parts / H / 4, 1), 128);            // the slices dhz_bias_table_grad would launch for this entry
+    if ((int)blockIdx.x >= z) return;
+    const float* __restrict__ part = d.part[m];
+    if (t < 225) tab[t] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int e4 = q * 256 + t;
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int p = h + H * blockIdx.x; p < parts; p += H * z) {
+            const float4 v = reinterpret_cast<const float4*>(part + (size_t)p * NT * NT)[e4];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        const int e = e4 * 4, i = e >> 6, j = e & 63;
+        const int rel = ((i >> 3) - (j >> 3) + 7) * 15 + ((i & 7) - (j & 7) + 7);
+        atomicAdd(&tab[rel], s.x); atomicAdd(&tab[rel - 1], s.y); atomicAdd(&tab[rel - 2], s.z); atomicAdd(&tab[rel - 3], s.w);
+    }
+    __syncthreads();
+    if (t < 225) atomicAdd(d.dtable[m] + t * H + h, tab[t]);
+}
+
 __global__ void shift_mask_kernel(float* __restrict__ mask, int Hres, int Wres, int shift) {
     // mask[w][i][j]; one thread per element
     const int nWw = Wres >> 3;
@@ -806,6 +835,26 @@ extern "C" int dhz_bias_table_grad(const float* dbias_part, int parts, float* dt
     if (z > 128) z = 128;
     hipLaunchKernelGGL(bias_table_grad_kernel, dim3(z, H), dim3(256), 0, s, dbias_part, parts, dtable, H);
     DHZ_CHECK_LAUNCH("dhz_bias_table_grad");
+    return DHZ_OK;
+}
+
+extern "C" int dhz_bias_table_grad_multi(const float* const* dbias_part, const int* parts, float* const* dtable, const int* heads, int n,
+                                         void* stream) {
+    DHZ_REQUIRE(dbias_part && parts && dtable && heads && n > 0 && n <= TGRAD_MULTI_MAX, "dhz_bias_table_grad_multi: null pointer or n=%d outside 1..%d",
+                n, TGRAD_MULTI_MAX);
+    TableGradMulti d = {};
+    int hmax = 0, zmax = 1;
+    for (int i = 0; i < n; ++i) {
+        DHZ_REQUIRE(dbias_part[i] && dtable[i] && heads[i] > 0 && parts[i] > 0 && parts[i] % heads[i] == 0,
+                    "dhz_bias_table_grad_multi: entry %d: bad arguments", i);
+        d.part[i] = dbias_part[i]; d.dtable[i] = dtable[i]; d.parts[i] = parts[i]; d.H[i] = heads[i];
+        hmax = heads[i] > hmax ? heads[i] : hmax;
+        int z = parts[i] / heads[i] / 4;
+        z = z < 1 ? 1 : (z > 128 ? 128 : z);
+        zmax = z > zmax ? z : zmax;
+    }
+    hipLaunchKernelGGL(bias_table_grad_multi_kernel, dim3(zmax, hmax, n), dim3(256), 0, (hipStream_t)stream, d);
+    DHZ_CHECK_LAUNCH("dhz_bias_table_grad_multi");
     return DHZ_OK;
 }
 

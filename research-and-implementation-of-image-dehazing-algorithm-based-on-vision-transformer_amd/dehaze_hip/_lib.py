@@ -45,6 +45,7 @@ SIGNATURES = {
     "dhz_bias_gather_multi": [c_p, c_p, c_p, c_i, c_p],
     "dhz_fused_attn_prepack_multi": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p],
     "dhz_bias_table_grad": [c_f, c_i, c_f, c_i, c_i, c_p],
+    "dhz_bias_table_grad_multi": [c_p, c_p, c_p, c_p, c_i, c_p],
     "dhz_shift_mask": [c_f, c_i, c_i, c_i, c_p],
     "dhz_thin_conv3x3_fwd": [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_p],
     "dhz_thin_conv3x3_dgrad": [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_p],
