@@ -215,6 +215,13 @@ int dhz_leff_fused_fwd(const float* x, const float* gamma, const float* beta, co
                        const float* wd, const float* bd, const float* w2, const float* b2, const float* drop_scale,
                        float* out, float* xn_save, float* stats_save, float* u_save, float* tp_save, float* z_save,
                        int B, int Hres, int Wres, int C, void* stream);
+/* The same kernel with its two weight products (linear1, linear2) as six-term products on the bf16 matrix pipe (the arithmetic of
+ * dhz_linear_fwd_split6: fp32-class results): w6 = the planes of both weights in the kernel's MFMA fragment order (dhz_leff_prepack6:
+ * 24 C^2 bf16), read by every wave straight from L1 / L2; the LayerNorm output and z live in LDS as bf16 piece images.  C = 32, 64. */
+int dhz_leff_fused_fwd6(const float* x, const float* gamma, const float* beta, const void* w6, const float* b1, const float* wd,
+                        const float* bd, const float* b2, const float* drop_scale, float* out, float* xn_save, float* stats_save,
+                        float* u_save, float* tp_save, float* z_save, int B, int Hres, int Wres, int C, void* stream);
+int dhz_leff_prepack6(const float* w1, const float* w2, void* w6, int C, void* stream);
 
 /* K2/K4/K5  forward and backward-data GEMMs of every token-major nn.Linear on the path (query/key/value/out
  *     projections ATT:420-422,454-458; LeFF linear1/linear2 M1:487-492,508,529; the 2x2/stride-2 transposed convolution

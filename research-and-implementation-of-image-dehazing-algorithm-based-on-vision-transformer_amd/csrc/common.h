@@ -138,6 +138,39 @@ __device__ __forceinline__ f32x4 gelu_f4(const f32x4 x) { f32x4 g, gp; gelu_both
 __device__ __forceinline__ float gelu_f(float x) { float g, gp; gelu_both(x, g, gp); return g; }
 __device__ __forceinline__ float gelu_grad_f(float x) { float g, gp; gelu_both(x, g, gp); return gp; }
 
+// ---- six-term products on the bf16 matrix pipe (csrc/split6_gemm.hip's arithmetic) for kernels that fuse a weight product: an fp32 value is
+// cut by truncation into three bf16 pieces (hi + mid + lo == x exactly); a product is hh + (hm + mh) + (hl + lh + mm), small terms first
+typedef __bf16 dhz_bf16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t dhz_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 dhz_mfma_bf16(dhz_u32x4 a, dhz_u32x4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(dhz_bf16x8, a), __builtin_bit_cast(dhz_bf16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ uint32_t dhz_pack_top(float x1, float x0) {              // (x1 & 0xffff0000) | (x0 >> 16)
+    return __builtin_amdgcn_perm(__float_as_uint(x1), __float_as_uint(x0), 0x07060302u);
+}
+// two fp32 values -> one packed pair per piece
+__device__ __forceinline__ void dhz_split2x3(float x0, float x1, uint32_t& hi, uint32_t& mid, uint32_t& lo) {
+    const float r0 = x0 - __uint_as_float(__float_as_uint(x0) & 0xffff0000u), r1 = x1 - __uint_as_float(__float_as_uint(x1) & 0xffff0000u);
+    const float q0 = r0 - __uint_as_float(__float_as_uint(r0) & 0xffff0000u), q1 = r1 - __uint_as_float(__float_as_uint(r1) & 0xffff0000u);
+    hi = dhz_pack_top(x1, x0);
+    mid = dhz_pack_top(r1, r0);
+    lo = dhz_pack_top(q1, q0);
+}
+// eight fp32 values (a lane's 8 consecutive k) -> the three MFMA operands
+__device__ __forceinline__ void dhz_split8x3(const f32x4 a, const f32x4 b, dhz_u32x4& hi, dhz_u32x4& mid, dhz_u32x4& lo) {
+    uint32_t h[4], m[4], l[4];
+    dhz_split2x3(a[0], a[1], h[0], m[0], l[0]);
+    dhz_split2x3(a[2], a[3], h[1], m[1], l[1]);
+    dhz_split2x3(b[0], b[1], h[2], m[2], l[2]);
+    dhz_split2x3(b[2], b[3], h[3], m[3], l[3]);
+    hi = dhz_u32x4{h[0], h[1], h[2], h[3]};
+    mid = dhz_u32x4{m[0], m[1], m[2], m[3]};
+    lo = dhz_u32x4{l[0], l[1], l[2], l[3]};
+}
+// 64-byte-row bf16 images ([row][32 k]): the four 16-byte chunks of a row XOR-ed with {0, 2, 3, 1}[(row >> 2) & 3] - a lane group's
+// ds_read_b128 of rows i16, chunk g is conflict-free (same image as csrc/split6_gemm.hip)
+__device__ __forceinline__ int dhz_off64(int row, int ch) { return row * 64 + 16 * (ch ^ ((0x78 >> (2 * ((row >> 2) & 3))) & 3)); }
+
 // position of token (hh,ww) of an Hres x Wres map inside the (shifted) window layout:
 // shifted map coords h' = (hh - shift) mod H  (torch.roll(x, -shift): shifted[h'] = x[(h'+shift)%H]),
 // window id = (h'/8)*(W/8) + w'/8, token in window = (h'%8)*8 + w'%8.

@@ -38,30 +38,39 @@ __device__ __forceinline__ int swz(int r, int k) {
     return r * R + 32 * kb + 4 * (((k >> 2) & 7) ^ ((r >> 1) & 7)) + (k & 3);
 }
 
-template <int C, int HC, int NW>
+// L6: the two weight products as six-term products on the bf16 matrix pipe (common.h; fp32-class results).  The weights arrive as bf16
+// planes in MFMA fragment order (dhz_leff_prepack6) straight from L1 / L2 into registers - a wave needs 3 (C/32) KiB of W1 and 3 (C/16) KiB
+// of W2 per 32-channel chunk, no LDS image; the LayerNorm output is split ONCE into the wave's A fragments (registers, reused by every chunk);
+// P3 writes z as three bf16 piece images, so P4 issues no vector instruction at all.  Beside a bf16 MFMA the vector work of the SIMD's other
+// wave (GELUs, stencil) issues half of the time; beside an fp32 MFMA it does not.
+template <int C, int HC, int NW, bool L6 = false>
 struct FwdCfg {
     static constexpr int NTHR = 64 * NW;
     static constexpr int Ch = 4 * C;
     static constexpr int NCHUNK = Ch / HC;
-    static constexpr int XN_F = NPOS * C;                  // rows 180..191 read by the MFMAs fall into the next region
+    static constexpr int XN_F = L6 ? (C / 32) * 3 * 192 * 16      // L6: bf16 piece images [k-block][piece][192 rows][64 bytes] (rows 180 .. 191: junk, their results are dropped)
+                                   : NPOS * C;             // rows 180..191 read by the MFMAs fall into the next region
     static constexpr int W1_F = HC * C, W2_F = C * HC;
     static constexpr int G_F = NPOS * HC, Z_F = NINT * HC;
-    static constexpr int OFF_W1 = XN_F, OFF_W2 = OFF_W1 + W1_F, OFF_G = OFF_W2 + W2_F, OFF_Z = OFF_G + G_F;
-    static constexpr int OFF_U = OFF_Z + Z_F;             // raw u of the interior tokens (training): stored by P3 as full lines
+    static constexpr int Z_IMG_F = L6 ? 3 * NINT * 16 : Z_F;      // L6: three bf16 piece images of 64-byte rows (HC = 32)
+    static constexpr int OFF_W1 = XN_F, OFF_W2 = OFF_W1 + (L6 ? 0 : W1_F), OFF_G = OFF_W2 + (L6 ? 0 : W2_F), OFF_Z = OFF_G + G_F;
+    static constexpr int OFF_U = OFF_Z + Z_IMG_F;         // raw u of the interior tokens (training): stored by P3 as full lines
     static constexpr int TOTAL_F = OFF_U + Z_F;
     static constexpr size_t SMEM = (size_t)TOTAL_F * sizeof(float);
-    static_assert(NINT * (C + 4) <= XN_F, "epilogue staging must fit in the xn image");
+    static_assert(NINT * (C + 4) <= XN_F + (L6 ? G_F : 0), "epilogue staging must fit in the xn image (L6: + the dead G image behind it)");
     static_assert(12 * 16 * C <= OFF_U, "padded rows of the xn image must stay inside the allocation");
+    static_assert(!L6 || HC == 32, "L6: one 32-deep k-block of the hidden dimension per chunk");
 };
 
-template <int C, int HC, int NW>
+template <int C, int HC, int NW, bool L6 = false>
 __global__ __launch_bounds__(64 * NW) void leff_fused_fwd_kernel(
     const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
     const float* __restrict__ W1, const float* __restrict__ b1, const float* __restrict__ wd, const float* __restrict__ bd,
     const float* __restrict__ W2, const float* __restrict__ b2, const float* __restrict__ scale, float* __restrict__ out,
     float* __restrict__ xn_save, float* __restrict__ stats_save, float* __restrict__ u_save, float* __restrict__ tp_save,
     float* __restrict__ z_save, int Hres, int Wres, int tiles_x, int tiles_y) {
-    using Cfg = FwdCfg<C, HC, NW>;
+    // L6: W1 points at the planes of dhz_leff_prepack6 (both weights), W2 is not read
+    using Cfg = FwdCfg<C, HC, NW, L6>;
     constexpr int NTHR = Cfg::NTHR, Ch = Cfg::Ch, NCHUNK = Cfg::NCHUNK;
     constexpr int NCT1 = HC / 16;                 // column tiles of P1
     static_assert(NW / NCT1 == 4, "P1: four wave groups of three row tiles");
@@ -121,7 +130,7 @@ __global__ __launch_bounds__(64 * NW) void leff_fused_fwd_kernel(
             if ((HC * C / 4) % NTHR == 0 || e < HC * C / 4) *reinterpret_cast<f32x4*>(&W2S[swz<HC>(e / Q, 4 * (e % Q))]) = rw2[i];
         }
     };
-    wload1(0);
+    if constexpr (!L6) wload1(0);
 
     // ---- LayerNorm (norm2) of the 180 tokens of tile + halo -> XN (swizzled); out-of-image tokens are clamped copies whose
     //      hidden activations are zeroed in P2
@@ -154,6 +163,16 @@ __global__ __launch_bounds__(64 * NW) void leff_fused_fwd_kernel(
 #pragma unroll
             for (int c = 0; c < 4; ++c) y[c] = dv[c] * rstd * gm[c] + bt[c];
             if (r < NPOS) {
+                if constexpr (L6) {
+                    // the token's 4 channels as bf16 pieces: k-block (4 li) / 32, 16-byte chunk ((4 li) % 32) / 8, half li & 1
+                    uint32_t h0, m0, l0, h1, m1, l1;
+                    dhz_split2x3(y[0], y[1], h0, m0, l0);
+                    dhz_split2x3(y[2], y[3], h1, m1, l1);
+                    unsigned char* xp = reinterpret_cast<unsigned char*>(XN) + ((4 * li) >> 5) * (3 * 192 * 64) + dhz_off64(r, ((4 * li) & 31) >> 3) + 8 * (li & 1);
+                    *reinterpret_cast<uint2*>(xp) = make_uint2(h0, h1);
+                    *reinterpret_cast<uint2*>(xp + 192 * 64) = make_uint2(m0, m1);
+                    *reinterpret_cast<uint2*>(xp + 2 * 192 * 64) = make_uint2(l0, l1);
+                } else
                 *reinterpret_cast<f32x4*>(&XN[swz<C>(r, 4 * li)]) = y;
                 const bool interior = hy >= 1 && hy <= TH && hx >= 1 && hx <= TW;
                 if (train && interior) {
@@ -163,7 +182,7 @@ __global__ __launch_bounds__(64 * NW) void leff_fused_fwd_kernel(
             }
         }
     }
-    wwrite1();
+    if constexpr (!L6) wwrite1();
 
     // ---- per-lane bookkeeping of the P1 rows this lane owns in the accumulator layout: row = 16 (rt0 + a) + 4 g + j
     const int rt0 = 3 * (w & 3), ct1 = w >> 2;
@@ -190,13 +209,42 @@ __global__ __launch_bounds__(64 * NW) void leff_fused_fwd_kernel(
 
     __syncthreads();
 
+    // L6: the LayerNorm output lies in LDS as bf16 piece images (written once, read by every chunk's P1); k-block kb <-> channels 32 kb + 8 g + e
+    constexpr int KB1 = C / 32;
+    const uint16_t* const w6 = reinterpret_cast<const uint16_t*>(W1);
+    constexpr size_t W2P_OFF = (size_t)(4 * C / 16) * KB1 * 3 * 512;         // elements of the W1 planes; the W2 planes follow
+    const unsigned char* const XN6 = reinterpret_cast<const unsigned char*>(XN);
+    unsigned char* const Z6 = reinterpret_cast<unsigned char*>(ZS);            // L6: hi | mid | lo images of z, 128 x 64 bytes each
+    // W1 fragments of (hidden 16-row tile ht, k-block kb, piece): run ((ht KB1 + kb) 3 + piece) of 1 KiB; W2 fragments of (hidden k-block hb,
+    // column tile b, piece): run ((hb C/16 + b) 3 + piece) behind them
+    dhz_u32x4 w1f[L6 ? KB1 : 1][3], w2f[L6 ? CT2 : 1][3];
+    auto load_w1f = [&](int hc0) {
+        const int ht = (hc0 >> 4) + ct1;
+#pragma unroll
+        for (int kb = 0; kb < KB1; ++kb)
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc)
+                w1f[kb][pc] = *reinterpret_cast<const dhz_u32x4*>(w6 + ((size_t)(ht * KB1 + kb) * 3 + pc) * 512 + lane * 8);
+    };
+    auto load_w2f = [&](int hc0) {
+        const int hb = hc0 >> 5;
+#pragma unroll
+        for (int b = 0; b < CT2; ++b)
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc)
+                w2f[b][pc] = *reinterpret_cast<const dhz_u32x4*>(w6 + W2P_OFF + ((size_t)(hb * CT2 + b) * 3 + pc) * 512 + lane * 8);
+    };
+    if constexpr (L6) load_w1f(0);
+
     const int c4 = t % Q, ps = t / Q;       // P3: channel quad and pixel slot of this thread
 #pragma unroll 1
     for (int ck = 0; ck < NCHUNK; ++ck) {
         const int hc0 = ck * HC;
         const bool more = ck + 1 < NCHUNK;
-        wload2(hc0);
-        if (more) wload1(hc0 + HC);
+        if constexpr (!L6) {
+            wload2(hc0);
+            if (more) wload1(hc0 + HC);
+        }
         // depthwise weights / bias of this thread's 4 channels (L2-resident, consumed in P3)
         f32x4 wkv[9];
 #pragma unroll
@@ -208,6 +256,24 @@ __global__ __launch_bounds__(64 * NW) void leff_fused_fwd_kernel(
         f32x4 acc[3];
 #pragma unroll
         for (int a = 0; a < 3; ++a) acc[a] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (L6) {
+            constexpr int TA[6] = {2, 0, 1, 0, 1, 0}, TB[6] = {0, 2, 1, 1, 0, 0};          // (token piece, weight piece): lh hl mm hm mh hh
+#pragma unroll
+            for (int kb = 0; kb < KB1; ++kb) {
+                dhz_u32x4 a1[3][3];
+#pragma unroll
+                for (int a = 0; a < 3; ++a)
+#pragma unroll
+                    for (int pc = 0; pc < 3; ++pc)
+                        a1[a][pc] = *reinterpret_cast<const dhz_u32x4*>(XN6 + (kb * 3 + pc) * (192 * 64) + dhz_off64(16 * (rt0 + a) + i16, g));
+#pragma unroll
+                for (int term = 0; term < 6; ++term)
+#pragma unroll
+                    for (int a = 0; a < 3; ++a) acc[a] = dhz_mfma_bf16(a1[a][TA[term]], w1f[kb][TB[term]], acc[a]);
+            }
+            load_w2f(hc0);                          // this chunk's W2 fragments: in flight during P2 / P3
+            if (more) load_w1f(hc0 + HC);           // the next chunk's W1 fragments
+        } else
 #pragma unroll
         for (int s = 0; s < C / 16; ++s) {
             const f32x4 bf = *reinterpret_cast<const f32x4*>(&W1S[swz<C>(16 * ct1 + i16, 16 * s + 4 * g)]);
@@ -236,8 +302,10 @@ __global__ __launch_bounds__(64 * NW) void leff_fused_fwd_kernel(
             }
         }
         __syncthreads();
-        wwrite2();
-        if (more) wwrite1();
+        if constexpr (!L6) {
+            wwrite2();
+            if (more) wwrite1();
+        }
         // ---- P3: t = dwconv3x3(G) + bd, z = gelu(t) -> Z (+ saves)
 #pragma unroll
         for (int it = 0; it < NINT / NPS; ++it) {
@@ -256,6 +324,16 @@ __global__ __launch_bounds__(64 * NW) void leff_fused_fwd_kernel(
                 }
             f32x4 zz, zp;
             gelu_both4(tacc, zz, zp);
+            if constexpr (L6) {
+                // z of the thread's 4 channels as bf16 pieces: 8 bytes per image, row p, 16-byte chunk c4 >> 1, half c4 & 1
+                uint32_t h0, m0, l0, h1, m1, l1;
+                dhz_split2x3(zz[0], zz[1], h0, m0, l0);
+                dhz_split2x3(zz[2], zz[3], h1, m1, l1);
+                unsigned char* zp8 = Z6 + dhz_off64(p, c4 >> 1) + 8 * (c4 & 1);
+                *reinterpret_cast<uint2*>(zp8) = make_uint2(h0, h1);
+                *reinterpret_cast<uint2*>(zp8 + NINT * 64) = make_uint2(m0, m1);
+                *reinterpret_cast<uint2*>(zp8 + 2 * NINT * 64) = make_uint2(l0, l1);
+            } else
             *reinterpret_cast<f32x4*>(&ZS[swz<HC>(p, 4 * c4)]) = zz;
             if (train) {
                 const size_t o = (tokbase + (size_t)(y0 + 1 + py) * Wres + (x0 + 1 + px)) * Ch + hc0 + 4 * c4;
@@ -266,6 +344,21 @@ __global__ __launch_bounds__(64 * NW) void leff_fused_fwd_kernel(
         }
         __syncthreads();
         // ---- P4: y += Z . W2[:, chunk]^T
+        if constexpr (L6) {
+            constexpr int TA[6] = {2, 0, 1, 0, 1, 0}, TB[6] = {0, 2, 1, 1, 0, 0};
+            dhz_u32x4 zf[RT2][3];
+#pragma unroll
+            for (int a = 0; a < RT2; ++a)
+#pragma unroll
+                for (int pc = 0; pc < 3; ++pc)
+                    zf[a][pc] = *reinterpret_cast<const dhz_u32x4*>(Z6 + pc * NINT * 64 + dhz_off64(16 * (RT2 * w + a) + i16, g));
+#pragma unroll
+            for (int term = 0; term < 6; ++term)
+#pragma unroll
+                for (int a = 0; a < RT2; ++a)
+#pragma unroll
+                    for (int b = 0; b < CT2; ++b) yacc[a][b] = dhz_mfma_bf16(zf[a][TA[term]], w2f[b][TB[term]], yacc[a][b]);
+        } else
 #pragma unroll
         for (int s = 0; s < HC / 16; ++s) {
             f32x4 af[RT2], bf[CT2];
@@ -304,13 +397,13 @@ __global__ __launch_bounds__(64 * NW) void leff_fused_fwd_kernel(
     }
 }
 
-template <int C, int HC, int NW>
+template <int C, int HC, int NW, bool L6 = false>
 int launch_fwd(const float* x, const float* gamma, const float* beta, const float* W1, const float* b1, const float* wd,
                const float* bd, const float* W2, const float* b2, const float* scale, float* out, float* xn_save,
                float* stats_save, float* u_save, float* tp_save, float* z_save, int B, int Hres, int Wres, hipStream_t s) {
-    using Cfg = FwdCfg<C, HC, NW>;
+    using Cfg = FwdCfg<C, HC, NW, L6>;
     const int tiles_x = Wres / TW, tiles_y = Hres / TH;
-    auto kern = &leff_fused_fwd_kernel<C, HC, NW>;
+    auto kern = &leff_fused_fwd_kernel<C, HC, NW, L6>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::SMEM);
     // the raw-u staging image is the last LDS region and only exists in training mode (two inference workgroups fit a CU without it)
     const size_t smem = u_save ? Cfg::SMEM : Cfg::SMEM - (size_t)Cfg::Z_F * sizeof(float);
@@ -320,7 +413,67 @@ int launch_fwd(const float* x, const float* gamma, const float* beta, const floa
 }
 
 
+// six-term planes of W1 [4C][C] and W2 [C][4C] in the fragment order of the L6 kernel (1 KiB runs = 64 lanes x 8 bf16):
+//   W1: run ((ht C/32 + kb) 3 + piece), element (lane = 16 g + i16, e) = piece of W1[16 ht + i16][32 kb + 8 g + e]      (ht: 16-row tile of the hidden dimension)
+//   W2: behind them, run ((hb C/16 + b) 3 + piece), element = piece of W2[16 b + i16][32 hb + 8 g + e]                   (hb: 32-deep k-block of the hidden dimension)
+__global__ void leff_prepack6_kernel(const float* __restrict__ w1, const float* __restrict__ w2, uint16_t* __restrict__ out, int C) {
+    const int n1 = (4 * C / 16) * (C / 32) * 512, n2 = (4 * C / 32) * (C / 16) * 512;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n1 + n2) return;
+    float x;
+    uint16_t* o;
+    if (t < n1) {
+        const int e = t & 7, lane = (t >> 3) & 63, rest = t >> 9;
+        const int kb = rest % (C / 32), ht = rest / (C / 32);
+        x = w1[(size_t)(16 * ht + (lane & 15)) * C + 32 * kb + 8 * (lane >> 4) + e];
+        o = out + ((size_t)(ht * (C / 32) + kb) * 3) * 512 + lane * 8 + e;
+    } else {
+        const int f = t - n1;
+        const int e = f & 7, lane = (f >> 3) & 63, rest = f >> 9;
+        const int b = rest % (C / 16), hb = rest / (C / 16);
+        x = w2[(size_t)(16 * b + (lane & 15)) * (4 * C) + 32 * hb + 8 * (lane >> 4) + e];
+        o = out + (size_t)3 * n1 + ((size_t)(hb * (C / 16) + b) * 3) * 512 + lane * 8 + e;
+    }
+    const float hi = __uint_as_float(__float_as_uint(x) & 0xffff0000u);
+    const float r1 = x - hi;
+    const float mid = __uint_as_float(__float_as_uint(r1) & 0xffff0000u);
+    const float r2 = r1 - mid;
+    o[0] = (uint16_t)(__float_as_uint(x) >> 16);
+    o[512] = (uint16_t)(__float_as_uint(r1) >> 16);
+    o[1024] = (uint16_t)(__float_as_uint(r2) >> 16);
+}
+
 }  // namespace
+
+extern "C" int dhz_leff_prepack6(const float* w1, const float* w2, void* w6, int C, void* stream) {
+    DHZ_REQUIRE(w1 && w2 && w6, "dhz_leff_prepack6: null pointer");
+    DHZ_REQUIRE(C == 32 || C == 64, "dhz_leff_prepack6: C=%d unsupported (32, 64)", C);
+    const int n = (4 * C / 16) * (C / 32) * 512 + (4 * C / 32) * (C / 16) * 512;
+    hipLaunchKernelGGL(leff_prepack6_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, w1, w2, (uint16_t*)w6, C);
+    DHZ_CHECK_LAUNCH("dhz_leff_prepack6");
+    return DHZ_OK;
+}
+
+// dhz_leff_fused_fwd with the two weight products as six-term products on the bf16 matrix pipe: w6 = the planes of dhz_leff_prepack6
+extern "C" int dhz_leff_fused_fwd6(const float* x, const float* gamma, const float* beta, const void* w6, const float* b1,
+                                   const float* wd, const float* bd, const float* b2, const float* drop_scale,
+                                   float* out, float* xn_save, float* stats_save, float* u_save, float* tp_save, float* z_save,
+                                   int B, int Hres, int Wres, int C, void* stream) {
+    DHZ_REQUIRE(x && gamma && beta && w6 && b1 && wd && bd && b2 && out, "dhz_leff_fused_fwd6: null pointer");
+    DHZ_REQUIRE(C == 32 || C == 64, "dhz_leff_fused_fwd6: C=%d (supported: 32, 64)", C);
+    DHZ_REQUIRE(B > 0 && Hres > 0 && Wres > 0 && Hres % TH == 0 && Wres % TW == 0,
+                "dhz_leff_fused_fwd6: map %dx%d must be a multiple of the %dx%d tile", Hres, Wres, TH, TW);
+    DHZ_REQUIRE(((uintptr_t)w6 & 15) == 0, "dhz_leff_fused_fwd6: the planes must be 16-byte aligned");
+    const bool all = xn_save && stats_save && u_save && tp_save && z_save;
+    const bool none = !xn_save && !stats_save && !u_save && !tp_save && !z_save;
+    DHZ_REQUIRE(all || none, "dhz_leff_fused_fwd6: the five save pointers must be all set (training) or all NULL (inference)");
+    hipStream_t s = (hipStream_t)stream;
+    const float* w = reinterpret_cast<const float*>(w6);
+    if (C == 32) launch_fwd<32, 32, 8, true>(x, gamma, beta, w, b1, wd, bd, w, b2, drop_scale, out, xn_save, stats_save, u_save, tp_save, z_save, B, Hres, Wres, s);
+    else launch_fwd<64, 32, 8, true>(x, gamma, beta, w, b1, wd, bd, w, b2, drop_scale, out, xn_save, stats_save, u_save, tp_save, z_save, B, Hres, Wres, s);
+    DHZ_CHECK_LAUNCH("dhz_leff_fused_fwd6");
+    return DHZ_OK;
+}
 
 extern "C" int dhz_leff_fused_fwd(const float* x, const float* gamma, const float* beta, const float* w1, const float* b1,
                                   const float* wd, const float* bd, const float* w2, const float* b2, const float* drop_scale,

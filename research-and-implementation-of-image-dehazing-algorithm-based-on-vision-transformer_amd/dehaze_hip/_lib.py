@@ -66,6 +66,8 @@ SIGNATURES = {
     "dhz_maxpool2x2_blocked_bwd": [c_f, c_f, c_f, c_i, c_i, c_i, c_p],
     "dhz_layout_blocked8": [c_f, c_f, c_i, c_i, c_i, c_i, c_f, c_i, c_p],
     "dhz_leff_fused_fwd": [c_f] * 16 + [c_i, c_i, c_i, c_i, c_p],
+    "dhz_leff_fused_fwd6": [c_f] * 15 + [c_i, c_i, c_i, c_i, c_p],
+    "dhz_leff_prepack6": [c_f, c_f, c_p, c_i, c_p],
     "dhz_linear_fwd": [c_f, c_i, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_p],
     "dhz_linear_dgrad": [c_f, c_i, c_f, c_f, c_i, c_i, c_i, c_i, c_p],
     "dhz_input_proj_fwd": [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_fl, c_p],

@@ -39,6 +39,13 @@ LEFF_FUSED_C = (32, 64)     # widths that take the fused forward
 # ... C = 64 only below this many tokens when the chain's GEMMs run in the six-term form (tools/bench_leff.py, bs 32, forward with the
 # training saves: 64 x 64 maps 204 us fused / 218 chain, 128 x 128 maps 794 / 765; forward + backward 2058 / 2010)
 LEFF_FUSED_C64_MAX_T = 262144
+# the fused LeFF forward with its two weight products six-term on the bf16 matrix pipe (csrc/leff_fused.hip, L6); DHZ_LEFF_P6=0: fp32 pipe
+LEFF_FUSED_P6 = __import__("os").environ.get("DHZ_LEFF_P6", "1") != "0"
+# measured (tools/bench_leff_p6.py, bs 32, forward with the training saves / inference, us): C = 64 at 64 x 64: 218.7 / 183.5 -> 196.6 / 168.1;
+# C = 64 at 128 x 128: 798.8 / 641.9 -> 741.5 / 625.3 (the kernel chain: 745.4 / 632.0 - the dispatch there does not change); C = 32 at
+# 128 x 128: 367.6 / 264.0 -> 393.4 / 308.8, SLOWER: at C = 32 the matrix share of this kernel is a fifth of its time and the piece images
+# cost more vector / LDS work than the shorter MFMAs return - the fp32-pipe instance stays there
+LEFF_FUSED_P6_C = (64,)
 
 
 def _wgrad(dy, off, x, w, b, row_scale=None):
@@ -171,6 +178,7 @@ def _table_backward(dpart, parts, table_p, H, dev):
 # parameter (consumed on use: a second forward without a new staging derives its own again) and derive it themselves otherwise.
 STAGED_BIAS = {}        # id(table parameter) -> [H, 64, 64]
 STAGED_PREPACK = {}     # id(query weight)    -> (wqkv_p, wo_p)
+STAGED_LEFF6 = {}       # id(linear1 weight)  -> six-term planes of linear1 / linear2 for the fused LeFF kernel
 
 
 def stage_block_operands(entries, device):
@@ -178,6 +186,7 @@ def stage_block_operands(entries, device):
     import ctypes
     STAGED_BIAS.clear()
     STAGED_PREPACK.clear()
+    STAGED_LEFF6.clear()
     _PENDING_TABLES.clear()          # (a backward pass that died before its end-of-pass callback)
     arr = lambda ptrs: ctypes.cast((ctypes.c_void_p * len(ptrs))(*ptrs), ctypes.c_void_p)
     tabs = [(t, H) for t, H, _, _ in entries if t is not None]
@@ -486,8 +495,19 @@ def _leff_fwd(train, x, gamma, beta, w1, b1, wd, bd, w2, b2, dscale, Hres, Wres)
             u = torch.empty((T, Ch), **f32)
             tg = torch.empty((T, Ch), **f32)
             z = torch.empty((T, Ch), **f32)
-        _lib.call("dhz_leff_fused_fwd", _p(x), _p(gamma), _p(beta), _p(w1), _p(b1), _p(wdc), _p(bd), _p(w2), _p(b2),
-                  _p(dscale), _p(out), _p(xn), _p(stats), _p(u), _p(tg), _p(z), B, Hres, Wres, C, _stream())
+        if LEFF_FUSED_P6 and C in LEFF_FUSED_P6_C:
+            # both weight products six-term on the bf16 matrix pipe: planes in the kernel's fragment order (staged per forward, or packed here)
+            hit = STAGED_LEFF6.pop(id(w1), None)
+            if hit is not None and hit[0] is w1 and hit[1].numel() == 24 * C * C and hit[1].device == dev:
+                w6 = hit[1]
+            else:
+                w6 = torch.empty(24 * C * C, device=dev, dtype=torch.bfloat16)
+                _lib.call("dhz_leff_prepack6", _p(w1), _p(w2), _p(w6), C, _stream())
+            _lib.call("dhz_leff_fused_fwd6", _p(x), _p(gamma), _p(beta), _p(w6), _p(b1), _p(wdc), _p(bd), _p(b2),
+                      _p(dscale), _p(out), _p(xn), _p(stats), _p(u), _p(tg), _p(z), B, Hres, Wres, C, _stream())
+        else:
+            _lib.call("dhz_leff_fused_fwd", _p(x), _p(gamma), _p(beta), _p(w1), _p(b1), _p(wdc), _p(bd), _p(w2), _p(b2),
+                      _p(dscale), _p(out), _p(xn), _p(stats), _p(u), _p(tg), _p(z), B, Hres, Wres, C, _stream())
     else:
         xn = torch.empty((T, C), device=dev, dtype=x.dtype)
         stats = torch.empty((T, 2), **f32)

@@ -48,9 +48,11 @@ def test_leff_fused_vs_fp64_and_chain(C, H, W, B, drop):
     for n_, p in list(n64.named_parameters(prefix="norm")) + list(m64.named_parameters(prefix="mlp")):
         ref[n_] = p.grad
 
-    def run(fused_on):
-        saved = (fused.LEFF_FUSED, fused.LEFF_FUSED_C)
+    def run(fused_on, p6_c=None):
+        saved = (fused.LEFF_FUSED, fused.LEFF_FUSED_C, fused.LEFF_FUSED_P6_C)
         fused.LEFF_FUSED, fused.LEFF_FUSED_C = fused_on, (32, 64, 128)
+        if p6_c is not None:
+            fused.LEFF_FUSED_P6_C = p6_c
         try:
             nd, md = copy.deepcopy(norm).to(dev), copy.deepcopy(mlp).to(dev)
             xd = x.to(dev).requires_grad_()
@@ -63,9 +65,19 @@ def test_leff_fused_vs_fp64_and_chain(C, H, W, B, drop):
                 out["y_eval"] = fused.leff_branch(x.to(dev), nd, md, None, H, W).cpu().double()
             return out
         finally:
-            fused.LEFF_FUSED, fused.LEFF_FUSED_C = saved
+            fused.LEFF_FUSED, fused.LEFF_FUSED_C, fused.LEFF_FUSED_P6_C = saved
 
     got, chain = run(True), run(False)                  # fused forward + chain backward (the shipped default), and the pure chain
+    if C in (32, 64):
+        # the other arithmetic of the fused forward at this width: six-term products on the bf16 pipe (round 6, dhz_leff_fused_fwd6; the
+        # default at C = 64) / the fp32 pipe - same tolerances against fp64
+        other = run(True, p6_c=(32, 64) if C not in fused.LEFF_FUSED_P6_C else ())
+        for k, r in ref.items():
+            tol = 3e-5 + 3e-5 * r.abs().max().item()
+            if k not in ("y", "dx"):
+                tol *= (B * H * W) ** 0.5
+            assert (other[k] - r).abs().max().item() < tol, ("other arithmetic", k, (other[k] - r).abs().max().item(), tol)
+        assert (other["y_eval"] - chain["y_eval"]).abs().max().item() < 3e-5
     for k, r in ref.items():
         tol = 3e-5 + 3e-5 * r.abs().max().item()
         if k not in ("y", "dx"):
