@@ -11,8 +11,8 @@ AdamW update.  Nothing is skipped or cached inside the timed region.
          bench.py --gpus N --steps K --warmup W
 
 Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
-  roofline     - the window-attention kernel (dhz_ps_attn_fwd), timed live with HIP events on the stream
-                 it is launched on; algorithmic work per DESIGN.md §4
+  roofline     - the fused window-attention kernel (dhz_fused_window_attn_fwd / _fwd6), timed live with HIP events on the stream
+                 it is launched on; algorithmic work per DESIGN.md §9
   cpu_baseline - the CPU oracle's training step timed on this node's host cores on a bounded sample
                  (rank 0, N=1 only).
 """
@@ -534,7 +534,7 @@ def main():
                                "avg_launch_us": round(1e3 * ms / len(ev), 2), "alg_flops_per_launch": int(flops / len(ev))}
         if timing and timing.get("dhz_vgg_conv3x3_bf16"):
             # config 4: the VGG19 convolutions of the contrastive loss as implicit GEMMs on the bf16 matrix pipe (direct-convolution
-            # FLOPs, nothing skipped); LDS bandwidth caps this tiling near 0.5 of the dense peak
+            # FLOPs, nothing skipped); LDS bandwidth caps this tiling near 0.5 of the dense peak (docs/history/DESIGN_rounds_1-5.md section 7)
             ev = timing["dhz_vgg_conv3x3_bf16"]
             ms = sum(e[0].elapsed_time(e[1]) for e in ev)
             flops = sum(e[2] for e in ev)
