@@ -158,10 +158,16 @@ def _flush_table_grads():
 def _table_backward(dpart, parts, table_p, H, dev):
     gt = _grad_buf(table_p)
     if gt is not None and DEFER_TABLE_GRADS and ops.GRAD_READY is None:
-        if not _PENDING_TABLES:
-            torch.autograd.Variable._execution_engine.queue_callback(_flush_table_grads)
-        _PENDING_TABLES.append((dpart, parts, gt, H))
-        return None
+        queued = bool(_PENDING_TABLES)
+        if not queued:
+            try:                                        # (only valid inside a running backward pass)
+                torch.autograd.Variable._execution_engine.queue_callback(_flush_table_grads)
+                queued = True
+            except RuntimeError:
+                queued = False
+        if queued:
+            _PENDING_TABLES.append((dpart, parts, gt, H))
+            return None
     if gt is not None:
         _lib.call("dhz_bias_table_grad", _p(dpart), parts, _p(gt), H, 1, _stream())
         _ready(table_p)
