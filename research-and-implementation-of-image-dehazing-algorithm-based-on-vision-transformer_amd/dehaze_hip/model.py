@@ -752,10 +752,11 @@ class Uformer(nn.Module):
         entries = []
         for st, sc in zip(self.stages(), scales + [1]):
             for b in st.blocks:
-                if b.attn.variant != "probsparse" or b.win_size != 8 or b.dim != 32 * b.num_heads or mask is not None:
+                if b.attn.variant != "probsparse" or b.win_size != 8 or mask is not None \
+                        or b.dim not in (16 * b.num_heads, 32 * b.num_heads, 64 * b.num_heads):
                     continue
                 lay = b.attn.ProbSpare
-                fused_fwd = self.act_dtype != torch.bfloat16 and fused.ENABLED and \
+                fused_fwd = self.act_dtype != torch.bfloat16 and fused.ENABLED and b.dim == 32 * b.num_heads and \
                     (b.dim in (32, 64) or (b.dim == 128 and (Himg // sc) * (Wimg // sc) <= fused.ATTN_FUSED_C128_MAX_HW))
                 w = (lay.query_projection.weight, lay.key_projection.weight, lay.value_projection.weight, lay.out_projection.weight) \
                     if fused_fwd else None
