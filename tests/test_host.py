@@ -300,3 +300,59 @@ def test_split_switch_values():
     for bad in ("2", "x", "-1"):
         with pytest.raises(ValueError, match="DHZ_SPLIT_BF16"):
             ops._split_terms(bad)
+
+
+def test_round6_entry_points_validate_without_gpu():
+    """the residual-epilogue GEMMs, the layout forms of the LayerNorm backward and the batched staging entry points refuse bad arguments before any
+    launch (DHZ_EINVAL with a message) - no device needed"""
+    import ctypes
+    from dehaze_hip import _lib
+    lib = _lib.load()
+    p = 16      # any non-null, 16-byte-aligned "pointer": the checks run before the first dereference
+    #                                    x  ldx hi mid lo bias res scale out ldo  T    N   K   HW  H  W shift win stream
+    assert lib.dhz_linear_fwd_split6_res(p, 64, p, p, p, None, p, None, p, 64, 192, 64, 64, 60, 6, 10, 0, 1, None) == -22      # HW % 64
+    assert b"multiple of 64" in lib.dhz_last_error()
+    assert lib.dhz_linear_fwd_split6_res(p, 64, p, p, p, None, p, None, p, 64, 192, 64, 64, 64, 8, 8, 8, 1, None) == -22       # shift range
+    assert lib.dhz_linear_fwd_split6_res(p, 64, p, p, p, None, 8, None, p, 64, 192, 64, 64, 64, 8, 8, 0, 1, None) == -22       # shortcut alignment
+    assert lib.dhz_linear_fwd_split_res(p, 64, p, None, p, None, p, 64, 192, 64, 64, 128, 8, 16, 0, 1, 6, None) == -22         # T % HW
+    assert lib.dhz_linear_fwd_bf16_res(p, 64, p, None, p, None, p, 64, 192, 64, 64, 64, 4, 16, 0, 1, None) == -22              # H % 8
+    assert lib.dhz_ln_partition_bwd_lay(p, p, p, p, p, p, p, p, 1, 8, 8, 64, 0, 0, 1, 0, 0, 0, None) == -22                    # windowed dres without partition
+    assert lib.dhz_ln_partition_bwd_lay(p, p, p, p, p, p, p, p, 1, 8, 8, 64, 0, 0, 0, 1, 0, 0, None) == -22                    # dx == dres with a windowed dx
+    assert lib.dhz_ln_partition_bwd_lay2(p, p, p, p, None, p, p, p, 1, 12, 8, 64, 0, 0, 0, 0, 4, 32, None, 0, None) == -22     # second output on a 12-row map
+    one = (ctypes.c_void_p * 1)(p)
+    arr = ctypes.cast(one, ctypes.c_void_p)
+    heads = ctypes.cast((ctypes.c_int * 1)(0), ctypes.c_void_p)
+    assert lib.dhz_bias_gather_multi(arr, arr, heads, 1, None) == -22                                                          # H = 0
+    assert lib.dhz_bias_gather_multi(arr, arr, heads, 33, None) == -22                                                         # more than 32 entries
+    c48 = ctypes.cast((ctypes.c_int * 1)(48), ctypes.c_void_p)
+    assert lib.dhz_fused_attn_prepack_multi(arr, arr, arr, arr, arr, arr, c48, 1, None) == -22 and b"C=48" in lib.dhz_last_error()
+    assert lib.dhz_fused_attn_prepack6(p, p, p, p, p, 32, None) == -22 and lib.dhz_leff_prepack6(p, p, p, 128, None) == -22
+    assert lib.dhz_fused_window_attn_fwd6(p, p, p, p, p, p, p, p, None, None, None, p, None, None, None, None, None, 1, 8, 8, 128, 0, None) == -22
+
+
+def test_zero_scratch_allocator():
+    """ops.zeros_f32: slices of the optimizer's pre-zeroed region, never handed out twice between two zero_grad() calls, fresh allocations when
+    the region is exhausted or its owner is gone"""
+    import torch
+    from dehaze_hip import ops
+    from dehaze_hip.train import FlatAdamW
+    lin = torch.nn.Sequential(torch.nn.Conv2d(3, 4, 3), torch.nn.Linear(8, 8))
+    opt = FlatAdamW(lin)
+    opt.zero_grad()
+    scr = ops.ZERO_SCRATCH[0]
+    a = ops.zeros_f32((5, 3), torch.device("cpu"))
+    b = ops.zeros_f32((7,), torch.device("cpu"))
+    assert a.untyped_storage().data_ptr() == scr.untyped_storage().data_ptr() == b.untyped_storage().data_ptr()
+    assert a.data_ptr() != b.data_ptr() and b.data_ptr() >= a.data_ptr() + 15 * 4 and (b.data_ptr() - scr.data_ptr()) % 32 == 0
+    a.fill_(3.0); b.fill_(4.0)
+    big = ops.zeros_f32((scr.numel() + 1,), torch.device("cpu"))              # does not fit: a fresh tensor
+    assert big.untyped_storage().data_ptr() != scr.untyped_storage().data_ptr() and float(big.abs().sum()) == 0.0
+    assert all(float(p.grad.abs().sum()) == 0.0 for p in lin.parameters())    # the scratch lies BEHIND the gradients
+    opt.zero_grad()                                                           # re-zeroes the region and rewinds it
+    c = ops.zeros_f32((5, 3), torch.device("cpu"))
+    assert c.data_ptr() == a.data_ptr() and float(c.abs().sum()) == 0.0
+    del opt
+    import gc
+    gc.collect()
+    d = ops.zeros_f32((5, 3), torch.device("cpu"))                            # owner gone: never a slice of a dead optimizer's buffer
+    assert d.untyped_storage().data_ptr() != scr.untyped_storage().data_ptr()
