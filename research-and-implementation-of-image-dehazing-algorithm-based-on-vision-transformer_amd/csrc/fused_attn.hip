@@ -806,13 +806,20 @@ static int fused_fwd_impl(bool p6, const float* x, const float* gamma, const flo
         else launch_fused<64, 0, 2>(s, nwin, x, gamma, beta, wqkv_p, bqkv, wo_p, bo, idx, bias, mask, drop_scale, out, nullptr, nullptr,
                                     nullptr, nullptr, nullptr, Hres, Wres, shift);
     } else if (p6) {
-        DHZ_REQUIRE(C == 64, "dhz_fused_window_attn_fwd6: C=%d (the six-term projection form exists for C = 64)", C);
-        if (save == 1) launch_fused<64, 1, 1, true>(s, nwin, x, gamma, beta, wqkv_p, bqkv, wo_p, bo, idx, bias, mask, drop_scale, out, xn_save,
-                                                    qkv_save, ctx_save, stats_save, rank_save, Hres, Wres, shift);
-        else if (save == 2) launch_fused<64, 2, 1, true>(s, nwin, x, gamma, beta, wqkv_p, bqkv, wo_p, bo, idx, bias, mask, drop_scale, out,
-                                                         nullptr, nullptr, nullptr, nullptr, rank_save, Hres, Wres, shift);
-        else launch_fused<64, 0, 1, true>(s, nwin, x, gamma, beta, wqkv_p, bqkv, wo_p, bo, idx, bias, mask, drop_scale, out, nullptr, nullptr,
-                                          nullptr, nullptr, nullptr, Hres, Wres, shift);
+        // C = 64: all four weight products six-term; C = 128: Q / K / V six-term (two 64-channel halves per head), the out-projection stays
+        // on the fp32 pipe with wo_p (its planes, 24 KiB per head, do not fit the S tile)
+        DHZ_REQUIRE(C == 64 || C == 128, "dhz_fused_window_attn_fwd6: C=%d (the six-term projection form exists for C = 64, 128)", C);
+#define GO6(CC)                                                                                                             \
+    do {                                                                                                                    \
+        if (save == 1) launch_fused<CC, 1, 1, true>(s, nwin, x, gamma, beta, wqkv_p, bqkv, wo_p, bo, idx, bias, mask, drop_scale, out, xn_save, \
+                                                    qkv_save, ctx_save, stats_save, rank_save, Hres, Wres, shift);         \
+        else if (save == 2) launch_fused<CC, 2, 1, true>(s, nwin, x, gamma, beta, wqkv_p, bqkv, wo_p, bo, idx, bias, mask, drop_scale, out, \
+                                                         nullptr, nullptr, nullptr, nullptr, rank_save, Hres, Wres, shift); \
+        else launch_fused<CC, 0, 1, true>(s, nwin, x, gamma, beta, wqkv_p, bqkv, wo_p, bo, idx, bias, mask, drop_scale, out, nullptr, nullptr, \
+                                          nullptr, nullptr, nullptr, Hres, Wres, shift);                                   \
+    } while (0)
+        if (C == 64) GO6(64); else GO6(128);
+#undef GO6
     } else if (C == 32) GO(32); else if (C == 64) GO(64); else GO(128);
 #undef GO
     DHZ_CHECK_LAUNCH("dhz_fused_window_attn_fwd");

@@ -33,7 +33,7 @@ ATTN_FUSED_BWD_C = (32,)
 # Six-term QKV projections inside the fused forward (csrc/fused_attn.hip, P6): weight planes brought once per workgroup by LDS-DMA into
 # the dead Q / K / V / S tiles.  DHZ_FUSED_P6=0 selects the fp32-pipe projections (A/B: tools/bench_fused.py).
 ATTN_FUSED_P6 = __import__("os").environ.get("DHZ_FUSED_P6", "1") != "0"
-ATTN_FUSED_P6_C = (64,)
+ATTN_FUSED_P6_C = (64, 128)
 LEFF_FUSED = True           # False forces the kernel chain everywhere
 LEFF_FUSED_C = (32, 64)     # widths that take the fused forward
 # ... C = 64 only below this many tokens when the chain's GEMMs run in the six-term form (tools/bench_leff.py, bs 32, forward with the
@@ -184,6 +184,7 @@ def _table_backward(dpart, parts, table_p, H, dev):
 # parameter (consumed on use: a second forward without a new staging derives its own again) and derive it themselves otherwise.
 STAGED_BIAS = {}        # id(table parameter) -> [H, 64, 64]
 STAGED_PREPACK = {}     # id(query weight)    -> (wqkv_p, wo_p)
+STAGED_PACK6 = {}       # id(query weight)    -> six-term planes of Q / K / V / out-projection for the fused attention kernel
 STAGED_LEFF6 = {}       # id(linear1 weight)  -> six-term planes of linear1 / linear2 for the fused LeFF kernel
 
 
@@ -192,6 +193,7 @@ def stage_block_operands(entries, device):
     import ctypes
     STAGED_BIAS.clear()
     STAGED_PREPACK.clear()
+    STAGED_PACK6.clear()
     STAGED_LEFF6.clear()
     _PENDING_TABLES.clear()          # (a backward pass that died before its end-of-pass callback)
     arr = lambda ptrs: ctypes.cast((ctypes.c_void_p * len(ptrs))(*ptrs), ctypes.c_void_p)
@@ -224,8 +226,8 @@ def stage_block_operands(entries, device):
             _lib.call("dhz_fused_attn_prepack6_multi", arr(ws[0]), arr(ws[1]), arr(ws[2]), arr(ws[3]), arr([_p(o) for _, o in part]),
                       ctypes.cast((ctypes.c_int * len(part))(*[C for (_, C), _ in part]), ctypes.c_void_p), len(part), _stream())
         for (w, _), o in zip(packs6, outs):
-            STAGED_PREPACK[id(w[0])] = (w[0], o)
-    packs = [(w, C) for _, _, w, C in entries if w is not None and not p6(C)]
+            STAGED_PACK6[id(w[0])] = (w[0], o)
+    packs = [(w, C) for _, _, w, C in entries if w is not None and (not p6(C) or C == 128)]     # (C = 128: the out-projection's fp32 pack too)
     if packs:
         flat = torch.empty((sum(4 * C * C for _, C in packs),), device=device, dtype=torch.float32)
         outs, off = [], 0
@@ -265,23 +267,25 @@ def _attn_fused_fwd(train, x, gamma, beta, wq, bq, wk, bk, wv, bv, wo, bo, table
     f32 = dict(device=dev, dtype=torch.float32)
     use6 = ATTN_FUSED_P6 and C in ATTN_FUSED_P6_C
     n6 = (C // 32) * ((C // 64) * 36 + (C // 16) * 3) * 512
-    hit = STAGED_PREPACK.pop(id(wq), None)
-    if hit is not None and hit[0] is not wq:
-        hit = None
+    wqkv_p = wo_p = None
+    if not use6 or C == 128:                                   # fp32 fragment packs (C = 128 with six-term Q / K / V: the out-projection's only)
+        hit = STAGED_PREPACK.pop(id(wq), None)
+        if hit is not None and hit[0] is wq and hit[1][0].numel() == 3 * C * C and hit[1][0].device == dev:
+            wqkv_p, wo_p = hit[1]
+        else:
+            wqkv_p = torch.empty(3 * C * C, **f32)
+            wo_p = torch.empty(C * C, **f32)
+            _lib.call("dhz_fused_attn_prepack", _p(wq), _p(wk), _p(wv), _p(wo), _p(wqkv_p), _p(wo_p), C, _stream())
     if use6:
-        # the QKV and out-projection products of every head on the bf16 matrix pipe (six-term, fp32-class): planes in the kernel's fragment order
-        if hit is not None and torch.is_tensor(hit[1]) and hit[1].numel() == n6 and hit[1].device == dev:
+        # the weight products of every head on the bf16 matrix pipe (six-term, fp32-class): planes in the kernel's fragment order
+        hit = STAGED_PACK6.pop(id(wq), None)
+        if hit is not None and hit[0] is wq and hit[1].numel() == n6 and hit[1].device == dev:
             wqkv_p = hit[1]
         else:
             wqkv_p = torch.empty(n6, device=dev, dtype=torch.bfloat16)
             _lib.call("dhz_fused_attn_prepack6", _p(wq), _p(wk), _p(wv), _p(wo), _p(wqkv_p), C, _stream())
-        wo_p = wqkv_p                                           # (not read by the six-term kernel; a valid pointer for the argument check)
-    elif hit is not None and not torch.is_tensor(hit[1]) and hit[1][0].numel() == 3 * C * C and hit[1][0].device == dev:
-        wqkv_p, wo_p = hit[1]
-    else:
-        wqkv_p = torch.empty(3 * C * C, **f32)
-        wo_p = torch.empty(C * C, **f32)
-        _lib.call("dhz_fused_attn_prepack", _p(wq), _p(wk), _p(wv), _p(wo), _p(wqkv_p), _p(wo_p), C, _stream())
+        if wo_p is None:
+            wo_p = wqkv_p                                       # (C = 64: not read by the six-term kernel; a valid pointer for the argument check)
     bqkv = ops.cat_rows([bq.detach(), bk.detach(), bv.detach()])
     bias = _bias_tile(table, H, dev)
     out = torch.empty_like(x)
