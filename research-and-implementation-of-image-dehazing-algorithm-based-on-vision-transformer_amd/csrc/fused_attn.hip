@@ -126,7 +126,7 @@ __global__ __launch_bounds__(256 * NW, NW == 2 ? 1 : (C == 64 ? 3 : (C == 128 ? 
     constexpr int KS4 = KS / 4;
     constexpr int P6_QKV_BYTES = (C / 32) * (C / 64 > 0 ? C / 64 : 1) * P6_RUNS * 1024;     // the Q / K / V planes; the out-projection's follow
     constexpr int P6O_RUNS = (C / 16) * 3;                                                    // 1 KiB runs of one head's out-projection planes
-    constexpr bool P6O = P6 && P6O_RUNS * 1024 <= (int)sizeof(float) * NT * SS && P6O_RUNS % 4 == 0;   // ... fit the S tile (C <= 64)
+    constexpr bool P6O = P6 && C >= 64 && P6O_RUNS * 1024 <= (int)sizeof(float) * NT * SS && P6O_RUNS % 4 == 0;   // ... fit the S tile (C = 64)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     // NW = 2: a 512-thread workgroup carries TWO windows, one per half (threads 0..255 / 256..511), each with its own LDS tiles; the
     // halves run the same phases in lockstep (the barriers are the workgroup's).  t, w, lane are the indices INSIDE the half.
@@ -153,8 +153,22 @@ __global__ __launch_bounds__(256 * NW, NW == 2 ? 1 : (C == 64 ? 3 : (C == 128 ? 
 
     // C == 32: all projection weights (64 VGPRs of B fragments) stay in registers for the kernel's lifetime
     constexpr bool WREG = (C == 32) && FUSED_PERSIST_C32;
-    float4 wr_qkv[WREG ? 12 : 1], wr_o[WREG ? 4 : 1];
-    if constexpr (WREG) {
+    constexpr bool WREG6 = WREG && P6;         // C = 32 with six-term products: the bf16 planes of all four weights live in registers (24 KiB per wave-set)
+    float4 wr_qkv[(WREG && !P6) ? 12 : 1], wr_o[(WREG && !P6) ? 4 : 1];
+    u32x4_ w6r[WREG6 ? 6 : 1][3], wo6r[WREG6 ? 2 : 1][3];
+    if constexpr (WREG6) {
+        // planes of dhz_fused_attn_prepack6 at C = 32: run ((j 3) + piece) for the six Q / K / V column tiles, then ((6 + tn) 3 + piece) for the
+        // out-projection's two
+        const unsigned char* pl = reinterpret_cast<const unsigned char*>(wqkv_p) + lane * 16;
+#pragma unroll
+        for (int j = 0; j < 6; ++j)
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) w6r[j][pc] = *reinterpret_cast<const u32x4_*>(pl + (j * 3 + pc) * 1024);
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) wo6r[tn][pc] = *reinterpret_cast<const u32x4_*>(pl + ((6 + tn) * 3 + pc) * 1024);
+    } else if constexpr (WREG) {
 #pragma unroll
         for (int i = 0; i < 12; ++i) wr_qkv[i] = wqkv_p[i * 64 + lane];
 #pragma unroll
@@ -232,7 +246,13 @@ __global__ __launch_bounds__(256 * NW, NW == 2 ? 1 : (C == 64 ? 3 : (C == 128 ? 
                     const float bj = sm.vec[3 * C + (j >> 1) * C + 32 * h + 16 * (j & 1) + i16];
                     acc[j] = f32x4{bj, bj, bj, bj};
                 }
-                if constexpr (P6) {
+                if constexpr (WREG6) {
+                    constexpr int TA[6] = {2, 0, 1, 0, 1, 0}, TB[6] = {0, 2, 1, 1, 0, 0};      // (token piece, weight piece): lh hl mm hm mh hh
+#pragma unroll
+                    for (int term = 0; term < 6; ++term)
+#pragma unroll
+                        for (int j = 0; j < 6; ++j) acc[j] = mfma_b16(a6[0][TA[term]], w6r[j][TB[term]], acc[j]);
+                } else if constexpr (P6) {
                     unsigned char* const Bimg = reinterpret_cast<unsigned char*>(sm.q);       // q | k | v | s: 45 KiB contiguous, dead here
                     const unsigned char* const planes = reinterpret_cast<const unsigned char*>(wqkv_p);
                     if (h == 0) __syncthreads();           // the previous window's epilogue staged through S (wave-local, no barrier of its own)
@@ -492,7 +512,15 @@ __global__ __launch_bounds__(256 * NW, NW == 2 ? 1 : (C == 64 ? 3 : (C == 128 ? 
                 float a[8];
                 ld4(&O[srow * HS + 8 * g], &a[0]);
                 ld4(&O[srow * HS + 8 * g + 4], &a[4]);
-                if constexpr (P6O) {
+                if constexpr (WREG6) {
+                    u32x4_ ao[3];
+                    split8x3_(a, ao[0], ao[1], ao[2]);
+                    constexpr int TA[6] = {2, 0, 1, 0, 1, 0}, TB[6] = {0, 2, 1, 1, 0, 0};
+#pragma unroll
+                    for (int term = 0; term < 6; ++term)
+#pragma unroll
+                        for (int tn = 0; tn < 2; ++tn) oacc[tn] = mfma_b16(ao[TA[term]], wo6r[tn][TB[term]], oacc[tn]);
+                } else if constexpr (P6O) {
                     u32x4_ ao[3];
                     split8x3_(a, ao[0], ao[1], ao[2]);                 // the lane's 8 consecutive k of its context row ARE a bf16 A fragment
                     const unsigned char* const Wimg = reinterpret_cast<const unsigned char*>(sm.s);
@@ -623,8 +651,32 @@ __global__ void prepack_weights_kernel(const float* __restrict__ wq, const float
 //   ((h (C/64) + ch) 36 + (j 2 + kbl) 3 + piece),   element (lane = 16 g + i16, e) = piece of W_m[32 h + 16 (j & 1) + i16][g C/4 + 8 (2 ch + kbl) + e],
 // m = j >> 1 (Q, K, V), pieces by truncation (hi + mid + lo == W exactly).  One thread per (run without piece, lane, e).
 // Behind them the out-projection's planes: run ((h C/16 + tn) 3 + piece), element = piece of Wo[16 tn + i16][32 h + 8 g + e].
+// C = 32 (one head, one 32-deep k-block; the kernel keeps all of it in registers): run (j 3 + piece) for Q / K / V column tile j, element
+// (lane, e) = piece of W_m[16 (j & 1) + i16][8 g + e]; then run ((6 + tn) 3 + piece), element = piece of Wo[16 tn + i16][8 g + e].
+__device__ __forceinline__ void prepack6_element_c32(const float* __restrict__ wq, const float* __restrict__ wk, const float* __restrict__ wv,
+                                                     const float* __restrict__ wo, uint16_t* __restrict__ out, int t) {
+    if (t >= 8 * 512) return;
+    const int e = t & 7, lane = (t >> 3) & 63, tile = t >> 9;
+    const int i16 = lane & 15, g = lane >> 4;
+    float x;
+    if (tile < 6) {
+        const float* W = (tile >> 1) == 0 ? wq : ((tile >> 1) == 1 ? wk : wv);
+        x = W[(16 * (tile & 1) + i16) * 32 + 8 * g + e];
+    } else {
+        x = wo[(16 * (tile - 6) + i16) * 32 + 8 * g + e];
+    }
+    const float hi = __uint_as_float(__float_as_uint(x) & 0xffff0000u);
+    const float r1 = x - hi;
+    const float mid = __uint_as_float(__float_as_uint(r1) & 0xffff0000u);
+    const float r2 = r1 - mid;
+    uint16_t* o = out + (size_t)(tile * 3) * 512 + lane * 8 + e;
+    o[0] = (uint16_t)(__float_as_uint(x) >> 16);
+    o[512] = (uint16_t)(__float_as_uint(r1) >> 16);
+    o[1024] = (uint16_t)(__float_as_uint(r2) >> 16);
+}
 __device__ __forceinline__ void prepack6_element(const float* __restrict__ wq, const float* __restrict__ wk, const float* __restrict__ wv,
                                                  const float* __restrict__ wo, uint16_t* __restrict__ out, int C, int t) {
+    if (C == 32) { prepack6_element_c32(wq, wk, wv, wo, out, t); return; }
     const int n = (C / 32) * (C / 64) * 12 * 512;              // (h, ch, j, kbl) x 64 lanes x 8 elements
     const int no = (C / 32) * (C / 16) * 512;                  // (h, tn) x 64 lanes x 8 elements
     if (t >= n + no) return;
@@ -806,9 +858,10 @@ static int fused_fwd_impl(bool p6, const float* x, const float* gamma, const flo
         else launch_fused<64, 0, 2>(s, nwin, x, gamma, beta, wqkv_p, bqkv, wo_p, bo, idx, bias, mask, drop_scale, out, nullptr, nullptr,
                                     nullptr, nullptr, nullptr, Hres, Wres, shift);
     } else if (p6) {
-        // C = 64: all four weight products six-term; C = 128: Q / K / V six-term (two 64-channel halves per head), the out-projection stays
-        // on the fp32 pipe with wo_p (its planes, 24 KiB per head, do not fit the S tile)
-        DHZ_REQUIRE(C == 64 || C == 128, "dhz_fused_window_attn_fwd6: C=%d (the six-term projection form exists for C = 64, 128)", C);
+        // C = 64: all four weight products six-term, planes by LDS-DMA; C = 128: Q / K / V six-term (two 64-channel halves per head), the
+        // out-projection stays on the fp32 pipe with wo_p (its planes, 24 KiB per head, do not fit the S tile); C = 32: all four six-term
+        // with the planes in registers of the persistent workgroups
+        DHZ_REQUIRE(C == 32 || C == 64 || C == 128, "dhz_fused_window_attn_fwd6: C=%d unsupported (32, 64, 128)", C);
 #define GO6(CC)                                                                                                             \
     do {                                                                                                                    \
         if (save == 1) launch_fused<CC, 1, 1, true>(s, nwin, x, gamma, beta, wqkv_p, bqkv, wo_p, bo, idx, bias, mask, drop_scale, out, xn_save, \
@@ -818,7 +871,7 @@ static int fused_fwd_impl(bool p6, const float* x, const float* gamma, const flo
         else launch_fused<CC, 0, 1, true>(s, nwin, x, gamma, beta, wqkv_p, bqkv, wo_p, bo, idx, bias, mask, drop_scale, out, nullptr, nullptr, \
                                           nullptr, nullptr, nullptr, Hres, Wres, shift);                                   \
     } while (0)
-        if (C == 64) GO6(64); else GO6(128);
+        if (C == 32) GO6(32); else if (C == 64) GO6(64); else GO6(128);
 #undef GO6
     } else if (C == 32) GO(32); else if (C == 64) GO(64); else GO(128);
 #undef GO
@@ -833,9 +886,9 @@ extern "C" int dhz_fused_attn_prepack6_multi(const float* const* wq, const float
     int tmax = 0;
     for (int i = 0; i < n; ++i) {
         DHZ_REQUIRE(wq[i] && wk[i] && wv[i] && wo[i] && wqkv6_p[i], "dhz_fused_attn_prepack6_multi: entry %d: null pointer", i);
-        DHZ_REQUIRE(C[i] == 64 || C[i] == 128, "dhz_fused_attn_prepack6_multi: entry %d: C=%d unsupported (64, 128)", i, C[i]);
+        DHZ_REQUIRE(C[i] == 32 || C[i] == 64 || C[i] == 128, "dhz_fused_attn_prepack6_multi: entry %d: C=%d unsupported (32, 64, 128)", i, C[i]);
         d.wq[i] = wq[i]; d.wk[i] = wk[i]; d.wv[i] = wv[i]; d.wo[i] = wo[i]; d.out[i] = (uint16_t*)wqkv6_p[i]; d.C[i] = C[i];
-        const int t = (C[i] / 32) * (C[i] / 64) * 12 * 512 + (C[i] / 32) * (C[i] / 16) * 512;
+        const int t = C[i] == 32 ? 8 * 512 : (C[i] / 32) * (C[i] / 64) * 12 * 512 + (C[i] / 32) * (C[i] / 16) * 512;
         tmax = t > tmax ? t : tmax;
     }
     hipLaunchKernelGGL(prepack6_multi_kernel, dim3((tmax + 255) / 256, n), dim3(256), 0, (hipStream_t)stream, d);
@@ -863,8 +916,8 @@ extern "C" int dhz_fused_window_attn_fwd6(const float* x, const float* gamma, co
 
 extern "C" int dhz_fused_attn_prepack6(const float* wq, const float* wk, const float* wv, const float* wo, void* wqkv6_p, int C, void* stream) {
     DHZ_REQUIRE(wq && wk && wv && wo && wqkv6_p, "dhz_fused_attn_prepack6: null pointer");
-    DHZ_REQUIRE(C == 64 || C == 128, "dhz_fused_attn_prepack6: C=%d unsupported (64, 128)", C);
-    const int n = (C / 32) * (C / 64) * 12 * 512 + (C / 32) * (C / 16) * 512;
+    DHZ_REQUIRE(C == 32 || C == 64 || C == 128, "dhz_fused_attn_prepack6: C=%d unsupported (32, 64, 128)", C);
+    const int n = C == 32 ? 8 * 512 : (C / 32) * (C / 64) * 12 * 512 + (C / 32) * (C / 16) * 512;
     hipLaunchKernelGGL(prepack6_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, wq, wk, wv, wo, (uint16_t*)wqkv6_p, C);
     DHZ_CHECK_LAUNCH("dhz_fused_attn_prepack6");
     return DHZ_OK;

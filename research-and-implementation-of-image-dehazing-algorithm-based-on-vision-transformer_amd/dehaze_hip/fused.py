@@ -33,6 +33,8 @@ ATTN_FUSED_BWD_C = (32,)
 # Six-term QKV projections inside the fused forward (csrc/fused_attn.hip, P6): weight planes brought once per workgroup by LDS-DMA into
 # the dead Q / K / V / S tiles.  DHZ_FUSED_P6=0 selects the fp32-pipe projections (A/B: tools/bench_fused.py).
 ATTN_FUSED_P6 = __import__("os").environ.get("DHZ_FUSED_P6", "1") != "0"
+# C = 32 (planes in registers of the persistent workgroups) exists and is tested, but is not dispatched: its extra 50 registers cost the third
+# workgroup per CU (tools/bench_fused_p6.py: 101.5 -> 100.1 us training, 100.0 -> 96.0 inference at 128 x 128)
 ATTN_FUSED_P6_C = (64, 128)
 LEFF_FUSED = True           # False forces the kernel chain everywhere
 LEFF_FUSED_C = (32, 64)     # widths that take the fused forward
@@ -188,6 +190,12 @@ STAGED_PACK6 = {}       # id(query weight)    -> six-term planes of Q / K / V / 
 STAGED_LEFF6 = {}       # id(linear1 weight)  -> six-term planes of linear1 / linear2 for the fused LeFF kernel
 
 
+def _n6(C):
+    """bf16 elements of dhz_fused_attn_prepack6's planes: C = 32: 8 tiles x 3 pieces of 512; else per head 36 KiB-runs per 64 channels of Q / K / V
+    and 3 per 16 output features of the out-projection"""
+    return 8 * 3 * 512 if C == 32 else (C // 32) * ((C // 64) * 36 + (C // 16) * 3) * 512
+
+
 def stage_block_operands(entries, device):
     """entries: [(table or None, H, (wq, wk, wv, wo) or None, C)] in execution order (Uformer.forward builds it)."""
     import ctypes
@@ -214,7 +222,7 @@ def stage_block_operands(entries, device):
     p6 = lambda C: ATTN_FUSED_P6 and C in ATTN_FUSED_P6_C
     packs6 = [(w, C) for _, _, w, C in entries if w is not None and p6(C)]
     if packs6:
-        n6 = lambda C: (C // 32) * ((C // 64) * 36 + (C // 16) * 3) * 512
+        n6 = _n6
         flat = torch.empty((sum(n6(C) for _, C in packs6),), device=device, dtype=torch.bfloat16)
         outs, off = [], 0
         for _, C in packs6:
@@ -227,7 +235,7 @@ def stage_block_operands(entries, device):
                       ctypes.cast((ctypes.c_int * len(part))(*[C for (_, C), _ in part]), ctypes.c_void_p), len(part), _stream())
         for (w, _), o in zip(packs6, outs):
             STAGED_PACK6[id(w[0])] = (w[0], o)
-    packs = [(w, C) for _, _, w, C in entries if w is not None and (not p6(C) or C == 128)]     # (C = 128: the out-projection's fp32 pack too)
+    packs = [(w, C) for _, _, w, C in entries if w is not None and (not p6(C) or C in (32, 128))]     # (C = 128: the out-projection's fp32 pack too; C = 32: the fused backward's)
     if packs:
         flat = torch.empty((sum(4 * C * C for _, C in packs),), device=device, dtype=torch.float32)
         outs, off = [], 0
@@ -266,9 +274,10 @@ def _attn_fused_fwd(train, x, gamma, beta, wq, bq, wk, bk, wv, bv, wo, bo, table
     T = B * L
     f32 = dict(device=dev, dtype=torch.float32)
     use6 = ATTN_FUSED_P6 and C in ATTN_FUSED_P6_C
-    n6 = (C // 32) * ((C // 64) * 36 + (C // 16) * 3) * 512
+    n6 = _n6(C)
     wqkv_p = wo_p = None
-    if not use6 or C == 128:                                   # fp32 fragment packs (C = 128 with six-term Q / K / V: the out-projection's only)
+    will_fuse_bwd = train and C in ATTN_FUSED_BWD_C and x.dtype == torch.float32      # (the fused backward reads the fp32 fragment pack)
+    if not use6 or C == 128 or will_fuse_bwd:                  # fp32 fragment packs (C = 128 with six-term Q / K / V: the out-projection's only)
         hit = STAGED_PREPACK.pop(id(wq), None)
         if hit is not None and hit[0] is wq and hit[1][0].numel() == 3 * C * C and hit[1][0].device == dev:
             wqkv_p, wo_p = hit[1]
@@ -276,6 +285,7 @@ def _attn_fused_fwd(train, x, gamma, beta, wq, bq, wk, bk, wv, bv, wo, bo, table
             wqkv_p = torch.empty(3 * C * C, **f32)
             wo_p = torch.empty(C * C, **f32)
             _lib.call("dhz_fused_attn_prepack", _p(wq), _p(wk), _p(wv), _p(wo), _p(wqkv_p), _p(wo_p), C, _stream())
+    wqkv_f32 = wqkv_p
     if use6:
         # the weight products of every head on the bf16 matrix pipe (six-term, fp32-class): planes in the kernel's fragment order
         hit = STAGED_PACK6.pop(id(wq), None)
@@ -315,7 +325,7 @@ def _attn_fused_fwd(train, x, gamma, beta, wq, bq, wk, bk, wv, bv, wo, bo, table
     if fused_bwd:
         wt = torch.empty(4096, **f32)
         _lib.call("dhz_fused_attn_bwd_prepack", _p(wq), _p(wk), _p(wv), _p(wo), _p(wt), C, _stream())
-        rec = _Rec("attn_fused_bwd", (x, gamma, beta, rank, bias, mask, dscale, wqkv_p, bqkv, wt), params, geom)
+        rec = _Rec("attn_fused_bwd", (x, gamma, beta, rank, bias, mask, dscale, wqkv_f32, bqkv, wt), params, geom)
     elif train:
         rec = _Rec("attn_chain_bwd", (x, gamma, stats, xn, qkv, cx, rank, bias, mask, dscale, wq, wk, wv, wo), params, geom)
     return out, rec

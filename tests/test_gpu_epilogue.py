@@ -272,3 +272,41 @@ def test_bf16_block_dual_gradient_copy():
         # (absolute floors: d(b_k) is zero in exact arithmetic - bf16 rounding noise of ~1e-4 against gradients of O(1))
         assert (u - v).abs().max().item() <= 5e-2 * v.abs().max().item() + 1e-3, (i, (u - v).abs().max().item(), v.abs().max().item())
         assert (u - v).abs().mean().item() <= 1e-2 * v.abs().mean().item() + 1e-4, i
+
+
+@pytest.mark.parametrize("C,heads,res", [(32, 1, 32), (64, 2, 32), (128, 4, 16)])
+@pytest.mark.parametrize("shift", [0, 4])
+def test_fused_attention_six_term_equals_fp32_pipe(C, heads, res, shift):
+    """the fused window-attention forward with its weight products as six-term bf16-pipe products (dhz_fused_window_attn_fwd6: LDS-DMA planes
+    at C = 64 / 128, register-resident planes at C = 32) against the fp32-pipe form of the same kernel: outputs and gradients equal to fp32
+    rounding, except where a near-tie of the sparsity measure flips a selection (a handful of tokens at most)"""
+    import My_model_1 as M1
+    from dehaze_hip import fused
+    dev = torch.device("cuda:0")
+    out = {}
+    saved = (fused.ATTN_FUSED_P6, fused.ATTN_FUSED_P6_C)
+    try:
+        for p6 in (False, True):
+            fused.ATTN_FUSED_P6, fused.ATTN_FUSED_P6_C = p6, (32, 64, 128)
+            torch.manual_seed(C + shift)
+            blk = M1.LeWinTransformerBlock(dim=C, input_resolution=(res, res), num_heads=heads, win_size=8, shift_size=shift, mlp_ratio=4.,
+                                           drop_path=0.2, token_projection='linear', token_mlp='leff').to(dev).train()
+            x = torch.randn(4, res * res, C, generator=torch.Generator().manual_seed(1)).to(dev).requires_grad_(True)
+            gy = torch.randn(4, res * res, C, generator=torch.Generator().manual_seed(2)).to(dev)
+            idx = torch.randint(64, (64, 25), generator=torch.Generator().manual_seed(3)).to(torch.uint8).to(dev)
+            mask = blk._shift_mask(res, res, dev) if shift else None
+            sc = torch.tensor([1.25, 0.0, 1.25, 1.25], device=dev)
+            y = fused.fused_attn_branch(x, blk.norm1, blk.attn.ProbSpare, blk.attn.relative_position_bias_table, idx, mask, sc, res, res, shift, heads)
+            y.backward(gy)
+            with torch.no_grad():
+                ye = fused.fused_attn_branch(x.detach(), blk.norm1, blk.attn.ProbSpare, blk.attn.relative_position_bias_table, idx, mask, None, res, res,
+                                             shift, heads)
+            out[p6] = [y.detach(), ye, x.grad.detach()] + [p.grad.detach() for p in blk.attn.ProbSpare.parameters() if p.grad is not None]
+    finally:
+        fused.ATTN_FUSED_P6, fused.ATTN_FUSED_P6_C = saved
+    assert len(out[True]) == len(out[False]) > 5
+    for i, (u, v) in enumerate(zip(out[True], out[False])):
+        d = (u - v).abs()
+        scale = max(v.abs().max().item(), 1e-3)
+        assert d.mean().item() <= 2e-6 * scale + 1e-7, (i, d.mean().item(), scale)   # (+ floor: d(b_k) is zero in exact arithmetic, ~1e-9 of noise)
+        assert (d > 1e-4 * scale).float().mean().item() <= 2e-3, (i, (d > 1e-4 * scale).float().mean().item())

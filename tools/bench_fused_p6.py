@@ -21,7 +21,7 @@ def timeit(f, n=20):
     return 1e3 * sum(a.elapsed_time(b) for a, b, _, _ in ev) / len(ev)
 
 
-for res, C, heads in [(64, 64, 2), (128, 64, 2), (32, 128, 4)]:
+for res, C, heads in [(64, 64, 2), (128, 64, 2), (32, 128, 4), (128, 32, 1)]:
     for shift in (0, 4):
         torch.manual_seed(res + shift)
         blk = M1.LeWinTransformerBlock(dim=C, input_resolution=(res, res), num_heads=heads, win_size=8, shift_size=shift, token_mlp='leff',
