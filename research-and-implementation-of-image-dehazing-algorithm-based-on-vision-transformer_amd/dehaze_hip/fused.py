@@ -21,7 +21,7 @@ from .ops import NTOK, _p, _require_gpu, _stream
 
 SUPPORTED_C = (32, 64, 128)
 ENABLED = True      # set False to force the unfused chain (tests compare the two)
-ATTN_FUSED_C128_MAX_HW = 1024   # C = 128 takes the fused attention forward up to this map size (32 x 32), the chain above
+ATTN_FUSED_C128_MAX_HW = int(__import__("os").environ.get("DHZ_FUSED_C128_MAX_HW", "1024"))   # C = 128 takes the fused attention forward up to this map size (32 x 32), the chain above
 # Fused LeFF kernels (csrc/leff_fused.hip).  Measured on MI355X (tools/bench_leff.py, bs 32): the fused forward wins at C = 32 / 64
 # (inference 0.76-0.85x of the chain, training 0.87-0.95x) and loses at C = 128; a fused backward-data kernel (round 2, removed
 # in round 3) was 1.5-2x slower than the kernel chain in fp32 - fp32-input MFMA and fp32 VALU instructions share the SIMD's
