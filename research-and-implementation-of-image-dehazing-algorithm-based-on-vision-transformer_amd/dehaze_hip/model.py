@@ -757,7 +757,7 @@ class Uformer(nn.Module):
                     continue
                 lay = b.attn.ProbSpare
                 fused_fwd = self.act_dtype != torch.bfloat16 and fused.ENABLED and b.dim == 32 * b.num_heads and \
-                    (b.dim in (32, 64) or (b.dim == 128 and (Himg // sc) * (Wimg // sc) <= fused.ATTN_FUSED_C128_MAX_HW))
+                    (b.dim in (32, 64) or (b.dim == 128 and fused.fused_c128_ok((Himg // sc) * (Wimg // sc))))
                 w = (lay.query_projection.weight, lay.key_projection.weight, lay.value_projection.weight, lay.out_projection.weight) \
                     if fused_fwd else None
                 entries.append((b.attn.relative_position_bias_table if rel else None, b.num_heads, w, b.dim))
