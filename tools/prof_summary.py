@@ -24,6 +24,7 @@ def main():
     ap.add_argument("trace")
     ap.add_argument("--skip", type=int, default=3)
     ap.add_argument("--top", type=int, default=40)
+    ap.add_argument("--delim", default="adamw_kernel", help="kernel (substring) launched exactly once per step: the step delimiter (inference runs: input_proj_fwd)")
     ap.add_argument("--launches", default=None, help="regex: also list every launch of the matching kernels in ONE steady step (grid x block, us, gap to the previous kernel)")
     a = ap.parse_args()
     rows = list(csv.DictReader(open(a.trace)))
@@ -32,7 +33,7 @@ def main():
     for r in rows:
         if step >= a.skip:
             kept.append(r)
-        if "adamw_kernel" in r["Kernel_Name"]:
+        if a.delim in r["Kernel_Name"]:
             step += 1
     nsteps = step - a.skip
     agg = collections.defaultdict(lambda: [0.0, 0])
