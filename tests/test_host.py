@@ -326,8 +326,8 @@ def test_round6_entry_points_validate_without_gpu():
     assert lib.dhz_bias_gather_multi(arr, arr, heads, 33, None) == -22                                                         # more than 32 entries
     c48 = ctypes.cast((ctypes.c_int * 1)(48), ctypes.c_void_p)
     assert lib.dhz_fused_attn_prepack_multi(arr, arr, arr, arr, arr, arr, c48, 1, None) == -22 and b"C=48" in lib.dhz_last_error()
-    assert lib.dhz_fused_attn_prepack6(p, p, p, p, p, 32, None) == -22 and lib.dhz_leff_prepack6(p, p, p, 128, None) == -22
-    assert lib.dhz_fused_window_attn_fwd6(p, p, p, p, p, p, p, p, None, None, None, p, None, None, None, None, None, 1, 8, 8, 128, 0, None) == -22
+    assert lib.dhz_fused_attn_prepack6(p, p, p, p, p, 48, None) == -22 and lib.dhz_leff_prepack6(p, p, p, 128, None) == -22
+    assert lib.dhz_fused_window_attn_fwd6(p, p, p, p, p, p, p, p, None, None, None, p, None, None, None, None, None, 1, 8, 8, 48, 0, None) == -22
 
 
 def test_zero_scratch_allocator():
