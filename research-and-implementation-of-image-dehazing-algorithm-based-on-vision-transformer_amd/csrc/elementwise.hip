@@ -239,14 +239,28 @@ __global__ __launch_bounds__(256) void reverse_residual_kernel(const T* __restri
 #endif
 constexpr int TW = 16, TH = 8;                 // spatial tile (positions)
 constexpr int HWID = TW + 2, HHGT = TH + 2;    // with halo
-constexpr int CT = 32;                         // channels per workgroup (128 B per position)
+constexpr int CT = 32;                         // channels per workgroup of the 8-lane form (128 B of fp32 per position)
+// LPP = lanes per position (4 channels each): a workgroup is 32 position slots x LPP lanes and covers 4 LPP channels.  Measured on one
+// box (tools/bench_dwconv.py, sums over the step's shapes): forward LPP 8 -> 16: fp32 846 -> 813 us, bf16 465 -> 447 us (whole 128-byte
+// lines per position in bf16, 256 B in fp32); backward LPP 8 -> 16: fp32 1211 -> 1513 us, bf16 647 -> 707 us (78 KB of LDS: two
+// workgroups of 512 threads per CU, 128 VGPRs with spills).  The forward runs 16 where Ch allows, the backward 8.
+// The bf16 backward moves 2.7 - 3.1 TB/s: per tile and wave ~1250 VALU issue slots (a quarter of them the 64-bit address arithmetic of
+// the staging loads) - issuing the next tile's loads as raw bf16 pairs before the position loop (32 more registers) measured 640 ->
+// 670 us at two workgroups per CU and 970 us with the spills of three: it is the issue slots, not the load latency.
+#ifndef DW_FWD_LPP
+#define DW_FWD_LPP 16
+#endif
+#ifndef DW_BWD_LPP
+#define DW_BWD_LPP 8
+#endif
 
 // LDS tile: [HHGT][HWID][CT] floats
-template <typename T>
-__global__ __launch_bounds__(256) void leff_dwconv_fwd_kernel(const T* __restrict__ u, const float* __restrict__ w,
+template <typename T, int LPP>
+__global__ __launch_bounds__(32 * LPP) void leff_dwconv_fwd_kernel(const T* __restrict__ u, const float* __restrict__ w,
                                                               const float* __restrict__ bconv, T* __restrict__ tpre,
                                                               T* __restrict__ z, int Hres, int Wres, int Ch,
                                                               int tiles_x, int tiles_y) {
+    constexpr int CT = 4 * LPP;
     __shared__ __attribute__((aligned(16))) float g[HHGT * HWID * CT];
     const int t = threadIdx.x;
     // workgroups are dealt round-robin to the 8 XCDs: renumber so that the channel groups of one tile - the 128-byte pieces of
@@ -258,7 +272,7 @@ __global__ __launch_bounds__(256) void leff_dwconv_fwd_kernel(const T* __restric
     const int tx = rest % tiles_x; rest /= tiles_x;
     const int ty = rest % tiles_y;
     const int bimg = rest / tiles_y;
-    const int c4 = t & 7, ch0 = cg * CT + c4 * 4;
+    const int c4 = t % LPP, ch0 = cg * CT + c4 * 4;
     const int x0 = tx * TW - 1, y0 = ty * TH - 1;
     const T* ub = u + (size_t)bimg * Hres * Wres * Ch;
     // stage gelu(u) with a 1-pixel halo (zero outside the image: Conv2d padding=1)
@@ -268,7 +282,7 @@ __global__ __launch_bounds__(256) void leff_dwconv_fwd_kernel(const T* __restric
         bool ok[NIT];
 #pragma unroll
         for (int i = 0; i < NIT; ++i) {                       // all loads in flight before the first GELU
-            const int pos = (t >> 3) + 32 * i;
+            const int pos = (t / LPP) + 32 * i;
             const int pc = pos < NPOS ? pos : NPOS - 1;
             const int yy = y0 + pc / HWID, xx = x0 + pc % HWID;
             ok[i] = pos < NPOS && yy >= 0 && yy < Hres && xx >= 0 && xx < Wres;
@@ -277,7 +291,7 @@ __global__ __launch_bounds__(256) void leff_dwconv_fwd_kernel(const T* __restric
         }
 #pragma unroll
         for (int i = 0; i < NIT; ++i) {
-            const int pos = (t >> 3) + 32 * i;
+            const int pos = (t / LPP) + 32 * i;
             if (pos < NPOS) {
                 float4 val = make_float4(0, 0, 0, 0);
                 if (ok[i]) {
@@ -295,7 +309,7 @@ __global__ __launch_bounds__(256) void leff_dwconv_fwd_kernel(const T* __restric
         for (int kk = 0; kk < 9; ++kk) wk[c][kk] = w[(ch0 + c) * 9 + kk];
     const float4 bb = *reinterpret_cast<const float4*>(bconv + ch0);
     __syncthreads();
-    for (int pos = t >> 3; pos < TH * TW; pos += 32) {
+    for (int pos = t / LPP; pos < TH * TW; pos += 32) {
         const int py = pos / TW, px = pos % TW;
         const int yy = ty * TH + py, xx = tx * TW + px;
         if (yy >= Hres || xx >= Wres) continue;
@@ -328,18 +342,19 @@ __global__ __launch_bounds__(256) void leff_dwconv_fwd_kernel(const T* __restric
 // Written over p, BOTH sums use the same nine dt neighbours of a position and only its own u: the tile stages dt (with a
 // one-pixel halo) in LDS, u is read once per position straight into registers and one GELU evaluation yields g and g'.
 // (The earlier form staged gelu(u) with a halo as well: 19 LDS reads and 2.4 GELU evaluations per element, 3.6 TB/s.)
-template <typename T>
-__global__ __launch_bounds__(256, DWB_WAVES) void leff_dwconv_bwd_kernel(const T* __restrict__ dz, const T* __restrict__ u,
+template <typename T, int LPP>
+__global__ __launch_bounds__(32 * LPP, LPP == 8 ? DWB_WAVES : 4) void leff_dwconv_bwd_kernel(const T* __restrict__ dz, const T* __restrict__ u,
                                                               const T* __restrict__ tpre, const float* __restrict__ w,
                                                               T* __restrict__ du, float* __restrict__ dw,
                                                               float* __restrict__ db, const float* __restrict__ dzscale, int B,
                                                               int Hres, int Wres, int Ch, int tiles_x, int tiles_y, int wg_per_cg) {
+    constexpr int CT = 4 * LPP;
     __shared__ __attribute__((aligned(16))) float ds[HHGT * HWID * CT];    // dt = dz * gelu'(t) with halo
     __shared__ __attribute__((aligned(16))) float us[TH * TW * CT];        // u of the tile: each thread parks ITS OWN loads here
     const int t = threadIdx.x;
     const int cg = blockIdx.x % (Ch / CT);
     const int wslot = blockIdx.x / (Ch / CT);
-    const int c4 = t & 7, ch0 = cg * CT + c4 * 4;
+    const int c4 = t % LPP, ch0 = cg * CT + c4 * 4;
     float wk[4][9], dwk[4][9], dbk[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int c = 0; c < 4; ++c)
@@ -358,7 +373,7 @@ __global__ __launch_bounds__(256, DWB_WAVES) void leff_dwconv_bwd_kernel(const T
         if (!(DW_ABL & 4)) {
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
-                const int pos = (t >> 3) + 32 * it;
+                const int pos = (t / LPP) + 32 * it;
                 const int yy = min(ty * TH + pos / TW, Hres - 1), xx = min(tx * TW + pos % TW, Wres - 1);
                 uv[it] = ld4(u + (ib + (size_t)yy * Wres + xx) * Ch + ch0);
             }
@@ -372,7 +387,7 @@ __global__ __launch_bounds__(256, DWB_WAVES) void leff_dwconv_bwd_kernel(const T
             bool ok[3];
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
-                const int pos = (t >> 3) + 32 * (3 * half + i);
+                const int pos = (t / LPP) + 32 * (3 * half + i);
                 const int pc = pos < NPOS ? pos : NPOS - 1;
                 const int yy = y0 + pc / HWID, xx = x0 + pc % HWID;
                 ok[i] = pos < NPOS && yy >= 0 && yy < Hres && xx >= 0 && xx < Wres;
@@ -383,7 +398,7 @@ __global__ __launch_bounds__(256, DWB_WAVES) void leff_dwconv_bwd_kernel(const T
             }
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
-                const int pos = (t >> 3) + 32 * (3 * half + i);
+                const int pos = (t / LPP) + 32 * (3 * half + i);
                 if (pos < NPOS) {
                     float4 dv = make_float4(0, 0, 0, 0);
                     if (ok[i]) dv = make_float4(zsc * rz[i].x * rt[i].x, zsc * rz[i].y * rt[i].y, zsc * rz[i].z * rt[i].z, zsc * rz[i].w * rt[i].w);
@@ -393,14 +408,14 @@ __global__ __launch_bounds__(256, DWB_WAVES) void leff_dwconv_bwd_kernel(const T
         }
         if (!(DW_ABL & 4)) {
 #pragma unroll
-            for (int it = 0; it < NIT; ++it) *reinterpret_cast<float4*>(&us[((t >> 3) + 32 * it) * CT + c4 * 4]) = uv[it];
+            for (int it = 0; it < NIT; ++it) *reinterpret_cast<float4*>(&us[((t / LPP) + 32 * it) * CT + c4 * 4]) = uv[it];
         }
         __syncthreads();
         // the position loop is NOT unrolled (unrolled, the 36 neighbour reads of four positions are hoisted: 222 VGPRs, two
         // workgroups per CU instead of three)
 #pragma unroll 1
         for (int it = 0; it < NIT; ++it) {
-            const int pos = (t >> 3) + 32 * it;
+            const int pos = (t / LPP) + 32 * it;
             const int py = pos / TW, px = pos % TW;
             const int yy = ty * TH + py, xx = tx * TW + px;
             if (yy >= Hres || xx >= Wres) continue;
@@ -431,10 +446,10 @@ __global__ __launch_bounds__(256, DWB_WAVES) void leff_dwconv_bwd_kernel(const T
             st4(du + o, make_float4(dg.x * gp.x, dg.y * gp.y, dg.z * gp.z, dg.w * gp.w));
         }
     }
-    // reduce the 32 position-slots (t >> 3) that share a channel quad: five quantities per round through the dead dt tile
+    // reduce the 32 position-slots (t / LPP) that share a channel quad: five quantities per round through the dead dt tile
     // ([5][32 slots][CT]: two rounds, four barriers - ten rounds of one quantity with a serial 32-term sum by 32 threads each
     // cost 7 - 11 us per launch)
-    const int ps = t >> 3;
+    const int ps = t / LPP;
     float* red5 = ds;
     static_assert(HHGT * HWID * CT >= 5 * 32 * CT, "reduction scratch must fit the dt tile");
 #pragma unroll
@@ -815,15 +830,20 @@ extern "C" int dhz_gelu_bwd_dt(const void* dy, const void* u, void* du, int64_t 
     return DHZ_OK;
 }
 
+// lanes per position of the two depthwise kernels: 16 (64 channels per workgroup) where asked for and Ch allows
+static int dw_lanes_per_position(int want, int Ch) { return (want == 16 && Ch % 64 == 0) ? 16 : 8; }
+
 extern "C" int dhz_leff_dwconv_fwd_dt(const void* u, const float* w, const float* b, void* t, void* z, int B, int Hres,
                                       int Wres, int Ch, int dtype, void* stream) {
     DHZ_REQUIRE(u && w && b && z, "dhz_leff_dwconv_fwd: null pointer");
     DHZ_REQUIRE(B > 0 && Hres > 0 && Wres > 0 && Ch % CT == 0, "dhz_leff_dwconv_fwd: Ch=%d must be a multiple of %d", Ch, CT);
     const int tiles_x = (Wres + TW - 1) / TW, tiles_y = (Hres + TH - 1) / TH;
-    const int grid = B * tiles_x * tiles_y * (Ch / CT);
-    DT_SWITCH(dtype, "dhz_leff_dwconv_fwd",
-              hipLaunchKernelGGL((leff_dwconv_fwd_kernel<T>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const T*)u, w, b, (T*)t,
-                                 (T*)z, Hres, Wres, Ch, tiles_x, tiles_y));
+    const int lpp = dw_lanes_per_position(DW_FWD_LPP, Ch);
+    const int grid = B * tiles_x * tiles_y * (Ch / (4 * lpp));
+#define DW_FWD(LPP_) hipLaunchKernelGGL((leff_dwconv_fwd_kernel<T, LPP_>), dim3(grid), dim3(32 * LPP_), 0, (hipStream_t)stream, (const T*)u, \
+                                        w, b, (T*)t, (T*)z, Hres, Wres, Ch, tiles_x, tiles_y)
+    DT_SWITCH(dtype, "dhz_leff_dwconv_fwd", if (lpp == 16) DW_FWD(16); else DW_FWD(8));
+#undef DW_FWD
     DHZ_CHECK_LAUNCH("dhz_leff_dwconv_fwd");
     return DHZ_OK;
 }
@@ -838,13 +858,16 @@ extern "C" int dhz_leff_dwconv_bwd_scaled_dt(const void* dz, const void* u, cons
     DHZ_REQUIRE(dz && u && t && w && du && dw && db, "dhz_leff_dwconv_bwd: null pointer");
     DHZ_REQUIRE(B > 0 && Hres > 0 && Wres > 0 && Ch % CT == 0, "dhz_leff_dwconv_bwd: Ch=%d must be a multiple of %d", Ch, CT);
     const int tiles_x = (Wres + TW - 1) / TW, tiles_y = (Hres + TH - 1) / TH;
-    const int ntiles = B * tiles_x * tiles_y, ncg = Ch / CT;
-    int wg_per_cg = 768 / ncg;                     // one resident round: 3 workgroups per CU (LDS), persistent over tiles
+    const int lpp = dw_lanes_per_position(DW_BWD_LPP, Ch);
+    const int ntiles = B * tiles_x * tiles_y, ncg = Ch / (4 * lpp);
+    int wg_per_cg = (lpp == 16 ? 512 : 256 * DWB_WAVES) / ncg;   // one resident round: 3 (2 at 512 threads) workgroups per CU, persistent over tiles
     if (wg_per_cg < 1) wg_per_cg = 1;
     if (wg_per_cg > ntiles) wg_per_cg = ntiles;
-    DT_SWITCH(dtype, "dhz_leff_dwconv_bwd",
-              hipLaunchKernelGGL((leff_dwconv_bwd_kernel<T>), dim3(wg_per_cg * ncg), dim3(256), 0, (hipStream_t)stream, (const T*)dz,
-                                 (const T*)u, (const T*)t, w, (T*)du, dw, db, dz_scale, B, Hres, Wres, Ch, tiles_x, tiles_y, wg_per_cg));
+#define DW_BWD(LPP_) hipLaunchKernelGGL((leff_dwconv_bwd_kernel<T, LPP_>), dim3(wg_per_cg * ncg), dim3(32 * LPP_), 0, (hipStream_t)stream,   \
+                                        (const T*)dz, (const T*)u, (const T*)t, w, (T*)du, dw, db, dz_scale, B, Hres, Wres, Ch, tiles_x,      \
+                                        tiles_y, wg_per_cg)
+    DT_SWITCH(dtype, "dhz_leff_dwconv_bwd", if (lpp == 16) DW_BWD(16); else DW_BWD(8));
+#undef DW_BWD
     DHZ_CHECK_LAUNCH("dhz_leff_dwconv_bwd");
     return DHZ_OK;
 }

@@ -187,7 +187,7 @@ def test_reverse_residual(dev, ops, C, res, shift):
 
 
 # ----------------------------------------------------------------------------- K5
-@pytest.mark.parametrize("Ch,res", [(128, 16), (128, 8), (256, 32), (2048, 8), (64, 24)])
+@pytest.mark.parametrize("Ch,res", [(128, 16), (128, 8), (256, 32), (2048, 8), (64, 24), (96, 16)])      # 96: the 8-lane forward
 def test_leff_dwconv(dev, ops, Ch, res):
     g = torch.Generator().manual_seed(Ch + res)
     B = 2
