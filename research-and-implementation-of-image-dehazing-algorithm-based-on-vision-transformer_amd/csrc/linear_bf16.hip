@@ -32,6 +32,18 @@ typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int BK = 64;
+#ifndef BF_WABL
+#define BF_WABL 0       // weight gradient diagnostics: 1 no MFMAs (and no fragment reads), 2 no global loads after the first stage
+#endif
+#ifndef BF_WPAIR
+#define BF_WPAIR 1      // weight gradient: two slabs per workgroup of 512 threads (half the atomics) where a tile has two slabs or more
+#endif
+#ifndef BF_WPAIR_MAX_STAGES
+#define BF_WPAIR_MAX_STAGES 32
+#endif
+#ifndef BF_WSPLIT
+#define BF_WSPLIT 2     // workgroups per CU the token split aims at
+#endif
 
 __device__ __forceinline__ f32x4 mfma_bf16(s16x8 a, s16x8 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
@@ -301,16 +313,22 @@ struct WgradOut {
 };
 
 // dW tile [32 WM rows of N] x [32 WN cols of K] per workgroup for one slab of tokens; FM = 32 WM, FN = 32 WN in {64, 128}
-template <int WM, int WN>
-__global__ __launch_bounds__(256) void wgrad_bf16_kernel(const uint16_t* __restrict__ dy, int ldy,
-                                                         const uint16_t* __restrict__ x, int ldx, int T, int N, int K,
-                                                         WgradOut out, int nsplit) {
-    constexpr int FM = 32 * WM, FN = 32 * WN;
+// G = 2: a workgroup is TWO groups of four waves, each with its own token slab and its own pair of stage buffers; their accumulators meet
+// in LDS before the atomics.  Same waves, loads in flight and LDS per CU as two workgroups of the one-group form, HALF the atomics: the
+// fp32 atomics of a launch (2 workgroups per CU x 256 CUs x 16 K floats = 8.4 M, ~2.7 ps each whatever the shape) were 23 us of the 33 - 58 us
+// that the config-4 shapes below 20 GFLOP take (tools/variants.sh, BF_ABL = 8: sum over the step's 36 shapes 2517 -> 1839 us without them).
+template <int WM, int WN, int G>
+__global__ __launch_bounds__(256 * G) void wgrad_bf16_kernel(const uint16_t* __restrict__ dy, int ldy,
+                                                             const uint16_t* __restrict__ x, int ldx, int T, int N, int K,
+                                                             WgradOut out, int nsplit) {
+    constexpr int FM = 32 * WM, FN = 32 * WN, NT = 256 * G;
     constexpr int A_BYTES = BK * FM * 2, B_BYTES = BK * FN * 2;
     constexpr int STAGE = A_BYTES + B_BYTES;
     constexpr int NA = BK * (FM / 8) / 256, NB = BK * (FN / 8) / 256;       // chunks per thread per stage (2 or 4)
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
+    const int grp = G == 1 ? 0 : (int)(threadIdx.x >> 8);                   // wave-uniform
+    unsigned char* const smem = smem_all + grp * 2 * STAGE;
+    const int t = threadIdx.x & 255, lane = t & 63, w = t >> 6;
     const int i16 = lane & 15, g = lane >> 4;
     const int wm = w >> 1, wn = w & 1;
     const int tiles_n = K / FN;
@@ -321,8 +339,14 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const uint16_t* __restr
     const int mat = n0 / out.nper, nloc = n0 - mat * out.nper;
     float* __restrict__ const dw = out.dw[mat];
     float* __restrict__ const db = out.db[mat];
-    const int nst = T / BK;
-    const int st0 = (int)((long long)nst * split / nsplit), st1 = (int)((long long)nst * (split + 1) / nsplit);
+    const int nst = T / BK, nslab = nsplit * G, slab = split * G + grp;
+    const int st0 = (int)((long long)nst * slab / nslab), st1 = (int)((long long)nst * (slab + 1) / nslab);
+    int nit = st1 - st0;                                                    // the groups share the barriers: common trip count
+    if (G == 2) {
+        const int o = split * G + (grp ^ 1);
+        const int no = (int)((long long)nst * (o + 1) / nslab) - (int)((long long)nst * o / nslab);
+        nit = nit > no ? nit : no;
+    }
 
     f32x4 acc[WM][WN];
 #pragma unroll
@@ -373,76 +397,103 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const uint16_t* __restr
         swrite(0);
     }
     __syncthreads();
-    for (int st = st0; st < st1; ++st) {
-        const int buf = (st - st0) & 1;
-        const bool more = st + 1 < st1;
-        if (more) gload(st + 1);
+    for (int it = 0; it < nit; ++it) {
+        const int st = st0 + it;
+        const int buf = it & 1;
+        const bool have = st < st1, more = st + 1 < st1;
+        if (more && !(BF_WABL & 2)) gload(st + 1);
         const unsigned char* As = smem + buf * STAGE;
         const unsigned char* Bs = As + A_BYTES;
+        if (have) {
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            s16x8 af[WM], bf[WN];
+            for (int s = 0; s < 2; ++s) {
+                s16x8 af[WM], bf[WN];
 #pragma unroll
-            for (int a = 0; a < WM; ++a) af[a] = tr_frag<FM>(As, 32 * s + 8 * g, wm * WM + a, lane);
+                for (int a = 0; a < WM; ++a) af[a] = tr_frag<FM>(As, 32 * s + 8 * g, wm * WM + a, lane);
 #pragma unroll
-            for (int b = 0; b < WN; ++b) bf[b] = tr_frag<FN>(Bs, 32 * s + 8 * g, wn * WN + b, lane);
+                for (int b = 0; b < WN; ++b) bf[b] = tr_frag<FN>(Bs, 32 * s + 8 * g, wn * WN + b, lane);
 #pragma unroll
-            for (int a = 0; a < WM; ++a)
+                for (int a = 0; a < WM; ++a)
 #pragma unroll
-                for (int b = 0; b < WN; ++b) acc[a][b] = mfma_bf16(af[a], bf[b], acc[a][b]);
+                    for (int b = 0; b < WN; ++b) { if (!(BF_WABL & 1)) acc[a][b] = mfma_bf16(af[a], bf[b], acc[a][b]); }
+            }
         }
         if (more) swrite(buf ^ 1);
         __syncthreads();
     }
-    // ---- epilogue: tile -> LDS (row-major FM x FN fp32) -> full-line fp32 atomics
-    float* Cs = reinterpret_cast<float*>(smem);
+    // ---- epilogue: tile -> LDS (row-major FM x FN fp32; G = 2: the second group's tile first, the first group adds its own) ->
+    // full-line fp32 atomics
+    float* Cs = reinterpret_cast<float*>(smem_all);
+    if (grp == G - 1) {
 #pragma unroll
-    for (int a = 0; a < WM; ++a)
+        for (int a = 0; a < WM; ++a)
 #pragma unroll
-        for (int b = 0; b < WN; ++b)
+            for (int b = 0; b < WN; ++b)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) Cs[(wm * WM * 16 + a * 16 + 4 * g + j) * FN + wn * WN * 16 + b * 16 + i16] = acc[a][b][j];
+                for (int j = 0; j < 4; ++j) Cs[(wm * WM * 16 + a * 16 + 4 * g + j) * FN + wn * WN * 16 + b * 16 + i16] = acc[a][b][j];
+    }
     __syncthreads();
+    if (G == 2) {
+        if (grp == 0) {
+#pragma unroll
+            for (int a = 0; a < WM; ++a)
+#pragma unroll
+                for (int b = 0; b < WN; ++b)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) Cs[(wm * WM * 16 + a * 16 + 4 * g + j) * FN + wn * WN * 16 + b * 16 + i16] += acc[a][b][j];
+        }
+        __syncthreads();
+    }
     // (each of a tile's nsplit workgroups starts its walk over the FM x FN addresses at another row: they finish together, and
     // queueing on the same cache lines was a quarter of the kernel)
     if (!(BF_ABL & 8)) {
         const int rot = (int)(((unsigned)split * 2654435761u) % (unsigned)FM) * FN;
-        for (int i = t; i < FM * FN; i += 256) {
+        for (int i = threadIdx.x; i < FM * FN; i += NT) {
             int e = i + rot;
             if (e >= FM * FN) e -= FM * FN;
             atomicAdd(dw + (size_t)(nloc + e / FN) * K + k0 + e % FN, Cs[e]);
         }
     }
     if (do_db) {
-        // thread t always staged chunk (t % (FM/8)) of rows (t / (FM/8)) + k * 256 / (FM/8): fold the 256 / (FM/8) row groups
+        // thread t always staged chunk (t % (FM/8)) of rows (t / (FM/8)) + k * 256 / (FM/8): fold the row groups of all threads
         __syncthreads();
-        float* red = reinterpret_cast<float*>(smem);          // [256 / (FM/8)][FM]
+        float* red = reinterpret_cast<float*>(smem_all);      // [NT / (FM/8)][FM]
         constexpr int CPR = FM / 8;
 #pragma unroll
-        for (int c = 0; c < 8; ++c) red[(t / CPR) * FM + 8 * (t % CPR) + c] = dbacc[c];
+        for (int c = 0; c < 8; ++c) red[((grp * 256 + t) / CPR) * FM + 8 * (t % CPR) + c] = dbacc[c];
         __syncthreads();
-        if (t < FM) {
+        if (threadIdx.x < FM) {
             float tot = 0.f;
-            for (int r = 0; r < 256 / CPR; ++r) tot += red[r * FM + t];
-            atomicAdd(db + nloc + t, tot);
+            for (int r = 0; r < NT / CPR; ++r) tot += red[r * FM + threadIdx.x];
+            atomicAdd(db + nloc + threadIdx.x, tot);
         }
     }
+}
+
+template <int WM, int WN, int G>
+void launch_wgrad_g(const uint16_t* dy, int ldy, const uint16_t* x, int ldx, int T, int N, int K, const WgradOut& out, int tiles, int nwg,
+                    hipStream_t s) {
+    constexpr int FM = 32 * WM, FN = 32 * WN;
+    constexpr size_t stage = (size_t)BK * (FM + FN) * 2;
+    constexpr size_t smem = 2 * G * stage > (size_t)FM * FN * 4 ? 2 * G * stage : (size_t)FM * FN * 4;
+    if (smem > 48 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_bf16_kernel<WM, WN, G>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)smem);
+    hipLaunchKernelGGL((wgrad_bf16_kernel<WM, WN, G>), dim3(tiles * nwg), dim3(256 * G), smem, s, dy, ldy, x, ldx, T, N, K, out, nwg);
 }
 
 template <int WM, int WN>
 void launch_wgrad(const uint16_t* dy, int ldy, const uint16_t* x, int ldx, int T, int N, int K, const WgradOut& out, hipStream_t s) {
     constexpr int FM = 32 * WM, FN = 32 * WN;
-    constexpr size_t stage = (size_t)BK * (FM + FN) * 2;
-    constexpr size_t smem = 2 * stage > (size_t)FM * FN * 4 ? 2 * stage : (size_t)FM * FN * 4;
     const int tiles = (N / FM) * (K / FN);
-    int nsplit = 2 * dhz_num_cus() / tiles;
-    const int max_split = T / (BK * 4) > 0 ? T / (BK * 4) : 1;           // at least 4 stages per workgroup
+    int nsplit = BF_WSPLIT * dhz_num_cus() / tiles;                      // token slabs per tile
+    const int max_split = T / (BK * 4) > 0 ? T / (BK * 4) : 1;           // at least 4 stages per slab
     if (nsplit > max_split) nsplit = max_split;
     if (nsplit < 1) nsplit = 1;
-    if (smem > 48 * 1024)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_bf16_kernel<WM, WN>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)smem);
-    hipLaunchKernelGGL((wgrad_bf16_kernel<WM, WN>), dim3(tiles * nsplit), dim3(256), smem, s, dy, ldy, x, ldx, T, N, K, out, nsplit);
+    // two slabs per workgroup where the slabs are short (the atomics are then a third of the launch); long slabs keep independent
+    // workgroups (the two groups of a pair share every barrier: T = 8192, N = 3072, K = 1024 measured 86 -> 104 us paired)
+    if (BF_WPAIR && nsplit >= 2 && (nsplit % 2 == 0 || nsplit >= 16) && T / BK / nsplit <= BF_WPAIR_MAX_STAGES) launch_wgrad_g<WM, WN, 2>(dy, ldy, x, ldx, T, N, K, out, tiles, nsplit / 2, s);
+    else launch_wgrad_g<WM, WN, 1>(dy, ldy, x, ldx, T, N, K, out, tiles, nsplit, s);
 }
 
 int dispatch_wgrad(const char* who, const uint16_t* dy, int ldy, const uint16_t* x, int ldx, int T, int nmat, int nper, int K,

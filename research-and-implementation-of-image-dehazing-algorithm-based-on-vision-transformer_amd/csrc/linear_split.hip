@@ -526,8 +526,13 @@ constexpr int BK2 = 32;
 #ifndef DHZ_W6_ABL
 #define DHZ_W6_ABL 0
 #endif
-template <int WM, int WN, int WAVES_M, int WAVES_N>
-__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_M * WAVES_N == 4 ? 2 : 1) void wgrad_split6_kernel(const float* __restrict__ dy, int ldy, const float* __restrict__ x,
+// G = 2 (four-wave configurations): a workgroup is TWO groups of four waves, each with its own token slab and its own pair of stage
+// buffers - the waves, loads in flight and LDS of two workgroups of the one-group form - whose accumulators meet in LDS before the
+// atomics: half the fp32 atomics of the launch (2 x 256 workgroups x FM x FN floats, ~2.7 ps each whatever the shape: 6 - 12 us of the
+// launches below 50 us, tools/variants.sh with DHZ_W6_ABL = 32).  The groups share the one barrier per stage; the group with the
+// shorter slab (by at most one stage) pays the difference with bare barriers.
+template <int WM, int WN, int WAVES_M, int WAVES_N, int G = 1>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N * G, WAVES_M * WAVES_N == 4 ? 2 : 1) void wgrad_split6_kernel(const float* __restrict__ dy, int ldy, const float* __restrict__ x,
                                                               int ldx, int T, int N, int K, WgradOut out, int nsplit,
                                                               const float* __restrict__ row_scale, int rows_per_scale) {
     constexpr int NT = 64 * WAVES_M * WAVES_N;
@@ -536,8 +541,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_M * WAVES_N == 4 ? 2 
     constexpr int STAGE = 3 * (A_BYTES + B_BYTES);
     constexpr int NA = BK2 * (FM / 8) / NT, NB = BK2 * (FN / 8) / NT;    // 8-element chunks per thread per stage (1 or 2)
     static_assert(NA >= 1 && NB >= 1, "tile too narrow for the workgroup");
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    static_assert(G == 1 || NT == 256, "two groups: four-wave configurations only");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
+    const int grp = G == 1 ? 0 : (int)(threadIdx.x / NT);                   // wave-uniform
+    unsigned char* const smem = smem_all + grp * 2 * STAGE;
+    const int t = G == 1 ? (int)threadIdx.x : (int)(threadIdx.x % NT), lane = t & 63, w = t >> 6;
     const int i16 = lane & 15, g = lane >> 4;
     const int wm = w / WAVES_N, wn = w % WAVES_N;
     const int tiles_n = K / FN;
@@ -548,8 +556,14 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_M * WAVES_N == 4 ? 2 
     const int mat = n0 / out.nper, nloc = n0 - mat * out.nper;
     float* __restrict__ const dw = out.dw[mat];
     float* __restrict__ const db = out.db[mat];
-    const int nst = T / BK2;
-    const int st0 = (int)((long long)nst * split / nsplit), st1 = (int)((long long)nst * (split + 1) / nsplit);
+    const int nst = T / BK2, nslab = nsplit * G, slab = split * G + grp;
+    const int st0 = (int)((long long)nst * slab / nslab), st1 = (int)((long long)nst * (slab + 1) / nslab);
+    int idle = 0;                                                           // stages the OTHER group of the pair runs beyond this one's
+    if (G == 2) {
+        const int o = split * G + (grp ^ 1);
+        const int no = (int)((long long)nst * (o + 1) / nslab) - (int)((long long)nst * o / nslab);
+        idle = no - (st1 - st0) > 0 ? no - (st1 - st0) : 0;
+    }
 
     f32x4 acc[WM][WN];
 #pragma unroll
@@ -699,54 +713,91 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_M * WAVES_N == 4 ? 2 
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
     }
-    // ---- epilogue: tile -> LDS (row-major FM x FN fp32) -> full-line fp32 atomics
-    float* Cs = reinterpret_cast<float*>(smem);
+    for (int i = 0; i < idle; ++i) __builtin_amdgcn_s_barrier();
+    // ---- epilogue: tile -> LDS (row-major FM x FN fp32; G = 2: the second group's tile first, the first group adds its own) ->
+    // full-line fp32 atomics
+    float* Cs = reinterpret_cast<float*>(smem_all);
+    if (G == 2) __syncthreads();                                            // both groups are done with their stage buffers
+    if (grp == G - 1) {
 #pragma unroll
-    for (int a = 0; a < WM; ++a)
+        for (int a = 0; a < WM; ++a)
 #pragma unroll
-        for (int b = 0; b < WN; ++b)
+            for (int b = 0; b < WN; ++b)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) Cs[(wm * WM * 16 + a * 16 + 4 * g + j) * FN + wn * WN * 16 + b * 16 + i16] = acc[a][b][j];
+                for (int j = 0; j < 4; ++j) Cs[(wm * WM * 16 + a * 16 + 4 * g + j) * FN + wn * WN * 16 + b * 16 + i16] = acc[a][b][j];
+    }
     __syncthreads();
-    if constexpr (DHZ_W6_ABL & 32) { if (Cs[t] == 123.456f) dw[t] = 1.f; }
+    if (G == 2) {
+        if (grp == 0) {
+#pragma unroll
+            for (int a = 0; a < WM; ++a)
+#pragma unroll
+                for (int b = 0; b < WN; ++b)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) Cs[(wm * WM * 16 + a * 16 + 4 * g + j) * FN + wn * WN * 16 + b * 16 + i16] += acc[a][b][j];
+        }
+        __syncthreads();
+    }
+    const int tt = threadIdx.x;
+    if constexpr (DHZ_W6_ABL & 32) { if (Cs[tt] == 123.456f) dw[tt] = 1.f; }
     else
-    for (int e = t; e < FM * FN; e += NT) atomicAdd(dw + (size_t)(nloc + e / FN) * K + k0 + e % FN, Cs[e]);
+    for (int e = tt; e < FM * FN; e += NT * G) atomicAdd(dw + (size_t)(nloc + e / FN) * K + k0 + e % FN, Cs[e]);
     if (do_db) {
         __syncthreads();
-        float* red = reinterpret_cast<float*>(smem);          // [rows of chunks][FM]
+        float* red = reinterpret_cast<float*>(smem_all);      // [rows of chunks][FM]
         constexpr int CPR = FM / 8;
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
-            const int e = t + NT * i;
+            const int e = grp * NT * NA + t + NT * i;
 #pragma unroll
             for (int c = 0; c < 8; ++c) red[(e / CPR) * FM + 8 * (e % CPR) + c] = dbacc[i][c];
         }
         __syncthreads();
-        if (t < FM) {
+        if (tt < FM) {
             float tot = 0.f;
-            for (int r = 0; r < NT * NA / CPR; ++r) tot += red[r * FM + t];
-            atomicAdd(db + nloc + t, tot);
+            for (int r = 0; r < G * NT * NA / CPR; ++r) tot += red[r * FM + tt];
+            atomicAdd(db + nloc + tt, tot);
         }
     }
+}
+
+#ifndef DHZ_W6_PAIR
+#define DHZ_W6_PAIR 1
+#endif
+#ifndef DHZ_W6_PAIR_MAX_STAGES
+#define DHZ_W6_PAIR_MAX_STAGES 32      // slabs longer than this keep independent workgroups: the two groups share every barrier, and at 48 - 64
+                                       // stages pairing measured +3 % (T = 32768, N = 1024, K = 256: 106.9 -> 110.7 us)
+#endif
+template <int WM, int WN, int WAVES_M, int WAVES_N, int G>
+void launch_wgrad_split6_g(const float* dy, int ldy, const float* x, int ldx, int T, int N, int K, const WgradOut& out,
+                           const float* row_scale, int rows_per_scale, int tiles, int nwg, hipStream_t s) {
+    constexpr int FM = 16 * WM * WAVES_M, FN = 16 * WN * WAVES_N, NT = 64 * WAVES_M * WAVES_N;
+    constexpr size_t stage = (size_t)BK2 * (FM + FN) * 2 * 3;
+    constexpr size_t ring = 2 * G * stage;
+    constexpr size_t smem = ring > (size_t)FM * FN * 4 ? ring : (size_t)FM * FN * 4;
+    if (smem > 48 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_split6_kernel<WM, WN, WAVES_M, WAVES_N, G>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipLaunchKernelGGL((wgrad_split6_kernel<WM, WN, WAVES_M, WAVES_N, G>), dim3(tiles * nwg), dim3(NT * G), smem, s, dy, ldy, x, ldx, T, N, K,
+                       out, nwg, row_scale, rows_per_scale);
 }
 
 template <int WM, int WN, int WAVES_M, int WAVES_N>
 void launch_wgrad_split6(const float* dy, int ldy, const float* x, int ldx, int T, int N, int K, const WgradOut& out,
                          const float* row_scale, int rows_per_scale, hipStream_t s) {
     constexpr int FM = 16 * WM * WAVES_M, FN = 16 * WN * WAVES_N, NT = 64 * WAVES_M * WAVES_N;
-    constexpr size_t stage = (size_t)BK2 * (FM + FN) * 2 * 3;
-    constexpr size_t ring = 2 * stage;
-    constexpr size_t smem = ring > (size_t)FM * FN * 4 ? ring : (size_t)FM * FN * 4;
     const int tiles = (N / FM) * (K / FN);
-    int nsplit = (NT == 256 ? 2 : 1) * dhz_num_cus() / tiles;
-    const int max_split = T / (BK2 * 8) > 0 ? T / (BK2 * 8) : 1;          // at least 8 stages per workgroup
+    int nsplit = (NT == 256 ? 2 : 1) * dhz_num_cus() / tiles;            // token slabs per tile
+    const int max_split = T / (BK2 * 8) > 0 ? T / (BK2 * 8) : 1;          // at least 8 stages per slab
     if (nsplit > max_split) nsplit = max_split;
     if (nsplit < 1) nsplit = 1;
-    if (smem > 48 * 1024)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_split6_kernel<WM, WN, WAVES_M, WAVES_N>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)smem);
-    hipLaunchKernelGGL((wgrad_split6_kernel<WM, WN, WAVES_M, WAVES_N>), dim3(tiles * nsplit), dim3(NT), smem, s, dy, ldy, x, ldx, T, N, K, out, nsplit,
-                       row_scale, rows_per_scale);
+    if constexpr (NT == 256) {
+        if (DHZ_W6_PAIR && nsplit >= 2 && (nsplit % 2 == 0 || nsplit >= 16) && T / BK2 / nsplit <= DHZ_W6_PAIR_MAX_STAGES) {      // (an odd count loses a slab)
+            launch_wgrad_split6_g<WM, WN, WAVES_M, WAVES_N, 2>(dy, ldy, x, ldx, T, N, K, out, row_scale, rows_per_scale, tiles, nsplit / 2, s);
+            return;
+        }
+    }
+    launch_wgrad_split6_g<WM, WN, WAVES_M, WAVES_N, 1>(dy, ldy, x, ldx, T, N, K, out, row_scale, rows_per_scale, tiles, nsplit, s);
 }
 
 template <int WM, int WN, bool SIX>
