@@ -48,7 +48,8 @@ def test_linear_bf16_c_abi(T, N, K):
 
 @pytest.mark.parametrize("T,n,N,K", [(4096, 1, 64, 64), (8192, 3, 64, 64), (4096, 1, 256, 64), (2048, 1, 64, 256),
                                      (8192, 3, 128, 128), (1024, 1, 512, 128), (512, 1, 1536, 512), (65536, 1, 128, 128),
-                                     (320, 1, 2048, 512), (131072, 3, 64, 64)])
+                                     (320, 1, 2048, 512), (131072, 3, 64, 64),
+                                     (4736, 1, 128, 128)])      # 18 slabs of 4 or 5 stages: paired groups with unequal trip counts
 def test_linear_wgrad_bf16_c_abi(T, n, N, K):
     """dW_i += dy[:, iN:(i+1)N]^T x, db_i += column sums, for n parameters sharing x: fp32 accumulation of bf16 products."""
     from dehaze_hip import _lib

@@ -79,7 +79,8 @@ def test_six_term_split_is_the_default_and_the_switch_routes():
                                                   # step-sized problems: many token splits per tile, the packed three-matrix form, the
                                                   # row-scaled form, a token count that does not divide evenly over the splits
                                                   (16384, 1, 256, 256, False), (65536, 1, 256, 64, True), (65536, 1, 64, 256, False),
-                                                  (32768, 3, 128, 128, False), (33280, 1, 128, 256, True)])
+                                                  (32768, 3, 128, 128, False), (33280, 1, 128, 256, True),
+                                                  (4736, 1, 128, 128, False)])     # 18 slabs of 8 or 9 stages: paired groups, unequal trip counts
 def test_split_wgrad_vs_fp64(T, nmat, nper, K, scaled, terms):
     import ctypes
     from dehaze_hip import _lib
