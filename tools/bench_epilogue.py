@@ -1,5 +1,7 @@
+"""The residual epilogue of the six-term token-Linear GEMM (K4 in the GEMM: ops.gemm_fwd_res) against the plain GEMM followed by the separate
+reverse_residual pass, on the out-projection / linear2 shapes of the step: us per call."""
 import os, sys
-ROOT = "/root/repo"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "research-and-implementation-of-image-dehazing-algorithm-based-on-vision-transformer_amd"))
 import torch
 from dehaze_hip import ops, _lib
